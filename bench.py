@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""
+bench.py -- the hot path of Gretel on MI355X, measured the way BASELINE.json asks.
+
+One "step" = one whole pass of the hot path over one synthetic contig window whose support
+table is already resident in HBM:   clear -> BAM->Hansel fill -> 100 x {path extension,
+1% clamp, reweight}   (reference gretel/util.py:226-286 + gretel/cmd.py:148-179).
+Workload at every N: BASELINE.json config C3, one 10k-SNP / 1M-read / k=5 (L=5) contig PER GPU
+(seed = rank): independent windows, weak scaling, results gathered to rank 0 over RCCL.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--paths 100]
+
+Prints ONE JSON line (rank 0).  `value` = haplotypes/s over all ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--paths", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-snps", type=int, default=1500, help="SNP prefix used for the Python CPU baseline sample")
+    return ap.parse_args()
+
+
+def edge_evals_per_path(cmask, n, L):
+    """conditional lookups  sum_snp S_snp*min(L,snp)  +  reweight cells N(N+3)/2+1."""
+    S = np.array([bin(int(m)).count("1") for m in cmask[1:n + 1]], dtype=np.int64)
+    lag = np.minimum(L, np.arange(1, n + 1))
+    return int((S * lag).sum()), n * (n + 3) // 2 + 1
+
+
+def cpu_baseline_python(table, n_prefix, n_full):
+    """The reference's own call structure (Python loop, one NumPy-backed call per Hansel cell:
+    oracle/hansel_ref.py + oracle/gretel_ref.py) on a bounded sample: the first `n_prefix`
+    SNPs of the same contig, ONE full spin; extrapolated to the full contig by call counts
+    (path extension ~ N, reweight = N(N+3)/2+1 calls)."""
+    from oracle import gretel_ref as G
+    from oracle.hansel_ref import Hansel as PyHansel, SYMBOLS, UNSYMBOLS
+    k = np.diff(table.off)
+    keep = np.flatnonzero(table.rank + k <= n_prefix)
+    reads = []
+    b = table.bases.tobytes()
+    for r in keep:
+        reads.append((int(table.rank[r]), b[table.off[r]:table.off[r + 1]].decode()))
+    h = PyHansel.init_matrix(SYMBOLS, UNSYMBOLS, n_prefix, band=max(1, int(k.max()) - 1))
+    t0 = time.perf_counter()
+    G.fill_from_support(h, reads, n_prefix)
+    t_fill = time.perf_counter() - t0
+    orig = h.copy()
+    t0 = time.perf_counter()
+    path, prob, mn = G.generate_path(n_prefix, h, orig)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    G.reweight_hansel_from_path(h, path, max(mn, 0.01))
+    t_rw = time.perf_counter() - t0
+    calls_s = n_prefix * (n_prefix + 3) // 2 + 1
+    calls_f = n_full * (n_full + 3) // 2 + 1
+    t_path_full = t_gen * (n_full / n_prefix) + t_rw * (calls_f / calls_s)
+    return dict(value=1.0 / t_path_full, unit="haplotypes/s", cores=1, kind="port",
+                sample="Python oracle (reference call structure), SNP prefix %d of the contig, %d reads, 1 spin: "
+                       "fill %.2fs, generate_path %.2fs, reweight %.2fs; per-path time extrapolated to N=%d by call "
+                       "counts (x%.1f extension, x%.1f reweight)" % (n_prefix, len(reads), t_fill, t_gen, t_rw, n_full,
+                                                                      n_full / n_prefix, calls_f / calls_s))
+
+
+def cpu_baseline_c(table, paths=3):
+    """The compiled scalar port (oracle/c/gretel_oracle.c), full contig, reference pair
+    enumeration (all N(N+3)/2+1 reweight calls per path), a few paths."""
+    from oracle.c_oracle import COracle
+    o = COracle(table.n_snps, table.band, use_libm=True)
+    t0 = time.perf_counter()
+    o.fill(table)
+    t_fill = time.perf_counter() - t0
+    o.set_full_enum(1)
+    t0 = time.perf_counter()
+    r = o.spin(paths)
+    t_spin = time.perf_counter() - t0
+    return dict(value=r["n"] / t_spin, unit="haplotypes/s", cores=1, kind="port",
+                sample="C oracle, whole contig, %d spins with the reference's full pair enumeration: fill %.2fs, spins %.2fs"
+                       % (r["n"], t_fill, t_spin))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gretel_amd.hansel import Hansel, DeviceReads
+    from gretel_amd.synth import make_config
+    from gretel_amd.dist import broadcast_descriptor, gather_results
+
+    # rank 0 decides the run, everybody learns it over RCCL
+    desc = broadcast_descriptor(dict(paths=args.paths, steps=args.steps, warmup=args.warmup,
+                                     config={"C2": 2, "C3": 3, "C5": 5}[args.config]), dev, world, rank)
+    cfg_name = "C%d" % desc["config"]
+    paths = desc["paths"]
+
+    table = make_config(cfg_name, seed=rank)               # one independent window per GPU
+    h = Hansel(table.n_snps, band=table.band, device=local)
+    reads = DeviceReads(h, table.rank, table.off, table.bases)   # inputs resident in HBM before timing
+
+    def step():
+        h.clear()
+        stats = h.fill_from_support(None, None, None, reads_handle=reads)
+        res = h.spin(paths)
+        gathered = gather_results(res, table.n_snps, paths, dev, world, rank)
+        return stats, res, gathered
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        h.sync()
+
+    for _ in range(desc["warmup"]):
+        step()
+    h.profile_enable(True)
+    h.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    n_paths_local = 0
+    for _ in range(desc["steps"]):
+        stats, res, gathered = step()
+        n_paths_local += res["n"]
+    fence()
+    dt = time.perf_counter() - t0
+    prof = h.profile_get()
+    h.profile_enable(False)
+
+    tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, n_paths_total = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, n_paths_total = dt, float(n_paths_local)
+
+    if rank == 0:
+        n, L = table.n_snps, h.L
+        h.clear()
+        h.fill_from_support(None, None, None, reads_handle=reads)
+        cond_evals, rw_cells = edge_evals_per_path(h.candidate_masks(), n, L)
+        hap_s = n_paths_total / dt_max
+        walk = prof["walk"]
+        walk_ms = walk["ms"] / max(1, walk["launches"])
+        achieved = walk["bytes_per_launch"] / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+        out = {
+            "metric": "haplotypes/sec + SNP-edge-evals/sec on 10k-SNP synthetic contig",
+            "value": hap_s,
+            "unit": "haplotypes/s",
+            "n_gpus": world,
+            "steps": desc["steps"],
+            "warmup": desc["warmup"],
+            "ms_per_step": dt_max / desc["steps"] * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 counts / f64 log-likelihoods",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d-SNP / %d-read synthetic contig per GPU, k=%s SNPs/read, L=%d, %d paths per step "
+                                   "(fill + spins), seed=rank" % (cfg_name, n, table.n_reads, table.max_k, L, paths),
+                       "n_snps": n, "n_reads": table.n_reads, "L": L, "band": table.band, "paths": paths,
+                       "parallelism": "%d independent window(s), one per GPU; RCCL broadcast/gather" % world},
+            "edge_evals_per_s": hap_s * (cond_evals + rw_cells),
+            "edge_evals_per_path": {"conditionals": cond_evals, "reweight_cells": rw_cells},
+            "fill": {"n_slices": stats[0], "n_crumbs": stats[1],
+                     "crumbs_per_s": stats[1] / (prof["fill"]["ms"] / max(1, prof["fill"]["launches"]) * 1e-3) if prof["fill"]["ms"] else None},
+            "kernels_ms_per_launch": {k: (v["ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()},
+            "kernels_launches": {k: v["launches"] for k, v in prof.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_walk (path extension, serial chain over N SNPs)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "note": "latency-bound dependent chain: one wavefront, N sequential steps; see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_python(table, min(args.cpu_snps, n), n)
+            out["cpu_baseline_c"] = cpu_baseline_c(table, 3 if n >= 5000 else 10)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,1316 @@
+// gretel_hip.hip -- MI355X (gfx950 / CDNA4) kernels and the C ABI of include/gretel_hip.h.
+//
+// Data layout in HBM:
+//   band    T[(N+2)][W][7][7]      cell (i, j=i+d), d in 1..W, at ((i*W)+(d-1))*49 ; T = float | double
+//   cnt     f64[(N+2)][8]          c_s(p) = sum_t H[s,t,p,p+1]  (s<7), [7] = total
+//   marg    f64[(N+2)][8]          c_s/total
+//   logm    f64[(N+2)][8]          log10(marg)            (logm0 = snapshot of the original matrix)
+//   nvalid  i32[(N+2)]             V(p): valid symbols with c_s(p) > 0
+//   cmask   u32[(N+2)]             bit s set <=> s is a candidate at p
+//   lt      f64[(N+1)][L][7][7]    log10 conditional of (a @ snp-l) -> (b @ snp), l = 1..L
+//
+// Kernels (all integer/float lookups, HBM/L2-bound or latency-bound; no MFMA):
+//   k_fill       gretel/util.py:226-286   one thread per read, float atomics into the band
+//   k_marg       hansel get_counts_at / get_marginal_of_at for every position at once
+//   k_lt         hansel conditional (App. A-6) for every (snp, lag, from, to) at once
+//   k_walk       gretel/gretel.py:143-189 the serial chain over N SNPs (one wavefront)
+//   k_reweight   gretel/gretel.py:79-98   every band cell on the path at once
+//
+// Arithmetic contract (identical to oracle/hansel_ref.py): row/column sums accumulate
+// sequentially in the storage dtype, everything else is IEEE binary64 with NO fma
+// contraction (build with -ffp-contract=off) and gh_log10 from gh_detlog.h.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gretel_hip.h"
+#include "gh_detlog.h"
+
+#define NSYM 7
+#define CELL 49
+#define SYM_N 4
+#define SYM_US 6
+#define VALID_MASK 0x2Fu /* A C G T - : bits 0,1,2,3,5 */
+
+// ---------------------------------------------------------------------------------------------
+// error handling
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(GH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+extern "C" const char *gh_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct dev_state {
+    int stop;        // set by the walker at a hole: later launches of the spin become no-ops
+    int hole_at;
+    int n_done;
+    int _pad;
+    double ratio;    // clamped min marginal of the path just walked
+    unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
+};
+
+struct prof_slot {
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;
+    double ms = 0.0;
+    int64_t launches = 0;
+    double bytes = 0.0;
+};
+
+struct gh_handle {
+    gh_config cfg;
+    int N, W, L;
+    int dev;
+    hipStream_t stream;
+    size_t n_cells;
+    void *band;
+    double *cnt, *marg, *logm, *logm0;
+    int32_t *nvalid;
+    uint32_t *cmask;
+    double *lt;
+    int lt_L;
+    bool dirty_marg, dirty_lt, have_orig;
+    dev_state *dstate;
+    double *partial;       // reweight block partial sums
+    int partial_cap;
+    uint8_t *d_path;       // [N+1] scratch path
+    gh_path_rec *d_rec;    // 1 scratch record
+    gh_fill_stats stats;
+    bool prof;
+    prof_slot ps[GH_K_COUNT];
+};
+
+struct gh_reads {
+    int dev;
+    int64_t n_reads, n_bases;
+    int32_t *rank;
+    int64_t *off;
+    uint8_t *bases;
+    int max_k;
+};
+
+static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STORAGE_F64 ? 8 : 4; }
+
+static int set_dev(const gh_handle *h)
+{
+    HIPCHK(hipSetDevice(h->dev));
+    return GH_OK;
+}
+
+// profiling brackets --------------------------------------------------------------------------
+static void prof_begin(gh_handle *h, int k)
+{
+    if (!h->prof) return;
+    prof_slot &s = h->ps[k];
+    if (s.used + 2 > s.ev.size()) {
+        for (int q = 0; q < 2; q++) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            s.ev.push_back(e);
+        }
+    }
+    hipEventRecord(s.ev[s.used], h->stream);
+}
+
+static void prof_end(gh_handle *h, int k, double bytes)
+{
+    if (!h->prof) return;
+    prof_slot &s = h->ps[k];
+    if (s.used + 2 > s.ev.size()) return;
+    hipEventRecord(s.ev[s.used + 1], h->stream);
+    s.used += 2;
+    s.bytes = bytes;
+}
+
+static void prof_collect(gh_handle *h)
+{
+    for (int k = 0; k < GH_K_COUNT; k++) {
+        prof_slot &s = h->ps[k];
+        for (size_t q = 0; q + 1 < s.used; q += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.ev[q], s.ev[q + 1]) == hipSuccess) {
+                s.ms += ms;
+                s.launches++;
+            }
+        }
+        s.used = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__constant__ int8_t c_sym_of_char[256];
+
+template <typename T>
+__device__ __forceinline__ double rowsum(const T *cell, int a)
+{
+    T acc = (T)0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) acc = acc + cell[a * NSYM + x];
+    return (double)acc;
+}
+
+template <typename T>
+__device__ __forceinline__ double colsum(const T *cell, int b)
+{
+    T acc = (T)0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) acc = acc + cell[x * NSYM + b];
+    return (double)acc;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    // lane is wave-uniform
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fill: gretel/util.py:226-286
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void add_obs(T *band, int N, int W, int a, int b, int i, int j,
+                                        unsigned long long *oob)
+{
+    int d = j - i;
+    if (d < 1 || d > W || i < 0 || j > N + 1) {
+        atomicAdd(oob, 1ULL);
+        return;
+    }
+    atomicAdd(&band[((size_t)i * W + (d - 1)) * CELL + a * NSYM + b], (T)1);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fill(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank,
+       const int64_t *__restrict__ off, const uint8_t *__restrict__ bases, int64_t n_reads,
+       int use_end_sentinels, dev_state *st)
+{
+    __shared__ unsigned long long s_acc[3];
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+
+    unsigned long long slices = 0, crumbs = 0, covered = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o0 = off[r];
+        const int k = (int)(off[r + 1] - o0);
+        if (!(k > 1)) continue;                                  // util.py:230
+        const int rk = rank[r];
+        const uint8_t *s = bases + o0;
+        slices++;                                                // util.py:233
+        bool bad = false;
+        for (int i = 0; i < k; i++) {
+            int c = s[i];
+            if (c_sym_of_char[c] < 0) bad = true;
+            if (c != 'N' && c != '_') covered++;                 // util.py:239
+        }
+        if (bad) { atomicAdd(&st->fill[3], 1ULL); continue; }
+        for (int i = 0; i < k; i++) {
+            const int a = c_sym_of_char[s[i]];
+            if (a == SYM_US || a == SYM_N) continue;             // util.py:258
+            for (int j = i + 1; j < k; j++) {
+                const int b = c_sym_of_char[s[j]];
+                if (i == 0 && j == 1 && rk == 0) {               // util.py:262
+                    add_obs(band, N, W, SYM_US, a, 0, 1, &st->fill[4]);
+                    add_obs(band, N, W, a, b, 1, 2, &st->fill[4]);
+                } else if ((j + rk + 1) == N && (j - i) == 1) {  // util.py:271
+                    add_obs(band, N, W, a, b, N - 1, N, &st->fill[4]);
+                    add_obs(band, N, W, b, SYM_US, N, N + 1, &st->fill[4]);
+                } else {                                         // util.py:279
+                    add_obs(band, N, W, a, b, i + rk + 1, j + rk + 1, &st->fill[4]);
+                    if (use_end_sentinels && j == k - 1 && (j - i) == 1)      // util.py:283
+                        add_obs(band, N, W, b, SYM_US, j + rk + 1, j + rk + 2, &st->fill[4]);
+                }
+                crumbs++;
+            }
+        }
+    }
+    atomicAdd(&s_acc[0], slices);
+    atomicAdd(&s_acc[1], crumbs);
+    atomicAdd(&s_acc[2], covered);
+    __syncthreads();
+    if (threadIdx.x < 3 && s_acc[threadIdx.x]) atomicAdd(&st->fill[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+template <typename T>
+__global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a, const uint8_t *b,
+                            const int32_t *i, const int32_t *j, int64_t n, dev_state *st)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    if (a[q] >= NSYM || b[q] >= NSYM) { atomicAdd(&st->fill[3], 1ULL); return; }
+    add_obs(band, N, W, a[q], b[q], i[q], j[q], &st->fill[4]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_marg: counts / marginals / candidate masks for every position p in [0, N]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_marg(const T *__restrict__ band, int N, int W, double *__restrict__ cnt, double *__restrict__ marg,
+       double *__restrict__ logm, int32_t *__restrict__ nvalid, uint32_t *__restrict__ cmask)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t >> 3, s = t & 7;
+    if (p > N) return;
+    const T *cell = band + ((size_t)p * W) * CELL;       // cell (p, p+1)
+    double c[NSYM];
+    double tot = 0.0;
+    int nv = 0;
+    uint32_t cm = 0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) {
+        c[x] = rowsum(cell, x);
+        if (c[x] > 0) {
+            tot += c[x];
+            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; }
+        }
+    }
+    if (s < NSYM) {
+        double m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
+        cnt[(size_t)p * 8 + s] = c[s];
+        marg[(size_t)p * 8 + s] = m;
+        logm[(size_t)p * 8 + s] = gh_log10(m);
+    } else {
+        cnt[(size_t)p * 8 + 7] = tot;
+        marg[(size_t)p * 8 + 7] = 0.0;
+        logm[(size_t)p * 8 + 7] = 0.0;
+        nvalid[p] = nv;
+        cmask[p] = cm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lt: lt[snp][l-1][a][b] = log10( (1 + H[a,b,snp-l,snp]) / den )
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_lt(const T *__restrict__ band, int N, int W, int L, int cond_mode,
+     const double *__restrict__ cnt, const int32_t *__restrict__ nvalid, double *__restrict__ lt)
+{
+    const size_t total = (size_t)N * L * CELL;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(t % CELL);
+        const size_t r = t / CELL;
+        const int l = (int)(r % L) + 1;
+        const int snp = (int)(r / L) + 1;
+        if (l > snp) continue;
+        const int i = snp - l;
+        const int a = e / NSYM, b = e - a * NSYM;
+        double obs = 0.0, sum = 0.0;
+        if (l <= W) {
+            const T *cell = band + ((size_t)i * W + (l - 1)) * CELL;
+            obs = (double)cell[e];
+            if (cond_mode == GH_COND_A) sum = rowsum(cell, a);
+            else if (cond_mode == GH_COND_C) sum = colsum(cell, b);
+        }
+        double den;
+        if (cond_mode == GH_COND_A) den = (double)nvalid[snp] + sum;
+        else if (cond_mode == GH_COND_B) den = (double)nvalid[i] + cnt[(size_t)i * 8 + a];
+        else den = (double)nvalid[i] + sum;
+        lt[((size_t)snp * L + (l - 1)) * CELL + e] = gh_log10((1.0 + obs) / den);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_walk (v0): gretel/gretel.py:143-189, one wavefront, lanes 0..6 = candidate symbols.
+// ---------------------------------------------------------------------------------------------
+struct walk_params {
+    int N, L, marginal_term;
+    const double *lt;
+    const double *marg, *logm, *logm0;
+    const uint32_t *cmask;
+    uint8_t *path_out;        // device [N+1]
+    gh_path_rec *rec;         // device
+    dev_state *st;
+    double min_remove;
+    int hist_len;             // power of two > L
+};
+
+__global__ void __launch_bounds__(64) k_walk(walk_params P)
+{
+    extern __shared__ uint8_t lpath[];
+    dev_state *st = P.st;
+    if (st->stop) return;
+    const int lane = threadIdx.x;
+    const int hmask = P.hist_len - 1;
+    const int L = P.L;
+    double hp_cur = 0.0, hp_orig = 0.0, minm = INFINITY;
+
+    if (lane == 0) { lpath[0] = SYM_US; P.path_out[0] = SYM_US; }
+    __syncthreads();
+
+    for (int snp = 1; snp <= P.N; snp++) {
+        const uint32_t cm = P.cmask[snp];
+        if (cm == 0) {                                   // gretel.py:176-180
+            if (lane == 0) { st->stop = 1; st->hole_at = snp; }
+            return;
+        }
+        const bool isc = lane < NSYM && ((cm >> lane) & 1);
+        double acc = 0.0;
+        if (isc) {
+            if (P.marginal_term) acc += P.logm[(size_t)snp * 8 + lane];
+            const int lmax = L < snp ? L : snp;
+            const double *row = P.lt + ((size_t)snp * L) * CELL + lane;
+            for (int l0 = 1; l0 <= lmax; l0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int l = l0 + q;
+                    x[q] = 0.0;
+                    if (l <= lmax) {
+                        const int a = lpath[(snp - l) & hmask];
+                        x[q] = row[(size_t)(l - 1) * CELL + a * NSYM];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (l0 + q <= lmax) acc += x[q];     // l ascending
+            }
+        }
+        // gretel.py:166-174: first candidate is the incumbent, later ones win on strict >
+        int best = -1;
+        double bw = 0.0;
+#pragma unroll
+        for (int b = 0; b < NSYM; b++) {
+            if (!((VALID_MASK >> b) & 1)) continue;
+            if (!((cm >> b) & 1)) continue;
+            const double wq = readlane_f64(acc, b);
+            if (best < 0) { best = b; bw = wq; }
+            else if (wq > bw) { best = b; bw = wq; }
+        }
+        const int li = lane < 8 ? lane : 0;
+        const double m = readlane_f64(P.marg[(size_t)snp * 8 + li], best);        // gretel.py:182
+        const double lm = readlane_f64(P.logm[(size_t)snp * 8 + li], best);
+        const double lm0 = readlane_f64(P.logm0[(size_t)snp * 8 + li], best);
+        if (m < minm) minm = m;
+        hp_cur += lm;                                    // gretel.py:185
+        hp_orig += lm0;                                  // gretel.py:186
+        if (lane == 0) {
+            lpath[snp & hmask] = (uint8_t)best;
+            P.path_out[snp] = (uint8_t)best;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        double r = minm;
+        if (r < P.min_remove) r = P.min_remove;          // cmd.py:157-160
+        P.rec->hp_current = hp_cur;
+        P.rec->hp_original = hp_orig;
+        P.rec->ratio = minm;
+        P.rec->magnitude = 0.0;
+        st->ratio = r;
+        st->n_done += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reweight: gretel/gretel.py:79-98 restricted to the band (all other cells are zero and
+// stay zero).  Multiplicities of the reference's pair enumeration:
+//   (p,p+1), p <= N-2 : twice      (N-1,N) : once      (p,q), q-p>=2, q <= N-1 : once
+//   (p,N), p < N-1    : never      (N,N+1) with symbols (path[N], path[0]) : once
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_reweight(T *__restrict__ band, int N, int W, const uint8_t *__restrict__ path,
+           const dev_state *st, double ratio_arg, int use_state_ratio, double *__restrict__ partial)
+{
+    __shared__ double s_red[256];
+    double removed = 0.0;
+    if (!(use_state_ratio && st->stop)) {
+        const double ratio = use_state_ratio ? st->ratio : ratio_arg;
+        const size_t total = (size_t)(N + 1) * W;
+        const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < total) {
+            const int i = (int)(t / W);
+            const int d = (int)(t % W) + 1;
+            const int j = i + d;
+            int mult = 0;
+            if (j <= N - 1) mult = (d == 1) ? 2 : 1;
+            else if (j == N) mult = (d == 1) ? 1 : 0;
+            else if (j == N + 1) mult = (i == N) ? 1 : 0;
+            if (mult) {
+                const int a = path[i];
+                const int b = (j == N + 1) ? path[0] : path[j];
+                T *p = band + ((size_t)i * W + (d - 1)) * CELL + a * NSYM + b;
+                T cur = *p;
+                for (int q = 0; q < mult; q++) {
+                    const double old = (double)cur;
+                    const double nw = old - ratio * old;
+                    cur = (T)nw;
+                    removed += old - nw;
+                }
+                *p = cur;
+            }
+        }
+    }
+    // fixed-order tree so the sum is run-to-run reproducible
+    s_red[threadIdx.x] = removed;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+
+__global__ void __launch_bounds__(256)
+k_reweight_finish(const double *__restrict__ partial, int nb, const dev_state *st, int use_state,
+                  gh_path_rec *rec)
+{
+    __shared__ double s_red[256];
+    if (use_state && st->stop) return;
+    double acc = 0.0;
+    for (int q = threadIdx.x; q < nb; q += 256) acc += partial[q];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rec->magnitude = s_red[0];
+        if (use_state) rec->ratio = st->ratio;
+    }
+}
+
+// one-cell helpers ----------------------------------------------------------------------------
+template <typename T>
+__global__ void k_reweight_one(T *p, double ratio, double *removed)
+{
+    const double old = (double)*p;
+    const double nw = old - ratio * old;
+    *p = (T)nw;
+    *removed = old - nw;
+}
+
+template <typename T>
+__global__ void k_export(const T *__restrict__ band, double *__restrict__ out, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (double)band[t];
+}
+
+template <typename T>
+__global__ void k_import(T *__restrict__ band, const double *__restrict__ in, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) band[t] = (T)in[t];
+}
+
+// edge weights for an arbitrary host-supplied history (compat API; one wave)
+__global__ void k_edge_weights(int p, int L, int marginal_term, const double *lt, const double *logm,
+                               const uint32_t *cmask, const uint8_t *hist /* hist[l-1] = path[p-l] */,
+                               double *w, int *mask)
+{
+    const int lane = threadIdx.x;
+    const uint32_t cm = cmask[p];
+    if (lane == 0) *mask = (int)cm;
+    if (lane >= NSYM) return;
+    double acc = 0.0;
+    if ((cm >> lane) & 1) {
+        if (marginal_term) acc += logm[(size_t)p * 8 + lane];
+        const int lmax = L < p ? L : p;
+        for (int l = 1; l <= lmax; l++)
+            acc += lt[((size_t)p * L + (l - 1)) * CELL + hist[l - 1] * NSYM + lane];
+    }
+    w[lane] = acc;
+}
+
+__global__ void k_gap(const double *cnt, int N, int *first_gap)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > N) return;
+    if (cnt[(size_t)p * 8 + 7] == 0.0) atomicMin(first_gap, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int init_constants()
+{
+    int8_t lut[256];
+    memset(lut, -1, sizeof lut);
+    lut['A'] = 0; lut['C'] = 1; lut['G'] = 2; lut['T'] = 3; lut['N'] = 4; lut['-'] = 5; lut['_'] = 6;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_sym_of_char), lut, sizeof lut));
+    return GH_OK;
+}
+
+extern "C" int gh_device_count(int *n)
+{
+    if (!n) return fail(GH_ERR_ARG, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return GH_OK;
+}
+
+static void free_handle(gh_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->dev);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->logm); hipFree(h->logm0);
+    hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->dstate); hipFree(h->partial);
+    hipFree(h->d_path); hipFree(h->d_rec);
+    for (int k = 0; k < GH_K_COUNT; k++)
+        for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int gh_create(const gh_config *cfg, gh_t **out)
+{
+    if (!cfg || !out) return fail(GH_ERR_ARG, "null argument");
+    if (cfg->n_snps < 1) return fail(GH_ERR_ARG, "n_snps must be >= 1 (got %d)", cfg->n_snps);
+    if (cfg->band < 1) return fail(GH_ERR_ARG, "band must be >= 1 (got %d)", cfg->band);
+    if (cfg->storage != GH_STORAGE_F32 && cfg->storage != GH_STORAGE_F64)
+        return fail(GH_ERR_ARG, "bad storage %d", cfg->storage);
+    if (cfg->cond_mode < 0 || cfg->cond_mode > 2) return fail(GH_ERR_ARG, "bad cond_mode %d", cfg->cond_mode);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) return fail(GH_ERR_HIP, "no HIP device visible");
+    int dev = cfg->device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(GH_ERR_ARG, "device %d out of range (%d devices)", dev, ndev);
+    HIPCHK(hipSetDevice(dev));
+    int rc = init_constants();
+    if (rc) return rc;
+
+    gh_handle *h = new (std::nothrow) gh_handle();
+    if (!h) return fail(GH_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->cfg.device = dev;
+    h->dev = dev;
+    h->N = cfg->n_snps;
+    h->W = cfg->band;
+    h->L = 1;
+    h->n_cells = (size_t)(h->N + 2) * h->W;
+    h->lt = nullptr; h->lt_L = 0;
+    h->dirty_marg = h->dirty_lt = true;
+    h->have_orig = false;
+    h->prof = false;
+    h->partial = nullptr; h->partial_cap = 0;
+    memset(&h->stats, 0, sizeof h->stats);
+    h->stats.L = 1;
+    const size_t np = (size_t)h->N + 2;
+#define ALLOC(ptr, bytes)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));                                  \
+        if (e_ != hipSuccess) {                                                               \
+            free_handle(h);                                                                   \
+            return fail(GH_ERR_NOMEM, "hipMalloc(%zu) failed: %s", (size_t)(bytes),           \
+                        hipGetErrorString(e_));                                               \
+        }                                                                                     \
+    } while (0)
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        free_handle(h);
+        return fail(GH_ERR_HIP, "hipStreamCreate failed");
+    }
+    ALLOC(h->band, h->n_cells * CELL * esize(h));
+    ALLOC(h->cnt, np * 8 * sizeof(double));
+    ALLOC(h->marg, np * 8 * sizeof(double));
+    ALLOC(h->logm, np * 8 * sizeof(double));
+    ALLOC(h->logm0, np * 8 * sizeof(double));
+    ALLOC(h->nvalid, np * sizeof(int32_t));
+    ALLOC(h->cmask, np * sizeof(uint32_t));
+    ALLOC(h->dstate, sizeof(dev_state));
+    ALLOC(h->d_path, np);
+    ALLOC(h->d_rec, sizeof(gh_path_rec));
+#undef ALLOC
+    hipMemsetAsync(h->band, 0, h->n_cells * CELL * esize(h), h->stream);
+    hipMemsetAsync(h->dstate, 0, sizeof(dev_state), h->stream);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = h;
+    return GH_OK;
+}
+
+extern "C" int gh_destroy(gh_t *h)
+{
+    free_handle(h);
+    return GH_OK;
+}
+
+extern "C" int gh_sync(gh_t *h)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    if (set_dev(h)) return GH_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_clear(gh_t *h)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    if (set_dev(h)) return GH_ERR_HIP;
+    HIPCHK(hipMemsetAsync(h->band, 0, h->n_cells * CELL * esize(h), h->stream));
+    HIPCHK(hipMemsetAsync(h->dstate, 0, sizeof(dev_state), h->stream));
+    memset(&h->stats, 0, sizeof h->stats);
+    h->stats.L = 1;
+    h->L = 1;
+    h->dirty_marg = h->dirty_lt = true;
+    h->have_orig = false;
+    return GH_OK;
+}
+
+extern "C" int gh_copy(const gh_t *src, gh_t **out)
+{
+    if (!src || !out) return fail(GH_ERR_ARG, "null argument");
+    gh_t *h = nullptr;
+    int rc = gh_create(&src->cfg, &h);
+    if (rc) return rc;
+    hipStreamSynchronize(src->stream);
+    hipError_t e = hipMemcpy(h->band, src->band, src->n_cells * CELL * esize(src), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { free_handle(h); return fail(GH_ERR_HIP, "copy failed: %s", hipGetErrorString(e)); }
+    h->L = src->L;
+    h->stats = src->stats;
+    *out = h;
+    return GH_OK;
+}
+
+extern "C" int gh_set_L(gh_t *h, int32_t L)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    if (L < 1) return fail(GH_ERR_ARG, "L must be >= 1 (got %d)", L);
+    if (L > 32767) return fail(GH_ERR_ARG, "L > 32767 unsupported (got %d)", L);
+    if (L != h->L) h->dirty_lt = true;
+    h->L = L;
+    h->stats.L = L;
+    return GH_OK;
+}
+
+extern "C" int gh_get_L(const gh_t *h, int32_t *L)
+{
+    if (!h || !L) return fail(GH_ERR_ARG, "null argument");
+    *L = h->L;
+    return GH_OK;
+}
+
+extern "C" int gh_get_fill_stats(const gh_t *h, gh_fill_stats *out)
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    *out = h->stats;
+    out->L = h->L;
+    return GH_OK;
+}
+
+extern "C" int gh_set_fill_stats(gh_t *h, const gh_fill_stats *in)
+{
+    if (!h || !in) return fail(GH_ERR_ARG, "null argument");
+    h->stats.n_slices = in->n_slices;
+    h->stats.n_crumbs = in->n_crumbs;
+    h->stats.covered_snps = in->covered_snps;
+    return GH_OK;
+}
+
+// reads ---------------------------------------------------------------------------------------
+extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t *off,
+                               const uint8_t *bases, int64_t n_reads, gh_reads_t **out)
+{
+    if (!h || !out || n_reads < 0 || (n_reads > 0 && (!rank || !off))) return fail(GH_ERR_ARG, "bad argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    gh_reads *r = new (std::nothrow) gh_reads();
+    if (!r) return fail(GH_ERR_NOMEM, "host allocation failed");
+    r->dev = h->dev;
+    r->n_reads = n_reads;
+    r->n_bases = n_reads ? off[n_reads] : 0;
+    r->rank = nullptr; r->off = nullptr; r->bases = nullptr;
+    r->max_k = 0;
+    for (int64_t q = 0; q < n_reads; q++) {
+        int64_t k = off[q + 1] - off[q];
+        if (k < 0) { delete r; return fail(GH_ERR_ARG, "off[] not monotone at read %lld", (long long)q); }
+        if (k > r->max_k) r->max_k = (int)k;
+    }
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void **)&r->rank, (size_t)(n_reads ? n_reads : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->off, (size_t)(n_reads + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&r->bases, (size_t)(r->n_bases ? r->n_bases : 1));
+    if (e == hipSuccess && n_reads) e = hipMemcpy(r->rank, rank, (size_t)n_reads * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_reads) e = hipMemcpy(r->off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && r->n_bases) e = hipMemcpy(r->bases, bases, (size_t)r->n_bases, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(r->rank); hipFree(r->off); hipFree(r->bases);
+        delete r;
+        return fail(GH_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+    }
+    *out = r;
+    return GH_OK;
+}
+
+extern "C" int gh_reads_free(gh_reads_t *r)
+{
+    if (!r) return GH_OK;
+    hipSetDevice(r->dev);
+    hipFree(r->rank); hipFree(r->off); hipFree(r->bases);
+    delete r;
+    return GH_OK;
+}
+
+static int pull_fill_state(gh_handle *h, unsigned long long before[6], const char *what)
+{
+    dev_state hs;
+    HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stats.n_slices += (int64_t)(hs.fill[0] - before[0]);
+    h->stats.n_crumbs += (int64_t)(hs.fill[1] - before[1]);
+    h->stats.covered_snps += (int64_t)(hs.fill[2] - before[2]);
+    if (hs.fill[3] != before[3])
+        return fail(GH_ERR_SYMBOL, "%s: %llu item(s) carry a symbol outside \"ACGTN-_\"", what,
+                    hs.fill[3] - before[3]);
+    if (hs.fill[4] != before[4])
+        return fail(GH_ERR_BAND, "%s: %llu observation(s) outside band %d / positions [0,%d]", what,
+                    hs.fill[4] - before[4], h->W, h->N + 1);
+    return GH_OK;
+}
+
+extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_fill_stats *out)
+{
+    if (!h || !r) return fail(GH_ERR_ARG, "null argument");
+    if (r->dev != h->dev) return fail(GH_ERR_ARG, "reads live on device %d, handle on %d", r->dev, h->dev);
+    if (set_dev(h)) return GH_ERR_HIP;
+    dev_state before;
+    HIPCHK(hipMemcpyAsync(&before, h->dstate, sizeof before, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (r->n_reads > 0) {
+        const int block = 256;
+        int64_t nb = (r->n_reads + block - 1) / block;
+        if (nb > 256 * 32) nb = 256 * 32;
+        const double bytes = 8.0 * 0 + (double)r->n_reads * 12.0 + (double)r->n_bases;   // + 8*adds, added below
+        prof_begin(h, GH_K_FILL);
+        if (h->cfg.storage == GH_STORAGE_F64)
+            hipLaunchKernelGGL(k_fill<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (double *)h->band,
+                               h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);
+        else
+            hipLaunchKernelGGL(k_fill<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (float *)h->band,
+                               h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);
+        prof_end(h, GH_K_FILL, bytes);
+        HIPCHK(hipGetLastError());
+    }
+    h->dirty_marg = h->dirty_lt = true;
+    int rc = pull_fill_state(h, before.fill, "gh_fill");
+    if (h->stats.n_slices > 0) {                                   // util.py:333
+        int L = (int)std::ceil((double)h->stats.covered_snps / (double)h->stats.n_slices);
+        if (L < 1) L = 1;
+        h->L = L;
+        h->stats.L = L;
+    }
+    if (h->prof) {
+        // algorithmic bytes: one 4/8-byte read-modify-write per add_observation + the table itself
+        h->ps[GH_K_FILL].bytes = 2.0 * esize(h) * (double)h->stats.n_crumbs * 1.0 + (double)r->n_reads * 12.0 + (double)r->n_bases;
+    }
+    if (out) { *out = h->stats; out->L = h->L; }
+    return rc;
+}
+
+// one-cell API --------------------------------------------------------------------------------
+static int cell_index(const gh_handle *h, int a, int b, int i, int j, size_t *idx)
+{
+    if (a < 0 || a >= NSYM || b < 0 || b >= NSYM) return fail(GH_ERR_SYMBOL, "symbol index out of range (%d,%d)", a, b);
+    int d = j - i;
+    if (i < 0 || j > h->N + 1 || d < 1 || d > h->W) return 1;    // outside the band: a zero cell
+    *idx = ((size_t)i * h->W + (d - 1)) * CELL + a * NSYM + b;
+    return 0;
+}
+
+extern "C" int gh_get(gh_t *h, int a, int b, int i, int j, double *out)
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    size_t idx;
+    int rc = cell_index(h, a, b, i, j, &idx);
+    if (rc < 0) return rc;
+    if (rc == 1) { *out = 0.0; return GH_OK; }
+    if (h->cfg.storage == GH_STORAGE_F64) {
+        HIPCHK(hipMemcpyAsync(out, (double *)h->band + idx, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+        float f;
+        HIPCHK(hipMemcpyAsync(&f, (float *)h->band + idx, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *out = (double)f;
+    }
+    return GH_OK;
+}
+
+extern "C" int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const int32_t *i, const int32_t *j, int64_t n)
+{
+    if (!h || n < 0 || (n > 0 && (!a || !b || !i || !j))) return fail(GH_ERR_ARG, "bad argument");
+    if (n == 0) return GH_OK;
+    if (set_dev(h)) return GH_ERR_HIP;
+    uint8_t *da = nullptr, *db = nullptr;
+    int32_t *di = nullptr, *dj = nullptr;
+    hipError_t e = hipMalloc((void **)&da, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&db, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&di, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&dj, n * 4);
+    if (e == hipSuccess) e = hipMemcpy(da, a, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, b, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(di, i, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dj, j, n * 4, hipMemcpyHostToDevice);
+    int rc = GH_OK;
+    if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_add_batch staging failed: %s", hipGetErrorString(e));
+    if (rc == GH_OK) {
+        dev_state before;
+        hipMemcpyAsync(&before, h->dstate, sizeof before, hipMemcpyDeviceToHost, h->stream);
+        hipStreamSynchronize(h->stream);
+        const int block = 256;
+        const unsigned nb = (unsigned)((n + block - 1) / block);
+        if (h->cfg.storage == GH_STORAGE_F64)
+            hipLaunchKernelGGL(k_add_batch<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
+        else
+            hipLaunchKernelGGL(k_add_batch<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
+        h->dirty_marg = h->dirty_lt = true;
+        int64_t s0 = h->stats.n_slices, c0 = h->stats.n_crumbs, v0 = h->stats.covered_snps;
+        rc = pull_fill_state(h, before.fill, "gh_add_batch");
+        h->stats.n_slices = s0; h->stats.n_crumbs = c0; h->stats.covered_snps = v0;
+    }
+    hipFree(da); hipFree(db); hipFree(di); hipFree(dj);
+    return rc;
+}
+
+extern "C" int gh_add(gh_t *h, int a, int b, int i, int j)
+{
+    if (a < 0 || a >= NSYM || b < 0 || b >= NSYM) return fail(GH_ERR_SYMBOL, "symbol index out of range (%d,%d)", a, b);
+    uint8_t ua = (uint8_t)a, ub = (uint8_t)b;
+    int32_t ii = i, jj = j;
+    return gh_add_batch(h, &ua, &ub, &ii, &jj, 1);
+}
+
+extern "C" int gh_reweight_obs(gh_t *h, int a, int b, int i, int j, double ratio, double *removed)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    if (set_dev(h)) return GH_ERR_HIP;
+    size_t idx;
+    int rc = cell_index(h, a, b, i, j, &idx);
+    if (rc < 0) return rc;
+    double rem = 0.0;
+    if (rc == 0) {
+        double *d_rem = &h->d_rec->magnitude;
+        if (h->cfg.storage == GH_STORAGE_F64)
+            hipLaunchKernelGGL(k_reweight_one<double>, dim3(1), dim3(1), 0, h->stream, (double *)h->band + idx, ratio, d_rem);
+        else
+            hipLaunchKernelGGL(k_reweight_one<float>, dim3(1), dim3(1), 0, h->stream, (float *)h->band + idx, ratio, d_rem);
+        HIPCHK(hipMemcpyAsync(&rem, d_rem, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->dirty_marg = h->dirty_lt = true;
+    }
+    if (removed) *removed = rem;
+    return GH_OK;
+}
+
+// tables --------------------------------------------------------------------------------------
+static int ensure_marg(gh_handle *h)
+{
+    if (!h->dirty_marg) return GH_OK;
+    const int threads = (h->N + 1) * 8;
+    const int block = 256;
+    prof_begin(h, GH_K_MARG);
+    if (h->cfg.storage == GH_STORAGE_F64)
+        hipLaunchKernelGGL(k_marg<double>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
+                           (const double *)h->band, h->N, h->W, h->cnt, h->marg, h->logm, h->nvalid, h->cmask);
+    else
+        hipLaunchKernelGGL(k_marg<float>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
+                           (const float *)h->band, h->N, h->W, h->cnt, h->marg, h->logm, h->nvalid, h->cmask);
+    prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 3 * 64 + 8));
+    HIPCHK(hipGetLastError());
+    h->dirty_marg = false;
+    return GH_OK;
+}
+
+static int ensure_lt(gh_handle *h)
+{
+    int rc = ensure_marg(h);
+    if (rc) return rc;
+    if (!h->dirty_lt && h->lt && h->lt_L == h->L) return GH_OK;
+    if (!h->lt || h->lt_L != h->L) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->lt) hipFree(h->lt);
+        h->lt = nullptr;
+        size_t bytes = (size_t)(h->N + 1) * h->L * CELL * sizeof(double);
+        hipError_t e = hipMalloc((void **)&h->lt, bytes);
+        if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
+        h->lt_L = h->L;
+    }
+    const size_t total = (size_t)h->N * h->L * CELL;
+    const int block = 256;
+    size_t nb = (total + block - 1) / block;
+    if (nb > 256 * 16) nb = 256 * 16;
+    prof_begin(h, GH_K_LT);
+    if (h->cfg.storage == GH_STORAGE_F64)
+        hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
+                           h->N, h->W, h->L, h->cfg.cond_mode, h->cnt, h->nvalid, h->lt);
+    else
+        hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
+                           h->N, h->W, h->L, h->cfg.cond_mode, h->cnt, h->nvalid, h->lt);
+    const int wl = h->W < h->L ? h->W : h->L;
+    prof_end(h, GH_K_LT, (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * CELL * 8.0));
+    HIPCHK(hipGetLastError());
+    h->dirty_lt = false;
+    return GH_OK;
+}
+
+extern "C" int gh_counts_at(gh_t *h, int p, double out[8])
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    if (p < 0 || p > h->N) return fail(GH_ERR_ARG, "position %d outside [0,%d]", p, h->N);
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_marg(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, h->cnt + (size_t)p * 8, 64, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_marginal_of_at(gh_t *h, int s, int p, double *out)
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    if (s < 0 || s >= NSYM) return fail(GH_ERR_SYMBOL, "symbol index %d out of range", s);
+    if (p < 0 || p > h->N) return fail(GH_ERR_ARG, "position %d outside [0,%d]", p, h->N);
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_marg(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, h->marg + (size_t)p * 8 + s, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_edge_weights_at(gh_t *h, int p, const uint8_t *path, double w[GH_NSYM], int *cand_mask)
+{
+    if (!h || !path || !w || !cand_mask) return fail(GH_ERR_ARG, "null argument");
+    if (p < 1 || p > h->N) return fail(GH_ERR_ARG, "position %d outside [1,%d]", p, h->N);
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_lt(h);
+    if (rc) return rc;
+    const int lmax = h->L < p ? h->L : p;
+    std::vector<uint8_t> hist(lmax);
+    for (int l = 1; l <= lmax; l++) {
+        if (path[p - l] >= NSYM) return fail(GH_ERR_SYMBOL, "path[%d] = %d is not a symbol index", p - l, path[p - l]);
+        hist[l - 1] = path[p - l];
+    }
+    uint8_t *d_hist = nullptr;
+    double *d_w = nullptr;
+    HIPCHK(hipMalloc((void **)&d_hist, lmax));
+    hipError_t e = hipMalloc((void **)&d_w, 8 * sizeof(double));
+    if (e != hipSuccess) { hipFree(d_hist); return fail(GH_ERR_NOMEM, "hipMalloc failed"); }
+    hipMemcpyAsync(d_hist, hist.data(), lmax, hipMemcpyHostToDevice, h->stream);
+    hipLaunchKernelGGL(k_edge_weights, dim3(1), dim3(64), 0, h->stream, p, h->L, h->cfg.marginal_term, h->lt,
+                       h->logm, h->cmask, d_hist, d_w, (int *)(d_w + 7));
+    double hw[8];
+    e = hipMemcpyAsync(hw, d_w, sizeof hw, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_hist); hipFree(d_w);
+    if (e != hipSuccess) return fail(GH_ERR_HIP, "gh_edge_weights_at failed: %s", hipGetErrorString(e));
+    memcpy(w, hw, 7 * sizeof(double));
+    memcpy(cand_mask, &hw[7], sizeof(int));
+    return GH_OK;
+}
+
+extern "C" int gh_gap_check(gh_t *h, int *first_gap)
+{
+    if (!h || !first_gap) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_marg(h);
+    if (rc) return rc;
+    int *d_gap = &h->dstate->_pad;
+    int big = 0x7fffffff;
+    HIPCHK(hipMemcpyAsync(d_gap, &big, 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_gap, dim3((h->N + 1 + 255) / 256), dim3(256), 0, h->stream, h->cnt, h->N, d_gap);
+    int g;
+    HIPCHK(hipMemcpyAsync(&g, d_gap, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *first_gap = (g == big) ? -1 : g;
+    return GH_OK;
+}
+
+extern "C" int gh_export_cmask(gh_t *h, uint32_t *out)
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_marg(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, h->cmask, (size_t)(h->N + 1) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_snapshot_original(gh_t *h)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_marg(h);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->logm0, h->logm, (size_t)(h->N + 2) * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->have_orig = true;
+    return GH_OK;
+}
+
+// path extension / reweight -------------------------------------------------------------------
+static int hist_len_for(int L)
+{
+    int hl = 16;
+    while (hl <= L) hl <<= 1;
+    return hl;
+}
+
+static int launch_walk(gh_handle *h, const double *logm0, uint8_t *d_path, gh_path_rec *d_rec, double min_remove)
+{
+    walk_params P;
+    P.N = h->N; P.L = h->L; P.marginal_term = h->cfg.marginal_term;
+    P.lt = h->lt; P.marg = h->marg; P.logm = h->logm; P.logm0 = logm0; P.cmask = h->cmask;
+    P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
+    P.hist_len = hist_len_for(h->L);
+    prof_begin(h, GH_K_WALK);
+    hipLaunchKernelGGL(k_walk, dim3(1), dim3(64), (size_t)P.hist_len, h->stream, P);
+    // algorithmic bytes: per step the marginal cell's tables + L table rows of 7 doubles
+    prof_end(h, GH_K_WALK, (double)h->N * ((double)h->L * 56.0 + 3 * 56.0 + 4.0 + 1.0));
+    HIPCHK(hipGetLastError());
+    return GH_OK;
+}
+
+static int launch_reweight(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec)
+{
+    const size_t total = (size_t)(h->N + 1) * h->W;
+    const int block = 256;
+    const int nb = (int)((total + block - 1) / block);
+    if (nb > h->partial_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->partial) hipFree(h->partial);
+        h->partial = nullptr;
+        HIPCHK(hipMalloc((void **)&h->partial, (size_t)nb * sizeof(double)));
+        h->partial_cap = nb;
+    }
+    prof_begin(h, GH_K_REWEIGHT);
+    if (h->cfg.storage == GH_STORAGE_F64)
+        hipLaunchKernelGGL(k_reweight<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
+                           d_path, h->dstate, ratio, use_state, h->partial);
+    else
+        hipLaunchKernelGGL(k_reweight<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
+                           d_path, h->dstate, ratio, use_state, h->partial);
+    hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec);
+    prof_end(h, GH_K_REWEIGHT, (double)total * 2.0 * esize(h) + (double)(h->N + 1));
+    HIPCHK(hipGetLastError());
+    h->dirty_marg = h->dirty_lt = true;
+    return GH_OK;
+}
+
+static int reset_spin_state(gh_handle *h)
+{
+    int zeros[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h->dstate, zeros, sizeof zeros, hipMemcpyHostToDevice, h->stream));
+    return GH_OK;
+}
+
+extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out, double *hp_current,
+                                double *hp_original, double *min_marginal, int *hole_at)
+{
+    if (!h || !path_out || !hole_at) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    int rc = ensure_lt(h);
+    if (rc) return rc;
+    const double *logm0 = h->have_orig ? h->logm0 : h->logm;
+    if (original && original != h) {
+        gh_handle *o = const_cast<gh_handle *>(original);
+        if (o->N != h->N) return fail(GH_ERR_ARG, "original has %d SNPs, hansel has %d", o->N, h->N);
+        if (o->dev != h->dev) return fail(GH_ERR_ARG, "original lives on another device");
+        if ((rc = ensure_marg(o))) return rc;
+        HIPCHK(hipStreamSynchronize(o->stream));
+        logm0 = o->logm;
+    }
+    if ((rc = reset_spin_state(h))) return rc;
+    if ((rc = launch_walk(h, logm0, h->d_path, h->d_rec, 0.0))) return rc;
+    dev_state hs;
+    gh_path_rec rec;
+    HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(&rec, h->d_rec, sizeof rec, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(path_out, h->d_path, (size_t)h->N + 1, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *hole_at = hs.stop ? hs.hole_at : 0;
+    if (!hs.stop) {
+        if (hp_current) *hp_current = rec.hp_current;
+        if (hp_original) *hp_original = rec.hp_original;
+        if (min_marginal) *min_marginal = rec.ratio;
+    }
+    return GH_OK;
+}
+
+extern "C" int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, double *removed)
+{
+    if (!h || !path) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    for (int q = 0; q <= h->N; q++)
+        if (path[q] >= NSYM) return fail(GH_ERR_SYMBOL, "path[%d] = %d is not a symbol index", q, path[q]);
+    HIPCHK(hipMemcpyAsync(h->d_path, path, (size_t)h->N + 1, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_reweight(h, h->d_path, ratio, 0, h->d_rec);
+    if (rc) return rc;
+    gh_path_rec rec;
+    HIPCHK(hipMemcpyAsync(&rec, h->d_rec, sizeof rec, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (removed) *removed = rec.magnitude;
+    return GH_OK;
+}
+
+extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
+                       int *n_out, int *hole_at)
+{
+    if (!h || !paths_out || !recs || !n_out || !hole_at) return fail(GH_ERR_ARG, "null argument");
+    if (max_paths < 0) return fail(GH_ERR_ARG, "max_paths < 0");
+    if (set_dev(h)) return GH_ERR_HIP;
+    *n_out = 0; *hole_at = 0;
+    if (max_paths == 0) return GH_OK;
+    int rc;
+    if (!h->have_orig && (rc = gh_snapshot_original(h))) return rc;
+    const size_t n1 = (size_t)h->N + 1;
+    uint8_t *d_paths = nullptr;
+    gh_path_rec *d_recs = nullptr;
+    HIPCHK(hipMalloc((void **)&d_paths, n1 * max_paths));
+    hipError_t e = hipMalloc((void **)&d_recs, sizeof(gh_path_rec) * max_paths);
+    if (e != hipSuccess) { hipFree(d_paths); return fail(GH_ERR_NOMEM, "hipMalloc failed"); }
+    rc = reset_spin_state(h);
+    for (int s = 0; s < max_paths && rc == GH_OK; s++) {
+        if ((rc = ensure_lt(h))) break;
+        if ((rc = launch_walk(h, h->logm0, d_paths + n1 * s, d_recs + s, min_remove))) break;
+        if ((rc = launch_reweight(h, d_paths + n1 * s, 0.0, 1, d_recs + s))) break;
+    }
+    dev_state hs;
+    memset(&hs, 0, sizeof hs);
+    if (rc == GH_OK) {
+        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess && hs.n_done > 0) {
+            e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+    }
+    hipFree(d_paths); hipFree(d_recs);
+    if (rc) return rc;
+    *n_out = hs.n_done;
+    *hole_at = hs.stop ? hs.hole_at : 0;
+    return GH_OK;
+}
+
+// export / import -----------------------------------------------------------------------------
+extern "C" int gh_export_band(gh_t *h, double *out)
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    const size_t n = h->n_cells * CELL;
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, n * sizeof(double)));
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (h->cfg.storage == GH_STORAGE_F64)
+        hipLaunchKernelGGL(k_export<double>, dim3(nb), dim3(256), 0, h->stream, (const double *)h->band, d, n);
+    else
+        hipLaunchKernelGGL(k_export<float>, dim3(nb), dim3(256), 0, h->stream, (const float *)h->band, d, n);
+    hipError_t e = hipMemcpyAsync(out, d, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(GH_ERR_HIP, "export failed: %s", hipGetErrorString(e));
+    return GH_OK;
+}
+
+extern "C" int gh_import_band(gh_t *h, const double *in)
+{
+    if (!h || !in) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    const size_t n = h->n_cells * CELL;
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, n * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, in, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    if (h->cfg.storage == GH_STORAGE_F64)
+        hipLaunchKernelGGL(k_import<double>, dim3(nb), dim3(256), 0, h->stream, (double *)h->band, d, n);
+    else
+        hipLaunchKernelGGL(k_import<float>, dim3(nb), dim3(256), 0, h->stream, (float *)h->band, d, n);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    h->dirty_marg = h->dirty_lt = true;
+    if (e != hipSuccess) return fail(GH_ERR_HIP, "import failed: %s", hipGetErrorString(e));
+    return GH_OK;
+}
+
+extern "C" int gh_export_dense(gh_t *h, double *out)
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    const size_t np = (size_t)h->N + 2;
+    std::vector<double> band(h->n_cells * CELL);
+    int rc = gh_export_band(h, band.data());
+    if (rc) return rc;
+    memset(out, 0, sizeof(double) * NSYM * NSYM * np * np);
+    for (size_t i = 0; i < np; i++)
+        for (int d = 1; d <= h->W; d++) {
+            size_t j = i + d;
+            if (j >= np) break;
+            const double *cell = band.data() + (i * h->W + (d - 1)) * CELL;
+            for (int a = 0; a < NSYM; a++)
+                for (int b = 0; b < NSYM; b++)
+                    out[(((size_t)a * NSYM + b) * np + i) * np + j] = cell[a * NSYM + b];
+        }
+    return GH_OK;
+}
+
+// profiling -----------------------------------------------------------------------------------
+extern "C" int gh_profile_enable(gh_t *h, int on)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    h->prof = on != 0;
+    return GH_OK;
+}
+
+extern "C" int gh_profile_reset(gh_t *h)
+{
+    if (!h) return fail(GH_ERR_ARG, "null handle");
+    if (set_dev(h)) return GH_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < GH_K_COUNT; k++) {
+        h->ps[k].used = 0; h->ps[k].ms = 0.0; h->ps[k].launches = 0;
+    }
+    return GH_OK;
+}
+
+extern "C" int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches)
+{
+    if (!h || kernel < 0 || kernel >= GH_K_COUNT) return fail(GH_ERR_ARG, "bad argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    if (total_ms) *total_ms = h->ps[kernel].ms;
+    if (launches) *launches = h->ps[kernel].launches;
+    return GH_OK;
+}
+
+extern "C" int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch)
+{
+    if (!h || !bytes_per_launch || kernel < 0 || kernel >= GH_K_COUNT) return fail(GH_ERR_ARG, "bad argument");
+    *bytes_per_launch = h->ps[kernel].bytes;
+    return GH_OK;
+}

@@ -1,0 +1,395 @@
+"""
+Device-backed `Hansel`: the drop-in for `hansel.Hansel` (hanselx==0.0.92, reference
+setup.py:8) as Gretel consumes it.  The tensor lives in HBM behind libgretel_hip.so;
+this class only marshals arguments (ctypes) and re-exposes the reference's names:
+
+    Hansel.init_matrix(symbols, unsymbols, n)      gretel/util.py:83
+    add_observation / get_observation              gretel/util.py:266-286, tests/test_test.py:41-52
+    reweight_observation                           gretel/gretel.py:84,96
+    get_counts_at / get_marginal_of_at             gretel/cmd.py:86,127, gretel/gretel.py:182,186
+    get_edge_weights_at                            gretel/gretel.py:155
+    copy / save_hansel_dump                        gretel/cmd.py:79,82
+    symbols_d, L, n_slices, n_crumbs               gretel/gretel.py:138, gretel/util.py:329-333
+
+plus the fused fast paths used by gretel_amd.gretel / gretel_amd.util
+(`fill_from_support`, `generate_path`, `reweight_from_path`, `spin`).
+
+There is no CPU implementation here: without libgretel_hip.so or without a GPU
+every operation raises (gretel_amd._lib).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+SYMBOLS = ['A', 'C', 'G', 'T', 'N', '-', '_']
+UNSYMBOLS = ['N', '_']
+_SYM_LUT = np.frombuffer("".join(SYMBOLS).encode(), dtype=np.uint8)
+
+
+class HanselSymbol(str):
+    """Prints as its character (gretel/cmd.py:128,164,211), equal to itself
+    (gretel/cmd.py:201), hashable (dict key of get_counts_at)."""
+    __slots__ = ("i",)
+
+    def __new__(cls, char, i):
+        o = str.__new__(cls, char)
+        o.i = i
+        return o
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Hansel:
+    def __init__(self, n_snps, band=None, storage="f32", cond_mode="A", marginal_term=False, device=-1):
+        self._lib = _lib.load()
+        self.n = int(n_snps)
+        self._cfg = dict(storage=storage, cond_mode=cond_mode, marginal_term=bool(marginal_term), device=device)
+        self.symbols = [HanselSymbol(c, i) for i, c in enumerate(SYMBOLS)]
+        self.unsymbols = list(UNSYMBOLS)
+        self.symbols_d = {str(s): s for s in self.symbols}
+        self.is_weighted = False
+        self._h = None
+        self._band = None
+        self._L = 1
+        # observations staged on the host until the band width is known (init_matrix gives no hint)
+        self._staged = []
+        if band is not None:
+            self._create(int(band))
+
+    # -- construction ----------------------------------------------------------------------
+    @staticmethod
+    def init_matrix(symbols, unsymbols, n_snps, band=None, **kw):
+        """gretel/util.py:83.  The reference's fixed alphabet is the only one supported."""
+        if list(symbols) != SYMBOLS or list(unsymbols) != UNSYMBOLS:
+            raise ValueError("gretel_amd.Hansel supports the alphabet %r / unsymbols %r only" % (SYMBOLS, UNSYMBOLS))
+        return Hansel(n_snps, band=band, **kw)
+
+    def _create(self, band):
+        cfg = _lib.gh_config(self.n, max(1, band), _lib.GH_STORAGE[self._cfg["storage"]],
+                             _lib.GH_COND[self._cfg["cond_mode"]], int(self._cfg["marginal_term"]),
+                             self._cfg["device"])
+        h = C.c_void_p()
+        check(self._lib.gh_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._band = max(1, band)
+        check(self._lib.gh_set_L(self._h, self._L))
+
+    def _destroy(self):
+        if getattr(self, "_h", None):
+            self._lib.gh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def _ensure(self, need_band=1):
+        """Make the device tensor exist with band >= need_band and no staged observations."""
+        if self._staged:
+            need_band = max(need_band, max(j - i for (_, _, i, j) in self._staged))
+        if self._h is None:
+            self._create(need_band)
+        elif need_band > self._band:
+            self._reband(need_band)
+        if self._staged:
+            st = self._staged
+            self._staged = []
+            a = np.array([s[0] for s in st], dtype=np.uint8)
+            b = np.array([s[1] for s in st], dtype=np.uint8)
+            i = np.array([s[2] for s in st], dtype=np.int32)
+            j = np.array([s[3] for s in st], dtype=np.int32)
+            check(self._lib.gh_add_batch(self._h, _p(a), _p(b), _p(i), _p(j), len(st)))
+
+    def _reband(self, band):
+        old = self.export_band()
+        stats = self._get_stats()
+        self._destroy()
+        self._create(band)
+        new = np.zeros((self.n + 2, band, 7, 7))
+        new[:, :old.shape[1]] = old
+        check(self._lib.gh_import_band(self._h, _p(new)))
+        check(self._lib.gh_set_fill_stats(self._h, C.byref(stats)))
+
+    def copy(self):
+        """gretel/cmd.py:79"""
+        self._ensure()
+        o = Hansel(self.n, **self._cfg)
+        h = C.c_void_p()
+        check(self._lib.gh_copy(self._h, C.byref(h)))
+        o._h, o._band, o._L = h, self._band, self._L
+        o.is_weighted = self.is_weighted
+        return o
+
+    # -- attributes ------------------------------------------------------------------------
+    def _get_stats(self):
+        st = _lib.gh_fill_stats()
+        check(self._lib.gh_get_fill_stats(self._h, C.byref(st)))
+        return st
+
+    @property
+    def L(self):
+        return self._L
+
+    @L.setter
+    def L(self, v):
+        self._L = int(v)
+        if self._h is not None:
+            check(self._lib.gh_set_L(self._h, self._L))
+
+    @property
+    def n_slices(self):
+        return int(self._get_stats().n_slices) if self._h is not None else getattr(self, "_n_slices", 0)
+
+    @n_slices.setter
+    def n_slices(self, v):
+        self._ensure()
+        st = self._get_stats()
+        st.n_slices = int(v)
+        check(self._lib.gh_set_fill_stats(self._h, C.byref(st)))
+
+    @property
+    def n_crumbs(self):
+        return int(self._get_stats().n_crumbs) if self._h is not None else len(self._staged)
+
+    @n_crumbs.setter
+    def n_crumbs(self, v):
+        self._ensure()
+        st = self._get_stats()
+        st.n_crumbs = int(v)
+        check(self._lib.gh_set_fill_stats(self._h, C.byref(st)))
+
+    @property
+    def band(self):
+        return self._band
+
+    # -- symbols ---------------------------------------------------------------------------
+    def _num(self, sym):
+        if isinstance(sym, HanselSymbol):
+            return sym.i
+        if isinstance(sym, (int, np.integer)):
+            return int(sym)
+        return self.symbols_d[sym].i        # KeyError like the reference for an unknown symbol
+
+    def _path_indices(self, path, upto=None):
+        n = len(path) if upto is None else upto
+        return np.fromiter((self._num(path[q]) for q in range(n)), dtype=np.uint8, count=n)
+
+    # -- one-cell API (compatibility; a host round trip per call) ---------------------------
+    def add_observation(self, symbol_from, symbol_to, pos_from, pos_to):
+        a, b = self._num(symbol_from), self._num(symbol_to)
+        if not (0 <= pos_from < pos_to <= self.n + 1):
+            raise IndexError("observation positions (%d,%d) outside 0 <= i < j <= %d" % (pos_from, pos_to, self.n + 1))
+        self._staged.append((a, b, int(pos_from), int(pos_to)))
+        if len(self._staged) >= (1 << 20):
+            self._ensure()
+
+    def get_observation(self, symbol_from, symbol_to, pos_from, pos_to):
+        self._ensure()
+        out = C.c_double()
+        check(self._lib.gh_get(self._h, self._num(symbol_from), self._num(symbol_to), int(pos_from), int(pos_to), C.byref(out)))
+        return out.value
+
+    def reweight_observation(self, symbol_from, symbol_to, pos_from, pos_to, ratio):
+        self._ensure()
+        out = C.c_double()
+        check(self._lib.gh_reweight_obs(self._h, self._num(symbol_from), self._num(symbol_to),
+                                        int(pos_from), int(pos_to), float(ratio), C.byref(out)))
+        return out.value
+
+    # -- lookups ---------------------------------------------------------------------------
+    def counts_array(self, at_pos):
+        self._ensure()
+        out = np.zeros(8)
+        check(self._lib.gh_counts_at(self._h, int(at_pos), _p(out)))
+        return out
+
+    def get_counts_at(self, at_pos):
+        """gretel/cmd.py:86,127 -- keys: symbol objects with a positive count, plus "total"."""
+        c = self.counts_array(at_pos)
+        marg = {"total": float(c[7])}
+        for s in self.symbols:
+            if c[s.i] > 0:
+                marg[s] = float(c[s.i])
+        return marg
+
+    def get_marginal_of_at(self, of_symbol, at_pos):
+        """gretel/gretel.py:182,186"""
+        self._ensure()
+        out = C.c_double()
+        check(self._lib.gh_marginal_of_at(self._h, self._num(of_symbol), int(at_pos), C.byref(out)))
+        return out.value
+
+    def get_edge_weights_at(self, at_pos, current_path, debug=False):
+        """gretel/gretel.py:155"""
+        self._ensure()
+        path = self._path_indices(current_path, upto=at_pos)
+        w = np.zeros(7)
+        mask = C.c_int()
+        check(self._lib.gh_edge_weights_at(self._h, int(at_pos), _p(path), _p(w), C.byref(mask)))
+        return {s: float(w[s.i]) for s in self.symbols if (mask.value >> s.i) & 1}
+
+    def candidate_masks(self):
+        """uint32[N+1]: bit s set <=> valid symbol s is a candidate at that position."""
+        self._ensure()
+        out = np.zeros(self.n + 1, dtype=np.uint32)
+        check(self._lib.gh_export_cmask(self._h, _p(out)))
+        return out
+
+    def gap_check(self):
+        """gretel/cmd.py:85-118: first position in [0,N] without evidence, or -1."""
+        self._ensure()
+        g = C.c_int()
+        check(self._lib.gh_gap_check(self._h, C.byref(g)))
+        return g.value
+
+    # -- fused fast paths --------------------------------------------------------------------
+    def fill_from_support(self, rank, off, bases, use_end_sentinels=False, reads_handle=None):
+        """The pair loop of gretel/util.py:226-286 for a whole support table at once.
+        Returns (n_slices, n_crumbs, covered_snps) and sets L like util.py:333."""
+        if reads_handle is None:
+            rank = np.ascontiguousarray(rank, dtype=np.int32)
+            off = np.ascontiguousarray(off, dtype=np.int64)
+            bases = np.ascontiguousarray(bases, dtype=np.uint8)
+            max_k = int(np.diff(off).max()) if len(rank) else 0
+            self._ensure(max(1, max_k - 1))
+            reads_handle = DeviceReads(self, rank, off, bases)
+        else:
+            self._ensure(max(1, reads_handle.max_k - 1))
+        st = _lib.gh_fill_stats()
+        check(self._lib.gh_fill(self._h, reads_handle._r, int(bool(use_end_sentinels)), C.byref(st)))
+        self._L = int(st.L)
+        return int(st.n_slices), int(st.n_crumbs), int(st.covered_snps)
+
+    def clear(self):
+        self._staged = []
+        if self._h is not None:
+            check(self._lib.gh_clear(self._h))
+        self._L = 1
+
+    def snapshot_original(self):
+        self._ensure()
+        check(self._lib.gh_snapshot_original(self._h))
+
+    def generate_path(self, original=None):
+        """gretel/gretel.py:102-189 as one kernel.  Returns (indices uint8[N+1], hp_current,
+        hp_original, min_marginal) or (None, hole_at, prefix walked)."""
+        self._ensure()
+        oh = None
+        if original is not None and original is not self:
+            original._ensure()
+            oh = original._h
+        path = np.zeros(self.n + 1, dtype=np.uint8)
+        hc, ho, mn, hole = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        check(self._lib.gh_generate_path(self._h, oh, _p(path), C.byref(hc), C.byref(ho), C.byref(mn), C.byref(hole)))
+        if hole.value:
+            return None, hole.value, path[:hole.value]
+        return path, hc.value, ho.value, mn.value
+
+    def reweight_from_path(self, path_indices, ratio):
+        """gretel/gretel.py:79-98 as one kernel."""
+        self._ensure()
+        p = np.ascontiguousarray(path_indices, dtype=np.uint8)
+        if p.shape[0] != self.n + 1:
+            raise ValueError("path must have N+1 = %d entries" % (self.n + 1))
+        out = C.c_double()
+        check(self._lib.gh_reweight_path(self._h, _p(p), float(ratio), C.byref(out)))
+        self.is_weighted = True
+        return out.value
+
+    def spin(self, max_paths=100, min_remove=0.01):
+        """gretel/cmd.py:148-179 on the device.  Returns dict(n, hole_at, paths uint8[n][N+1],
+        hp_current, hp_original, ratio, magnitude)."""
+        self._ensure()
+        paths = np.zeros((max_paths, self.n + 1), dtype=np.uint8)
+        recs = (_lib.gh_path_rec * max(1, max_paths))()
+        n, hole = C.c_int(), C.c_int()
+        check(self._lib.gh_spin(self._h, int(max_paths), float(min_remove), _p(paths), recs, C.byref(n), C.byref(hole)))
+        k = n.value
+        if k:
+            self.is_weighted = True
+        return dict(n=k, hole_at=hole.value, paths=paths[:k],
+                    hp_current=np.array([recs[q].hp_current for q in range(k)]),
+                    hp_original=np.array([recs[q].hp_original for q in range(k)]),
+                    ratio=np.array([recs[q].ratio for q in range(k)]),
+                    magnitude=np.array([recs[q].magnitude for q in range(k)]))
+
+    def path_symbols(self, indices):
+        return [self.symbols[int(q)] for q in indices]
+
+    @staticmethod
+    def path_str(indices):
+        return _SYM_LUT[np.asarray(indices, dtype=np.uint8)].tobytes().decode()
+
+    # -- export ----------------------------------------------------------------------------
+    def export_band(self):
+        self._ensure()
+        out = np.zeros((self.n + 2, self._band, 7, 7))
+        check(self._lib.gh_export_band(self._h, _p(out)))
+        return out
+
+    def export_dense(self):
+        """[7][7][N+2][N+2] like the reference tensor (gretel/cmd.py:76-77); small N only."""
+        self._ensure()
+        out = np.zeros((7, 7, self.n + 2, self.n + 2))
+        check(self._lib.gh_export_dense(self._h, _p(out)))
+        return out
+
+    def save_hansel_dump(self, path):
+        """gretel/cmd.py:82 (--dumpmatrix).  hanselx's dump format is not in the reference
+        tree; this writes an .npz with the banded tensor and the attributes."""
+        np.savez_compressed(path, band=self.export_band(), n_snps=self.n, L=self.L,
+                            n_slices=self.n_slices, n_crumbs=self.n_crumbs, symbols=np.array(SYMBOLS))
+
+    # -- profiling (bench.py) ----------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ensure()
+        check(self._lib.gh_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        check(self._lib.gh_profile_reset(self._h))
+
+    def profile_get(self):
+        out = {}
+        for name, k in _lib.GH_K.items():
+            ms, n, by = C.c_double(), C.c_int64(), C.c_double()
+            check(self._lib.gh_profile_get(self._h, k, C.byref(ms), C.byref(n)))
+            check(self._lib.gh_profile_bytes(self._h, k, C.byref(by)))
+            out[name] = dict(ms=ms.value, launches=n.value, bytes_per_launch=by.value)
+        return out
+
+    def sync(self):
+        if self._h is not None:
+            check(self._lib.gh_sync(self._h))
+
+
+class DeviceReads:
+    """A support table resident in HBM (gh_reads_upload)."""
+
+    def __init__(self, hansel, rank, off, bases):
+        rank = np.ascontiguousarray(rank, dtype=np.int32)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        self.n_reads = len(rank)
+        self.max_k = int(np.diff(off).max()) if self.n_reads else 0
+        hansel._ensure(max(1, self.max_k - 1))
+        self._lib = hansel._lib
+        r = C.c_void_p()
+        check(self._lib.gh_reads_upload(hansel._h, _p(rank), _p(off), _p(bases), self.n_reads, C.byref(r)))
+        self._r = r
+
+    def __del__(self):
+        try:
+            if getattr(self, "_r", None):
+                self._lib.gh_reads_free(self._r)
+                self._r = None
+        except Exception:
+            pass

@@ -67,7 +67,7 @@ def make_support_table(n_snps, n_reads, k=None, n_haps=8, err=0.01, seed=0,
     # K haplotypes, iid uniform alleles, forced >= 2 distinct alleles per SNP
     haps = rng.integers(0, 4, size=(n_haps, n_snps), dtype=np.int64)
     same = (haps == haps[0:1]).all(axis=0)
-    if same.any():
+    if n_haps > 1 and same.any():
         haps[1, same] = (haps[0, same] + 1) % 4
     abund = rng.dirichlet(np.ones(n_haps))
 

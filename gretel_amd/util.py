@@ -1,0 +1,224 @@
+"""
+Drop-in for the ingest half of the reference's `gretel/util.py`:
+
+    process_vcf(vcf_path, contig_name, start_pos, end_pos)      gretel/util.py:354-414
+    load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, ...)
+                                                                 gretel/util.py:33-335
+    get_ref_len_from_bam(bam_path, target_contig)                gretel/util.py:10-31
+
+The reference reads BAM through pysam (htslib pileup) and VCF through PyVCF (tabix);
+neither is available here, so the host side decodes BGZF/BAM and bgzipped VCF with the
+standard library (BGZF is multi-member gzip) and turns every read into one row of the
+*support table* `(rank, support_seq)` -- what the reference holds per read at
+util.py:235-238 -- by walking the CIGAR the way htslib's pileup resolves it.  The pair
+loop itself (util.py:226-286) and the counters / L (util.py:329-333) run on the GPU
+(`Hansel.fill_from_support` -> k_fill).
+
+Known divergences from pysam's pileup, all irrelevant to the synthetic configs:
+  * no max_depth cap (pysam default 8000);
+  * stepper "samtools" is modelled as: drop UNMAP/SECONDARY/QCFAIL/DUP reads and
+    paired reads that are not properly paired (ignore_orphans); stepper "all"
+    (reference --pepper, gretel/cmd.py:39,78) only drops the four flags;
+  * `n_threads` is accepted and ignored: the reference's windows (util.py:294-301) only
+    partition the reads by leftmost position, the observations are the same.
+"""
+from __future__ import annotations
+
+import gzip
+import struct
+import sys
+
+import numpy as np
+
+from .hansel import Hansel, SYMBOLS, UNSYMBOLS
+
+_SEQ_DECODE = "=ACMGRSVTWYHKDBN"
+_FLAG_DROP = 0x4 | 0x100 | 0x200 | 0x400
+
+
+# ---------------------------------------------------------------------------------------------
+# VCF
+# ---------------------------------------------------------------------------------------------
+def process_vcf(vcf_path, contig_name, start_pos, end_pos):
+    """gretel/util.py:354-414: SNP positions of `contig_name` inside [start_pos, end_pos]."""
+    n_snps = 0
+    snp_reverse = {}
+    snp_forward = {}
+    region = np.zeros(end_pos + 1, dtype=int)                 # util.py:393
+    opener = gzip.open if _is_gzip(vcf_path) else open
+    i = 0
+    with opener(vcf_path, "rb") as fp:
+        for line in fp:
+            if not line or line[:1] == b"#":
+                continue
+            f = line.split(b"\t", 2)
+            if len(f) < 2 or f[0].decode() != contig_name:
+                continue
+            pos = int(f[1])
+            if pos < start_pos or pos > end_pos:              # util.py:397-400
+                continue
+            n_snps += 1
+            region[pos] = 1
+            snp_reverse[i] = pos
+            snp_forward[pos] = i
+            i += 1
+    return {"N": n_snps, "snp_fwd": snp_forward, "snp_rev": snp_reverse, "region": region}
+
+
+def _is_gzip(path):
+    with open(path, "rb") as fh:
+        return fh.read(2) == b"\x1f\x8b"
+
+
+# ---------------------------------------------------------------------------------------------
+# BAM
+# ---------------------------------------------------------------------------------------------
+class BamRecord:
+    __slots__ = ("ref_id", "pos", "flag", "name", "cigar", "l_seq", "seq_raw", "qual")
+
+    def base(self, q):
+        b = self.seq_raw[q >> 1]
+        return _SEQ_DECODE[(b >> 4) if (q & 1) == 0 else (b & 15)]
+
+
+def read_bam(bam_path):
+    """Yields (header_refs, iterator of BamRecord).  header_refs = [(name, length)]."""
+    with gzip.open(bam_path, "rb") as fh:
+        data = fh.read()
+    if data[:4] != b"BAM\x01":
+        raise ValueError("%s is not a BAM file" % bam_path)
+    (l_text,) = struct.unpack_from("<i", data, 4)
+    o = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", data, o)
+    o += 4
+    refs = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", data, o)
+        o += 4
+        name = data[o:o + l_name - 1].decode()
+        o += l_name
+        (l_ref,) = struct.unpack_from("<i", data, o)
+        o += 4
+        refs.append((name, l_ref))
+
+    def records(o=o):
+        n = len(data)
+        while o + 4 <= n:
+            (block_size,) = struct.unpack_from("<i", data, o)
+            o += 4
+            (ref_id, pos, l_read_name, _mapq, _bin, n_cigar, flag, l_seq, _nref, _npos, _tlen) = \
+                struct.unpack_from("<iiBBHHHiiii", data, o)
+            p = o + 32
+            r = BamRecord()
+            r.ref_id, r.pos, r.flag, r.l_seq = ref_id, pos, flag, l_seq
+            r.name = data[p:p + l_read_name - 1].decode()
+            p += l_read_name
+            r.cigar = [(c & 15, c >> 4) for c in struct.unpack_from("<%dI" % n_cigar, data, p)]
+            p += 4 * n_cigar
+            r.seq_raw = data[p:p + (l_seq + 1) // 2]
+            p += (l_seq + 1) // 2
+            r.qual = data[p:p + l_seq]
+            o += block_size
+            yield r
+
+    return refs, records()
+
+
+def get_ref_len_from_bam(bam_path, target_contig):
+    """gretel/util.py:10-31"""
+    refs, _ = read_bam(bam_path)
+    for name, ln in refs:
+        if name == target_contig:
+            return ln
+    raise KeyError(target_contig)
+
+
+def _support_of_read(rec, region, start_pos, end_pos):
+    """Walk the CIGAR like htslib's pileup and return (leftmost_1pos, aligned_query_len,
+    [support chars at the SNP columns the read covers, in reference order])."""
+    ref = rec.pos            # 0-based
+    q = 0
+    chars = []
+    qalen = 0
+    hi = min(end_pos, len(region) - 1)
+    for op, ln in rec.cigar:
+        if op in (0, 7, 8):                       # M = X : one pileup column per base
+            lo1 = max(ref + 1, 1)
+            hi1 = min(ref + ln, hi)
+            if hi1 >= lo1:
+                for pos1 in np.flatnonzero(region[lo1:hi1 + 1]) + lo1:
+                    chars.append(rec.base(q + (int(pos1) - 1 - ref)))     # util.py:186-189: b[0] is this base
+            ref += ln
+            q += ln
+            qalen += ln
+        elif op in (2, 3):                        # D / N : is_del columns -> "-" (util.py:180-182)
+            lo1 = max(ref + 1, 1)
+            hi1 = min(ref + ln, hi)
+            if hi1 >= lo1:
+                chars.extend("-" * int(region[lo1:hi1 + 1].sum()))
+            ref += ln
+        elif op == 1:                             # I
+            q += ln
+            qalen += ln
+        elif op == 4:                             # S
+            q += ln
+        # H, P: nothing
+    return rec.pos + 1, qalen, chars
+
+
+def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper="samtools"):
+    """The pileup half of load_from_bam (gretel/util.py:137-209) -> support table arrays."""
+    refs, records = read_bam(bam_path)
+    names = [n for n, _ in refs]
+    if target_contig not in names:
+        raise KeyError("contig %r not in %s" % (target_contig, bam_path))
+    tid = names.index(target_contig)
+    region = np.asarray(vcf_handler["region"])
+    csum = np.concatenate([[0], np.cumsum(region)])          # csum[x] = sum(region[0:x])
+    reads = {}
+    order = []
+    for rec in records:
+        if rec.ref_id != tid or rec.flag & _FLAG_DROP:
+            continue
+        if stepper == "samtools" and (rec.flag & 0x1) and not (rec.flag & 0x2):
+            continue
+        if rec.l_seq == 0:
+            continue
+        one_or_two = 0
+        if rec.flag & 0x1:
+            one_or_two = 1 if rec.flag & 0x40 else (2 if rec.flag & 0x80 else 0)
+        key = "%s_%s_%d" % (rec.name, str(rec.flag), one_or_two)          # util.py:160
+        leftmost, qalen, chars = _support_of_read(rec, region, start_pos, end_pos)
+        if leftmost < start_pos:                                          # util.py:165-171
+            if leftmost + qalen < start_pos:
+                continue
+            leftmost = start_pos
+        if not chars:
+            continue
+        if key not in reads:
+            lm = min(leftmost, len(region))
+            rank = int(csum[lm] - csum[1]) if lm >= 1 else 0              # util.py:198 sum(region[1:LEFTMOST])
+            reads[key] = [rank, []]
+            order.append(key)
+        reads[key][1].extend(c[0] for c in chars)
+    rank = np.array([reads[k][0] for k in order], dtype=np.int32)
+    seqs = ["".join(reads[k][1]) for k in order]
+    off = np.zeros(len(order) + 1, dtype=np.int64)
+    if order:
+        np.cumsum([len(s) for s in seqs], out=off[1:])
+    bases = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy()
+    return rank, off, bases
+
+
+def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_end_sentinels=False,
+                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", **hansel_kw):
+    """gretel/util.py:33-335.  Returns a device-backed Hansel with n_slices, n_crumbs and L set."""
+    rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper)
+    max_k = int(np.diff(off).max()) if len(rank) else 0
+    hansel = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, vcf_handler["N"], band=max(1, max_k - 1), **hansel_kw)
+    n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels)
+    sys.stderr.write("[NOTE] Loaded %d breadcrumbs from %d bread slices.\n" % (n_crumbs, n_slices))   # util.py:331
+    if n_slices == 0:
+        raise ZeroDivisionError("no read carries more than one SNP (gretel/util.py:333 divides by n_reads)")
+    sys.stderr.write("[NOTE] Setting Gretel.L to %d\n" % hansel.L)                                    # util.py:334
+    return hansel

@@ -1,0 +1,169 @@
+/*
+ * gretel_hip.h -- C ABI of libgretel_hip.so, the MI355X (gfx950) implementation of
+ * Gretel's hot path: the Hansel SNP-pair co-observation tensor and the three
+ * loops that run over it (BAM->Hansel fill, L'th-order Markov path extension,
+ * per-path reweighting).
+ *
+ * The reference has no FFI for this path: its seam is the Python object protocol
+ * of `hansel.Hansel` (third-party hanselx==0.0.92, reference setup.py:8) plus
+ * two functions of gretel/gretel.py.  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference tree);
+ * gretel_amd/hansel.py, gretel_amd/gretel.py and gretel_amd/util.py bind them
+ * with ctypes and re-expose the reference's Python names.
+ *
+ * Conventions
+ *   - every function returns GH_OK (0) or a negative gh_status; the message of
+ *     the last failure on the calling thread is gh_last_error().
+ *   - "no branch at SNP k" (reference gretel/gretel.py:176-180 returns a None
+ *     triple) is a VALUE (hole_at >= 1), not an error.
+ *   - symbols are indices in the reference's order (gretel/util.py:83):
+ *       A=0 C=1 G=2 T=3 N=4 -=5 _=6 ; unsymbols are N and _.
+ *   - positions are 0..n_snps+1 (0 and n_snps+1 are the sentinels).
+ *   - a handle owns its device buffers and one HIP stream; it is not
+ *     thread-safe; one handle per (contig,start,end) window.
+ *   - all output buffers are caller-allocated host memory unless stated.
+ */
+#ifndef GRETEL_HIP_H
+#define GRETEL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gh_handle gh_t;          /* one Hansel tensor resident in HBM */
+typedef struct gh_reads gh_reads_t;     /* one support table resident in HBM */
+
+typedef enum {
+    GH_OK = 0,
+    GH_ERR_ARG = -1,        /* bad argument */
+    GH_ERR_HIP = -2,        /* HIP runtime failure (no device, launch error, ...) */
+    GH_ERR_BAND = -3,       /* observation with pos_to-pos_from outside [1, band] */
+    GH_ERR_SYMBOL = -4,     /* byte that is not one of "ACGTN-_" in a support_seq */
+    GH_ERR_NOMEM = -5,
+    GH_ERR_STATE = -6       /* call order (e.g. generate_path before any fill) */
+} gh_status;
+
+#define GH_NSYM 7
+#define GH_STORAGE_F32 0
+#define GH_STORAGE_F64 1
+#define GH_COND_A 0   /* (1+H[a,b,i,j]) / (V(j) + sum_x H[a,x,i,j])   frozen default */
+#define GH_COND_B 1   /* (1+H[a,b,i,j]) / (V(i) + c_a(i))                            */
+#define GH_COND_C 2   /* (1+H[a,b,i,j]) / (V(i) + sum_x H[x,b,i,j])                  */
+
+typedef struct {
+    int32_t n_snps;         /* N: number of SNPs of the window (VCF_h["N"], gretel/util.py:409) */
+    int32_t band;           /* W: largest pos_to-pos_from stored (= max SNPs on a read - 1, >= 1) */
+    int32_t storage;        /* GH_STORAGE_F32 | GH_STORAGE_F64 */
+    int32_t cond_mode;      /* GH_COND_*  */
+    int32_t marginal_term;  /* 1: edge weight also adds log10(marginal) (App. A-7) */
+    int32_t device;         /* HIP device ordinal, -1 = current */
+} gh_config;
+
+typedef struct {
+    int64_t n_slices;       /* reads with >1 SNP            gretel/util.py:233,329 */
+    int64_t n_crumbs;       /* pair observations            gretel/util.py:268,276,281,330 */
+    int64_t covered_snps;   /* informative SNPs on them     gretel/util.py:239 */
+    int32_t L;              /* ceil(covered/slices)         gretel/util.py:333 */
+    int32_t _pad;
+} gh_fill_stats;
+
+typedef struct {
+    double hp_current;      /* gretel/gretel.py:185,189 */
+    double hp_original;     /* gretel/gretel.py:186,189 */
+    double ratio;           /* min marginal after the 1% clamp, gretel/cmd.py:157-160 */
+    double magnitude;       /* reweight_hansel_from_path return, gretel/cmd.py:161 */
+} gh_path_rec;
+
+const char *gh_last_error(void);
+int gh_device_count(int *n);
+
+/* Hansel.init_matrix(['A','C','G','T','N','-','_'], ['N','_'], N) -- gretel/util.py:83.
+ * Allocates the zeroed banded tensor [(N+2)][band][7][7] in HBM. */
+int gh_create(const gh_config *cfg, gh_t **out);
+int gh_destroy(gh_t *h);
+/* hansel.copy() -- gretel/cmd.py:79 (deep copy incl. L, n_slices, n_crumbs). */
+int gh_copy(const gh_t *src, gh_t **out);
+/* zero the tensor and the fill counters (re-use a handle for another window of the same shape) */
+int gh_clear(gh_t *h);
+int gh_sync(gh_t *h);
+
+/* hansel.L / n_slices / n_crumbs attributes -- gretel/util.py:329-333, gretel/cmd.py:227-229 */
+int gh_set_L(gh_t *h, int32_t L);
+int gh_get_L(const gh_t *h, int32_t *L);
+int gh_get_fill_stats(const gh_t *h, gh_fill_stats *out);
+int gh_set_fill_stats(gh_t *h, const gh_fill_stats *in);
+
+/* Support table (per read: rank of gretel/util.py:198, support_seq of util.py:238 as ASCII)
+ * copied to HBM once; off has n_reads+1 entries. */
+int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t *off, const uint8_t *bases,
+                    int64_t n_reads, gh_reads_t **out);
+int gh_reads_free(gh_reads_t *r);
+
+/* The per-read pair loop of load_from_bam -- gretel/util.py:226-286 -- and the
+ * counters/L of util.py:329-333, over a device-resident support table.
+ * Accumulates into the tensor (call gh_clear first for a fresh fill). */
+int gh_fill(gh_t *h, const gh_reads_t *reads, int use_end_sentinels, gh_fill_stats *out);
+
+/* hansel.add_observation / get_observation / reweight_observation --
+ * gretel/util.py:266-286, tests/test_test.py:41-52, gretel/gretel.py:84,96.
+ * One-cell compatibility API (a host round trip each): not the fast path. */
+int gh_add(gh_t *h, int a, int b, int i, int j);
+int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const int32_t *i, const int32_t *j, int64_t n);
+int gh_get(gh_t *h, int a, int b, int i, int j, double *out);
+int gh_reweight_obs(gh_t *h, int a, int b, int i, int j, double ratio, double *removed);
+
+/* hansel.get_counts_at(p) -- gretel/cmd.py:86,127: out[s] = c_s(p), out[7] = total. */
+int gh_counts_at(gh_t *h, int p, double out[8]);
+/* hansel.get_marginal_of_at(s, p) -- gretel/gretel.py:182,186 */
+int gh_marginal_of_at(gh_t *h, int s, int p, double *out);
+/* hansel.get_edge_weights_at(p, current_path) -- gretel/gretel.py:155.
+ * path[0..p-1] are the selected symbol indices (path[0] = '_'); w[s] is set for
+ * the candidate symbols, *cand_mask has bit s set for each candidate. */
+int gh_edge_weights_at(gh_t *h, int p, const uint8_t *path, double w[GH_NSYM], int *cand_mask);
+/* the gap check of gretel/cmd.py:85-118: first position in [0,N] whose total is 0, else -1 */
+int gh_gap_check(gh_t *h, int *first_gap);
+
+/* candidate bitmask per position (bit s set <=> valid symbol s has c_s(p) > 0), out[0..N] */
+int gh_export_cmask(gh_t *h, uint32_t *out);
+
+/* Freeze the current marginals as the "original" ones: what gretel/cmd.py:79's
+ * hansel.copy() is used for at gretel/gretel.py:186 (M0[p][s] replaces a second tensor). */
+int gh_snapshot_original(gh_t *h);
+
+/* gretel.generate_path(n_snps, hansel, original_hansel) -- gretel/gretel.py:102-189.
+ * `original` may be NULL (then h's snapshot, or h itself if none was taken).
+ * path_out: N+1 symbol indices, path_out[0] = '_'.  *hole_at = 0 on success, else the
+ * SNP at which no branch could be selected (gretel.py:176-180); then path_out[0..hole_at-1]
+ * holds the prefix walked so far and the three doubles are not written. */
+int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out,
+                     double *hp_current, double *hp_original, double *min_marginal, int *hole_at);
+
+/* gretel.reweight_hansel_from_path(hansel, path, ratio) -- gretel/gretel.py:79-98. */
+int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, double *removed);
+
+/* The spin loop of gretel/cmd.py:148-179 without host round trips: up to max_paths x
+ * { generate_path, clamp ratio to >= min_remove (cmd.py:157-160), reweight }.
+ * Stops at the first hole (cmd.py:153).  paths_out: [max_paths][N+1]. */
+int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
+            int *n_out, int *hole_at);
+
+/* tensor export/import for --dumpmatrix (gretel/cmd.py:81-82) and tests:
+ * band layout [(N+2)][band][7][7] as doubles; dense layout [7][7][N+2][N+2] (gretel/cmd.py:76-77). */
+int gh_export_band(gh_t *h, double *out);
+int gh_import_band(gh_t *h, const double *in);
+int gh_export_dense(gh_t *h, double *out);
+
+/* Per-kernel HIP-event timing on the handle's own stream (bench.py's roofline leg). */
+enum { GH_K_FILL = 0, GH_K_MARG = 1, GH_K_LT = 2, GH_K_WALK = 3, GH_K_REWEIGHT = 4, GH_K_COUNT = 5 };
+int gh_profile_enable(gh_t *h, int on);
+int gh_profile_reset(gh_t *h);
+int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches);
+/* algorithmic bytes of the last launch of each kernel */
+int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRETEL_HIP_H */

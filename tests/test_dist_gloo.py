@@ -1,0 +1,75 @@
+"""The N>1 path (descriptor broadcast, window ownership, result gather) with world_size 2
+over gloo on CPU.  The records travel as tensors exactly as they do over RCCL."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+from gretel_amd import dist as gdist
+
+
+def test_window_ownership_partitions():
+    for world in (1, 2, 3, 8):
+        owned = sorted(w for r in range(world) for w in gdist.windows_of_rank(19, world, r))
+        assert owned == list(range(19))
+
+
+def test_pack_roundtrip():
+    rng = np.random.default_rng(0)
+    res = dict(n=3, hole_at=7, paths=rng.integers(0, 7, (3, 11), dtype=np.uint8), hp_current=rng.random(3),
+               hp_original=rng.random(3), ratio=rng.random(3), magnitude=rng.random(3))
+    back = gdist.unpack_result(*gdist.pack_result(res, 10, 5))
+    assert back["n"] == 3 and back["hole_at"] == 7
+    for k in ("paths", "hp_current", "hp_original", "ratio", "magnitude"):
+        assert np.array_equal(back[k], res[k])
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from gretel_amd import dist as gdist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    d = gdist.broadcast_descriptor(dict(paths=4, steps=2, warmup=1, config=3) if rank == 0 else {}, dev, world, rank)
+    assert d == dict(paths=4, steps=2, warmup=1, config=3), d
+    rng = np.random.default_rng(rank)
+    k = 2 + rank
+    res = dict(n=k, hole_at=rank * 5, paths=rng.integers(0, 7, (k, 9), dtype=np.uint8), hp_current=rng.random(k),
+               hp_original=rng.random(k), ratio=rng.random(k), magnitude=rng.random(k))
+    got = gdist.gather_results(res, 8, d["paths"], dev, world, rank)
+    if rank == 0:
+        assert len(got) == world
+        for r in range(world):
+            rr = np.random.default_rng(r)
+            kk = 2 + r
+            assert got[r]["n"] == kk and got[r]["hole_at"] == r * 5
+            assert np.array_equal(got[r]["paths"], rr.integers(0, 7, (kk, 9), dtype=np.uint8))
+            assert np.array_equal(got[r]["hp_current"], rr.random(kk))
+        print("GATHER_OK")
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_broadcast_and_gather_world2(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHER_OK" in outs[0]
