@@ -33,11 +33,6 @@
 #include "gretel_hip.h"
 #include "gh_detlog.h"
 
-#define NSYM 7
-#define CELL 49
-#define SYM_N 4
-#define SYM_US 6
-#define VALID_MASK 0x2Fu /* A C G T - : bits 0,1,2,3,5 */
 
 // ---------------------------------------------------------------------------------------------
 // error handling
@@ -63,18 +58,11 @@ static int fail(int code, const char *fmt, ...)
 
 extern "C" const char *gh_last_error(void) { return g_err; }
 
+#include "kernels.hpp"
+
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
-struct dev_state {
-    int stop;        // set by the walker at a hole: later launches of the spin become no-ops
-    int hole_at;
-    int n_done;
-    int _pad;
-    double ratio;    // clamped min marginal of the path just walked
-    unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
-};
-
 struct prof_slot {
     std::vector<hipEvent_t> ev;   // start/stop pairs
     size_t used = 0;
@@ -90,7 +78,7 @@ struct gh_handle {
     hipStream_t stream;
     size_t n_cells;
     void *band;
-    double *cnt, *marg, *logm, *logm0;
+    double *cnt, *marg, *minfo;
     int32_t *nvalid;
     uint32_t *cmask;
     double *lt;
@@ -120,6 +108,16 @@ static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STO
 static int set_dev(const gh_handle *h)
 {
     HIPCHK(hipSetDevice(h->dev));
+    return GH_OK;
+}
+
+// launch check: GH_DEBUG_SYNC=1 synchronises after every launch so that a fault names its kernel
+static int post_launch(gh_handle *h, const char *what)
+{
+    static const bool dbg = getenv("GH_DEBUG_SYNC") && atoi(getenv("GH_DEBUG_SYNC"));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && dbg) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(GH_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return GH_OK;
 }
 
@@ -164,398 +162,6 @@ static void prof_collect(gh_handle *h)
 }
 
 // ---------------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------------
-__constant__ int8_t c_sym_of_char[256];
-
-template <typename T>
-__device__ __forceinline__ double rowsum(const T *cell, int a)
-{
-    T acc = (T)0;
-#pragma unroll
-    for (int x = 0; x < NSYM; x++) acc = acc + cell[a * NSYM + x];
-    return (double)acc;
-}
-
-template <typename T>
-__device__ __forceinline__ double colsum(const T *cell, int b)
-{
-    T acc = (T)0;
-#pragma unroll
-    for (int x = 0; x < NSYM; x++) acc = acc + cell[x * NSYM + b];
-    return (double)acc;
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    // lane is wave-uniform
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_fill: gretel/util.py:226-286
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ void add_obs(T *band, int N, int W, int a, int b, int i, int j,
-                                        unsigned long long *oob)
-{
-    int d = j - i;
-    if (d < 1 || d > W || i < 0 || j > N + 1) {
-        atomicAdd(oob, 1ULL);
-        return;
-    }
-    atomicAdd(&band[((size_t)i * W + (d - 1)) * CELL + a * NSYM + b], (T)1);
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_fill(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank,
-       const int64_t *__restrict__ off, const uint8_t *__restrict__ bases, int64_t n_reads,
-       int use_end_sentinels, dev_state *st)
-{
-    __shared__ unsigned long long s_acc[3];
-    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
-    __syncthreads();
-
-    unsigned long long slices = 0, crumbs = 0, covered = 0;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads;
-         r += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t o0 = off[r];
-        const int k = (int)(off[r + 1] - o0);
-        if (!(k > 1)) continue;                                  // util.py:230
-        const int rk = rank[r];
-        const uint8_t *s = bases + o0;
-        slices++;                                                // util.py:233
-        bool bad = false;
-        for (int i = 0; i < k; i++) {
-            int c = s[i];
-            if (c_sym_of_char[c] < 0) bad = true;
-            if (c != 'N' && c != '_') covered++;                 // util.py:239
-        }
-        if (bad) { atomicAdd(&st->fill[3], 1ULL); continue; }
-        for (int i = 0; i < k; i++) {
-            const int a = c_sym_of_char[s[i]];
-            if (a == SYM_US || a == SYM_N) continue;             // util.py:258
-            for (int j = i + 1; j < k; j++) {
-                const int b = c_sym_of_char[s[j]];
-                if (i == 0 && j == 1 && rk == 0) {               // util.py:262
-                    add_obs(band, N, W, SYM_US, a, 0, 1, &st->fill[4]);
-                    add_obs(band, N, W, a, b, 1, 2, &st->fill[4]);
-                } else if ((j + rk + 1) == N && (j - i) == 1) {  // util.py:271
-                    add_obs(band, N, W, a, b, N - 1, N, &st->fill[4]);
-                    add_obs(band, N, W, b, SYM_US, N, N + 1, &st->fill[4]);
-                } else {                                         // util.py:279
-                    add_obs(band, N, W, a, b, i + rk + 1, j + rk + 1, &st->fill[4]);
-                    if (use_end_sentinels && j == k - 1 && (j - i) == 1)      // util.py:283
-                        add_obs(band, N, W, b, SYM_US, j + rk + 1, j + rk + 2, &st->fill[4]);
-                }
-                crumbs++;
-            }
-        }
-    }
-    atomicAdd(&s_acc[0], slices);
-    atomicAdd(&s_acc[1], crumbs);
-    atomicAdd(&s_acc[2], covered);
-    __syncthreads();
-    if (threadIdx.x < 3 && s_acc[threadIdx.x]) atomicAdd(&st->fill[threadIdx.x], s_acc[threadIdx.x]);
-}
-
-template <typename T>
-__global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a, const uint8_t *b,
-                            const int32_t *i, const int32_t *j, int64_t n, dev_state *st)
-{
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    if (a[q] >= NSYM || b[q] >= NSYM) { atomicAdd(&st->fill[3], 1ULL); return; }
-    add_obs(band, N, W, a[q], b[q], i[q], j[q], &st->fill[4]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_marg: counts / marginals / candidate masks for every position p in [0, N]
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_marg(const T *__restrict__ band, int N, int W, double *__restrict__ cnt, double *__restrict__ marg,
-       double *__restrict__ logm, int32_t *__restrict__ nvalid, uint32_t *__restrict__ cmask)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int p = t >> 3, s = t & 7;
-    if (p > N) return;
-    const T *cell = band + ((size_t)p * W) * CELL;       // cell (p, p+1)
-    double c[NSYM];
-    double tot = 0.0;
-    int nv = 0;
-    uint32_t cm = 0;
-#pragma unroll
-    for (int x = 0; x < NSYM; x++) {
-        c[x] = rowsum(cell, x);
-        if (c[x] > 0) {
-            tot += c[x];
-            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; }
-        }
-    }
-    if (s < NSYM) {
-        double m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
-        cnt[(size_t)p * 8 + s] = c[s];
-        marg[(size_t)p * 8 + s] = m;
-        logm[(size_t)p * 8 + s] = gh_log10(m);
-    } else {
-        cnt[(size_t)p * 8 + 7] = tot;
-        marg[(size_t)p * 8 + 7] = 0.0;
-        logm[(size_t)p * 8 + 7] = 0.0;
-        nvalid[p] = nv;
-        cmask[p] = cm;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_lt: lt[snp][l-1][a][b] = log10( (1 + H[a,b,snp-l,snp]) / den )
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_lt(const T *__restrict__ band, int N, int W, int L, int cond_mode,
-     const double *__restrict__ cnt, const int32_t *__restrict__ nvalid, double *__restrict__ lt)
-{
-    const size_t total = (size_t)N * L * CELL;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(t % CELL);
-        const size_t r = t / CELL;
-        const int l = (int)(r % L) + 1;
-        const int snp = (int)(r / L) + 1;
-        if (l > snp) continue;
-        const int i = snp - l;
-        const int a = e / NSYM, b = e - a * NSYM;
-        double obs = 0.0, sum = 0.0;
-        if (l <= W) {
-            const T *cell = band + ((size_t)i * W + (l - 1)) * CELL;
-            obs = (double)cell[e];
-            if (cond_mode == GH_COND_A) sum = rowsum(cell, a);
-            else if (cond_mode == GH_COND_C) sum = colsum(cell, b);
-        }
-        double den;
-        if (cond_mode == GH_COND_A) den = (double)nvalid[snp] + sum;
-        else if (cond_mode == GH_COND_B) den = (double)nvalid[i] + cnt[(size_t)i * 8 + a];
-        else den = (double)nvalid[i] + sum;
-        lt[((size_t)snp * L + (l - 1)) * CELL + e] = gh_log10((1.0 + obs) / den);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_walk (v0): gretel/gretel.py:143-189, one wavefront, lanes 0..6 = candidate symbols.
-// ---------------------------------------------------------------------------------------------
-struct walk_params {
-    int N, L, marginal_term;
-    const double *lt;
-    const double *marg, *logm, *logm0;
-    const uint32_t *cmask;
-    uint8_t *path_out;        // device [N+1]
-    gh_path_rec *rec;         // device
-    dev_state *st;
-    double min_remove;
-    int hist_len;             // power of two > L
-};
-
-__global__ void __launch_bounds__(64) k_walk(walk_params P)
-{
-    extern __shared__ uint8_t lpath[];
-    dev_state *st = P.st;
-    if (st->stop) return;
-    const int lane = threadIdx.x;
-    const int hmask = P.hist_len - 1;
-    const int L = P.L;
-    double hp_cur = 0.0, hp_orig = 0.0, minm = INFINITY;
-
-    if (lane == 0) { lpath[0] = SYM_US; P.path_out[0] = SYM_US; }
-    __syncthreads();
-
-    for (int snp = 1; snp <= P.N; snp++) {
-        const uint32_t cm = P.cmask[snp];
-        if (cm == 0) {                                   // gretel.py:176-180
-            if (lane == 0) { st->stop = 1; st->hole_at = snp; }
-            return;
-        }
-        const bool isc = lane < NSYM && ((cm >> lane) & 1);
-        double acc = 0.0;
-        if (isc) {
-            if (P.marginal_term) acc += P.logm[(size_t)snp * 8 + lane];
-            const int lmax = L < snp ? L : snp;
-            const double *row = P.lt + ((size_t)snp * L) * CELL + lane;
-            for (int l0 = 1; l0 <= lmax; l0 += 8) {
-                double x[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int l = l0 + q;
-                    x[q] = 0.0;
-                    if (l <= lmax) {
-                        const int a = lpath[(snp - l) & hmask];
-                        x[q] = row[(size_t)(l - 1) * CELL + a * NSYM];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++)
-                    if (l0 + q <= lmax) acc += x[q];     // l ascending
-            }
-        }
-        // gretel.py:166-174: first candidate is the incumbent, later ones win on strict >
-        int best = -1;
-        double bw = 0.0;
-#pragma unroll
-        for (int b = 0; b < NSYM; b++) {
-            if (!((VALID_MASK >> b) & 1)) continue;
-            if (!((cm >> b) & 1)) continue;
-            const double wq = readlane_f64(acc, b);
-            if (best < 0) { best = b; bw = wq; }
-            else if (wq > bw) { best = b; bw = wq; }
-        }
-        const int li = lane < 8 ? lane : 0;
-        const double m = readlane_f64(P.marg[(size_t)snp * 8 + li], best);        // gretel.py:182
-        const double lm = readlane_f64(P.logm[(size_t)snp * 8 + li], best);
-        const double lm0 = readlane_f64(P.logm0[(size_t)snp * 8 + li], best);
-        if (m < minm) minm = m;
-        hp_cur += lm;                                    // gretel.py:185
-        hp_orig += lm0;                                  // gretel.py:186
-        if (lane == 0) {
-            lpath[snp & hmask] = (uint8_t)best;
-            P.path_out[snp] = (uint8_t)best;
-        }
-        __syncthreads();
-    }
-    if (lane == 0) {
-        double r = minm;
-        if (r < P.min_remove) r = P.min_remove;          // cmd.py:157-160
-        P.rec->hp_current = hp_cur;
-        P.rec->hp_original = hp_orig;
-        P.rec->ratio = minm;
-        P.rec->magnitude = 0.0;
-        st->ratio = r;
-        st->n_done += 1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_reweight: gretel/gretel.py:79-98 restricted to the band (all other cells are zero and
-// stay zero).  Multiplicities of the reference's pair enumeration:
-//   (p,p+1), p <= N-2 : twice      (N-1,N) : once      (p,q), q-p>=2, q <= N-1 : once
-//   (p,N), p < N-1    : never      (N,N+1) with symbols (path[N], path[0]) : once
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_reweight(T *__restrict__ band, int N, int W, const uint8_t *__restrict__ path,
-           const dev_state *st, double ratio_arg, int use_state_ratio, double *__restrict__ partial)
-{
-    __shared__ double s_red[256];
-    double removed = 0.0;
-    if (!(use_state_ratio && st->stop)) {
-        const double ratio = use_state_ratio ? st->ratio : ratio_arg;
-        const size_t total = (size_t)(N + 1) * W;
-        const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (t < total) {
-            const int i = (int)(t / W);
-            const int d = (int)(t % W) + 1;
-            const int j = i + d;
-            int mult = 0;
-            if (j <= N - 1) mult = (d == 1) ? 2 : 1;
-            else if (j == N) mult = (d == 1) ? 1 : 0;
-            else if (j == N + 1) mult = (i == N) ? 1 : 0;
-            if (mult) {
-                const int a = path[i];
-                const int b = (j == N + 1) ? path[0] : path[j];
-                T *p = band + ((size_t)i * W + (d - 1)) * CELL + a * NSYM + b;
-                T cur = *p;
-                for (int q = 0; q < mult; q++) {
-                    const double old = (double)cur;
-                    const double nw = old - ratio * old;
-                    cur = (T)nw;
-                    removed += old - nw;
-                }
-                *p = cur;
-            }
-        }
-    }
-    // fixed-order tree so the sum is run-to-run reproducible
-    s_red[threadIdx.x] = removed;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
-}
-
-__global__ void __launch_bounds__(256)
-k_reweight_finish(const double *__restrict__ partial, int nb, const dev_state *st, int use_state,
-                  gh_path_rec *rec)
-{
-    __shared__ double s_red[256];
-    if (use_state && st->stop) return;
-    double acc = 0.0;
-    for (int q = threadIdx.x; q < nb; q += 256) acc += partial[q];
-    s_red[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        rec->magnitude = s_red[0];
-        if (use_state) rec->ratio = st->ratio;
-    }
-}
-
-// one-cell helpers ----------------------------------------------------------------------------
-template <typename T>
-__global__ void k_reweight_one(T *p, double ratio, double *removed)
-{
-    const double old = (double)*p;
-    const double nw = old - ratio * old;
-    *p = (T)nw;
-    *removed = old - nw;
-}
-
-template <typename T>
-__global__ void k_export(const T *__restrict__ band, double *__restrict__ out, size_t n)
-{
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[t] = (double)band[t];
-}
-
-template <typename T>
-__global__ void k_import(T *__restrict__ band, const double *__restrict__ in, size_t n)
-{
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) band[t] = (T)in[t];
-}
-
-// edge weights for an arbitrary host-supplied history (compat API; one wave)
-__global__ void k_edge_weights(int p, int L, int marginal_term, const double *lt, const double *logm,
-                               const uint32_t *cmask, const uint8_t *hist /* hist[l-1] = path[p-l] */,
-                               double *w, int *mask)
-{
-    const int lane = threadIdx.x;
-    const uint32_t cm = cmask[p];
-    if (lane == 0) *mask = (int)cm;
-    if (lane >= NSYM) return;
-    double acc = 0.0;
-    if ((cm >> lane) & 1) {
-        if (marginal_term) acc += logm[(size_t)p * 8 + lane];
-        const int lmax = L < p ? L : p;
-        for (int l = 1; l <= lmax; l++)
-            acc += lt[((size_t)p * L + (l - 1)) * CELL + hist[l - 1] * NSYM + lane];
-    }
-    w[lane] = acc;
-}
-
-__global__ void k_gap(const double *cnt, int N, int *first_gap)
-{
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > N) return;
-    if (cnt[(size_t)p * 8 + 7] == 0.0) atomicMin(first_gap, p);
-}
-
-// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static int init_constants()
@@ -579,7 +185,7 @@ static void free_handle(gh_handle *h)
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
-    hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->logm); hipFree(h->logm0);
+    hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->d_path); hipFree(h->d_rec);
     for (int k = 0; k < GH_K_COUNT; k++)
@@ -639,8 +245,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     ALLOC(h->band, h->n_cells * CELL * esize(h));
     ALLOC(h->cnt, np * 8 * sizeof(double));
     ALLOC(h->marg, np * 8 * sizeof(double));
-    ALLOC(h->logm, np * 8 * sizeof(double));
-    ALLOC(h->logm0, np * 8 * sizeof(double));
+    ALLOC(h->minfo, np * MINFO * sizeof(double));
     ALLOC(h->nvalid, np * sizeof(int32_t));
     ALLOC(h->cmask, np * sizeof(uint32_t));
     ALLOC(h->dstate, sizeof(dev_state));
@@ -649,6 +254,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
 #undef ALLOC
     hipMemsetAsync(h->band, 0, h->n_cells * CELL * esize(h), h->stream);
     hipMemsetAsync(h->dstate, 0, sizeof(dev_state), h->stream);
+    hipMemsetAsync(h->minfo, 0, np * MINFO * sizeof(double), h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     *out = h;
     return GH_OK;
@@ -689,7 +295,9 @@ extern "C" int gh_copy(const gh_t *src, gh_t **out)
     int rc = gh_create(&src->cfg, &h);
     if (rc) return rc;
     hipStreamSynchronize(src->stream);
-    hipError_t e = hipMemcpy(h->band, src->band, src->n_cells * CELL * esize(src), hipMemcpyDeviceToDevice);
+    // device-to-device copies are asynchronous to the host: order it on the new handle's stream
+    hipError_t e = hipMemcpyAsync(h->band, src->band, src->n_cells * CELL * esize(src), hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { free_handle(h); return fail(GH_ERR_HIP, "copy failed: %s", hipGetErrorString(e)); }
     h->L = src->L;
     h->stats = src->stats;
@@ -813,7 +421,7 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
             hipLaunchKernelGGL(k_fill<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (float *)h->band,
                                h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);
         prof_end(h, GH_K_FILL, bytes);
-        HIPCHK(hipGetLastError());
+        { int rc_ = post_launch(h, "k_fill"); if (rc_) return rc_; }
     }
     h->dirty_marg = h->dirty_lt = true;
     int rc = pull_fill_state(h, before.fill, "gh_fill");
@@ -933,15 +541,18 @@ static int ensure_marg(gh_handle *h)
     if (!h->dirty_marg) return GH_OK;
     const int threads = (h->N + 1) * 8;
     const int block = 256;
+    // re-arm the "first SNP without a candidate" word that k_marg min-reduces into
+    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, sizeof(int), h->stream));
     prof_begin(h, GH_K_MARG);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_marg<double>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
-                           (const double *)h->band, h->N, h->W, h->cnt, h->marg, h->logm, h->nvalid, h->cmask);
+                           (const double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate);
     else
         hipLaunchKernelGGL(k_marg<float>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
-                           (const float *)h->band, h->N, h->W, h->cnt, h->marg, h->logm, h->nvalid, h->cmask);
-    prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 3 * 64 + 8));
-    HIPCHK(hipGetLastError());
+                           (const float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate);
+    // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
+    prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
+    { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
     h->dirty_marg = false;
     return GH_OK;
 }
@@ -955,25 +566,27 @@ static int ensure_lt(gh_handle *h)
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->lt) hipFree(h->lt);
         h->lt = nullptr;
-        size_t bytes = (size_t)(h->N + 1) * h->L * CELL * sizeof(double);
+        size_t bytes = (size_t)(h->N + LT_PAD) * h->L * LT_BLK * sizeof(double);
         hipError_t e = hipMalloc((void **)&h->lt, bytes);
         if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
         h->lt_L = h->L;
     }
-    const size_t total = (size_t)h->N * h->L * CELL;
+    const size_t total = (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
     size_t nb = (total + block - 1) / block;
     if (nb > 256 * 16) nb = 256 * 16;
     prof_begin(h, GH_K_LT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
-                           h->N, h->W, h->L, h->cfg.cond_mode, h->cnt, h->nvalid, h->lt);
+                           h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
+                           h->minfo, h->lt);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
-                           h->N, h->W, h->L, h->cfg.cond_mode, h->cnt, h->nvalid, h->lt);
+                           h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
+                           h->minfo, h->lt);
     const int wl = h->W < h->L ? h->W : h->L;
-    prof_end(h, GH_K_LT, (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * CELL * 8.0));
-    HIPCHK(hipGetLastError());
+    prof_end(h, GH_K_LT, (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * LT_BLK * 8.0));
+    { int rc_ = post_launch(h, "k_lt"); if (rc_) return rc_; }
     h->dirty_lt = false;
     return GH_OK;
 }
@@ -1008,7 +621,7 @@ extern "C" int gh_edge_weights_at(gh_t *h, int p, const uint8_t *path, double w[
     if (!h || !path || !w || !cand_mask) return fail(GH_ERR_ARG, "null argument");
     if (p < 1 || p > h->N) return fail(GH_ERR_ARG, "position %d outside [1,%d]", p, h->N);
     if (set_dev(h)) return GH_ERR_HIP;
-    int rc = ensure_lt(h);
+    int rc = ensure_marg(h);
     if (rc) return rc;
     const int lmax = h->L < p ? h->L : p;
     std::vector<uint8_t> hist(lmax);
@@ -1022,8 +635,14 @@ extern "C" int gh_edge_weights_at(gh_t *h, int p, const uint8_t *path, double w[
     hipError_t e = hipMalloc((void **)&d_w, 8 * sizeof(double));
     if (e != hipSuccess) { hipFree(d_hist); return fail(GH_ERR_NOMEM, "hipMalloc failed"); }
     hipMemcpyAsync(d_hist, hist.data(), lmax, hipMemcpyHostToDevice, h->stream);
-    hipLaunchKernelGGL(k_edge_weights, dim3(1), dim3(64), 0, h->stream, p, h->L, h->cfg.marginal_term, h->lt,
-                       h->logm, h->cmask, d_hist, d_w, (int *)(d_w + 7));
+    if (h->cfg.storage == GH_STORAGE_F64)
+        hipLaunchKernelGGL(k_edge_weights<double>, dim3(1), dim3(64), 0, h->stream, (const double *)h->band, h->W,
+                           h->cfg.cond_mode, p, h->L, h->cfg.marginal_term, h->cnt, h->marg, h->nvalid, h->cmask,
+                           d_hist, d_w, (int *)(d_w + 7));
+    else
+        hipLaunchKernelGGL(k_edge_weights<float>, dim3(1), dim3(64), 0, h->stream, (const float *)h->band, h->W,
+                           h->cfg.cond_mode, p, h->L, h->cfg.marginal_term, h->cnt, h->marg, h->nvalid, h->cmask,
+                           d_hist, d_w, (int *)(d_w + 7));
     double hw[8];
     e = hipMemcpyAsync(hw, d_w, sizeof hw, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1040,7 +659,7 @@ extern "C" int gh_gap_check(gh_t *h, int *first_gap)
     if (set_dev(h)) return GH_ERR_HIP;
     int rc = ensure_marg(h);
     if (rc) return rc;
-    int *d_gap = &h->dstate->_pad;
+    int *d_gap = &h->dstate->scratch;
     int big = 0x7fffffff;
     HIPCHK(hipMemcpyAsync(d_gap, &big, 4, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_gap, dim3((h->N + 1 + 255) / 256), dim3(256), 0, h->stream, h->cnt, h->N, d_gap);
@@ -1068,31 +687,57 @@ extern "C" int gh_snapshot_original(gh_t *h)
     if (set_dev(h)) return GH_ERR_HIP;
     int rc = ensure_marg(h);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(h->logm0, h->logm, (size_t)(h->N + 2) * 8 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_snapshot, dim3(((h->N + 1) * 8 + 255) / 256), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N);
+    { int rc_ = post_launch(h, "k_snapshot"); if (rc_) return rc_; }
     h->have_orig = true;
     return GH_OK;
 }
 
 // path extension / reweight -------------------------------------------------------------------
-static int hist_len_for(int L)
+#define WALK_LDS_BUDGET (144 * 1024)
+#define WALK_THREADS 512
+#define WALK_MAX_LC 16
+
+static void launch_walk_src(int LC, size_t lds, hipStream_t stream, const walk_params &P)
 {
-    int hl = 16;
-    while (hl <= L) hl <<= 1;
-    return hl;
+#define GH_WALK_CASE(n)                                                                              \
+    case n:                                                                                          \
+        hipFuncSetAttribute((const void *)k_walk_src<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_walk_src<n>), dim3(1), dim3(WALK_THREADS), lds, stream, P);            \
+        break;
+    switch (LC) {
+        GH_WALK_CASE(1) GH_WALK_CASE(2) GH_WALK_CASE(3) GH_WALK_CASE(4)
+        GH_WALK_CASE(5) GH_WALK_CASE(6) GH_WALK_CASE(7) GH_WALK_CASE(8)
+        GH_WALK_CASE(9) GH_WALK_CASE(10) GH_WALK_CASE(11) GH_WALK_CASE(12)
+        GH_WALK_CASE(13) GH_WALK_CASE(14) GH_WALK_CASE(15) GH_WALK_CASE(16)
+    }
+#undef GH_WALK_CASE
 }
 
-static int launch_walk(gh_handle *h, const double *logm0, uint8_t *d_path, gh_path_rec *d_rec, double min_remove)
+static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove)
 {
     walk_params P;
-    P.N = h->N; P.L = h->L; P.marginal_term = h->cfg.marginal_term;
-    P.lt = h->lt; P.marg = h->marg; P.logm = h->logm; P.logm0 = logm0; P.cmask = h->cmask;
+    P.N = h->N; P.L = h->L;
+    P.G = h->lt; P.minfo = h->minfo;
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
-    P.hist_len = hist_len_for(h->L);
+    const size_t blk = (size_t)h->L * LT_BLK * sizeof(double);        // bytes per source position
+    int chunk = (int)((WALK_LDS_BUDGET / 2) / blk);
+    if (chunk > 64) chunk = 64;
+    chunk = (chunk / h->L) * h->L;                                    // whole unrolled groups
     prof_begin(h, GH_K_WALK);
-    hipLaunchKernelGGL(k_walk, dim3(1), dim3(64), (size_t)P.hist_len, h->stream, P);
-    // algorithmic bytes: per step the marginal cell's tables + L table rows of 7 doubles
-    prof_end(h, GH_K_WALK, (double)h->N * ((double)h->L * 56.0 + 3 * 56.0 + 4.0 + 1.0));
-    HIPCHK(hipGetLastError());
+    if (h->L <= WALK_MAX_LC && chunk >= h->L) {
+        P.chunk = chunk;
+        const size_t lds = 2 * (size_t)chunk * blk + 2 * 64 * sizeof(unsigned long long);
+        launch_walk_src(h->L, lds, h->stream, P);
+    } else {
+        int hl = 16;
+        while (hl <= h->L) hl <<= 1;
+        P.chunk = 0;
+        hipLaunchKernelGGL(k_walk_global, dim3(1), dim3(64), (size_t)hl, h->stream, P, hl);
+    }
+    // algorithmic bytes: per step one table row (L x 5 doubles) + the selected symbol's 3 marginal words + 1 path byte
+    prof_end(h, GH_K_WALK, (double)h->N * ((double)h->L * 40.0 + 24.0 + 1.0));
+    { int rc_ = post_launch(h, "k_walk"); if (rc_) return rc_; }
     return GH_OK;
 }
 
@@ -1117,7 +762,7 @@ static int launch_reweight(gh_handle *h, const uint8_t *d_path, double ratio, in
                            d_path, h->dstate, ratio, use_state, h->partial);
     hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec);
     prof_end(h, GH_K_REWEIGHT, (double)total * 2.0 * esize(h) + (double)(h->N + 1));
-    HIPCHK(hipGetLastError());
+    { int rc_ = post_launch(h, "k_reweight"); if (rc_) return rc_; }
     h->dirty_marg = h->dirty_lt = true;
     return GH_OK;
 }
@@ -1136,17 +781,20 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
     if (set_dev(h)) return GH_ERR_HIP;
     int rc = ensure_lt(h);
     if (rc) return rc;
-    const double *logm0 = h->have_orig ? h->logm0 : h->logm;
+    const int nb8 = ((h->N + 1) * 8 + 255) / 256;
     if (original && original != h) {
         gh_handle *o = const_cast<gh_handle *>(original);
         if (o->N != h->N) return fail(GH_ERR_ARG, "original has %d SNPs, hansel has %d", o->N, h->N);
         if (o->dev != h->dev) return fail(GH_ERR_ARG, "original lives on another device");
         if ((rc = ensure_marg(o))) return rc;
         HIPCHK(hipStreamSynchronize(o->stream));
-        logm0 = o->logm;
+        hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, o->minfo, h->N);
+        h->have_orig = true;
+    } else if (!h->have_orig) {
+        hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N);
     }
     if ((rc = reset_spin_state(h))) return rc;
-    if ((rc = launch_walk(h, logm0, h->d_path, h->d_rec, 0.0))) return rc;
+    if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0))) return rc;
     dev_state hs;
     gh_path_rec rec;
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
@@ -1197,7 +845,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     rc = reset_spin_state(h);
     for (int s = 0; s < max_paths && rc == GH_OK; s++) {
         if ((rc = ensure_lt(h))) break;
-        if ((rc = launch_walk(h, h->logm0, d_paths + n1 * s, d_recs + s, min_remove))) break;
+        if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove))) break;
         if ((rc = launch_reweight(h, d_paths + n1 * s, 0.0, 1, d_recs + s))) break;
     }
     dev_state hs;

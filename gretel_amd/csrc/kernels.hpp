@@ -1,0 +1,656 @@
+// kernels.hpp -- the gfx950 kernels of the Gretel hot path (included by gretel_hip.hip).
+//
+// Symbol indices (reference order, gretel/util.py:83):  A0 C1 G2 T3 N4 -5 _6.
+// "Compact" indices used by the path-extension tables:
+//     to-symbols   (candidates, the 5 valid symbols)      b5: A0 C1 G2 T3 -4
+//     from-symbols (what a path can contain)              a6: A0 C1 G2 T3 -4 _5
+//
+// Tables rebuilt from the band before every path:
+//   cnt[p][8], marg[p][8]   f64   c_s(p) (s<7), [7]=total ; c_s/total          (lookup API)
+//   nvalid[p] i32, cmask[p] u32   V(p), candidate bitmask over the 7 symbols     (lookup API)
+//   minfo[p][16] f64              [0..4] log10 marginal of b5, [5..9] marginal of b5,
+//                                 [10] candidate bitmask over b5 (as u64 bits),
+//                                 [11..15] log10 ORIGINAL marginal of b5 (written by the snapshot)
+//   G[i][a6][l-1][b5] f64         source-major conditional table, see k_lt
+#pragma once
+
+#define NSYM 7
+#define CELL 49
+#define SYM_N 4
+#define SYM_US 6
+#define VALID_MASK 0x2Fu /* A C G T - : bits 0,1,2,3,5 */
+#define LT_ROW 5
+#define LT_BLK 30        /* 6 from-symbols x 5 to-symbols */
+#define MINFO 16
+
+struct dev_state {
+    int stop;        // set by the walker at a hole: later launches of the spin become no-ops
+    int hole_at;
+    int n_done;
+    int scratch;
+    double ratio;    // clamped min marginal of the path just walked
+    unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
+    int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish
+    int _pad;
+};
+
+__constant__ int8_t c_sym_of_char[256];
+
+__device__ __forceinline__ int vsym(int b5) { return b5 < 4 ? b5 : 5; }            // b5 -> symbol
+__device__ __forceinline__ int fsym(int a6) { return a6 < 4 ? a6 : a6 + 1; }       // a6 -> symbol (4->5, 5->6)
+__device__ __forceinline__ int a6_of_sym(int s) { return s < 4 ? s : s - 1; }      // symbol -> a6 (5->4, 6->5); N invalid
+
+template <typename T>
+__device__ __forceinline__ double rowsum(const T *cell, int a)
+{
+    T acc = (T)0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) acc = acc + cell[a * NSYM + x];
+    return (double)acc;
+}
+
+template <typename T>
+__device__ __forceinline__ double colsum(const T *cell, int b)
+{
+    T acc = (T)0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) acc = acc + cell[x * NSYM + b];
+    return (double)acc;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// hansel conditional, shared by the table builder and the per-call lookup
+template <typename T>
+__device__ __forceinline__ double log_conditional(const T *__restrict__ band, int W, int cond_mode,
+                                                  const double *__restrict__ cnt,
+                                                  const int32_t *__restrict__ nvalid, int a, int b, int i, int j)
+{
+    const int l = j - i;
+    double obs = 0.0, sum = 0.0;
+    if (l <= W) {
+        const T *cell = band + ((size_t)i * W + (l - 1)) * CELL;
+        obs = (double)cell[a * NSYM + b];
+        if (cond_mode == GH_COND_A) sum = rowsum(cell, a);
+        else if (cond_mode == GH_COND_C) sum = colsum(cell, b);
+    }
+    double den;
+    if (cond_mode == GH_COND_A) den = (double)nvalid[j] + sum;
+    else if (cond_mode == GH_COND_B) den = (double)nvalid[i] + cnt[(size_t)i * 8 + a];
+    else den = (double)nvalid[i] + sum;
+    return gh_log10((1.0 + obs) / den);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fill: gretel/util.py:226-286, one thread per read, float atomics (+1 is exact and
+// order-independent up to 2^24, where float32 += 1 saturates exactly like NumPy's).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void add_obs(T *band, int N, int W, int a, int b, int i, int j,
+                                        unsigned long long *oob)
+{
+    int d = j - i;
+    if (d < 1 || d > W || i < 0 || j > N + 1) {
+        atomicAdd(oob, 1ULL);
+        return;
+    }
+    atomicAdd(&band[((size_t)i * W + (d - 1)) * CELL + a * NSYM + b], (T)1);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fill(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank,
+       const int64_t *__restrict__ off, const uint8_t *__restrict__ bases, int64_t n_reads,
+       int use_end_sentinels, dev_state *st)
+{
+    __shared__ unsigned long long s_acc[3];
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+
+    unsigned long long slices = 0, crumbs = 0, covered = 0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t o0 = off[r];
+        const int k = (int)(off[r + 1] - o0);
+        if (!(k > 1)) continue;                                  // util.py:230
+        const int rk = rank[r];
+        const uint8_t *s = bases + o0;
+        slices++;                                                // util.py:233
+        bool bad = false;
+        for (int i = 0; i < k; i++) {
+            int c = s[i];
+            if (c_sym_of_char[c] < 0) bad = true;
+            if (c != 'N' && c != '_') covered++;                 // util.py:239
+        }
+        if (bad) { atomicAdd(&st->fill[3], 1ULL); continue; }
+        for (int i = 0; i < k; i++) {
+            const int a = c_sym_of_char[s[i]];
+            if (a == SYM_US || a == SYM_N) continue;             // util.py:258
+            for (int j = i + 1; j < k; j++) {
+                const int b = c_sym_of_char[s[j]];
+                if (i == 0 && j == 1 && rk == 0) {               // util.py:262
+                    add_obs(band, N, W, SYM_US, a, 0, 1, &st->fill[4]);
+                    add_obs(band, N, W, a, b, 1, 2, &st->fill[4]);
+                } else if ((j + rk + 1) == N && (j - i) == 1) {  // util.py:271
+                    add_obs(band, N, W, a, b, N - 1, N, &st->fill[4]);
+                    add_obs(band, N, W, b, SYM_US, N, N + 1, &st->fill[4]);
+                } else {                                         // util.py:279
+                    add_obs(band, N, W, a, b, i + rk + 1, j + rk + 1, &st->fill[4]);
+                    if (use_end_sentinels && j == k - 1 && (j - i) == 1)      // util.py:283
+                        add_obs(band, N, W, b, SYM_US, j + rk + 1, j + rk + 2, &st->fill[4]);
+                }
+                crumbs++;
+            }
+        }
+    }
+    atomicAdd(&s_acc[0], slices);
+    atomicAdd(&s_acc[1], crumbs);
+    atomicAdd(&s_acc[2], covered);
+    __syncthreads();
+    if (threadIdx.x < 3 && s_acc[threadIdx.x]) atomicAdd(&st->fill[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+template <typename T>
+__global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a, const uint8_t *b,
+                            const int32_t *i, const int32_t *j, int64_t n, dev_state *st)
+{
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    if (a[q] >= NSYM || b[q] >= NSYM) { atomicAdd(&st->fill[3], 1ULL); return; }
+    add_obs(band, N, W, a[q], b[q], i[q], j[q], &st->fill[4]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_marg: counts / marginals / candidate masks for every position p in [0, N]
+// (hansel get_counts_at + get_marginal_of_at, call sites gretel/cmd.py:86, gretel/gretel.py:182)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_marg(const T *__restrict__ band, int N, int W, double *__restrict__ cnt, double *__restrict__ marg,
+       int32_t *__restrict__ nvalid, uint32_t *__restrict__ cmask, double *__restrict__ minfo, dev_state *st)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t >> 3, s = t & 7;
+    if (p > N) return;
+    const T *cell = band + ((size_t)p * W) * CELL;       // cell (p, p+1)
+    double c[NSYM];
+    double tot = 0.0;
+    int nv = 0;
+    uint32_t cm = 0, cm5 = 0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) {
+        c[x] = rowsum(cell, x);
+        if (c[x] > 0) {
+            tot += c[x];
+            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; cm5 |= 1u << a6_of_sym(x); }
+        }
+    }
+    if (s < NSYM) {
+        const double m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
+        cnt[(size_t)p * 8 + s] = c[s];
+        marg[(size_t)p * 8 + s] = m;
+        if ((VALID_MASK >> s) & 1) {
+            const int b5 = a6_of_sym(s);
+            minfo[(size_t)p * MINFO + b5] = gh_log10(m);
+            minfo[(size_t)p * MINFO + 5 + b5] = m;
+        }
+    } else {
+        cnt[(size_t)p * 8 + 7] = tot;
+        marg[(size_t)p * 8 + 7] = 0.0;
+        nvalid[p] = nv;
+        cmask[p] = cm;
+        minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
+        if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
+    }
+}
+
+// freeze the current log-marginals as the original ones (slot [11..15] of minfo)
+__global__ void k_snapshot(double *__restrict__ dst_minfo, const double *__restrict__ src_minfo, int N)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int p = t >> 3, q = t & 7;
+    if (p > N || q >= 5) return;
+    dst_minfo[(size_t)p * MINFO + 11 + q] = src_minfo[(size_t)p * MINFO + q];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lt: the conditional table, SOURCE-major:
+//   G[i][a6][l-1][b5]  (i = source position 0..N-1, target snp = i+l)
+//     = -inf                                   if b5 is not a candidate at snp (bakes the
+//                                              candidate mask of gretel.py:166-174 into the sum)
+//     = log10( (1 + H[a,b,i,snp]) / den )      otherwise   (+ log10 marginal(b,snp) pre-added
+//                                              to the lag-1 entry when marginal_term is on:
+//                                              (0.0 + lm) + x1 == lm + x1 bit for bit)
+//     = 0.0                                    for snp > N, i >= N (padding) and rows a path can
+//                                              never select ('_' anywhere but position 0)
+// One row G[i][a6] (L x 5 doubles) is everything position i contributes to the next L steps once
+// symbol a6 has been selected there: the walker reads exactly one row per step.
+// ---------------------------------------------------------------------------------------------
+#define LT_PAD 16      /* zero source blocks behind N so the unrolled walker may overrun */
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_lt(const T *__restrict__ band, int N, int W, int L, int cond_mode, int marginal_term,
+     const double *__restrict__ cnt, const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmask,
+     const double *__restrict__ minfo, double *__restrict__ G)
+{
+    const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const int b5 = (int)(t % LT_ROW);
+        size_t r = t / LT_ROW;
+        const int l = (int)(r % L) + 1;
+        r /= L;
+        const int a6 = (int)(r % 6);
+        const int i = (int)(r / 6);
+        const int snp = i + l;
+        double v = 0.0;
+        if (i < N && snp <= N && (a6 < 5 || i == 0)) {
+            const int b = vsym(b5);
+            if (!((cmask[snp] >> b) & 1)) {
+                v = -INFINITY;
+            } else {
+                v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(a6), b, i, snp);
+                if (marginal_term && l == 1) v = minfo[(size_t)snp * MINFO + b5] + v;
+            }
+        }
+        G[t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_walk_src: gretel/gretel.py:143-189 as one workgroup of 8 wavefronts:
+//   wave 0     the walker: N dependent steps, one LDS row read + (L-1) adds + a 3-level DPP
+//              max + ballot per step; fully unrolled over LC steps so that the L(L-1)/2 live
+//              lag terms rotate through registers by renaming, not by moves
+//   wave 1     the bookkeeper: one chunk behind the walker, turns the selected symbols into
+//              path bytes and the sequential log10-marginal sums (gretel.py:182-186)
+//   waves 2-7  the loaders: stream the next chunk of G from L2/HBM into the other LDS buffer
+// ---------------------------------------------------------------------------------------------
+struct walk_params {
+    int N, L;
+    int chunk;                // source positions per LDS buffer (multiple of L, <= 64)
+    const double *G;          // [(N+LT_PAD)][6][L][5]
+    const double *minfo;      // [N+2][16]
+    uint8_t *path_out;        // device [N+1]
+    gh_path_rec *rec;         // device
+    dev_state *st;
+    double min_remove;
+};
+
+__device__ __forceinline__ void copy_to_lds(double *dst, const double *src, size_t n_dbl, int tid, int nthr)
+{
+    // both sides are 16-byte aligned and n_dbl is even; 8 x 16-byte loads in flight per lane
+    const double2 *s = reinterpret_cast<const double2 *>(src);
+    double2 *d = reinterpret_cast<double2 *>(dst);
+    const unsigned n = (unsigned)(n_dbl >> 1), step = (unsigned)nthr * 8u;
+    unsigned q0 = 0;
+    for (; q0 + step <= n; q0 += step) {
+        const unsigned q = q0 + (unsigned)tid;
+        const double2 v0 = s[q], v1 = s[q + nthr], v2 = s[q + 2 * nthr], v3 = s[q + 3 * nthr];
+        const double2 v4 = s[q + 4 * nthr], v5 = s[q + 5 * nthr], v6 = s[q + 6 * nthr], v7 = s[q + 7 * nthr];
+        d[q] = v0; d[q + nthr] = v1; d[q + 2 * nthr] = v2; d[q + 3 * nthr] = v3;
+        d[q + 4 * nthr] = v4; d[q + 5 * nthr] = v5; d[q + 6 * nthr] = v6; d[q + 7 * nthr] = v7;
+    }
+    for (unsigned q = q0 + (unsigned)tid; q < n; q += (unsigned)nthr) d[q] = s[q];
+}
+
+// max without the sNaN-quieting v_max(x,x) pair the compiler adds around fmax
+__device__ __forceinline__ double vmax_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// arg-max over lanes 0..7 of each row, lowest lane among the maxima: gretel.py:166-174
+// (first candidate is the incumbent, later ones win on strict >).  Non-candidates carry -inf.
+__device__ __forceinline__ int argmax8(double acc)
+{
+    double m = acc;
+    m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
+    m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
+    m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
+    const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+    return (int)__builtin_ctzll(win);
+}
+
+struct walk_totals {
+    double hp_cur, hp_orig, minm;
+};
+
+// bookkeeper: lanes = steps of one chunk; gather in parallel, accumulate strictly in step order
+__device__ __forceinline__ void book_chunk(const walk_params &P, const unsigned long long *words, int LC, int s0, int ns,
+                                           int lane, walk_totals &T)
+{
+    double lm = 0.0, lm0 = 0.0, mg = 0.0;
+    if (lane < ns) {
+        const int t = s0 + lane;                        // target SNP of chunk-local step `lane`
+        const unsigned long long word = words[lane / LC];
+        const int w = (int)((word >> (4 * (LC - 1 - lane % LC))) & 15ull);
+        const double *inf = P.minfo + (size_t)t * MINFO;
+        lm = inf[w];
+        mg = inf[5 + w];
+        lm0 = inf[11 + w];
+        P.path_out[t] = (uint8_t)vsym(w);
+    }
+    for (int j = 0; j < ns; j++) {
+        const double m = readlane_f64(mg, j);           // gretel.py:182
+        if (m < T.minm) T.minm = m;
+        T.hp_cur += readlane_f64(lm, j);                // gretel.py:185
+        T.hp_orig += readlane_f64(lm0, j);              // gretel.py:186
+    }
+}
+
+template <int LC>
+__global__ void __launch_bounds__(512) k_walk_src(walk_params P)
+{
+    extern __shared__ __align__(16) double smem[];
+    dev_state *st = P.st;
+    if (st->stop) return;
+    constexpr int L = LC;
+    constexpr int ROW = L * LT_ROW;                 // doubles per (source, a6) row
+    constexpr int BLK = 6 * ROW;                    // doubles per source position
+    const int C = P.chunk;
+    double *const g0 = smem;
+    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)C * BLK);
+#define LDS_G(k) (g0 + (size_t)((k) & 1) * C * BLK)
+#define LDS_W(k) (words0 + ((k) & 1) * 64)
+
+    const int first_hole = st->first_hole;
+    const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;      // steps that can be decided
+    const int nchunks = (Nw + C - 1) / C;                         // chunk k = sources k*C .. k*C+C-1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform role
+
+    auto load_chunk = [&](int k, int t, int nt) {
+        // whole chunks: G is padded with LT_PAD zero blocks, and C <= 64 never outruns N+LT_PAD by more than
+        // the walker touches -- clip to the allocation all the same
+        const int i0 = k * C;
+        int nsrc = P.N + LT_PAD - i0;
+        if (nsrc > C) nsrc = C;
+        copy_to_lds(LDS_G(k), P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
+    };
+
+    if (nchunks > 0) load_chunk(0, tid, (int)blockDim.x);
+    __syncthreads();
+
+    if (wave >= 2) {
+        for (int k = 0; k < nchunks; k++) {
+            if (k + 1 < nchunks) load_chunk(k + 1, tid - 128, (int)blockDim.x - 128);
+            __syncthreads();
+        }
+        return;
+    }
+
+    if (wave == 1) {
+        walk_totals T = {0.0, 0.0, INFINITY};
+        if (lane == 0) P.path_out[0] = SYM_US;
+        for (int k = 0; k < nchunks; k++) {
+            if (k > 0) {
+                const int s0 = (k - 1) * C + 1;
+                book_chunk(P, LDS_W(k - 1), LC, s0, C, lane, T);
+            }
+            __syncthreads();
+        }
+        if (nchunks > 0) {
+            const int s0 = (nchunks - 1) * C + 1;
+            book_chunk(P, LDS_W(nchunks - 1), LC, s0, Nw - s0 + 1, lane, T);
+        }
+        if (lane == 0) {
+            if (first_hole <= P.N) {                                  // gretel.py:176-180
+                st->stop = 1;
+                st->hole_at = first_hole;
+            } else {
+                double r = T.minm;
+                if (r < P.min_remove) r = P.min_remove;               // cmd.py:157-160
+                P.rec->hp_current = T.hp_cur;
+                P.rec->hp_original = T.hp_orig;
+                P.rec->ratio = T.minm;
+                P.rec->magnitude = 0.0;
+                st->ratio = r;
+                st->n_done += 1;
+            }
+        }
+        return;
+    }
+
+    // ---- walker -------------------------------------------------------------------------------
+    const int bb = (lane & 7) < 5 ? (lane & 7) : 0;
+    double Y[LC][LC];                       // Y[slot][l-1]: lag-l term loaded at step slot (mod LC)
+#pragma unroll
+    for (int u = 0; u < LC; u++)
+#pragma unroll
+        for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
+    int wprev = 5;                          // path[0] = '_'
+
+    for (int k = 0; k < nchunks; k++) {
+        const double *gb = LDS_G(k) + bb;
+        unsigned long long *wk = LDS_W(k);
+        const int ngroups = C / LC;
+        for (int g = 0; g < ngroups; g++) {
+            unsigned long long word = 0;   // 4 bits per step, LC <= 16 steps per group
+#pragma unroll
+            for (int u = 0; u < LC; u++) {
+                // source i = k*C + g*LC + u, target t = i + 1
+                const double *row = gb + (size_t)(g * LC + u) * BLK + wprev * ROW;
+#pragma unroll
+                for (int l = 0; l < LC; l++) Y[u][l] = row[l * LT_ROW];
+                double acc = Y[u][0];
+#pragma unroll
+                for (int l = 1; l < LC; l++) acc += Y[(u - l + LC) % LC][l];      // l ascending
+                const int w = argmax8(acc);
+                word = (word << 4) + (unsigned long long)w;
+                wprev = w;
+            }
+            wk[g] = word;
+        }
+        __syncthreads();
+    }
+#undef LDS_G
+#undef LDS_W
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_walk_global: the same walk with G read straight from global memory by one wavefront.
+// Fallback for L > 16 (register rotation no longer fits); not a fast path.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len)
+{
+    extern __shared__ uint8_t lpath[];
+    dev_state *st = P.st;
+    if (st->stop) return;
+    const int lane = threadIdx.x;
+    const int hmask = hist_len - 1;
+    const int L = P.L;
+    const size_t ROW = (size_t)L * LT_ROW, BLK = 6 * ROW;
+    const int first_hole = st->first_hole;
+    const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;
+    double hp_cur = 0.0, hp_orig = 0.0, minm = INFINITY;
+    const int bb = (lane & 7) < 5 ? (lane & 7) : 0;
+
+    if (lane == 0) { lpath[0] = 5; P.path_out[0] = SYM_US; }
+    __syncthreads();
+
+    for (int snp = 1; snp <= Nw; snp++) {
+        const int lmax = L < snp ? L : snp;
+        double acc = 0.0;
+        for (int l0 = 1; l0 <= lmax; l0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int l = l0 + q;
+                x[q] = 0.0;
+                if (l <= lmax)
+                    x[q] = P.G[(size_t)(snp - l) * BLK + lpath[(snp - l) & hmask] * ROW + (size_t)(l - 1) * LT_ROW + bb];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (l0 + q <= lmax) acc += x[q];
+        }
+        const int w = __builtin_amdgcn_readfirstlane(argmax8(acc));
+        const double *inf = P.minfo + (size_t)snp * MINFO;
+        const double mg = inf[5 + w];
+        if (mg < minm) minm = mg;
+        hp_cur += inf[w];
+        hp_orig += inf[11 + w];
+        if (lane == 0) {
+            lpath[snp & hmask] = (uint8_t)w;
+            P.path_out[snp] = (uint8_t)vsym(w);
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (first_hole <= P.N) {
+            st->stop = 1;
+            st->hole_at = first_hole;
+        } else {
+            double r = minm;
+            if (r < P.min_remove) r = P.min_remove;
+            P.rec->hp_current = hp_cur;
+            P.rec->hp_original = hp_orig;
+            P.rec->ratio = minm;
+            P.rec->magnitude = 0.0;
+            st->ratio = r;
+            st->n_done += 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reweight: gretel/gretel.py:79-98 restricted to the band (all other cells are zero and
+// stay zero).  Multiplicities of the reference's pair enumeration:
+//   (p,p+1), p <= N-2 : twice      (N-1,N) : once      (p,q), q-p>=2, q <= N-1 : once
+//   (p,N), p < N-1    : never      (N,N+1) with symbols (path[N], path[0]) : once
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_reweight(T *__restrict__ band, int N, int W, const uint8_t *__restrict__ path,
+           const dev_state *st, double ratio_arg, int use_state_ratio, double *__restrict__ partial)
+{
+    __shared__ double s_red[256];
+    double removed = 0.0;
+    if (!(use_state_ratio && st->stop)) {
+        const double ratio = use_state_ratio ? st->ratio : ratio_arg;
+        const size_t total = (size_t)(N + 1) * W;
+        const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < total) {
+            const int i = (int)(t / W);
+            const int d = (int)(t % W) + 1;
+            const int j = i + d;
+            int mult = 0;
+            if (j <= N - 1) mult = (d == 1) ? 2 : 1;
+            else if (j == N) mult = (d == 1) ? 1 : 0;
+            else if (j == N + 1) mult = (i == N) ? 1 : 0;
+            if (mult) {
+                const int a = path[i];
+                const int b = (j == N + 1) ? path[0] : path[j];
+                T *p = band + ((size_t)i * W + (d - 1)) * CELL + a * NSYM + b;
+                T cur = *p;
+                for (int q = 0; q < mult; q++) {
+                    const double old = (double)cur;
+                    const double nw = old - ratio * old;
+                    cur = (T)nw;
+                    removed += old - nw;
+                }
+                *p = cur;
+            }
+        }
+    }
+    // fixed-order tree so the sum is run-to-run reproducible
+    s_red[threadIdx.x] = removed;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+
+__global__ void __launch_bounds__(256)
+k_reweight_finish(const double *__restrict__ partial, int nb, dev_state *st, int use_state,
+                  gh_path_rec *rec)
+{
+    __shared__ double s_red[256];
+    if (use_state && st->stop) return;
+    double acc = 0.0;
+    for (int q = threadIdx.x; q < nb; q += 256) acc += partial[q];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        rec->magnitude = s_red[0];
+        if (use_state) rec->ratio = st->ratio;
+        st->first_hole = 0x7fffffff;          // re-armed for the k_marg that follows the reweight
+    }
+}
+
+// one-cell helpers ----------------------------------------------------------------------------
+template <typename T>
+__global__ void k_reweight_one(T *p, double ratio, double *removed)
+{
+    const double old = (double)*p;
+    const double nw = old - ratio * old;
+    *p = (T)nw;
+    *removed = old - nw;
+}
+
+template <typename T>
+__global__ void k_export(const T *__restrict__ band, double *__restrict__ out, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = (double)band[t];
+}
+
+template <typename T>
+__global__ void k_import(T *__restrict__ band, const double *__restrict__ in, size_t n)
+{
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) band[t] = (T)in[t];
+}
+
+// hansel get_edge_weights_at for an arbitrary host-supplied history (compat API; one wave,
+// straight from the band so that any symbol -- N included -- may sit in the history)
+template <typename T>
+__global__ void k_edge_weights(const T *__restrict__ band, int W, int cond_mode, int p, int L, int marginal_term,
+                               const double *__restrict__ cnt, const double *__restrict__ marg,
+                               const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmask,
+                               const uint8_t *__restrict__ hist /* hist[l-1] = path[p-l] */,
+                               double *w, int *mask)
+{
+    const int lane = threadIdx.x;
+    const uint32_t cm = cmask[p];
+    if (lane == 0) *mask = (int)cm;
+    if (lane >= NSYM) return;
+    double acc = 0.0;
+    if ((cm >> lane) & 1) {
+        if (marginal_term) acc += gh_log10(marg[(size_t)p * 8 + lane]);
+        const int lmax = L < p ? L : p;
+        for (int l = 1; l <= lmax; l++)
+            acc += log_conditional(band, W, cond_mode, cnt, nvalid, hist[l - 1], lane, p - l, p);
+    }
+    w[lane] = acc;
+}
+
+__global__ void k_gap(const double *cnt, int N, int *first_gap)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > N) return;
+    if (cnt[(size_t)p * 8 + 7] == 0.0) atomicMin(first_gap, p);
+}

@@ -94,15 +94,14 @@ class Hansel:
 
     def _ensure(self, need_band=1):
         """Make the device tensor exist with band >= need_band and no staged observations."""
-        if self._staged:
-            need_band = max(need_band, max(j - i for (_, _, i, j) in self._staged))
+        st, self._staged = self._staged, []
+        if st:
+            need_band = max(need_band, max(j - i for (_, _, i, j) in st))
         if self._h is None:
             self._create(need_band)
         elif need_band > self._band:
             self._reband(need_band)
-        if self._staged:
-            st = self._staged
-            self._staged = []
+        if st:
             a = np.array([s[0] for s in st], dtype=np.uint8)
             b = np.array([s[1] for s in st], dtype=np.uint8)
             i = np.array([s[2] for s in st], dtype=np.int32)

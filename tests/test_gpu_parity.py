@@ -242,7 +242,7 @@ def test_per_cell_api_and_lazy_band():
     assert h.band == 4
     h.add_observation('G', 'G', 2, 9)                     # wider than the band: re-banded
     ph.add_observation('G', 'G', 2, 9)
-    assert h.band == 7 and h.get_observation('G', 'G', 2, 9) == 1 and h.get_observation('A', 'C', 1, 2) == 2
+    assert h.get_observation('G', 'G', 2, 9) == 1 and h.band == 7 and h.get_observation('A', 'C', 1, 2) == 2
     for (a, b, i, j) in obs[:3]:
         r1 = h.reweight_observation(a, b, i, j, 0.3)
         r2 = ph.reweight_observation(a, b, i, j, 0.3)
