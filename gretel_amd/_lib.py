@@ -100,6 +100,7 @@ def load():
         "gh_profile_reset": [vp],
         "gh_profile_get": [vp, i32, P(dbl), P(i64)],
         "gh_profile_bytes": [vp, i32, P(dbl)],
+        "gh_debug_walk_clock": [vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(L, name)          # AttributeError if the ABI drifted

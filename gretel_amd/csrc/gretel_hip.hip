@@ -542,7 +542,7 @@ static int ensure_marg(gh_handle *h)
     const int threads = (h->N + 1) * 8;
     const int block = 256;
     // re-arm the "first SNP without a candidate" word that k_marg min-reduces into
-    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, 2 * sizeof(int), h->stream));   // first_hole and nodel
     prof_begin(h, GH_K_MARG);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_marg<double>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
@@ -698,13 +698,21 @@ extern "C" int gh_snapshot_original(gh_t *h)
 #define WALK_THREADS 512
 #define WALK_MAX_LC 16
 
-static void launch_walk_src(int LC, size_t lds, hipStream_t stream, const walk_params &P)
+template <int LC>
+static void launch_walk_lc(bool spec, size_t lds, hipStream_t stream, const walk_params &P)
 {
-#define GH_WALK_CASE(n)                                                                              \
-    case n:                                                                                          \
-        hipFuncSetAttribute((const void *)k_walk_src<n>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_walk_src<n>), dim3(1), dim3(WALK_THREADS), lds, stream, P);            \
-        break;
+    if (spec) {
+        hipFuncSetAttribute((const void *)k_walk_spec<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_walk_spec<LC>), dim3(1), dim3(WALK_THREADS), lds, stream, P);
+    } else {
+        hipFuncSetAttribute((const void *)k_walk_src<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_walk_src<LC>), dim3(1), dim3(WALK_THREADS), lds, stream, P);
+    }
+}
+
+static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, const walk_params &P)
+{
+#define GH_WALK_CASE(n) case n: launch_walk_lc<n>(spec, lds, stream, P); break;
     switch (LC) {
         GH_WALK_CASE(1) GH_WALK_CASE(2) GH_WALK_CASE(3) GH_WALK_CASE(4)
         GH_WALK_CASE(5) GH_WALK_CASE(6) GH_WALK_CASE(7) GH_WALK_CASE(8)
@@ -721,14 +729,16 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
     P.G = h->lt; P.minfo = h->minfo;
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
     const size_t blk = (size_t)h->L * LT_BLK * sizeof(double);        // bytes per source position
-    int chunk = (int)((WALK_LDS_BUDGET / 2) / blk);
+    int chunk = (int)((WALK_LDS_BUDGET / 2) / blk) - 1;                // k_walk_spec keeps one extra block per buffer
     if (chunk > 64) chunk = 64;
     chunk = (chunk / h->L) * h->L;                                    // whole unrolled groups
     prof_begin(h, GH_K_WALK);
     if (h->L <= WALK_MAX_LC && chunk >= h->L) {
         P.chunk = chunk;
-        const size_t lds = 2 * (size_t)chunk * blk + 2 * 64 * sizeof(unsigned long long);
-        launch_walk_src(h->L, lds, h->stream, P);
+        const size_t lds = 2 * (size_t)(chunk + 1) * blk + 2 * 64 * sizeof(unsigned long long);
+        // GH_WALK=src selects the non-speculative walker (A/B measurements); default: depth-1 speculation
+        static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
+        launch_walk_src(h->L, spec, lds, h->stream, P);
     } else {
         int hl = 16;
         while (hl <= h->L) hl <<= 1;
@@ -953,6 +963,17 @@ extern "C" int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *la
     prof_collect(h);
     if (total_ms) *total_ms = h->ps[kernel].ms;
     if (launches) *launches = h->ps[kernel].launches;
+    return GH_OK;
+}
+
+extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[3])
+{
+    if (!h || !out) return fail(GH_ERR_ARG, "null argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    dev_state hs;
+    HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out[0] = hs.dbg[0]; out[1] = hs.dbg[1]; out[2] = hs.dbg[2];
     return GH_OK;
 }
 

@@ -31,7 +31,8 @@ struct dev_state {
     double ratio;    // clamped min marginal of the path just walked
     unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
     int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish
-    int _pad;
+    int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)
+    unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
 };
 
 __constant__ int8_t c_sym_of_char[256];
@@ -214,6 +215,7 @@ k_marg(const T *__restrict__ band, int N, int W, double *__restrict__ cnt, doubl
         cmask[p] = cm;
         minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
         if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
+        if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
     }
 }
 
@@ -465,6 +467,171 @@ __global__ void __launch_bounds__(512) k_walk_src(walk_params P)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_walk_spec: the walker with depth-1 speculation.  Lane = (hypothesis group ga = lane>>3,
+// candidate b = lane&7).  While symbol w_j of position j is still being resolved, group ga
+// already evaluates target j+1 under the hypothesis w_j == ga: its lag-1 term is read with a
+// lane-constant LDS address (no dependence on the path), lags 2..L come from rows selected by
+// the symbols resolved one and more steps earlier.  All groups run the same adds and the same
+// DPP arg-max, so the hypotheses cost no extra instructions; one ballot holds every group's
+// winner and resolving w_{j+1} is a 64-bit shift by 8*w_j and a find-first-one.
+// The sums are the same IEEE additions in the same order as in k_walk_src: bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <bool NODEL>
+__device__ __forceinline__ unsigned long long group_argmax(double acc)
+{
+    double m = acc;
+    m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
+    m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
+    if (!NODEL) m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
+    return __builtin_amdgcn_ballot_w64(acc == m);
+}
+
+// bookkeeper for k_walk_spec: words are indexed by POSITION j (j0 = first position of the chunk)
+__device__ __forceinline__ void book_positions(const walk_params &P, const unsigned long long *words, int LC,
+                                               int j0, int ns, int Nw, int lane, walk_totals &T)
+{
+    double lm = 0.0, lm0 = 0.0, mg = INFINITY;
+    const int j = j0 + lane;
+    if (lane < ns && j >= 1 && j <= Nw) {
+        const unsigned long long word = words[lane / LC];
+        const int w = (int)((word >> (4 * (LC - 1 - lane % LC))) & 15ull);
+        const double *inf = P.minfo + (size_t)j * MINFO;
+        lm = inf[w];
+        mg = inf[5 + w];
+        lm0 = inf[11 + w];
+        P.path_out[j] = (uint8_t)vsym(w);
+    }
+    for (int s = 0; s < ns; s++) {
+        const double m = readlane_f64(mg, s);           // gretel.py:182
+        if (m < T.minm) T.minm = m;
+        T.hp_cur += readlane_f64(lm, s);                // gretel.py:185 (+0.0 for unused lanes)
+        T.hp_orig += readlane_f64(lm0, s);              // gretel.py:186
+    }
+}
+
+template <int LC, bool NODEL>
+__device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, unsigned long long *words0,
+                                            int C, int nchunks, int lane)
+{
+    constexpr int ROW = LC * LT_ROW;
+    constexpr int BLK = 6 * ROW;
+    const int b = lane & 7;
+    const int bb = NODEL ? (lane & 3) : (b < 5 ? b : 0);
+    const int ga = (lane >> 3) < 6 ? (lane >> 3) : 5;
+    double Y[LC][LC];                       // Y[slot][l]: lag-(l+1) term of the source resolved at `slot`
+#pragma unroll
+    for (int u = 0; u < LC; u++)
+#pragma unroll
+        for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
+    int wprev = 0;
+    unsigned long long B = 1ull << 5;       // "ballot" that resolves position 0 to '_' (a6 = 5)
+    // target 1 has a single lag: source 0 under the hypothesis w_0 == ga (only ga == '_' is ever used)
+    double acc = g0[bb + ga * ROW];
+
+    for (int k = 0; k < nchunks; k++) {
+        const double *gb = g0 + (size_t)(k & 1) * (C + 1) * BLK + bb;    // real rows: + w*ROW
+        const double *gh = gb + ga * ROW;                                 // hypothesis rows (lag 1)
+        unsigned long long *wk = words0 + (k & 1) * 64;
+        const int ngroups = C / LC;
+        for (int g = 0; g < ngroups; g++) {
+            unsigned long long word = 0;
+#pragma unroll
+            for (int u = 0; u < LC; u++) {
+                const int s = g * LC + u;                                  // position j = k*C + s
+                // resolve w_j from the ballot built for target j
+                const int w = (int)(__builtin_ctzll(B >> (8 * wprev)) & 7);
+                word = (word << 4) + (unsigned long long)w;
+                wprev = w;
+                // row of source j under its real symbol: lags 2..L of targets j+2..j+L
+                const double *row = gb + (size_t)s * BLK + w * ROW;
+#pragma unroll
+                for (int l = 1; l < LC; l++) Y[u][l] = row[l * LT_ROW];
+                // lag 1 of target j+2: source j+1 under every hypothesis (the chunk buffer carries one extra block)
+                const double hyp = gh[(size_t)(s + 1) * BLK];
+                // arg-max of target j+1 (sum finished in the previous iteration) ...
+                B = group_argmax<NODEL>(acc);
+                // ... while the sum of target j+2 starts: lag l+1 comes from the source resolved l-1 steps ago
+                acc = hyp;
+#pragma unroll
+                for (int l = 1; l < LC; l++) acc += Y[(u - (l - 1) + LC) % LC][l];   // l ascending
+            }
+            wk[g] = word;
+        }
+        __syncthreads();
+    }
+}
+
+template <int LC>
+__global__ void __launch_bounds__(512) k_walk_spec(walk_params P)
+{
+    extern __shared__ __align__(16) double smem[];
+    dev_state *st = P.st;
+    if (st->stop) return;
+    constexpr int BLK = 6 * LC * LT_ROW;
+    const int C = P.chunk;
+    double *const g0 = smem;
+    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + 1) * BLK);
+
+    const int first_hole = st->first_hole;
+    const bool nodel = st->nodel != 0;
+    const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;      // positions that can be decided
+    const int nchunks = (Nw + 1 + C - 1) / C;                     // positions 0..Nw, chunk k = k*C..k*C+C-1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    auto load_chunk = [&](int k, int t, int nt) {
+        const int i0 = k * C;
+        int nsrc = P.N + LT_PAD - i0;
+        if (nsrc > C + 1) nsrc = C + 1;      // one block of overlap: source j+1 of the chunk's last position
+        copy_to_lds(g0 + (size_t)(k & 1) * (C + 1) * BLK, P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
+    };
+
+    load_chunk(0, tid, (int)blockDim.x);
+    __syncthreads();
+
+    if (wave >= 2) {
+        for (int k = 0; k < nchunks; k++) {
+            if (k + 1 < nchunks) load_chunk(k + 1, tid - 128, (int)blockDim.x - 128);
+            __syncthreads();
+        }
+        return;
+    }
+    if (wave == 1) {
+        walk_totals T = {0.0, 0.0, INFINITY};
+        if (lane == 0) P.path_out[0] = SYM_US;
+        for (int k = 0; k < nchunks; k++) {
+            if (k > 0) book_positions(P, words0 + ((k - 1) & 1) * 64, LC, (k - 1) * C, C, Nw, lane, T);
+            __syncthreads();
+        }
+        book_positions(P, words0 + ((nchunks - 1) & 1) * 64, LC, (nchunks - 1) * C, C, Nw, lane, T);
+        if (lane == 0) {
+            if (first_hole <= P.N) {                                  // gretel.py:176-180
+                st->stop = 1;
+                st->hole_at = first_hole;
+            } else {
+                double r = T.minm;
+                if (r < P.min_remove) r = P.min_remove;               // cmd.py:157-160
+                P.rec->hp_current = T.hp_cur;
+                P.rec->hp_original = T.hp_orig;
+                P.rec->ratio = T.minm;
+                P.rec->magnitude = 0.0;
+                st->ratio = r;
+                st->n_done += 1;
+            }
+        }
+        return;
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    if (nodel) spec_walker<LC, true>(P, g0, words0, C, nchunks, lane);
+    else spec_walker<LC, false>(P, g0, words0, C, nchunks, lane);
+    if (lane == 0) {
+        st->dbg[0] = __builtin_amdgcn_s_memtime() - t0;          // shader cycles of the walk
+        st->dbg[1] = __builtin_amdgcn_s_memrealtime() - r0;      // 100 MHz ticks of the walk
+        st->dbg[2] = (unsigned long long)nchunks * C;            // steps executed
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_walk_global: the same walk with G read straight from global memory by one wavefront.
 // Fallback for L > 16 (register rotation no longer fits); not a fast path.
 // ---------------------------------------------------------------------------------------------
@@ -597,7 +764,6 @@ k_reweight_finish(const double *__restrict__ partial, int nb, dev_state *st, int
     if (threadIdx.x == 0) {
         rec->magnitude = s_red[0];
         if (use_state) rec->ratio = st->ratio;
-        st->first_hole = 0x7fffffff;          // re-armed for the k_marg that follows the reweight
     }
 }
 

@@ -365,6 +365,12 @@ class Hansel:
             out[name] = dict(ms=ms.value, launches=n.value, bytes_per_launch=by.value)
         return out
 
+    def walk_clock(self):
+        """(shader cycles, 100 MHz ticks, steps) of the walker wave in the last path-extension launch."""
+        out = (C.c_uint64 * 3)()
+        check(self._lib.gh_debug_walk_clock(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def sync(self):
         if self._h is not None:
             check(self._lib.gh_sync(self._h))

@@ -160,6 +160,9 @@ enum { GH_K_FILL = 0, GH_K_MARG = 1, GH_K_LT = 2, GH_K_WALK = 3, GH_K_REWEIGHT =
 int gh_profile_enable(gh_t *h, int on);
 int gh_profile_reset(gh_t *h);
 int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches);
+/* diagnostics of the last path-extension launch: out[0] = shader cycles (s_memtime) the walker wave spent,
+ * out[1] = the same interval in 100 MHz ticks (s_memrealtime), out[2] = steps it executed */
+int gh_debug_walk_clock(gh_t *h, uint64_t out[3]);
 /* algorithmic bytes of the last launch of each kernel */
 int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch);
 
