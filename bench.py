@@ -172,6 +172,7 @@ def main():
 
     if rank == 0:
         n, L = table.n_snps, h.L
+        cyc, ticks, nsteps = h.walk_clock()
         h.clear()
         h.fill_from_support(None, None, None, reads_handle=reads)
         cond_evals, rw_cells = edge_evals_per_path(h.candidate_masks(), n, L)
@@ -179,6 +180,15 @@ def main():
         walk = prof["walk"]
         walk_ms = walk["ms"] / max(1, walk["launches"])
         achieved = walk["bytes_per_launch"] / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected per the
+        # MI355X guide: separate --pmc runs, FETCH_SIZE x2 on gfx950); null when no profile matches
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            if cfg_name == "C3":
+                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("k_walk"))
+        except Exception:
+            traffic = None
         out = {
             "metric": "haplotypes/sec + SNP-edge-evals/sec on 10k-SNP synthetic contig",
             "value": hap_s,
@@ -202,10 +212,15 @@ def main():
                      "crumbs_per_s": stats[1] / (prof["fill"]["ms"] / max(1, prof["fill"]["launches"]) * 1e-3) if prof["fill"]["ms"] else None},
             "kernels_ms_per_launch": {k: (v["ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()},
             "kernels_launches": {k: v["launches"] for k, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_walk (path extension, serial chain over N SNPs)",
+            "roofline": {"bound": "hbm", "kernel": "k_walk_spec (path extension: N dependent steps, one wavefront walks)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "note": "latency-bound dependent chain: one wavefront, N sequential steps; see DESIGN.md"},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": walk["bytes_per_launch"],
+                         "avg_launch_ms_hip_events": walk_ms,
+                         "walker_cycles_per_step": (cyc / nsteps) if nsteps else None,
+                         "walker_clock_ghz": (cyc / (ticks * 10.0)) if ticks else None,
+                         "note": "dependency-chain bound, not bandwidth bound: each step needs the previous step's "
+                                 "arg-max (gretel.py:143-187); see DESIGN.md section 4 for the cycle budget per step"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_python(table, min(args.cpu_snps, n), n)
