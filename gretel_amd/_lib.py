@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libgretel_hip.so")
+SO_PATH = os.environ.get("GH_LIB") or os.path.join(_HERE, "libgretel_hip.so")   # GH_LIB: alternative build (A/B experiments)
 
 GH_OK = 0
 GH_ERR_ARG, GH_ERR_HIP, GH_ERR_BAND, GH_ERR_SYMBOL, GH_ERR_NOMEM, GH_ERR_STATE = -1, -2, -3, -4, -5, -6

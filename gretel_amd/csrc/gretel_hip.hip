@@ -695,7 +695,12 @@ extern "C" int gh_snapshot_original(gh_t *h)
 
 // path extension / reweight -------------------------------------------------------------------
 #define WALK_LDS_BUDGET (144 * 1024)
-#define WALK_THREADS 512
+static int walk_threads()
+{
+    static const int n = getenv("GH_WALK_THREADS") ? atoi(getenv("GH_WALK_THREADS")) : 512;
+    return (n >= 192 && n <= 512 && n % 64 == 0) ? n : 512;
+}
+#define WALK_THREADS walk_threads()
 #define WALK_MAX_LC 16
 
 template <int LC>
@@ -729,13 +734,13 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
     P.G = h->lt; P.minfo = h->minfo;
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
     const size_t blk = (size_t)h->L * LT_BLK * sizeof(double);        // bytes per source position
-    int chunk = (int)((WALK_LDS_BUDGET / 2) / blk) - 1;                // k_walk_spec keeps one extra block per buffer
+    int chunk = (int)((WALK_LDS_BUDGET / 2) / blk) - 2;                // k_walk_spec keeps two extra blocks per buffer
     if (chunk > 64) chunk = 64;
     chunk = (chunk / h->L) * h->L;                                    // whole unrolled groups
     prof_begin(h, GH_K_WALK);
     if (h->L <= WALK_MAX_LC && chunk >= h->L) {
         P.chunk = chunk;
-        const size_t lds = 2 * (size_t)(chunk + 1) * blk + 2 * 64 * sizeof(unsigned long long);
+        const size_t lds = 2 * (size_t)(chunk + 2) * blk + 2 * 64 * sizeof(unsigned long long);
         // GH_WALK=src selects the non-speculative walker (A/B measurements); default: depth-1 speculation
         static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
         launch_walk_src(h->L, spec, lds, h->stream, P);

@@ -384,7 +384,9 @@ __global__ void __launch_bounds__(512) k_walk_src(walk_params P)
         const int i0 = k * C;
         int nsrc = P.N + LT_PAD - i0;
         if (nsrc > C) nsrc = C;
+        if (nsrc < 0) nsrc = 0;
         copy_to_lds(LDS_G(k), P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
+        for (int q = nsrc * BLK + t; q < C * BLK; q += nt) LDS_G(k)[q] = 0.0;     // never walk over stale LDS bits
     };
 
     if (nchunks > 0) load_chunk(0, tid, (int)blockDim.x);
@@ -486,13 +488,13 @@ __device__ __forceinline__ unsigned long long group_argmax(double acc)
     return __builtin_amdgcn_ballot_w64(acc == m);
 }
 
-// bookkeeper for k_walk_spec: words are indexed by POSITION j (j0 = first position of the chunk)
+// bookkeeper for k_walk_spec: word g of a chunk holds the symbols of positions j0+g*LC+1 .. j0+g*LC+LC
 __device__ __forceinline__ void book_positions(const walk_params &P, const unsigned long long *words, int LC,
                                                int j0, int ns, int Nw, int lane, walk_totals &T)
 {
     double lm = 0.0, lm0 = 0.0, mg = INFINITY;
-    const int j = j0 + lane;
-    if (lane < ns && j >= 1 && j <= Nw) {
+    const int j = j0 + lane + 1;
+    if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
         const int w = (int)((word >> (4 * (LC - 1 - lane % LC))) & 15ull);
         const double *inf = P.minfo + (size_t)j * MINFO;
@@ -509,6 +511,13 @@ __device__ __forceinline__ void book_positions(const walk_params &P, const unsig
     }
 }
 
+// Body j of the walk (j = 0 .. Nw-1).  Entering it: w_j is resolved (sh = 8*w_j), B is the ballot of
+// target j+1, the row of source j (Y_j) and the lag-1 hypothesis terms of target j+2 are in flight.
+//   A  resolve w_{j+1} = ffs(B >> sh)                                   scalar chain
+//   S  acc_{j+2} = hyp_{j+2}[ga] + Y_j[lag 2] + Y_{j-1}[lag 3] + ...     vector chain, independent of A
+//   R  issue the row of source j+1 under w_{j+1} and the hypothesis terms of target j+3
+//   M  B = group-wise arg-max of acc_{j+2}                               independent of R
+// so the LDS latency of R is covered by M and by the next body's A and S.
 template <int LC, bool NODEL>
 __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, unsigned long long *words0,
                                             int C, int nchunks, int lane)
@@ -518,18 +527,21 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
     const int b = lane & 7;
     const int bb = NODEL ? (lane & 3) : (b < 5 ? b : 0);
     const int ga = (lane >> 3) < 6 ? (lane >> 3) : 5;
-    double Y[LC][LC];                       // Y[slot][l]: lag-(l+1) term of the source resolved at `slot`
+    double Y[LC][LC];                       // Y[slot][l]: lag-(l+1) term of the source with index == slot (mod LC)
 #pragma unroll
     for (int u = 0; u < LC; u++)
 #pragma unroll
         for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
-    int wprev = 0;
-    unsigned long long B = 1ull << 5;       // "ballot" that resolves position 0 to '_' (a6 = 5)
-    // target 1 has a single lag: source 0 under the hypothesis w_0 == ga (only ga == '_' is ever used)
-    double acc = g0[bb + ga * ROW];
+
+    // state entering body 0: w_0 = '_' (a6 = 5); target 1 has the single lag-1 term of source 0
+    int sh = 8 * 5;
+    unsigned long long B = group_argmax<NODEL>(g0[bb + ga * ROW]);
+#pragma unroll
+    for (int l = 1; l < LC; l++) Y[0][l] = g0[bb + 5 * ROW + l * LT_ROW];
+    double hyp = g0[bb + BLK + ga * ROW];   // lag 1 of target 2: source 1 under every hypothesis
 
     for (int k = 0; k < nchunks; k++) {
-        const double *gb = g0 + (size_t)(k & 1) * (C + 1) * BLK + bb;    // real rows: + w*ROW
+        const double *gb = g0 + (size_t)(k & 1) * (C + 2) * BLK + bb;    // real rows: + w*ROW
         const double *gh = gb + ga * ROW;                                 // hypothesis rows (lag 1)
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
@@ -537,23 +549,25 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
             unsigned long long word = 0;
 #pragma unroll
             for (int u = 0; u < LC; u++) {
-                const int s = g * LC + u;                                  // position j = k*C + s
-                // resolve w_j from the ballot built for target j
-                const int w = (int)(__builtin_ctzll(B >> (8 * wprev)) & 7);
-                word = (word << 4) + (unsigned long long)w;
-                wprev = w;
-                // row of source j under its real symbol: lags 2..L of targets j+2..j+L
-                const double *row = gb + (size_t)s * BLK + w * ROW;
+                const int s = g * LC + u;                                  // body j = k*C + s
+                // A: resolve w_{j+1}
+                const int w = (int)__builtin_ctzll(B >> sh);
+                sh = 8 * w;
+                word = (word << 4) | (unsigned long long)w;
+                // S: finish the sum of target j+2 (lag l+1 comes from source j-(l-1)), l ascending
+                double acc = hyp;
 #pragma unroll
-                for (int l = 1; l < LC; l++) Y[u][l] = row[l * LT_ROW];
-                // lag 1 of target j+2: source j+1 under every hypothesis (the chunk buffer carries one extra block)
-                const double hyp = gh[(size_t)(s + 1) * BLK];
-                // arg-max of target j+1 (sum finished in the previous iteration) ...
+                for (int l = 1; l < LC; l++) acc += Y[(u - (l - 1) + LC) % LC][l];
+                // R: row of source j+1 under its real symbol; lag-1 terms of target j+3 (source j+2)
+                const double *row = gb + (size_t)(s + 1) * BLK + w * ROW;
+#pragma unroll
+                for (int l = 1; l < LC; l++) Y[(u + 1) % LC][l] = row[l * LT_ROW];
+                hyp = gh[(size_t)(s + 2) * BLK];
+                // M: ballot of target j+2
                 B = group_argmax<NODEL>(acc);
-                // ... while the sum of target j+2 starts: lag l+1 comes from the source resolved l-1 steps ago
-                acc = hyp;
-#pragma unroll
-                for (int l = 1; l < LC; l++) acc += Y[(u - (l - 1) + LC) % LC][l];   // l ascending
+                // keep the next body's adds (which wait for the reads issued above) behind this arg-max:
+                // an in-order wave that stalls on them early would serialise the whole chain
+                __builtin_amdgcn_sched_barrier(0);
             }
             wk[g] = word;
         }
@@ -570,20 +584,25 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P)
     constexpr int BLK = 6 * LC * LT_ROW;
     const int C = P.chunk;
     double *const g0 = smem;
-    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + 1) * BLK);
+    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + 2) * BLK);
 
     const int first_hole = st->first_hole;
     const bool nodel = st->nodel != 0;
     const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;      // positions that can be decided
-    const int nchunks = (Nw + 1 + C - 1) / C;                     // positions 0..Nw, chunk k = k*C..k*C+C-1
+    const int nchunks = (Nw + C - 1) / C;                         // bodies 0..Nw-1, chunk k = k*C..k*C+C-1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     auto load_chunk = [&](int k, int t, int nt) {
         const int i0 = k * C;
         int nsrc = P.N + LT_PAD - i0;
-        if (nsrc > C + 1) nsrc = C + 1;      // one block of overlap: source j+1 of the chunk's last position
-        copy_to_lds(g0 + (size_t)(k & 1) * (C + 1) * BLK, P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
+        if (nsrc > C + 2) nsrc = C + 2;      // two blocks of overlap: the last body reads sources j+1 and j+2
+        if (nsrc < 0) nsrc = 0;
+        double *dst = g0 + (size_t)(k & 1) * (C + 2) * BLK;
+        copy_to_lds(dst, P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
+        // the walker always runs whole chunks: what lies behind the table must read as 0.0 (finite sums,
+        // symbol 0 wins), never as stale LDS bits
+        for (int q = nsrc * BLK + t; q < (C + 2) * BLK; q += nt) dst[q] = 0.0;
     };
 
     load_chunk(0, tid, (int)blockDim.x);
@@ -603,7 +622,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P)
             if (k > 0) book_positions(P, words0 + ((k - 1) & 1) * 64, LC, (k - 1) * C, C, Nw, lane, T);
             __syncthreads();
         }
-        book_positions(P, words0 + ((nchunks - 1) & 1) * 64, LC, (nchunks - 1) * C, C, Nw, lane, T);
+        if (nchunks > 0) book_positions(P, words0 + ((nchunks - 1) & 1) * 64, LC, (nchunks - 1) * C, C, Nw, lane, T);
         if (lane == 0) {
             if (first_hole <= P.N) {                                  // gretel.py:176-180
                 st->stop = 1;
@@ -621,6 +640,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P)
         }
         return;
     }
+    __builtin_amdgcn_s_setprio(3);          // the walker is the critical path; loaders and bookkeeper have slack
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     if (nodel) spec_walker<LC, true>(P, g0, words0, C, nchunks, lane);
     else spec_walker<LC, false>(P, g0, words0, C, nchunks, lane);

@@ -1,0 +1,44 @@
+// standalone harness: run k_walk_spec<LC> (variant 0 and 1) on a random table, compare paths, print cycles
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "../include/gretel_hip.h"
+#include "../include/gh_detlog.h"
+#include "../gretel_amd/csrc/kernels.hpp"
+#ifndef HLC
+#define HLC 5
+#endif
+int main(int argc, char** argv){
+    const int N = argc > 1 ? atoi(argv[1]) : 2000, LC = HLC;
+    const int variant_only = argc > 2 ? atoi(argv[2]) : -1;
+    const size_t nG = (size_t)(N + LT_PAD) * 6 * LC * 5;
+    std::vector<double> G(nG), minfo((size_t)(N + 2) * MINFO, 0.0);
+    srand(1);
+    for (size_t i = 0; i < nG; i++) G[i] = -(double)(rand() % 100000) * 1e-4;
+    for (int p = 0; p <= N + 1; p++) { for (int q = 0; q < 16; q++) minfo[(size_t)p*MINFO+q] = -0.3; for (int q=5;q<10;q++) minfo[(size_t)p*MINFO+q]=0.25; long long cm=15; memcpy(&minfo[(size_t)p*MINFO+10], &cm, 8); }
+    double *dG, *dmi; uint8_t* dpath[2]; gh_path_rec* drec; dev_state* dst;
+    hipMalloc(&dG, nG*8); hipMalloc(&dmi, minfo.size()*8); hipMalloc(&dpath[0], N+2); hipMalloc(&dpath[1], N+2); hipMalloc(&drec, sizeof(gh_path_rec)); hipMalloc(&dst, sizeof(dev_state));
+    hipMemcpy(dG, G.data(), nG*8, hipMemcpyHostToDevice); hipMemcpy(dmi, minfo.data(), minfo.size()*8, hipMemcpyHostToDevice);
+    const size_t blk = (size_t)LC * LT_BLK * 8;
+    int chunk = (int)((144*1024/2)/blk) - 2; if (chunk > 64) chunk = 64; chunk = (chunk/LC)*LC;
+    const size_t lds = 2*(size_t)(chunk+2)*blk + 2*64*8;
+    hipFuncSetAttribute((const void*)k_walk_spec<HLC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<uint8_t> path[2]; 
+    for (int v = 0; v < 2; v++) {
+        path[v].assign(N+1, 255);
+        if (variant_only >= 0 && v != variant_only) continue;
+        dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1;
+        hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
+        walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
+        hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P);
+        hipError_t e = hipDeviceSynchronize();
+        hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
+        hipMemcpy(path[v].data(), dpath[v], N+1, hipMemcpyDeviceToHost);
+        printf("variant %d: %s  cycles/step %.1f  n_done %d\n", v, hipGetErrorString(e), hs.dbg[2] ? (double)hs.dbg[0]/hs.dbg[2] : 0.0, hs.n_done); fflush(stdout);
+    }
+    if (variant_only < 0) { int diff = 0; for (int i = 0; i <= N; i++) diff += path[0][i] != path[1][i]; printf("path differences: %d of %d\n", diff, N+1); }
+    return 0;
+}
