@@ -1,0 +1,182 @@
+"""
+`gretel` command line on top of the MI355X hot path: same positional arguments, options,
+stdout table and output files as the reference driver (gretel/cmd.py:11-240), with the
+SPINS loop (cmd.py:148-179) executed on the device by `Hansel.spin`.
+
+Files written (formats: docs/protocol.rst:48-77):
+    <out>/out.fasta       one record per distinct haplotype, in order of discovery   cmd.py:183-216
+    <out>/snp.fasta       the SNP alleles only                                       cmd.py:218-219
+    <out>/gretel.crumbs   "# N n_crumbs n_slices L" + one line per haplotype         cmd.py:224-240
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+from . import __version__
+from . import util
+from .hansel import Hansel
+
+MIN_REMOVE = 0.01          # cmd.py:157
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="gretel", description="Gretel: A metagenomic haplotyper (MI355X hot path).")
+    p.add_argument("bam")
+    p.add_argument("vcf")
+    p.add_argument("contig")
+    p.add_argument("-s", "--start", type=int, default=1, help="1-indexed included start base position [default: 1]")
+    p.add_argument("-e", "--end", type=int, default=-1, help="1-indexed included end base position [default: reference length]")
+    p.add_argument("-p", "--paths", type=int, default=100, help="maximum number of paths to generate [default: 100]")
+    p.add_argument("--master", default=None, help="master FASTA used to fill the non-SNP positions (otherwise --gapchar)")
+    p.add_argument("--gapchar", default="N", help="character for non-SNP positions without --master [default: N]")
+    p.add_argument("--delchar", default="", help="character written for a deletion [default: nothing]")
+    p.add_argument("--quiet", default=False, action="store_true", help="do not print the per-SNP table")
+    p.add_argument("-o", "--out", default=".", help="output directory [default: .]")
+    p.add_argument("-@", "--threads", type=int, default=1, help="accepted for compatibility (the fill runs on the GPU)")
+    p.add_argument("--debugreads", type=str, default="", help="accepted for compatibility")
+    p.add_argument("--debugpos", type=str, default="", help="accepted for compatibility")
+    p.add_argument("--debughpos", type=str, default=",", help="comma delimited 1-indexed SNP ranks to print branch weights for")
+    p.add_argument("--dumpmatrix", type=str, default=None, help="dump the Hansel tensor (.npz) to this path")
+    p.add_argument("--dumpsnps", type=str, default=None, help="dump the SNP positions to this path")
+    p.add_argument("--pepper", action="store_true", help="permissive read filter (pysam stepper 'all' in the reference)")
+    p.add_argument("--version", action="version", version="%(prog)s " + __version__)
+    return p
+
+
+def read_first_fasta_record(path):
+    """What cmd.py:187-188 takes from pysam.FastaFile: the sequence of the first record."""
+    seq = []
+    seen = False
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith(">"):
+                if seen:
+                    break
+                seen = True
+                continue
+            if seen:
+                seq.append(line.strip())
+    return "".join(seq)
+
+
+def gap_report(hansel, vcf_h, out=None):
+    """cmd.py:85-118: returns True (and explains) when some SNP has no pairwise evidence."""
+    out = out or sys.stderr
+    i = hansel.gap_check()
+    if i < 0:
+        return False
+    pos = vcf_h["snp_rev"][i - 1] if i > 0 else 0
+    out.write("[FAIL] Unable to recover pairwise evidence concerning SNP #%d at position %d\n"
+              "       Gretel needs every SNP to appear on a read with at least one other SNP, at least once.\n"
+              "       There is no read in your data set that bridges SNP #%d with any of its neighbours.\n" % (i, pos, i))
+    return True
+
+
+def print_snp_table(hansel, vcf_h, out=None):
+    """cmd.py:123-145"""
+    out = out or sys.stdout
+    out.write("i\tpos\tgap\tA\tC\tG\tT\tN\t-\t_\ttot\n")
+    last = 0
+    for i in range(0, vcf_h["N"] + 1):
+        c = hansel.counts_array(i)
+        pos = vcf_h["snp_rev"][i - 1] if i > 0 else 0
+        out.write("%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n" % (
+            i, pos, pos - last, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]))
+        last = pos
+
+
+def recover(hansel, n_snps, max_paths, log=None):
+    """cmd.py:148-179 on the device; returns the PATHS table in order of discovery."""
+    log = log or sys.stderr
+    res = hansel.spin(max_paths, MIN_REMOVE)
+    paths = {}
+    for i in range(res["n"]):
+        log.write("[NOTE] *Establishing next path\n")
+        log.write("[RWGT] Ratio %.3f, Removed %.1f\n" % (res["ratio"][i], res["magnitude"][i]))
+        key = Hansel.path_str(res["paths"][i])
+        if key not in paths:
+            paths[key] = {"hp_current": [], "hp_original": [], "i": [], "i_0": i, "n": 0, "magnitude": 0,
+                          "hansel_path": hansel.path_symbols(res["paths"][i])}
+        rec = paths[key]
+        rec["n"] += 1
+        rec["i"].append(i)
+        rec["magnitude"] += float(res["magnitude"][i])
+        rec["hp_current"].append(float(res["hp_current"][i]))
+        rec["hp_original"].append(float(res["hp_original"][i]))
+    if res["hole_at"]:
+        log.write("[NOTE] Unable to select next branch from SNP %d to %d\n       Recovery will intentionally terminate now.\n"
+                  % (res["hole_at"] - 1, res["hole_at"]))
+    return paths
+
+
+def write_outputs(paths, hansel, vcf_h, args):
+    """cmd.py:181-240, byte for byte."""
+    dirn = args.out + "/"
+    if args.master:
+        master_seq = read_first_fasta_record(args.master)
+    else:
+        master_seq = [' '] * args.end
+    with open(dirn + "out.fasta", "w") as fasta, open(dirn + "snp.fasta", "w") as hfasta:
+        for key in sorted(paths, key=lambda x: paths[x]["i_0"]):
+            p = paths[key]
+            seq = list(master_seq[:])
+            for j, mallele in enumerate(p["hansel_path"][1:]):
+                pos = vcf_h["snp_rev"][j]
+                seq[pos - 1] = args.delchar if mallele == hansel.symbols_d["-"] else mallele
+            text = "".join(str(x) for x in seq[args.start - 1: args.end])
+            if not args.master:
+                text = text.replace(' ', args.gapchar)
+            fasta.write(">%d__%.2f\n" % (p["i_0"], p["hp_current"][0]))
+            fasta.write("%s\n" % text)
+            hfasta.write(">%d__%.2f\n" % (p["i_0"], p["hp_current"][0]))
+            hfasta.write("%s\n" % "".join(str(x) for x in p["hansel_path"][1:]))
+    with open(dirn + "gretel.crumbs", "w") as crumbs:
+        crumbs.write("# %d\t%d\t%d\t%.2f\n" % (vcf_h["N"], hansel.n_crumbs, hansel.n_slices, hansel.L))
+        for key in sorted(paths, key=lambda x: paths[x]["hp_current"][0], reverse=True):
+            p = paths[key]
+            crumbs.write("%d\t%d\t%s\t%s\t%.2f\n" % (
+                p["i_0"], p["n"], ",".join("%.2f" % x for x in p["hp_current"]),
+                ",".join("%.2f" % x for x in p["hp_original"]), p["magnitude"]))
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.end == -1:
+        args.end = util.get_ref_len_from_bam(args.bam, args.contig)               # cmd.py:53-55
+        sys.stderr.write("[NOTE] Setting end_pos to %d" % args.end)
+    vcf_h = util.process_vcf(args.vcf, args.contig, args.start, args.end)         # cmd.py:69
+    if args.dumpsnps:                                                             # cmd.py:70-74
+        with open(args.dumpsnps, "w") as fh:
+            for k in sorted(vcf_h["snp_fwd"].keys()):
+                fh.write("%d\t%d\t%d\n" % (vcf_h["snp_fwd"][k] + 1, k, k - args.start + 1))
+    hansel = util.load_from_bam(args.bam, args.contig, args.start, args.end, vcf_h, n_threads=args.threads,
+                                stepper="all" if args.pepper else "samtools")     # cmd.py:78
+    hansel.snapshot_original()                                                    # cmd.py:79 (what the copy is used for)
+    if args.dumpmatrix:
+        hansel.save_hansel_dump(args.dumpmatrix)                                  # cmd.py:81-82
+    if gap_report(hansel, vcf_h):
+        sys.exit(1)                                                               # cmd.py:118
+    if not args.quiet:
+        print_snp_table(hansel, vcf_h)
+    debug_hpos = []
+    for x in (args.debughpos or "").split(","):
+        try:
+            debug_hpos.append(int(x))
+        except ValueError:
+            pass
+    if debug_hpos:
+        # the reference prints the branch weights while it walks (gretel.py:147-164); here the spins run
+        # on the device, so the weights are shown for the first path only, before any reweighting
+        first = hansel.generate_path()
+        if first[0] is not None:
+            for snp in sorted(debug_hpos):
+                if 1 <= snp <= vcf_h["N"]:
+                    print(hansel.get_edge_weights_at(snp, first[0]))
+    paths = recover(hansel, vcf_h["N"], args.paths)
+    write_outputs(paths, hansel, vcf_h, args)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

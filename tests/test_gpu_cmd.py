@@ -1,0 +1,72 @@
+"""End to end: `gretel_amd.cmd.main` on the reference fixture writes the three files exactly as
+gretel/cmd.py:181-240 would for the haplotypes the oracle recovers."""
+import os
+
+import pytest
+
+from conftest import REFDATA
+from gretel_amd import cmd, util
+from oracle import gretel_ref as G
+from oracle.hansel_ref import Hansel, SYMBOLS, UNSYMBOLS
+
+pytestmark = pytest.mark.gpu
+BAM = os.path.join(REFDATA, "test.bam")
+VCF = os.path.join(REFDATA, "test.vcf.gz")
+
+
+def _expected(paths_n, start, end, gapchar="N", delchar=""):
+    v = util.process_vcf(VCF, 'hoot', start, end)
+    rank, off, bases = util.support_table_from_bam(BAM, 'hoot', start, end, v)
+    h = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, v["N"])
+    G.fill_from_support(h, [(int(rank[i]), bases[off[i]:off[i + 1]].tobytes().decode()) for i in range(len(rank))], v["N"])
+    crumbs_head = "# %d\t%d\t%d\t%.2f\n" % (v["N"], h.n_crumbs, h.n_slices, h.L)
+    recs, PATHS = G.recover_paths(h, v["N"], paths_n)
+    fasta, snp = [], []
+    for key in sorted(PATHS, key=lambda x: PATHS[x]["i_0"]):
+        p = PATHS[key]
+        seq = [' '] * end
+        for j, m in enumerate(p["hansel_path"][1:]):
+            seq[v["snp_rev"][j] - 1] = delchar if str(m) == '-' else str(m)
+        body = "".join(seq[start - 1:end]).replace(' ', gapchar)
+        head = ">%d__%.2f\n" % (p["i_0"], p["hp_current"][0])
+        fasta += [head, body + "\n"]
+        snp += [head, "".join(str(x) for x in p["hansel_path"][1:]) + "\n"]
+    cr = [crumbs_head]
+    for key in sorted(PATHS, key=lambda x: PATHS[x]["hp_current"][0], reverse=True):
+        p = PATHS[key]
+        cr.append("%d\t%d\t%s\t%s\t%.2f\n" % (p["i_0"], p["n"], ",".join("%.2f" % x for x in p["hp_current"]),
+                                               ",".join("%.2f" % x for x in p["hp_original"]), p["magnitude"]))
+    return "".join(fasta), "".join(snp), "".join(cr)
+
+
+def test_cli_outputs_byte_identical(tmp_path, capsys):
+    rc = cmd.main([BAM, VCF, "hoot", "-s", "1", "-e", "20", "-p", "12", "-o", str(tmp_path)])
+    assert rc == 0
+    fasta, snp, crumbs = _expected(12, 1, 20)
+    assert (tmp_path / "out.fasta").read_text() == fasta
+    assert (tmp_path / "snp.fasta").read_text() == snp
+    assert (tmp_path / "gretel.crumbs").read_text() == crumbs
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "i\tpos\tgap\tA\tC\tG\tT\tN\t-\t_\ttot"           # cmd.py:124
+    assert out[1] == "0\t0\t0\t0\t0\t0\t0\t0\t0\t4\t4"                 # the '_' row of SURVEY App. A-4
+    assert out[2] == "1\t1\t1\t1\t1\t0\t2\t0\t0\t0\t4"
+    assert len(out) == 1 + 5
+
+
+def test_cli_default_end_and_gapchar(tmp_path):
+    rc = cmd.main([BAM, VCF, "hoot", "-p", "3", "--gapchar", "x", "--quiet", "-o", str(tmp_path),
+                   "--dumpsnps", str(tmp_path / "snps.tsv"), "--dumpmatrix", str(tmp_path / "m.npz")])
+    assert rc == 0
+    fasta, snp, crumbs = _expected(3, 1, 20, gapchar="x")
+    assert (tmp_path / "out.fasta").read_text() == fasta
+    assert (tmp_path / "gretel.crumbs").read_text() == crumbs
+    assert (tmp_path / "snps.tsv").read_text() == "1\t1\t1\n2\t2\t2\n3\t10\t10\n4\t20\t20\n"      # cmd.py:70-74
+    assert (tmp_path / "m.npz").exists()
+
+
+def test_cli_reports_gap_and_exits(tmp_path):
+    # window 10..20 holds SNPs 10 and 20 and one read (GG, rank 0): the Sentinel->A rule fires (util.py:262), the
+    # B->Sentinel rule does not, so SNP #2 has no outgoing evidence and the driver must stop (cmd.py:92-118)
+    with pytest.raises(SystemExit) as e:
+        cmd.main([BAM, VCF, "hoot", "-s", "10", "-e", "20", "--quiet", "-o", str(tmp_path)])
+    assert e.value.code == 1
