@@ -93,6 +93,9 @@ def load():
         "gh_generate_path": [vp, vp, vp, P(dbl), P(dbl), P(dbl), P(i32)],
         "gh_reweight_path": [vp, vp, dbl, P(dbl)],
         "gh_spin": [vp, i32, dbl, vp, vp, P(i32), P(i32)],
+        "gh_batch_create": [P(vp), i32, P(vp)],
+        "gh_batch_destroy": [vp],
+        "gh_batch_spin": [vp, i32, dbl, vp, vp, vp, vp],
         "gh_export_band": [vp, vp],
         "gh_import_band": [vp, vp],
         "gh_export_dense": [vp, vp],

@@ -546,10 +546,10 @@ static int ensure_marg(gh_handle *h)
     prof_begin(h, GH_K_MARG);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_marg<double>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
-                           (const double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate);
+                           (const double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr);
     else
         hipLaunchKernelGGL(k_marg<float>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
-                           (const float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate);
+                           (const float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr);
     // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
     prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
     { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
@@ -557,12 +557,15 @@ static int ensure_marg(gh_handle *h)
     return GH_OK;
 }
 
+static int alloc_lt(gh_handle *h);
+
 static int ensure_lt(gh_handle *h)
 {
     int rc = ensure_marg(h);
     if (rc) return rc;
     if (!h->dirty_lt && h->lt && h->lt_L == h->L) return GH_OK;
-    if (!h->lt || h->lt_L != h->L) {
+    if ((rc = alloc_lt(h))) return rc;
+    if (false) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->lt) hipFree(h->lt);
         h->lt = nullptr;
@@ -579,11 +582,11 @@ static int ensure_lt(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt);
+                           h->minfo, h->lt, (const win_desc *)nullptr);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt);
+                           h->minfo, h->lt, (const win_desc *)nullptr);
     const int wl = h->W < h->L ? h->W : h->L;
     prof_end(h, GH_K_LT, (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * LT_BLK * 8.0));
     { int rc_ = post_launch(h, "k_lt"); if (rc_) return rc_; }
@@ -693,6 +696,20 @@ extern "C" int gh_snapshot_original(gh_t *h)
     return GH_OK;
 }
 
+static int alloc_lt(gh_handle *h)
+{
+    if (h->lt && h->lt_L == h->L) return GH_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->lt) hipFree(h->lt);
+    h->lt = nullptr;
+    size_t bytes = (size_t)(h->N + LT_PAD) * h->L * LT_BLK * sizeof(double);
+    hipError_t e = hipMalloc((void **)&h->lt, bytes);
+    if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
+    h->lt_L = h->L;
+    h->dirty_lt = true;
+    return GH_OK;
+}
+
 // path extension / reweight -------------------------------------------------------------------
 #define WALK_LDS_BUDGET (144 * 1024)
 static int walk_threads()
@@ -704,20 +721,21 @@ static int walk_threads()
 #define WALK_MAX_LC 16
 
 template <int LC>
-static void launch_walk_lc(bool spec, size_t lds, hipStream_t stream, const walk_params &P)
+static void launch_walk_lc(bool spec, size_t lds, hipStream_t stream, const walk_params &P, int grid, const win_desc *wd, int spin)
 {
     if (spec) {
         hipFuncSetAttribute((const void *)k_walk_spec<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_walk_spec<LC>), dim3(1), dim3(WALK_THREADS), lds, stream, P);
+        hipLaunchKernelGGL((k_walk_spec<LC>), dim3(grid), dim3(WALK_THREADS), lds, stream, P, wd, spin);
     } else {
         hipFuncSetAttribute((const void *)k_walk_src<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_walk_src<LC>), dim3(1), dim3(WALK_THREADS), lds, stream, P);
+        hipLaunchKernelGGL((k_walk_src<LC>), dim3(grid), dim3(WALK_THREADS), lds, stream, P, wd, spin);
     }
 }
 
-static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, const walk_params &P)
+static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, const walk_params &P, int grid = 1,
+                            const win_desc *wd = nullptr, int spin = 0)
 {
-#define GH_WALK_CASE(n) case n: launch_walk_lc<n>(spec, lds, stream, P); break;
+#define GH_WALK_CASE(n) case n: launch_walk_lc<n>(spec, lds, stream, P, grid, wd, spin); break;
     switch (LC) {
         GH_WALK_CASE(1) GH_WALK_CASE(2) GH_WALK_CASE(3) GH_WALK_CASE(4)
         GH_WALK_CASE(5) GH_WALK_CASE(6) GH_WALK_CASE(7) GH_WALK_CASE(8)
@@ -727,29 +745,35 @@ static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, c
 #undef GH_WALK_CASE
 }
 
-static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove)
+// launches the path-extension kernel for `grid` windows (grid == 1: the handle's own buffers in P)
+static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int grid, const win_desc *wd, int spin)
 {
-    walk_params P;
-    P.N = h->N; P.L = h->L;
-    P.G = h->lt; P.minfo = h->minfo;
-    P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
-    const size_t blk = (size_t)h->L * LT_BLK * sizeof(double);        // bytes per source position
+    const size_t blk = (size_t)L * LT_BLK * sizeof(double);           // bytes per source position
     int chunk = (int)((WALK_LDS_BUDGET / 2) / blk) - 2;                // k_walk_spec keeps two extra blocks per buffer
     if (chunk > 64) chunk = 64;
-    chunk = (chunk / h->L) * h->L;                                    // whole unrolled groups
-    prof_begin(h, GH_K_WALK);
-    if (h->L <= WALK_MAX_LC && chunk >= h->L) {
+    chunk = (chunk / L) * L;                                          // whole unrolled groups
+    if (L <= WALK_MAX_LC && chunk >= L) {
         P.chunk = chunk;
         const size_t lds = 2 * (size_t)(chunk + 2) * blk + 2 * 64 * sizeof(unsigned long long);
         // GH_WALK=src selects the non-speculative walker (A/B measurements); default: depth-1 speculation
         static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
-        launch_walk_src(h->L, spec, lds, h->stream, P);
+        launch_walk_src(L, spec, lds, stream, P, grid, wd, spin);
     } else {
         int hl = 16;
-        while (hl <= h->L) hl <<= 1;
+        while (hl <= L) hl <<= 1;
         P.chunk = 0;
-        hipLaunchKernelGGL(k_walk_global, dim3(1), dim3(64), (size_t)hl, h->stream, P, hl);
+        hipLaunchKernelGGL(k_walk_global, dim3(grid), dim3(64), (size_t)hl, stream, P, hl, wd, spin);
     }
+}
+
+static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove)
+{
+    walk_params P;
+    P.N = h->N; P.L = h->L; P.chunk = 0;
+    P.G = h->lt; P.minfo = h->minfo;
+    P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
+    prof_begin(h, GH_K_WALK);
+    launch_walk_any(h->N, h->L, P, h->stream, 1, nullptr, 0);
     // algorithmic bytes: per step one table row (L x 5 doubles) + the selected symbol's 3 marginal words + 1 path byte
     prof_end(h, GH_K_WALK, (double)h->N * ((double)h->L * 40.0 + 24.0 + 1.0));
     { int rc_ = post_launch(h, "k_walk"); if (rc_) return rc_; }
@@ -771,11 +795,11 @@ static int launch_reweight(gh_handle *h, const uint8_t *d_path, double ratio, in
     prof_begin(h, GH_K_REWEIGHT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_reweight<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
-                           d_path, h->dstate, ratio, use_state, h->partial);
+                           d_path, h->dstate, ratio, use_state, h->partial, (const win_desc *)nullptr, 0);
     else
         hipLaunchKernelGGL(k_reweight<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
-                           d_path, h->dstate, ratio, use_state, h->partial);
-    hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec);
+                           d_path, h->dstate, ratio, use_state, h->partial, (const win_desc *)nullptr, 0);
+    hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec, (const win_desc *)nullptr, 0);
     prof_end(h, GH_K_REWEIGHT, (double)total * 2.0 * esize(h) + (double)(h->N + 1));
     { int rc_ = post_launch(h, "k_reweight"); if (rc_) return rc_; }
     h->dirty_marg = h->dirty_lt = true;
@@ -878,6 +902,147 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     if (rc) return rc;
     *n_out = hs.n_done;
     *hole_at = hs.stop ? hs.hole_at : 0;
+    return GH_OK;
+}
+
+// batched recovery: many windows of one shape, every kernel launched over all of them ---------
+struct gh_batch {
+    int n, dev, N, W, L;
+    std::vector<gh_handle *> hs;
+    hipStream_t stream;
+    win_desc *d_wd;
+    uint8_t *d_paths;
+    gh_path_rec *d_recs;
+    double *d_partial;
+    int cap_paths, nb;
+};
+
+extern "C" int gh_batch_destroy(gh_batch_t *b)
+{
+    if (!b) return GH_OK;
+    hipSetDevice(b->dev);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    hipFree(b->d_wd); hipFree(b->d_paths); hipFree(b->d_recs); hipFree(b->d_partial);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+    return GH_OK;
+}
+
+extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
+{
+    if (!handles || n < 1 || !out) return fail(GH_ERR_ARG, "bad argument");
+    gh_handle *h0 = handles[0];
+    for (int w = 0; w < n; w++) {
+        gh_handle *h = handles[w];
+        if (!h) return fail(GH_ERR_ARG, "null handle at %d", w);
+        if (h->N != h0->N || h->W != h0->W || h->dev != h0->dev || h->cfg.storage != h0->cfg.storage ||
+            h->cfg.cond_mode != h0->cfg.cond_mode || h->cfg.marginal_term != h0->cfg.marginal_term)
+            return fail(GH_ERR_ARG, "window %d differs from window 0 in shape, storage, mode or device", w);
+        for (int v = 0; v < w; v++)
+            if (handles[v] == h) return fail(GH_ERR_ARG, "window %d is the same handle as window %d", w, v);
+    }
+    HIPCHK(hipSetDevice(h0->dev));
+    gh_batch *b = new (std::nothrow) gh_batch();
+    if (!b) return fail(GH_ERR_NOMEM, "host allocation failed");
+    b->n = n; b->dev = h0->dev; b->N = h0->N; b->W = h0->W; b->L = 0;
+    b->hs.assign(handles, handles + n);
+    b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
+    b->cap_paths = 0;
+    b->nb = (int)(((size_t)(b->N + 1) * b->W + 255) / 256);
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_wd, sizeof(win_desc) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_partial, sizeof(double) * (size_t)b->nb * n);
+    if (e != hipSuccess) { gh_batch_destroy(b); return fail(GH_ERR_NOMEM, "batch allocation failed: %s", hipGetErrorString(e)); }
+    *out = b;
+    return GH_OK;
+}
+
+extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out,
+                             gh_path_rec *recs, int *n_out, int *hole_at)
+{
+    if (!b || !paths_out || !recs || !n_out || !hole_at || max_paths < 1) return fail(GH_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->dev));
+    const int n = b->n;
+    const size_t n1 = (size_t)b->N + 1;
+    int rc;
+    for (int w = 0; w < n; w++) {
+        gh_handle *h = b->hs[w];
+        if (h->L != b->hs[0]->L)
+            return fail(GH_ERR_STATE, "window %d has L=%d but window 0 has L=%d: set one L (gh_set_L) for the batch", w, h->L, b->hs[0]->L);
+        if ((rc = alloc_lt(h))) return rc;
+        if (!h->have_orig && (rc = gh_snapshot_original(h))) return rc;
+        if ((rc = reset_spin_state(h))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    b->L = b->hs[0]->L;
+    if (max_paths > b->cap_paths) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        hipFree(b->d_paths); hipFree(b->d_recs);
+        b->d_paths = nullptr; b->d_recs = nullptr; b->cap_paths = 0;
+        HIPCHK(hipMalloc((void **)&b->d_paths, n1 * max_paths * n));
+        HIPCHK(hipMalloc((void **)&b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n));
+        b->cap_paths = max_paths;
+    }
+    std::vector<win_desc> wd(n);
+    for (int w = 0; w < n; w++) {
+        gh_handle *h = b->hs[w];
+        wd[w].band = h->band; wd[w].cnt = h->cnt; wd[w].marg = h->marg; wd[w].minfo = h->minfo;
+        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].G = h->lt; wd[w].st = h->dstate;
+        wd[w].partial = b->d_partial + (size_t)w * b->nb;
+        wd[w].paths = b->d_paths + n1 * max_paths * w;
+        wd[w].recs = b->d_recs + (size_t)max_paths * w;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
+
+    gh_handle *h0 = b->hs[0];
+    const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
+    const int N = b->N, W = b->W, L = b->L;
+    const unsigned marg_gx = (unsigned)(((N + 1) * 8 + 255) / 256);
+    size_t lt_nb = ((size_t)(N + LT_PAD) * L * LT_BLK + 255) / 256;
+    if (lt_nb > 4096) lt_nb = 4096;
+    walk_params P;
+    P.N = N; P.L = L; P.chunk = 0; P.G = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
+    P.min_remove = min_remove;
+    for (int s = 0; s < max_paths; s++) {
+        hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, b->d_wd);
+        if (f64) {
+            hipLaunchKernelGGL(k_marg<double>, dim3(marg_gx, n), dim3(256), 0, b->stream, (const double *)nullptr, N, W,
+                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                               (dev_state *)nullptr, b->d_wd);
+            hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)lt_nb, n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
+                               h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, b->d_wd);
+        } else {
+            hipLaunchKernelGGL(k_marg<float>, dim3(marg_gx, n), dim3(256), 0, b->stream, (const float *)nullptr, N, W,
+                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                               (dev_state *)nullptr, b->d_wd);
+            hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)lt_nb, n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
+                               h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, b->d_wd);
+        }
+        launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
+        if (f64)
+            hipLaunchKernelGGL(k_reweight<double>, dim3(b->nb, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
+                               (const uint8_t *)nullptr, (const dev_state *)nullptr, 0.0, 1, (double *)nullptr, b->d_wd, s);
+        else
+            hipLaunchKernelGGL(k_reweight<float>, dim3(b->nb, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
+                               (const uint8_t *)nullptr, (const dev_state *)nullptr, 0.0, 1, (double *)nullptr, b->d_wd, s);
+        hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, b->nb,
+                           (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, b->d_wd, s);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<dev_state> hs(n);
+    for (int w = 0; w < n; w++)
+        HIPCHK(hipMemcpyAsync(&hs[w], b->hs[w]->dstate, sizeof(dev_state), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(paths_out, b->d_paths, n1 * max_paths * n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(recs, b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int w = 0; w < n; w++) {
+        n_out[w] = hs[w].n_done;
+        hole_at[w] = hs[w].stop ? hs[w].hole_at : 0;
+        b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true;
+    }
     return GH_OK;
 }
 

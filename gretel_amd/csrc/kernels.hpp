@@ -35,6 +35,20 @@ struct dev_state {
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
 };
 
+// Batched launches (gh_batch_*): one entry per window; a kernel launched with `wd != nullptr` takes its
+// window from blockIdx.y (blockIdx.x for the walkers) and its buffers from wd[window].
+struct win_desc {
+    void *band;
+    double *cnt, *marg, *minfo;
+    int32_t *nvalid;
+    uint32_t *cmask;
+    double *G;
+    dev_state *st;
+    double *partial;
+    uint8_t *paths;        // [max_paths][N+1]
+    gh_path_rec *recs;     // [max_paths]
+};
+
 __constant__ int8_t c_sym_of_char[256];
 
 __device__ __forceinline__ int vsym(int b5) { return b5 < 4 ? b5 : 5; }            // b5 -> symbol
@@ -180,9 +194,14 @@ __global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_marg(const T *__restrict__ band, int N, int W, double *__restrict__ cnt, double *__restrict__ marg,
-       int32_t *__restrict__ nvalid, uint32_t *__restrict__ cmask, double *__restrict__ minfo, dev_state *st)
+k_marg(const T *band, int N, int W, double *cnt, double *marg,
+       int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st, const win_desc *wd)
 {
+    if (wd) {
+        const win_desc &d = wd[blockIdx.y];
+        band = (const T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st;
+        if (st->stop) return;
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 3, s = t & 7;
     if (p > N) return;
@@ -219,6 +238,13 @@ k_marg(const T *__restrict__ band, int N, int W, double *__restrict__ cnt, doubl
     }
 }
 
+// batched launches: re-arm the words k_marg min/and-reduces into (single windows use a memset)
+__global__ void k_rearm(const win_desc *wd)
+{
+    dev_state *st = wd[blockIdx.x].st;
+    if (threadIdx.x == 0) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; }
+}
+
 // freeze the current log-marginals as the original ones (slot [11..15] of minfo)
 __global__ void k_snapshot(double *__restrict__ dst_minfo, const double *__restrict__ src_minfo, int N)
 {
@@ -245,10 +271,15 @@ __global__ void k_snapshot(double *__restrict__ dst_minfo, const double *__restr
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_lt(const T *__restrict__ band, int N, int W, int L, int cond_mode, int marginal_term,
-     const double *__restrict__ cnt, const int32_t *__restrict__ nvalid, const uint32_t *__restrict__ cmask,
-     const double *__restrict__ minfo, double *__restrict__ G)
+k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
+     const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
+     const double *minfo, double *G, const win_desc *wd)
 {
+    if (wd) {
+        const win_desc &d = wd[blockIdx.y];
+        band = (const T *)d.band; cnt = d.cnt; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; G = d.G;
+        if (d.st->stop) return;
+    }
     const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (size_t)gridDim.x * blockDim.x) {
@@ -358,9 +389,14 @@ __device__ __forceinline__ void book_chunk(const walk_params &P, const unsigned 
 }
 
 template <int LC>
-__global__ void __launch_bounds__(512) k_walk_src(walk_params P)
+__global__ void __launch_bounds__(512) k_walk_src(walk_params P, const win_desc *wd, int spin)
 {
     extern __shared__ __align__(16) double smem[];
+    if (wd) {
+        const win_desc &d = wd[blockIdx.x];
+        P.G = d.G; P.minfo = d.minfo; P.st = d.st;
+        P.path_out = d.paths + (size_t)spin * (P.N + 1); P.rec = d.recs + spin;
+    }
     dev_state *st = P.st;
     if (st->stop) return;
     constexpr int L = LC;
@@ -576,9 +612,14 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 }
 
 template <int LC>
-__global__ void __launch_bounds__(512) k_walk_spec(walk_params P)
+__global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc *wd, int spin)
 {
     extern __shared__ __align__(16) double smem[];
+    if (wd) {
+        const win_desc &d = wd[blockIdx.x];
+        P.G = d.G; P.minfo = d.minfo; P.st = d.st;
+        P.path_out = d.paths + (size_t)spin * (P.N + 1); P.rec = d.recs + spin;
+    }
     dev_state *st = P.st;
     if (st->stop) return;
     constexpr int BLK = 6 * LC * LT_ROW;
@@ -655,9 +696,14 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P)
 // k_walk_global: the same walk with G read straight from global memory by one wavefront.
 // Fallback for L > 16 (register rotation no longer fits); not a fast path.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len)
+__global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len, const win_desc *wd, int spin)
 {
     extern __shared__ uint8_t lpath[];
+    if (wd) {
+        const win_desc &d = wd[blockIdx.x];
+        P.G = d.G; P.minfo = d.minfo; P.st = d.st;
+        P.path_out = d.paths + (size_t)spin * (P.N + 1); P.rec = d.recs + spin;
+    }
     dev_state *st = P.st;
     if (st->stop) return;
     const int lane = threadIdx.x;
@@ -725,10 +771,14 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_reweight(T *__restrict__ band, int N, int W, const uint8_t *__restrict__ path,
-           const dev_state *st, double ratio_arg, int use_state_ratio, double *__restrict__ partial)
+k_reweight(T *band, int N, int W, const uint8_t *path,
+           const dev_state *st, double ratio_arg, int use_state_ratio, double *partial, const win_desc *wd, int spin)
 {
     __shared__ double s_red[256];
+    if (wd) {
+        const win_desc &d = wd[blockIdx.y];
+        band = (T *)d.band; path = d.paths + (size_t)spin * (N + 1); st = d.st; partial = d.partial;
+    }
     double removed = 0.0;
     if (!(use_state_ratio && st->stop)) {
         const double ratio = use_state_ratio ? st->ratio : ratio_arg;
@@ -768,10 +818,14 @@ k_reweight(T *__restrict__ band, int N, int W, const uint8_t *__restrict__ path,
 }
 
 __global__ void __launch_bounds__(256)
-k_reweight_finish(const double *__restrict__ partial, int nb, dev_state *st, int use_state,
-                  gh_path_rec *rec)
+k_reweight_finish(const double *partial, int nb, dev_state *st, int use_state,
+                  gh_path_rec *rec, const win_desc *wd, int spin)
 {
     __shared__ double s_red[256];
+    if (wd) {
+        const win_desc &d = wd[blockIdx.x];
+        partial = d.partial; st = d.st; rec = d.recs + spin;
+    }
     if (use_state && st->stop) return;
     double acc = 0.0;
     for (int q = threadIdx.x; q < nb; q += 256) acc += partial[q];

@@ -376,6 +376,49 @@ class Hansel:
             check(self._lib.gh_sync(self._h))
 
 
+class HanselBatch:
+    """Many windows of one shape recovered together (gh_batch_*): every kernel of the spin loop
+    (gretel/cmd.py:148-179) is launched over all windows at once, one path-extension workgroup per
+    window.  The Hansels must already be filled and agree on n_snps, band, storage, modes and L."""
+
+    def __init__(self, hansels):
+        self.hansels = list(hansels)
+        if not self.hansels:
+            raise ValueError("empty batch")
+        for h in self.hansels:
+            h._ensure()
+        self._lib = self.hansels[0]._lib
+        arr = (C.c_void_p * len(self.hansels))(*[h._h for h in self.hansels])
+        b = C.c_void_p()
+        check(self._lib.gh_batch_create(arr, len(self.hansels), C.byref(b)))
+        self._b = b
+
+    def __del__(self):
+        try:
+            if getattr(self, "_b", None):
+                self._lib.gh_batch_destroy(self._b)
+                self._b = None
+        except Exception:
+            pass
+
+    def spin(self, max_paths=100, min_remove=0.01):
+        n = len(self.hansels)
+        n1 = self.hansels[0].n + 1
+        paths = np.zeros((n, max_paths, n1), dtype=np.uint8)
+        recs = np.zeros((n, max_paths, 4), dtype=np.float64)
+        n_out = np.zeros(n, dtype=np.int32)
+        hole = np.zeros(n, dtype=np.int32)
+        check(self._lib.gh_batch_spin(self._b, int(max_paths), float(min_remove), _p(paths), _p(recs), _p(n_out), _p(hole)))
+        out = []
+        for w in range(n):
+            k = int(n_out[w])
+            if k:
+                self.hansels[w].is_weighted = True
+            out.append(dict(n=k, hole_at=int(hole[w]), paths=paths[w, :k], hp_current=recs[w, :k, 0].copy(),
+                            hp_original=recs[w, :k, 1].copy(), ratio=recs[w, :k, 2].copy(), magnitude=recs[w, :k, 3].copy()))
+        return out
+
+
 class DeviceReads:
     """A support table resident in HBM (gh_reads_upload)."""
 

@@ -149,6 +149,16 @@ int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, double *removed
 int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
             int *n_out, int *hole_at);
 
+/* Batched recovery: the same spin loop over MANY windows of one shape (same n_snps, band, storage,
+ * modes, device and L) with every kernel launched over all of them -- one path-extension workgroup
+ * per window, so up to 256 windows walk concurrently on one MI355X.  The handles stay usable on
+ * their own; fill them first.  paths_out: [n][max_paths][N+1], recs: [n][max_paths], n_out/hole_at: [n]. */
+typedef struct gh_batch gh_batch_t;
+int gh_batch_create(gh_t **handles, int n, gh_batch_t **out);
+int gh_batch_destroy(gh_batch_t *b);
+int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
+                  int *n_out, int *hole_at);
+
 /* tensor export/import for --dumpmatrix (gretel/cmd.py:81-82) and tests:
  * band layout [(N+2)][band][7][7] as doubles; dense layout [7][7][N+2][N+2] (gretel/cmd.py:76-77). */
 int gh_export_band(gh_t *h, double *out);
