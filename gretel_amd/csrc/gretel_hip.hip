@@ -84,6 +84,8 @@ struct gh_handle {
     double *lt;
     int lt_L;
     bool dirty_marg, dirty_lt, have_orig;
+    const uint8_t *lt_inc_path;   // device path of the ONLY mutation since G was last built (a path reweight), else null
+    uint8_t *d_rw_path;           // [N+1] the path of gh_reweight_path (kept for the incremental table update)
     dev_state *dstate;
     double *partial;       // reweight block partial sums
     int partial_cap;
@@ -187,7 +189,7 @@ static void free_handle(gh_handle *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->dstate); hipFree(h->partial);
-    hipFree(h->d_path); hipFree(h->d_rec);
+    hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -222,8 +224,9 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->L = 1;
     h->n_cells = (size_t)(h->N + 2) * h->W;
     h->lt = nullptr; h->lt_L = 0;
-    h->dirty_marg = h->dirty_lt = true;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
+    h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
     h->prof = false;
     h->partial = nullptr; h->partial_cap = 0;
     memset(&h->stats, 0, sizeof h->stats);
@@ -250,6 +253,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     ALLOC(h->cmask, np * sizeof(uint32_t));
     ALLOC(h->dstate, sizeof(dev_state));
     ALLOC(h->d_path, np);
+    ALLOC(h->d_rw_path, np);
     ALLOC(h->d_rec, sizeof(gh_path_rec));
 #undef ALLOC
     hipMemsetAsync(h->band, 0, h->n_cells * CELL * esize(h), h->stream);
@@ -283,7 +287,7 @@ extern "C" int gh_clear(gh_t *h)
     memset(&h->stats, 0, sizeof h->stats);
     h->stats.L = 1;
     h->L = 1;
-    h->dirty_marg = h->dirty_lt = true;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
     return GH_OK;
 }
@@ -423,7 +427,7 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         prof_end(h, GH_K_FILL, bytes);
         { int rc_ = post_launch(h, "k_fill"); if (rc_) return rc_; }
     }
-    h->dirty_marg = h->dirty_lt = true;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     int rc = pull_fill_state(h, before.fill, "gh_fill");
     if (h->stats.n_slices > 0) {                                   // util.py:333
         int L = (int)std::ceil((double)h->stats.covered_snps / (double)h->stats.n_slices);
@@ -496,7 +500,7 @@ extern "C" int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const i
             hipLaunchKernelGGL(k_add_batch<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
         else
             hipLaunchKernelGGL(k_add_batch<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
-        h->dirty_marg = h->dirty_lt = true;
+        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
         int64_t s0 = h->stats.n_slices, c0 = h->stats.n_crumbs, v0 = h->stats.covered_snps;
         rc = pull_fill_state(h, before.fill, "gh_add_batch");
         h->stats.n_slices = s0; h->stats.n_crumbs = c0; h->stats.covered_snps = v0;
@@ -529,7 +533,7 @@ extern "C" int gh_reweight_obs(gh_t *h, int a, int b, int i, int j, double ratio
             hipLaunchKernelGGL(k_reweight_one<float>, dim3(1), dim3(1), 0, h->stream, (float *)h->band + idx, ratio, d_rem);
         HIPCHK(hipMemcpyAsync(&rem, d_rem, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        h->dirty_marg = h->dirty_lt = true;
+        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     }
     if (removed) *removed = rem;
     return GH_OK;
@@ -542,7 +546,7 @@ static int ensure_marg(gh_handle *h)
     const int threads = (h->N + 1) * 8;
     const int block = 256;
     // re-arm the "first SNP without a candidate" word that k_marg min-reduces into
-    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, 2 * sizeof(int), h->stream));   // first_hole and nodel
+    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, 3 * sizeof(int), h->stream));   // first_hole, nodel, cm_same
     prof_begin(h, GH_K_MARG);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_marg<double>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
@@ -574,7 +578,10 @@ static int ensure_lt(gh_handle *h)
         if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
         h->lt_L = h->L;
     }
-    const size_t total = (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
+    const bool inc_ok = h->lt_inc_path && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
+                        !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
+    const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
+    const size_t total = inc ? (size_t)h->N * h->L * LT_ROW : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
     size_t nb = (total + block - 1) / block;
     if (nb > 256 * 16) nb = 256 * 16;
@@ -582,15 +589,18 @@ static int ensure_lt(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, (const win_desc *)nullptr);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, (const win_desc *)nullptr);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0);
     const int wl = h->W < h->L ? h->W : h->L;
-    prof_end(h, GH_K_LT, (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * LT_BLK * 8.0));
+    // algorithmic bytes: full = read the band cells within reach + write G; incremental = one row per (source, lag)
+    prof_end(h, GH_K_LT, inc ? (double)h->N * ((double)wl * 7 * esize(h) + (double)h->L * LT_ROW * 8.0)
+                             : (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * LT_BLK * 8.0));
     { int rc_ = post_launch(h, "k_lt"); if (rc_) return rc_; }
     h->dirty_lt = false;
+    h->lt_inc_path = nullptr;
     return GH_OK;
 }
 
@@ -706,7 +716,7 @@ static int alloc_lt(gh_handle *h)
     hipError_t e = hipMalloc((void **)&h->lt, bytes);
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
     h->lt_L = h->L;
-    h->dirty_lt = true;
+    h->dirty_lt = true; h->lt_inc_path = nullptr;
     return GH_OK;
 }
 
@@ -802,6 +812,8 @@ static int launch_reweight(gh_handle *h, const uint8_t *d_path, double ratio, in
     hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec, (const win_desc *)nullptr, 0);
     prof_end(h, GH_K_REWEIGHT, (double)total * 2.0 * esize(h) + (double)(h->N + 1));
     { int rc_ = post_launch(h, "k_reweight"); if (rc_) return rc_; }
+    // the table can be updated row-wise if this reweight is the only change since it was built
+    h->lt_inc_path = (!h->dirty_lt && h->lt && h->lt_L == h->L) ? d_path : nullptr;
     h->dirty_marg = h->dirty_lt = true;
     return GH_OK;
 }
@@ -855,8 +867,8 @@ extern "C" int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, doub
     if (set_dev(h)) return GH_ERR_HIP;
     for (int q = 0; q <= h->N; q++)
         if (path[q] >= NSYM) return fail(GH_ERR_SYMBOL, "path[%d] = %d is not a symbol index", q, path[q]);
-    HIPCHK(hipMemcpyAsync(h->d_path, path, (size_t)h->N + 1, hipMemcpyHostToDevice, h->stream));
-    int rc = launch_reweight(h, h->d_path, ratio, 0, h->d_rec);
+    HIPCHK(hipMemcpyAsync(h->d_rw_path, path, (size_t)h->N + 1, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_reweight(h, h->d_rw_path, ratio, 0, h->d_rec);
     if (rc) return rc;
     gh_path_rec rec;
     HIPCHK(hipMemcpyAsync(&rec, h->d_rec, sizeof rec, hipMemcpyDeviceToHost, h->stream));
@@ -1004,22 +1016,29 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     walk_params P;
     P.N = N; P.L = L; P.chunk = 0; P.G = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
     P.min_remove = min_remove;
+    size_t lt_nb_inc = ((size_t)N * L * LT_ROW + 255) / 256;
+    if (lt_nb_inc > 4096) lt_nb_inc = 4096;
+    const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     for (int s = 0; s < max_paths; s++) {
+        // any non-null pointer switches k_lt to the row-wise update; the kernel takes the path of spin s-1 from wd
+        const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
         hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, b->d_wd);
         if (f64) {
             hipLaunchKernelGGL(k_marg<double>, dim3(marg_gx, n), dim3(256), 0, b->stream, (const double *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                (dev_state *)nullptr, b->d_wd);
-            hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)lt_nb, n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
+            hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, b->d_wd);
+                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
+                               inc, b->d_wd, s);
         } else {
             hipLaunchKernelGGL(k_marg<float>, dim3(marg_gx, n), dim3(256), 0, b->stream, (const float *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                (dev_state *)nullptr, b->d_wd);
-            hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)lt_nb, n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
+            hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, b->d_wd);
+                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
+                               inc, b->d_wd, s);
         }
         launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
         if (f64)
@@ -1081,7 +1100,7 @@ extern "C" int gh_import_band(gh_t *h, const double *in)
         hipLaunchKernelGGL(k_import<float>, dim3(nb), dim3(256), 0, h->stream, (float *)h->band, d, n);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(d);
-    h->dirty_marg = h->dirty_lt = true;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     if (e != hipSuccess) return fail(GH_ERR_HIP, "import failed: %s", hipGetErrorString(e));
     return GH_OK;
 }

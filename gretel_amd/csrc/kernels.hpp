@@ -32,6 +32,7 @@ struct dev_state {
     unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
     int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish
     int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)
+    int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
 };
 
@@ -231,6 +232,7 @@ k_marg(const T *band, int N, int W, double *cnt, double *marg,
         cnt[(size_t)p * 8 + 7] = tot;
         marg[(size_t)p * 8 + 7] = 0.0;
         nvalid[p] = nv;
+        if (cmask[p] != cm) atomicAnd(&st->cm_same, 0);       // the conditional table must then be rebuilt in full
         cmask[p] = cm;
         minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
         if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
@@ -242,7 +244,7 @@ k_marg(const T *band, int N, int W, double *cnt, double *marg,
 __global__ void k_rearm(const win_desc *wd)
 {
     dev_state *st = wd[blockIdx.x].st;
-    if (threadIdx.x == 0) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; }
+    if (threadIdx.x == 0) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
 }
 
 // freeze the current log-marginals as the original ones (slot [11..15] of minfo)
@@ -270,15 +272,47 @@ __global__ void k_snapshot(double *__restrict__ dst_minfo, const double *__restr
 #define LT_PAD 16      /* zero source blocks behind N so the unrolled walker may overrun */
 
 template <typename T>
+__device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond_mode, int marginal_term,
+                                           const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
+                                           const double *minfo, int i, int a6, int l, int b5)
+{
+    const int snp = i + l;
+    if (!(i < N && snp <= N && (a6 < 5 || i == 0))) return 0.0;
+    const int b = vsym(b5);
+    if (!((cmask[snp] >> b) & 1)) return -INFINITY;
+    double v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(a6), b, i, snp);
+    if (marginal_term && l == 1) v = minfo[(size_t)snp * MINFO + b5] + v;
+    return v;
+}
+
+// inc_path == nullptr: rebuild every entry.  Otherwise (conditional A or B, no marginal term, and the
+// tensor changed ONLY through reweight_hansel_from_path(inc_path)): every cell that changed is
+// H[path[i], path[j], i, j], which only enters the rows G[i][a6(path[i])][*][*] -- rebuild those
+// N*L*5 entries; if k_marg saw a candidate mask change (V(p) or the -inf masks moved), fall back to all.
+template <typename T>
 __global__ void __launch_bounds__(256)
 k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
      const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
-     const double *minfo, double *G, const win_desc *wd)
+     const double *minfo, double *G, const dev_state *st, const uint8_t *inc_path, const win_desc *wd, int spin)
 {
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
-        band = (const T *)d.band; cnt = d.cnt; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; G = d.G;
-        if (d.st->stop) return;
+        band = (const T *)d.band; cnt = d.cnt; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; G = d.G; st = d.st;
+        if (st->stop) return;
+        if (inc_path) inc_path = d.paths + (size_t)(spin - 1) * (N + 1);
+    }
+    if (inc_path && st->cm_same && !st->stop) {       // after a hole the last path buffer is incomplete: rebuild in full
+        const size_t total = (size_t)N * L * LT_ROW;
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+            const int b5 = (int)(t % LT_ROW);
+            const size_t r = t / LT_ROW;
+            const int l = (int)(r % L) + 1;
+            const int i = (int)(r / L);
+            const int a6 = a6_of_sym(inc_path[i]);
+            G[(((size_t)i * 6 + a6) * L + (l - 1)) * LT_ROW + b5] =
+                lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
+        }
+        return;
     }
     const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -289,18 +323,7 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
         r /= L;
         const int a6 = (int)(r % 6);
         const int i = (int)(r / 6);
-        const int snp = i + l;
-        double v = 0.0;
-        if (i < N && snp <= N && (a6 < 5 || i == 0)) {
-            const int b = vsym(b5);
-            if (!((cmask[snp] >> b) & 1)) {
-                v = -INFINITY;
-            } else {
-                v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(a6), b, i, snp);
-                if (marginal_term && l == 1) v = minfo[(size_t)snp * MINFO + b5] + v;
-            }
-        }
-        G[t] = v;
+        G[t] = lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
     }
 }
 
