@@ -103,6 +103,7 @@ struct gh_reads {
     int64_t *off;
     uint8_t *bases;
     int max_k;
+    bool sorted;      // ranks ascend: k_fill_sorted applies
 };
 
 static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STORAGE_F64 ? 8 : 4; }
@@ -357,10 +358,12 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
     r->n_bases = n_reads ? off[n_reads] : 0;
     r->rank = nullptr; r->off = nullptr; r->bases = nullptr;
     r->max_k = 0;
+    r->sorted = true;
     for (int64_t q = 0; q < n_reads; q++) {
         int64_t k = off[q + 1] - off[q];
         if (k < 0) { delete r; return fail(GH_ERR_ARG, "off[] not monotone at read %lld", (long long)q); }
         if (k > r->max_k) r->max_k = (int)k;
+        if (q > 0 && rank[q] < rank[q - 1]) r->sorted = false;
     }
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void **)&r->rank, (size_t)(n_reads ? n_reads : 1) * 4);
@@ -418,7 +421,28 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         if (nb > 256 * 32) nb = 256 * 32;
         const double bytes = 8.0 * 0 + (double)r->n_reads * 12.0 + (double)r->n_bases;   // + 8*adds, added below
         prof_begin(h, GH_K_FILL);
-        if (h->cfg.storage == GH_STORAGE_F64)
+        // sorted tables: LDS-privatised counting when a run of reads stays inside a slice that fits in LDS
+        static const bool no_sorted = getenv("GH_FILL_SCATTER") && atoi(getenv("GH_FILL_SCATTER"));
+        const int rpb = 2048;                                     // reads per workgroup
+        int max_pos = 0;
+        if (r->sorted && !no_sorted) {
+            const size_t per_pos = (size_t)h->W * CELL * sizeof(unsigned);
+            max_pos = (int)((96 * 1024) / per_pos);
+            if (max_pos > 1024) max_pos = 1024;
+        }
+        if (max_pos >= r->max_k + 8) {
+            const unsigned gb = (unsigned)((r->n_reads + rpb - 1) / rpb);
+            const size_t lds = (size_t)max_pos * h->W * CELL * sizeof(unsigned);
+            if (h->cfg.storage == GH_STORAGE_F64) {
+                hipFuncSetAttribute((const void *)k_fill_sorted<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k_fill_sorted<double>, dim3(gb), dim3(block), lds, h->stream, (double *)h->band, h->N, h->W,
+                                   r->rank, r->off, r->bases, r->n_reads, rpb, max_pos, r->max_k, use_end_sentinels, h->dstate);
+            } else {
+                hipFuncSetAttribute((const void *)k_fill_sorted<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(k_fill_sorted<float>, dim3(gb), dim3(block), lds, h->stream, (float *)h->band, h->N, h->W,
+                                   r->rank, r->off, r->bases, r->n_reads, rpb, max_pos, r->max_k, use_end_sentinels, h->dstate);
+            }
+        } else if (h->cfg.storage == GH_STORAGE_F64)
             hipLaunchKernelGGL(k_fill<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (double *)h->band,
                                h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);
         else

@@ -93,6 +93,13 @@ def make_support_table(n_snps, n_reads, k=None, n_haps=8, err=0.01, seed=0,
     all_start = np.concatenate([tile_starts, starts])
     all_hap = np.concatenate([np.full(n_tile, top, dtype=np.int64), hap_of])
 
+    # rank order, like the reads of a coordinate-sorted BAM (lets the fill count in LDS)
+    order = np.argsort(all_start, kind="stable")
+    all_k, all_start, all_hap = all_k[order], all_start[order], all_hap[order]
+    is_tile = np.zeros(len(order), dtype=bool)
+    is_tile[:n_tile] = True
+    is_tile = is_tile[order]
+
     off = np.zeros(len(all_k) + 1, dtype=np.int64)
     np.cumsum(all_k, out=off[1:])
     total = int(off[-1])
@@ -101,7 +108,7 @@ def make_support_table(n_snps, n_reads, k=None, n_haps=8, err=0.01, seed=0,
     snp = all_start[read_of] + within
     allele = haps[all_hap[read_of], snp]
     # substitution errors on the random reads only
-    is_rand = read_of >= n_tile
+    is_rand = ~is_tile[read_of]
     flip = (rng.random(total) < err) & is_rand
     shift = rng.integers(1, 4, size=total)
     allele = np.where(flip, (allele + shift) % 4, allele)

@@ -256,3 +256,29 @@ def test_per_cell_api_and_lazy_band():
     assert str(sym) == '-' and sym == h.symbols_d['-'] and sym != h.symbols_d['_']
     with pytest.raises(KeyError):
         h.add_observation('X', 'A', 1, 2)
+
+
+def test_fill_sorted_and_shuffled_tables_agree():
+    # rank-sorted tables take the LDS-counting kernel, shuffled ones the scattered-atomics kernel
+    t = make_support_table(700, 40000, k=None, seed=12)
+    assert (np.diff(t.rank) >= 0).all()
+    h1 = Hansel(t.n_snps, band=t.band)
+    st1 = h1.fill_from_support(t.rank, t.off, t.bases)
+    perm = np.random.default_rng(0).permutation(t.n_reads)
+    ks = np.diff(t.off)
+    off2 = np.concatenate([[0], np.cumsum(ks[perm])]).astype(np.int64)
+    bases2 = np.concatenate([t.bases[t.off[i]:t.off[i + 1]] for i in perm])
+    h2 = Hansel(t.n_snps, band=t.band)
+    st2 = h2.fill_from_support(t.rank[perm], off2, bases2)
+    assert st1 == st2
+    assert np.array_equal(h1.export_band(), h2.export_band())
+    o = COracle(t.n_snps, t.band)
+    assert o.fill(t) == st1
+    assert np.array_equal(h1.export_band(), o.export_band())
+    # a band narrower than the LDS slice logic expects, and the end sentinels, on the sorted path
+    h3 = Hansel(t.n_snps, band=t.band)
+    o3 = COracle(t.n_snps, t.band)
+    from oracle.c_oracle import lib, _p
+    assert lib().orc_fill(o3._h, _p(np.ascontiguousarray(t.rank)), _p(np.ascontiguousarray(t.off)), _p(t.bases), t.n_reads, 1) == 0
+    assert h3.fill_from_support(t.rank, t.off, t.bases, use_end_sentinels=True) == o3.stats()
+    assert np.array_equal(h3.export_band(), o3.export_band())
