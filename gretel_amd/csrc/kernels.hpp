@@ -668,6 +668,8 @@ __device__ __forceinline__ void book_positions(const walk_params &P, const unsig
 //   R  issue the row of source j+1 under w_{j+1} and the hypothesis terms of target j+3
 //   M  B = group-wise arg-max of acc_{j+2}                               independent of R
 // so the LDS latency of R is covered by M and by the next body's A and S.
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+
 template <int LC, bool NODEL>
 __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, unsigned long long *words0,
                                             int C, int nchunks, int lane)
@@ -690,17 +692,23 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
     for (int l = 1; l < LC; l++) Y[0][l] = g0[bb + 5 * ROW + l * LT_ROW];
     double hyp = g0[bb + BLK + ga * ROW];   // lag 1 of target 2: source 1 under every hypothesis
 
+    // LDS byte addresses are formed by hand: one v_mad_u32_u24 (row base + w * row bytes) right behind the
+    // scalar resolve replaces the s_mul / s_add / v_add / v_add chain hipcc emits for the pointer form
+    constexpr unsigned ROWB = ROW * 8, BLKB = BLK * 8;
+    const unsigned lds0 = (unsigned)(uintptr_t)g0 + (unsigned)bb * 8u;
+    unsigned rowb_v;
+    asm("v_mov_b32 %0, %1" : "=v"(rowb_v) : "i"(ROWB));
+
     for (int k = 0; k < nchunks; k++) {
-        const double *gb = g0 + (size_t)(k & 1) * (C + 2) * BLK + bb;    // real rows: + w*ROW
-        const double *gh = gb + ga * ROW;                                 // hypothesis rows (lag 1)
+        unsigned vg = lds0 + (unsigned)(k & 1) * (unsigned)(C + 2) * BLKB;          // block of source k*C + g*LC
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
         for (int g = 0; g < ngroups; g++) {
             unsigned long long word = 0;
+            const unsigned vgh = vg + (unsigned)ga * ROWB;
 #pragma unroll
             for (int u = 0; u < LC; u++) {
-                const int s = g * LC + u;                                  // body j = k*C + s
-                // A: resolve w_{j+1}
+                // A: resolve w_{j+1}   (body j = k*C + g*LC + u)
                 const int w = (int)__builtin_ctzll(B >> sh);
                 sh = 8 * w;
                 word = (word << 4) | (unsigned long long)w;
@@ -709,10 +717,13 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 #pragma unroll
                 for (int l = 1; l < LC; l++) acc += Y[(u - (l - 1) + LC) % LC][l];
                 // R: row of source j+1 under its real symbol; lag-1 terms of target j+3 (source j+2)
-                const double *row = gb + (size_t)(s + 1) * BLK + w * ROW;
+                unsigned vrow;
+                const unsigned vstep = vg + (unsigned)(u + 1) * BLKB;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(vrow) : "s"(w), "v"(rowb_v), "v"(vstep));
+                lds_cdouble *row = (lds_cdouble *)vrow;
 #pragma unroll
                 for (int l = 1; l < LC; l++) Y[(u + 1) % LC][l] = row[l * LT_ROW];
-                hyp = gh[(size_t)(s + 2) * BLK];
+                hyp = *(lds_cdouble *)(vgh + (unsigned)(u + 2) * BLKB);
                 // M: ballot of target j+2
                 B = group_argmax<NODEL>(acc);
                 // keep the next body's adds (which wait for the reads issued above) behind this arg-max:
@@ -720,6 +731,7 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
                 __builtin_amdgcn_sched_barrier(0);
             }
             wk[g] = word;
+            vg += (unsigned)LC * BLKB;
         }
         __syncthreads();
     }

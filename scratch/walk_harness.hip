@@ -33,7 +33,7 @@ int main(int argc, char** argv){
         dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1;
         hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
         walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
-        hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P);
+        hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P, (const win_desc*)nullptr, 0);
         hipError_t e = hipDeviceSynchronize();
         hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
         hipMemcpy(path[v].data(), dpath[v], N+1, hipMemcpyDeviceToHost);
