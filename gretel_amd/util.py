@@ -7,8 +7,9 @@ Drop-in for the ingest half of the reference's `gretel/util.py`:
     get_ref_len_from_bam(bam_path, target_contig)                gretel/util.py:10-31
 
 The reference reads BAM through pysam (htslib pileup) and VCF through PyVCF (tabix);
-neither is available here, so the host side decodes BGZF/BAM and bgzipped VCF with the
-standard library (BGZF is multi-member gzip) and turns every read into one row of the
+neither is available here, so the host side decodes BGZF/BAM natively (libgretel_io.so,
+gretel_amd/csrc/bam_support.cpp; a pure-Python restatement of the same rules lives below) and
+bgzipped VCF with the standard library, and turns every read into one row of the
 *support table* `(rank, support_seq)` -- what the reference holds per read at
 util.py:235-238 -- by walking the CIGAR the way htslib's pileup resolves it.  The pair
 loop itself (util.py:226-286) and the counters / L (util.py:329-333) run on the GPU
@@ -124,8 +125,11 @@ def read_bam(bam_path):
     return refs, records()
 
 
-def get_ref_len_from_bam(bam_path, target_contig):
+def get_ref_len_from_bam(bam_path, target_contig, decoder="native"):
     """gretel/util.py:10-31"""
+    if decoder == "native":
+        from . import bamio
+        return bamio.native_ref_len(bam_path, target_contig)
     refs, _ = read_bam(bam_path)
     for name, ln in refs:
         if name == target_contig:
@@ -166,8 +170,14 @@ def _support_of_read(rec, region, start_pos, end_pos):
     return rec.pos + 1, qalen, chars
 
 
-def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper="samtools"):
-    """The pileup half of load_from_bam (gretel/util.py:137-209) -> support table arrays."""
+def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper="samtools",
+                           decoder="native"):
+    """The pileup half of load_from_bam (gretel/util.py:137-209) -> support table arrays.
+    decoder="native": libgretel_io.so (C++/zlib, include/gretel_io.h); "python": the pure-Python restatement
+    below (same rules; kept as the readable specification and as a cross-check in the tests)."""
+    if decoder == "native":
+        from . import bamio
+        return bamio.native_support_table(bam_path, target_contig, start_pos, end_pos, vcf_handler["region"], stepper)
     refs, records = read_bam(bam_path)
     names = [n for n, _ in refs]
     if target_contig not in names:
@@ -211,9 +221,9 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
 
 
 def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_end_sentinels=False,
-                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", **hansel_kw):
+                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", decoder="native", **hansel_kw):
     """gretel/util.py:33-335.  Returns a device-backed Hansel with n_slices, n_crumbs and L set."""
-    rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper)
+    rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper, decoder)
     max_k = int(np.diff(off).max()) if len(rank) else 0
     hansel = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, vcf_handler["N"], band=max(1, max_k - 1), **hansel_kw)
     n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels)

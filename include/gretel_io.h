@@ -1,0 +1,51 @@
+/*
+ * gretel_io.h -- C ABI of libgretel_io.so: native BAM decoding for the ingest half of
+ * load_from_bam (reference gretel/util.py:120-209, which goes through pysam / htslib's pileup).
+ *
+ * It turns a coordinate-sorted BAM into the *support table* the GPU fill consumes
+ * (include/gretel_hip.h, gh_reads_upload): per read the rank of util.py:198 and the
+ * support_seq of util.py:238.  Host code only (zlib), no GPU.
+ *
+ * What it reproduces of the reference's per-read logic:
+ *   read key  "<qname>_<flag>_<1|2|0>"                       util.py:149-160
+ *   LEFTMOST / reads starting before start_pos               util.py:162-171
+ *   deletion / ref-skip columns -> "-"                       util.py:180-182
+ *   first base of every captured allele                      util.py:184-190,238
+ *   rank = number of SNPs in [1, LEFTMOST)                   util.py:198
+ *   stepper "samtools": UNMAP/SECONDARY/QCFAIL/DUP reads and paired-but-not-proper reads are
+ *   dropped; stepper "all" (--pepper, cmd.py:39,78) keeps the latter.
+ * Not reproduced: pysam's max_depth cap (8000).
+ */
+#ifndef GRETEL_IO_H
+#define GRETEL_IO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t *rank;      /* [n_reads] */
+    int64_t *off;       /* [n_reads + 1] */
+    uint8_t *bases;     /* [n_bases] ASCII */
+    int64_t n_reads;
+    int64_t n_bases;
+} gio_table;
+
+const char *gio_last_error(void);
+
+/* bam.lengths[bam.get_tid(contig)] -- gretel/util.py:27-29 */
+int gio_ref_len(const char *bam_path, const char *contig, int64_t *len);
+
+/* region: uint8[end_pos + 1], region[p] != 0 <=> 1-based position p is a SNP (VCF_h["region"],
+ * util.py:393-403).  Reads appear in the order the pileup first meets them (file order).
+ * Returns 0 or a negative error code; the table is released with gio_table_free. */
+int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                               const uint8_t *region, int stepper_all, gio_table *out);
+void gio_table_free(gio_table *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -21,6 +21,7 @@ def _built():
     import __graft_entry__ as g
     from gretel_amd import _lib
     from oracle import c_oracle
-    if not os.path.exists(_lib.SO_PATH) or not os.path.exists(c_oracle._SO):
+    from gretel_amd import bamio
+    if not os.path.exists(_lib.SO_PATH) or not os.path.exists(c_oracle._SO) or not os.path.exists(bamio.IO_SO):
         g.build()
     yield

@@ -52,3 +52,13 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt.replace("oracle/hansel_ref.py", "").replace("oracle/gretel_ref.py", ""):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_io_library_exports_its_header():
+    from gretel_amd import bamio
+    src = open(os.path.join(ROOT, "include", "gretel_io.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b(gio_[a-z_0-9]+)\s*\(", src)))
+    assert len(names) >= 4
+    so = ctypes.CDLL(bamio.IO_SO)
+    assert not [n for n in names if not hasattr(so, n)]

@@ -70,3 +70,32 @@ def test_cli_reports_gap_and_exits(tmp_path):
     with pytest.raises(SystemExit) as e:
         cmd.main([BAM, VCF, "hoot", "-s", "10", "-e", "20", "--quiet", "-o", str(tmp_path)])
     assert e.value.code == 1
+
+
+def test_cli_on_synthetic_files_matches_oracle(tmp_path):
+    """BAM/VCF written from a synthetic support table -> native decode -> GPU fill + spins -> files."""
+    import numpy as np
+    from gretel_amd import bamio
+    from gretel_amd.synth import make_support_table
+    from oracle.c_oracle import COracle, paths_to_str
+    t = make_support_table(150, 3000, k=4, seed=21)
+    bam, vcf = str(tmp_path / "s.bam"), str(tmp_path / "s.vcf.gz")
+    contig, s, e = bamio.synth_to_files(t, bam, vcf)
+    out = tmp_path / "out"
+    out.mkdir()
+    assert cmd.main([bam, vcf, contig, "-p", "20", "--quiet", "-o", str(out)]) == 0
+    o = COracle(t.n_snps, t.band)
+    st = o.fill(t)
+    ref = o.spin(20)
+    strs = paths_to_str(ref["paths"])
+    first_seen = {}
+    for i, p in enumerate(strs):
+        first_seen.setdefault(p, i)
+    lines = (out / "snp.fasta").read_text().splitlines()
+    got = [(int(lines[q][1:].split("__")[0]), lines[q + 1]) for q in range(0, len(lines), 2)]
+    want = [(i, p[1:]) for p, i in sorted(first_seen.items(), key=lambda x: x[1])]
+    assert got == want
+    head = (out / "gretel.crumbs").read_text().splitlines()[0]
+    assert head == "# %d\t%d\t%d\t%.2f" % (t.n_snps, st[1], st[0], o.L)
+    full = (out / "out.fasta").read_text().splitlines()[1]
+    assert len(full) == e and full[9] == want[0][1][0] and set(full) <= set("ACGTN")
