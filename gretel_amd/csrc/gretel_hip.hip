@@ -573,11 +573,13 @@ static int ensure_marg(gh_handle *h)
     HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, 3 * sizeof(int), h->stream));   // first_hole, nodel, cm_same
     prof_begin(h, GH_K_MARG);
     if (h->cfg.storage == GH_STORAGE_F64)
-        hipLaunchKernelGGL(k_marg<double>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
-                           (const double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr);
+        hipLaunchKernelGGL((k_marg<double, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
+                           (double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
     else
-        hipLaunchKernelGGL(k_marg<float>, dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
-                           (const float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr);
+        hipLaunchKernelGGL((k_marg<float, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
+                           (float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
     // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
     prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
     { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
@@ -814,11 +816,12 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
     return GH_OK;
 }
 
-static int launch_reweight(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec)
+// reweight along d_path AND refresh the marginal tables in one pass (k_marg<T, true>)
+static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec)
 {
-    const size_t total = (size_t)(h->N + 1) * h->W;
+    const int threads = (h->N + 1) * 8;
     const int block = 256;
-    const int nb = (int)((total + block - 1) / block);
+    const int nb = (threads + block - 1) / block;
     if (nb > h->partial_cap) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->partial) hipFree(h->partial);
@@ -826,19 +829,24 @@ static int launch_reweight(gh_handle *h, const uint8_t *d_path, double ratio, in
         HIPCHK(hipMalloc((void **)&h->partial, (size_t)nb * sizeof(double)));
         h->partial_cap = nb;
     }
+    hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, use_state);
     prof_begin(h, GH_K_REWEIGHT);
     if (h->cfg.storage == GH_STORAGE_F64)
-        hipLaunchKernelGGL(k_reweight<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
-                           d_path, h->dstate, ratio, use_state, h->partial, (const win_desc *)nullptr, 0);
+        hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
+                           h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
+                           d_path, ratio, use_state, h->partial, 0);
     else
-        hipLaunchKernelGGL(k_reweight<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
-                           d_path, h->dstate, ratio, use_state, h->partial, (const win_desc *)nullptr, 0);
-    hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec, (const win_desc *)nullptr, 0);
-    prof_end(h, GH_K_REWEIGHT, (double)total * 2.0 * esize(h) + (double)(h->N + 1));
-    { int rc_ = post_launch(h, "k_reweight"); if (rc_) return rc_; }
-    // the table can be updated row-wise if this reweight is the only change since it was built
+        hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
+                           h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
+                           d_path, ratio, use_state, h->partial, 0);
+    hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec,
+                       (const win_desc *)nullptr, 0);
+    // algorithmic bytes: the reweighted elements (read+write) + the marginal pass (read cell (p,p+1), write the tables)
+    prof_end(h, GH_K_REWEIGHT, (double)(h->N + 1) * ((double)h->W * 2.0 * esize(h) + 1.0 + CELL * esize(h) + 2 * 64 + 88 + 8));
+    { int rc_ = post_launch(h, "k_marg<reweight>"); if (rc_) return rc_; }
     h->lt_inc_path = (!h->dirty_lt && h->lt && h->lt_L == h->L) ? d_path : nullptr;
-    h->dirty_marg = h->dirty_lt = true;
+    h->dirty_lt = true;
+    h->dirty_marg = false;
     return GH_OK;
 }
 
@@ -892,7 +900,7 @@ extern "C" int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, doub
     for (int q = 0; q <= h->N; q++)
         if (path[q] >= NSYM) return fail(GH_ERR_SYMBOL, "path[%d] = %d is not a symbol index", q, path[q]);
     HIPCHK(hipMemcpyAsync(h->d_rw_path, path, (size_t)h->N + 1, hipMemcpyHostToDevice, h->stream));
-    int rc = launch_reweight(h, h->d_rw_path, ratio, 0, h->d_rec);
+    int rc = launch_reweight_marg(h, h->d_rw_path, ratio, 0, h->d_rec);
     if (rc) return rc;
     gh_path_rec rec;
     HIPCHK(hipMemcpyAsync(&rec, h->d_rec, sizeof rec, hipMemcpyDeviceToHost, h->stream));
@@ -921,7 +929,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     for (int s = 0; s < max_paths && rc == GH_OK; s++) {
         if ((rc = ensure_lt(h))) break;
         if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove))) break;
-        if ((rc = launch_reweight(h, d_paths + n1 * s, 0.0, 1, d_recs + s))) break;
+        if ((rc = launch_reweight_marg(h, d_paths + n1 * s, 0.0, 1, d_recs + s))) break;
     }
     dev_state hs;
     memset(&hs, 0, sizeof hs);
@@ -984,7 +992,7 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     b->hs.assign(handles, handles + n);
     b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
     b->cap_paths = 0;
-    b->nb = (int)(((size_t)(b->N + 1) * b->W + 255) / 256);
+    b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_reweight and of k_marg<.., true>
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_wd, sizeof(win_desc) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_partial, sizeof(double) * (size_t)b->nb * n);
@@ -1043,35 +1051,42 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     size_t lt_nb_inc = ((size_t)N * L * LT_ROW + 255) / 256;
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
+    const int post_nb = (int)marg_gx;        // k_marg<.., true> writes one partial per block (b->nb >= post_nb)
     for (int s = 0; s < max_paths; s++) {
         // any non-null pointer switches k_lt to the row-wise update; the kernel takes the path of spin s-1 from wd
         const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
-        hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, b->d_wd);
-        if (f64) {
-            hipLaunchKernelGGL(k_marg<double>, dim3(marg_gx, n), dim3(256), 0, b->stream, (const double *)nullptr, N, W,
-                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                               (dev_state *)nullptr, b->d_wd);
+        if (s == 0) {
+            hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, (dev_state *)nullptr, b->d_wd, 0);
+            if (f64)
+                hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
+                                   (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+            else
+                hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
+                                   (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+        }
+        if (f64)
             hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
                                inc, b->d_wd, s);
-        } else {
-            hipLaunchKernelGGL(k_marg<float>, dim3(marg_gx, n), dim3(256), 0, b->stream, (const float *)nullptr, N, W,
-                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                               (dev_state *)nullptr, b->d_wd);
+        else
             hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
                                inc, b->d_wd, s);
-        }
         launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
+        hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, (dev_state *)nullptr, b->d_wd, 1);
         if (f64)
-            hipLaunchKernelGGL(k_reweight<double>, dim3(b->nb, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
-                               (const uint8_t *)nullptr, (const dev_state *)nullptr, 0.0, 1, (double *)nullptr, b->d_wd, s);
+            hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
+                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s);
         else
-            hipLaunchKernelGGL(k_reweight<float>, dim3(b->nb, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
-                               (const uint8_t *)nullptr, (const dev_state *)nullptr, 0.0, 1, (double *)nullptr, b->d_wd, s);
-        hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, b->nb,
+            hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
+                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s);
+        hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, post_nb,
                            (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, b->d_wd, s);
     }
     HIPCHK(hipGetLastError());

@@ -284,57 +284,122 @@ __global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a
 // k_marg: counts / marginals / candidate masks for every position p in [0, N]
 // (hansel get_counts_at + get_marginal_of_at, call sites gretel/cmd.py:86, gretel/gretel.py:182)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// RW = true fuses gretel/gretel.py:79-98 in front: the 8-lane group of position p first reweights the
+// cells (p, p+d), d = 1..W, on `rw_path` (same element-wise arithmetic and multiplicities as k_reweight,
+// removed mass into partial[blockIdx.x]) and then takes the marginals of the cell (p, p+1) it has just
+// updated -- one pass over the band instead of two, one launch less per path.
+template <typename T, bool RW>
 __global__ void __launch_bounds__(256)
-k_marg(const T *band, int N, int W, double *cnt, double *marg,
-       int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st, const win_desc *wd)
+k_marg(T *band, int N, int W, double *cnt, double *marg,
+       int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st, const win_desc *wd,
+       const uint8_t *rw_path, double ratio_arg, int use_state_ratio, double *partial, int spin)
 {
+    __shared__ double s_red[256];
+    bool live = true;
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
-        band = (const T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st;
-        if (st->stop) return;
+        band = (T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st;
+        if (RW) { rw_path = d.paths + (size_t)spin * (N + 1); partial = d.partial; }
+        live = !st->stop;
     }
+    if (RW && use_state_ratio && st->stop) live = false;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 3, s = t & 7;
-    if (p > N) return;
-    const T *cell = band + ((size_t)p * W) * CELL;       // cell (p, p+1)
+    const bool act = live && p <= N;
+    T *cell = band + ((size_t)(act ? p : 0) * W) * CELL;       // cell (p, p+1)
+    double removed = 0.0;
+    int na = -1, nb = -1;
+    T nval = (T)0;
+    if (RW && act) {
+        const double ratio = use_state_ratio ? st->ratio : ratio_arg;
+        for (int d = s + 1; d <= W; d += 8) {
+            const int j = p + d;
+            int mult = 0;
+            if (j <= N - 1) mult = (d == 1) ? 2 : 1;
+            else if (j == N) mult = (d == 1) ? 1 : 0;
+            else if (j == N + 1) mult = (p == N) ? 1 : 0;
+            if (mult) {
+                const int a = rw_path[p];
+                const int b = (j == N + 1) ? rw_path[0] : rw_path[j];
+                T *e = band + ((size_t)p * W + (d - 1)) * CELL + a * NSYM + b;
+                T cur = *e;
+                for (int q = 0; q < mult; q++) {
+                    const double old = (double)cur;
+                    const double nw = old - ratio * old;
+                    cur = (T)nw;
+                    removed += old - nw;
+                }
+                *e = cur;
+                if (d == 1) { na = a; nb = b; nval = cur; }
+            }
+        }
+    }
+    if (RW) {
+        na = __shfl(na, 0, 8); nb = __shfl(nb, 0, 8);
+        nval = (T)__shfl((double)nval, 0, 8);
+    }
     double c[NSYM];
     double tot = 0.0;
     int nv = 0;
     uint32_t cm = 0, cm5 = 0;
+    // lane s of the 8-lane group sums row s once (sequentially, in the storage dtype); the group shares the sums
+    T acc = (T)0;
+    if (act && s < NSYM) {
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) {
+            T v = cell[s * NSYM + x];
+            if (RW && s == na && x == nb) v = nval;      // the element this group has just rewritten
+            acc = acc + v;
+        }
+    }
+    const double mine = (double)acc;
 #pragma unroll
     for (int x = 0; x < NSYM; x++) {
-        c[x] = rowsum(cell, x);
+        c[x] = __shfl(mine, x, 8);
         if (c[x] > 0) {
             tot += c[x];
             if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; cm5 |= 1u << a6_of_sym(x); }
         }
     }
-    if (s < NSYM) {
-        const double m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
-        cnt[(size_t)p * 8 + s] = c[s];
-        marg[(size_t)p * 8 + s] = m;
-        if ((VALID_MASK >> s) & 1) {
-            const int b5 = a6_of_sym(s);
-            minfo[(size_t)p * MINFO + b5] = gh_log10(m);
-            minfo[(size_t)p * MINFO + 5 + b5] = m;
+    if (act) {
+        if (s < NSYM) {
+            const double m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
+            cnt[(size_t)p * 8 + s] = c[s];
+            marg[(size_t)p * 8 + s] = m;
+            if ((VALID_MASK >> s) & 1) {
+                const int b5 = a6_of_sym(s);
+                minfo[(size_t)p * MINFO + b5] = gh_log10(m);
+                minfo[(size_t)p * MINFO + 5 + b5] = m;
+            }
+        } else {
+            cnt[(size_t)p * 8 + 7] = tot;
+            marg[(size_t)p * 8 + 7] = 0.0;
+            nvalid[p] = nv;
+            if (cmask[p] != cm) atomicAnd(&st->cm_same, 0);       // the conditional table must then be rebuilt in full
+            cmask[p] = cm;
+            minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
+            if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
+            if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
         }
-    } else {
-        cnt[(size_t)p * 8 + 7] = tot;
-        marg[(size_t)p * 8 + 7] = 0.0;
-        nvalid[p] = nv;
-        if (cmask[p] != cm) atomicAnd(&st->cm_same, 0);       // the conditional table must then be rebuilt in full
-        cmask[p] = cm;
-        minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
-        if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
-        if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
+    }
+    if (RW) {
+        // fixed-order tree so the removed mass is run-to-run reproducible
+        s_red[threadIdx.x] = removed;
+        __syncthreads();
+        for (int q = 128; q > 0; q >>= 1) {
+            if ((int)threadIdx.x < q) s_red[threadIdx.x] += s_red[threadIdx.x + q];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
     }
 }
 
 // batched launches: re-arm the words k_marg min/and-reduces into (single windows use a memset)
-__global__ void k_rearm(const win_desc *wd)
+__global__ void k_rearm(dev_state *st, const win_desc *wd, int skip_if_stopped)
 {
-    dev_state *st = wd[blockIdx.x].st;
+    if (wd) st = wd[blockIdx.x].st;
+    // a window that hit a hole keeps its last flags: the k_marg that would refresh them is skipped as well
+    if (skip_if_stopped && st->stop) return;
     if (threadIdx.x == 0) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
 }
 
@@ -890,59 +955,12 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_reweight: gretel/gretel.py:79-98 restricted to the band (all other cells are zero and
-// stay zero).  Multiplicities of the reference's pair enumeration:
+// reweighting: gretel/gretel.py:79-98 restricted to the band (all other cells are zero and stay
+// zero) lives in k_marg<T, true>.  Multiplicities of the reference's pair enumeration:
 //   (p,p+1), p <= N-2 : twice      (N-1,N) : once      (p,q), q-p>=2, q <= N-1 : once
 //   (p,N), p < N-1    : never      (N,N+1) with symbols (path[N], path[0]) : once
+// k_reweight_finish adds the per-block partial sums of the removed mass in a fixed order.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256)
-k_reweight(T *band, int N, int W, const uint8_t *path,
-           const dev_state *st, double ratio_arg, int use_state_ratio, double *partial, const win_desc *wd, int spin)
-{
-    __shared__ double s_red[256];
-    if (wd) {
-        const win_desc &d = wd[blockIdx.y];
-        band = (T *)d.band; path = d.paths + (size_t)spin * (N + 1); st = d.st; partial = d.partial;
-    }
-    double removed = 0.0;
-    if (!(use_state_ratio && st->stop)) {
-        const double ratio = use_state_ratio ? st->ratio : ratio_arg;
-        const size_t total = (size_t)(N + 1) * W;
-        const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-        if (t < total) {
-            const int i = (int)(t / W);
-            const int d = (int)(t % W) + 1;
-            const int j = i + d;
-            int mult = 0;
-            if (j <= N - 1) mult = (d == 1) ? 2 : 1;
-            else if (j == N) mult = (d == 1) ? 1 : 0;
-            else if (j == N + 1) mult = (i == N) ? 1 : 0;
-            if (mult) {
-                const int a = path[i];
-                const int b = (j == N + 1) ? path[0] : path[j];
-                T *p = band + ((size_t)i * W + (d - 1)) * CELL + a * NSYM + b;
-                T cur = *p;
-                for (int q = 0; q < mult; q++) {
-                    const double old = (double)cur;
-                    const double nw = old - ratio * old;
-                    cur = (T)nw;
-                    removed += old - nw;
-                }
-                *p = cur;
-            }
-        }
-    }
-    // fixed-order tree so the sum is run-to-run reproducible
-    s_red[threadIdx.x] = removed;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) s_red[threadIdx.x] += s_red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
-}
-
 __global__ void __launch_bounds__(256)
 k_reweight_finish(const double *partial, int nb, dev_state *st, int use_state,
                   gh_path_rec *rec, const win_desc *wd, int spin)
