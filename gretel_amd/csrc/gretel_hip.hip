@@ -802,10 +802,10 @@ static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int
     }
 }
 
-static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove)
+static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove, int rearm)
 {
     walk_params P;
-    P.N = h->N; P.L = h->L; P.chunk = 0;
+    P.N = h->N; P.L = h->L; P.chunk = 0; P.rearm = rearm;
     P.G = h->lt; P.minfo = h->minfo;
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
     prof_begin(h, GH_K_WALK);
@@ -829,7 +829,8 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         HIPCHK(hipMalloc((void **)&h->partial, (size_t)nb * sizeof(double)));
         h->partial_cap = nb;
     }
-    hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, use_state);
+    // in a spin the walker re-armed the flags when it finished; a lone reweight does it here
+    if (!use_state) hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, 0);
     prof_begin(h, GH_K_REWEIGHT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
@@ -877,7 +878,7 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
         hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N);
     }
     if ((rc = reset_spin_state(h))) return rc;
-    if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0))) return rc;
+    if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0, 0))) return rc;
     dev_state hs;
     gh_path_rec rec;
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
@@ -928,7 +929,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     rc = reset_spin_state(h);
     for (int s = 0; s < max_paths && rc == GH_OK; s++) {
         if ((rc = ensure_lt(h))) break;
-        if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove))) break;
+        if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1))) break;
         if ((rc = launch_reweight_marg(h, d_paths + n1 * s, 0.0, 1, d_recs + s))) break;
     }
     dev_state hs;
@@ -1046,12 +1047,11 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     size_t lt_nb = ((size_t)(N + LT_PAD) * L * LT_BLK + 255) / 256;
     if (lt_nb > 4096) lt_nb = 4096;
     walk_params P;
-    P.N = N; P.L = L; P.chunk = 0; P.G = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
+    P.N = N; P.L = L; P.chunk = 0; P.rearm = 1; P.G = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
     P.min_remove = min_remove;
     size_t lt_nb_inc = ((size_t)N * L * LT_ROW + 255) / 256;
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
-    const int post_nb = (int)marg_gx;        // k_marg<.., true> writes one partial per block (b->nb >= post_nb)
     for (int s = 0; s < max_paths; s++) {
         // any non-null pointer switches k_lt to the row-wise update; the kernel takes the path of spin s-1 from wd
         const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
@@ -1077,7 +1077,6 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
                                inc, b->d_wd, s);
         launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
-        hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, (dev_state *)nullptr, b->d_wd, 1);
         if (f64)
             hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
@@ -1086,7 +1085,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s);
-        hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, post_nb,
+        hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, (int)marg_gx,
                            (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, b->d_wd, s);
     }
     HIPCHK(hipGetLastError());

@@ -33,6 +33,7 @@ struct dev_state {
     int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish
     int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)
     int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one
+    int _pad2[2];
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
 };
 
@@ -495,6 +496,7 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
 struct walk_params {
     int N, L;
     int chunk;                // source positions per LDS buffer (multiple of L, <= 64)
+    int rearm;                // spin loops: re-arm first_hole/nodel/cm_same for the k_marg<T,true> that follows
     const double *G;          // [(N+LT_PAD)][6][L][5]
     const double *minfo;      // [N+2][16]
     uint8_t *path_out;        // device [N+1]
@@ -642,6 +644,7 @@ __global__ void __launch_bounds__(512) k_walk_src(walk_params P, const win_desc 
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
+                if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
             }
         }
         return;
@@ -868,6 +871,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
+                if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
             }
         }
         return;
@@ -950,6 +954,7 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
             P.rec->magnitude = 0.0;
             st->ratio = r;
             st->n_done += 1;
+            if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
         }
     }
 }
@@ -959,7 +964,8 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
 // zero) lives in k_marg<T, true>.  Multiplicities of the reference's pair enumeration:
 //   (p,p+1), p <= N-2 : twice      (N-1,N) : once      (p,q), q-p>=2, q <= N-1 : once
 //   (p,N), p < N-1    : never      (N,N+1) with symbols (path[N], path[0]) : once
-// k_reweight_finish adds the per-block partial sums of the removed mass in a fixed order.
+// k_reweight_finish adds the per-block partial sums of the removed mass in a fixed order (a per-block
+// __threadfence + ticket inside k_marg was tried: the agent-scope fences cost 2.5x in batched runs).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_reweight_finish(const double *partial, int nb, dev_state *st, int use_state,
