@@ -35,6 +35,7 @@ struct dev_state {
     int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one
     int _pad2[2];
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
+    unsigned long long dbg8[5];  // -DGH_STAMPS builds: cycles per body segment
 };
 
 // Batched launches (gh_batch_*): one entry per window; a kernel launched with `wd != nullptr` takes its
@@ -738,6 +739,22 @@ __device__ __forceinline__ void book_positions(const walk_params &P, const unsig
 // so the LDS latency of R is covered by M and by the next body's A and S.
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 
+// diagnostic builds only (-DGH_STAMPS): s_memtime stamps between the segments of a walker body, summed per
+// segment in scalar registers and stored once at the end into st->dbg[4..8]; never defined in the product build
+#ifdef GH_STAMPS
+#define GH_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        unsigned long long t_;                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        gh_seg[i] += t_ - gh_tprev;                                                                   \
+        gh_tprev = t_;                                                                                \
+    } while (0)
+#else
+#define GH_STAMP(i)
+#endif
+
 template <int LC, bool NODEL>
 __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, unsigned long long *words0,
                                             int C, int nchunks, int lane)
@@ -754,6 +771,9 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
         for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
 
     // state entering body 0: w_0 = '_' (a6 = 5); target 1 has the single lag-1 term of source 0
+#ifdef GH_STAMPS
+    unsigned long long gh_seg[5] = {0, 0, 0, 0, 0}, gh_tprev = __builtin_amdgcn_s_memtime();
+#endif
     int sh = 8 * 5;
     unsigned long long B = group_argmax<NODEL>(g0[bb + ga * ROW]);
 #pragma unroll
@@ -776,14 +796,17 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
             const unsigned vgh = vg + (unsigned)ga * ROWB;
 #pragma unroll
             for (int u = 0; u < LC; u++) {
+                GH_STAMP(0);
                 // A: resolve w_{j+1}   (body j = k*C + g*LC + u)
                 const int w = (int)__builtin_ctzll(B >> sh);
                 sh = 8 * w;
                 word = (word << 4) | (unsigned long long)w;
+                GH_STAMP(1);
                 // S: finish the sum of target j+2 (lag l+1 comes from source j-(l-1)), l ascending
                 double acc = hyp;
 #pragma unroll
                 for (int l = 1; l < LC; l++) acc += Y[(u - (l - 1) + LC) % LC][l];
+                GH_STAMP(2);
                 // R: row of source j+1 under its real symbol; lag-1 terms of target j+3 (source j+2)
                 unsigned vrow;
                 const unsigned vstep = vg + (unsigned)(u + 1) * BLKB;
@@ -792,8 +815,10 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 #pragma unroll
                 for (int l = 1; l < LC; l++) Y[(u + 1) % LC][l] = row[l * LT_ROW];
                 hyp = *(lds_cdouble *)(vgh + (unsigned)(u + 2) * BLKB);
+                GH_STAMP(3);
                 // M: ballot of target j+2
                 B = group_argmax<NODEL>(acc);
+                GH_STAMP(4);
                 // keep the next body's adds (which wait for the reads issued above) behind this arg-max:
                 // an in-order wave that stalls on them early would serialise the whole chain
                 __builtin_amdgcn_sched_barrier(0);
@@ -803,6 +828,10 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
         }
         __syncthreads();
     }
+#ifdef GH_STAMPS
+    if (lane == 0)
+        for (int q = 0; q < 5; q++) P.st->dbg8[q] = gh_seg[q];
+#endif
 }
 
 template <int LC>

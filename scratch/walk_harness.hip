@@ -32,12 +32,15 @@ int main(int argc, char** argv){
         if (variant_only >= 0 && v != variant_only) continue;
         dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1;
         hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
-        walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
+        walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.rearm = 0; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
         hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P, (const win_desc*)nullptr, 0);
         hipError_t e = hipDeviceSynchronize();
         hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
         hipMemcpy(path[v].data(), dpath[v], N+1, hipMemcpyDeviceToHost);
         printf("variant %d: %s  cycles/step %.1f  n_done %d\n", v, hipGetErrorString(e), hs.dbg[2] ? (double)hs.dbg[0]/hs.dbg[2] : 0.0, hs.n_done); fflush(stdout);
+#ifdef GH_STAMPS
+        { const char* nm[5] = {"loop/M-tail->A", "A resolve+pack", "S adds", "R reads issue", "M argmax"}; for (int q = 0; q < 5; q++) printf("   seg %d %-16s %.1f cycles/step (incl. ~stamp cost)\n", q, nm[q], (double)hs.dbg8[q]/hs.dbg[2]); }
+#endif
     }
     if (variant_only < 0) { int diff = 0; for (int i = 0; i <= N; i++) diff += path[0][i] != path[1][i]; printf("path differences: %d of %d\n", diff, N+1); }
     return 0;
