@@ -125,6 +125,7 @@ def io_lib():
         L.gio_support_table_from_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                                  C.POINTER(_gio_table)]
         L.gio_table_free.argtypes = [C.POINTER(_gio_table)]
+        L.gio_count_coverage.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
         _io = L
     return _io
 
@@ -156,3 +157,14 @@ def native_support_table(bam_path, contig, start_pos, end_pos, region, stepper="
     finally:
         L.gio_table_free(C.byref(t))
     return rank, off, bases
+
+
+def native_count_coverage(bam_path, contig, start0, stop):
+    """int32[4][stop-start0]: A,C,G,T counts per position, like pysam's count_coverage(..., quality_threshold=0,
+    read_callback='nofilter') as gretel/snpper.py:29 calls it."""
+    L = io_lib()
+    counts = np.zeros((4, max(0, stop - start0)), dtype=np.int32)
+    if L.gio_count_coverage(bam_path.encode(), contig.encode(), int(start0), int(stop), counts.ctypes.data):
+        msg = L.gio_last_error().decode()
+        raise (KeyError if "not in" in msg else IOError)(msg)
+    return counts

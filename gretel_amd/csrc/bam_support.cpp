@@ -221,3 +221,51 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
     out->n_bases = total;
     return 0;
 }
+
+extern "C" int gio_count_coverage(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts)
+{
+    if (!bam_path || !contig || !counts || start0 < 0 || stop < start0) return fail(-1, "bad argument");
+    bam_file b;
+    int rc = open_bam(bam_path, b);
+    if (rc) return rc;
+    int tid = -1;
+    for (size_t i = 0; i < b.refs.size(); i++)
+        if (b.refs[i].first == contig) tid = (int)i;
+    if (tid < 0) return fail(-5, "contig %s not in %s", contig, bam_path);
+    const int64_t len = (int64_t)stop - start0;
+    memset(counts, 0, sizeof(int32_t) * 4 * (size_t)len);
+    static const int8_t code2base[16] = {-1, 0, 1, -1, 2, -1, -1, -1, 3, -1, -1, -1, -1, -1, -1, -1};   // =ACMGRSVTWYHKDBN
+    const std::vector<uint8_t> &d = b.data;
+    size_t o = b.first_record;
+    while (o + 4 <= d.size()) {
+        const int32_t block_size = rd32(&d[o]);
+        o += 4;
+        if (block_size < 32 || o + (size_t)block_size > d.size()) return fail(-4, "truncated BAM record");
+        const uint8_t *r = &d[o];
+        o += block_size;
+        if (rd32(r) != tid || (rdu16(r + 14) & 0x4)) continue;           // other contig / unmapped
+        const int32_t pos = rd32(r + 4);
+        const int n_cigar = rdu16(r + 12);
+        const uint8_t *cig = r + 32 + r[8];
+        const uint8_t *seq = cig + 4 * (size_t)n_cigar;
+        if (rd32(r + 16) == 0) continue;
+        int64_t ref = pos, q = 0;
+        for (int c = 0; c < n_cigar; c++) {
+            const uint32_t v = rdu32(cig + 4 * c);
+            const int op = v & 15;
+            const int64_t ln = v >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                int64_t lo = ref < start0 ? start0 : ref, hi = ref + ln < stop ? ref + ln : stop;
+                for (int64_t p = lo; p < hi; p++) {
+                    const int64_t qi = q + (p - ref);
+                    const uint8_t byte = seq[qi >> 1];
+                    const int base = code2base[(qi & 1) ? (byte & 15) : (byte >> 4)];
+                    if (base >= 0) counts[(size_t)base * len + (p - start0)]++;
+                }
+                ref += ln; q += ln;
+            } else if (op == 2 || op == 3) ref += ln;
+            else if (op == 1 || op == 4) q += ln;
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,43 @@
+"""
+`gretel-snpper`: aggressively call every heterogeneous site of a contig as a SNP and print a placeholder VCF
+(reference gretel/snpper.py:12-56), on top of the native BAM decoder instead of pysam.
+
+A site is reported when more than one of A,C,G,T is seen on more than `--depth` reads (snpper.py:38-40);
+records are `contig  pos  .  A  C,T,G  0  .  INFO` (snpper.py:41-50).
+"""
+from __future__ import annotations
+
+import argparse
+import sys
+
+from . import bamio
+
+
+def call_sites(bam, contig, start1=1, end=None, depth=0):
+    """1-based positions of the called sites."""
+    if not end:
+        end = bamio.native_ref_len(bam, contig)                       # snpper.py:23-24
+    start0 = start1 - 1                                               # snpper.py:27
+    counts = bamio.native_count_coverage(bam, contig, start0, end)    # snpper.py:29
+    sites = (counts > depth).sum(axis=0)                              # snpper.py:38
+    return [int(i) + 1 + start0 for i in (sites > 1).nonzero()[0]]    # snpper.py:39-43
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser("gretel-snpper", description="Call every heterogeneous site and print a VCF",
+                                 epilog="coordinates are 1-based")
+    ap.add_argument("--bam", required=True, help="reads aligned to the (pseudo-)reference")
+    ap.add_argument("--contig", required=True, help="contig to call on")
+    ap.add_argument("-s", type=int, default=1, help="start [1]")
+    ap.add_argument("-e", type=int, help="end [length of the contig]")
+    ap.add_argument("--depth", type=int, default=0, help="a base counts as a variant if more than this many reads show it [0]")
+    args = ap.parse_args(argv)
+    out = sys.stdout
+    out.write("##fileformat=VCFv4.2\n")                               # snpper.py:33-35
+    for pos in call_sites(args.bam, args.contig, args.s, args.e, args.depth):
+        out.write("\t".join([args.contig, str(pos), ".", "A", "C,T,G", "0", ".", "INFO"]) + "\n")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

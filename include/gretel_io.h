@@ -45,6 +45,12 @@ int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t
                                const uint8_t *region, int stepper_all, gio_table *out);
 void gio_table_free(gio_table *t);
 
+/* pysam's bam.count_coverage(contig, start0, stop, quality_threshold=0, read_callback='nofilter') as
+ * gretel/snpper.py:29 uses it: counts[b][p - start0] = reads showing base b (A,C,G,T = 0..3) at 0-based
+ * position p in [start0, stop); every record on the contig counts (no flag filter), deletions,
+ * ref-skips, clips, insertions and N bases do not.  counts: int32[4][stop - start0], caller-allocated. */
+int gio_count_coverage(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts);
+
 #ifdef __cplusplus
 }
 #endif

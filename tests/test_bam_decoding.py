@@ -93,3 +93,17 @@ def test_synthetic_files_roundtrip(tmp_path):
     want = sorted(t.reads())
     assert sorted(rows) == want
     assert util.get_ref_len_from_bam(bam, contig) == e
+
+
+def test_snpper_on_fixture_and_cigar_cases(tmp_path, capsys):
+    from gretel_amd import snpper
+    # fixture: hoot has A/C/T at 1,2 ; A/C at 10 ; only G at 20 -> sites 1,2,10 (what the reference's own VCF lists, plus none at 20)
+    assert snpper.call_sites(BAM, "hoot") == [1, 2, 10]
+    assert snpper.call_sites(BAM, "hoot", depth=1) == []             # no base is seen on more than one read twice
+    assert snpper.call_sites(BAM, "hoot", 2, 9) == [2]
+    assert snpper.main(["--bam", BAM, "--contig", "hoot"]) == 0
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "##fileformat=VCFv4.2" and out[1] == "hoot\t1\t.\tA\tC,T,G\t0\t.\tINFO" and len(out) == 4
+    cov = bamio.native_count_coverage(BAM, "hoot", 0, 20)
+    assert cov.shape == (4, 20) and cov[:, 0].tolist() == [1, 1, 0, 2] and cov[:, 19].tolist() == [0, 0, 1, 0]
+    assert cov[:, 4].sum() == 0                                      # N bases are not counted
