@@ -726,7 +726,7 @@ extern "C" int gh_snapshot_original(gh_t *h)
     if (set_dev(h)) return GH_ERR_HIP;
     int rc = ensure_marg(h);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_snapshot, dim3(((h->N + 1) * 8 + 255) / 256), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N);
+    hipLaunchKernelGGL(k_snapshot, dim3(((h->N + 1) * 8 + 255) / 256), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N, (const win_desc *)nullptr);
     { int rc_ = post_launch(h, "k_snapshot"); if (rc_) return rc_; }
     h->have_orig = true;
     return GH_OK;
@@ -872,10 +872,10 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
         if (o->dev != h->dev) return fail(GH_ERR_ARG, "original lives on another device");
         if ((rc = ensure_marg(o))) return rc;
         HIPCHK(hipStreamSynchronize(o->stream));
-        hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, o->minfo, h->N);
+        hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, o->minfo, h->N, (const win_desc *)nullptr);
         h->have_orig = true;
     } else if (!h->have_orig) {
-        hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N);
+        hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N, (const win_desc *)nullptr);
     }
     if ((rc = reset_spin_state(h))) return rc;
     if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0, 0))) return rc;
@@ -1015,7 +1015,6 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         if (h->L != b->hs[0]->L)
             return fail(GH_ERR_STATE, "window %d has L=%d but window 0 has L=%d: set one L (gh_set_L) for the batch", w, h->L, b->hs[0]->L);
         if ((rc = alloc_lt(h))) return rc;
-        if (!h->have_orig && (rc = gh_snapshot_original(h))) return rc;
         if ((rc = reset_spin_state(h))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -1036,6 +1035,9 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         wd[w].partial = b->d_partial + (size_t)w * b->nb;
         wd[w].paths = b->d_paths + n1 * max_paths * w;
         wd[w].recs = b->d_recs + (size_t)max_paths * w;
+        wd[w].snap = h->have_orig ? 0 : 1;       // the first batched k_marg is followed by a batched snapshot
+        wd[w]._pad = 0;
+        h->have_orig = true;
     }
     HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
@@ -1065,6 +1067,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                 hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                    (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+            hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, (const double *)nullptr, N, b->d_wd);
         }
         if (f64)
             hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,

@@ -50,6 +50,8 @@ struct win_desc {
     double *partial;
     uint8_t *paths;        // [max_paths][N+1]
     gh_path_rec *recs;     // [max_paths]
+    int snap;              // batched k_snapshot: freeze this window's marginals as the original ones
+    int _pad;
 };
 
 __constant__ int8_t c_sym_of_char[256];
@@ -406,8 +408,13 @@ __global__ void k_rearm(dev_state *st, const win_desc *wd, int skip_if_stopped)
 }
 
 // freeze the current log-marginals as the original ones (slot [11..15] of minfo)
-__global__ void k_snapshot(double *__restrict__ dst_minfo, const double *__restrict__ src_minfo, int N)
+__global__ void k_snapshot(double *dst_minfo, const double *src_minfo, int N, const win_desc *wd)
 {
+    if (wd) {
+        if (!wd[blockIdx.y].snap) return;
+        dst_minfo = wd[blockIdx.y].minfo;
+        src_minfo = dst_minfo;
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 3, q = t & 7;
     if (p > N || q >= 5) return;
