@@ -1,20 +1,15 @@
-// gretel_hip.hip -- MI355X (gfx950 / CDNA4) kernels and the C ABI of include/gretel_hip.h.
+// gretel_hip.hip -- host side of libgretel_hip.so: the C ABI of include/gretel_hip.h over the gfx950 kernels
+// of kernels.hpp (which documents every kernel and table).
 //
-// Data layout in HBM:
+// Data in HBM per window:
 //   band    T[(N+2)][W][7][7]      cell (i, j=i+d), d in 1..W, at ((i*W)+(d-1))*49 ; T = float | double
-//   cnt     f64[(N+2)][8]          c_s(p) = sum_t H[s,t,p,p+1]  (s<7), [7] = total
-//   marg    f64[(N+2)][8]          c_s/total
-//   logm    f64[(N+2)][8]          log10(marg)            (logm0 = snapshot of the original matrix)
-//   nvalid  i32[(N+2)]             V(p): valid symbols with c_s(p) > 0
-//   cmask   u32[(N+2)]             bit s set <=> s is a candidate at p
-//   lt      f64[(N+1)][L][7][7]    log10 conditional of (a @ snp-l) -> (b @ snp), l = 1..L
+//   cnt, marg  f64[(N+2)][8]       c_s(p) = sum_t H[s,t,p,p+1] (+ total), c_s/total          (lookup API)
+//   nvalid, cmask                  V(p), candidate bitmask
+//   minfo   f64[(N+2)][16]         log10 marginal x5, marginal x5, candidate bits, log10 ORIGINAL marginal x5
+//   G (lt)  f64[(N+16)][6][L][5]   source-major log10 conditionals
 //
-// Kernels (all integer/float lookups, HBM/L2-bound or latency-bound; no MFMA):
-//   k_fill       gretel/util.py:226-286   one thread per read, float atomics into the band
-//   k_marg       hansel get_counts_at / get_marginal_of_at for every position at once
-//   k_lt         hansel conditional (App. A-6) for every (snp, lag, from, to) at once
-//   k_walk       gretel/gretel.py:143-189 the serial chain over N SNPs (one wavefront)
-//   k_reweight   gretel/gretel.py:79-98   every band cell on the path at once
+// Launch sequence of one spin (gretel/cmd.py:148-179):  k_lt (row-wise after the first) -> k_walk_spec ->
+// k_marg<T,true> (reweight + marginals) -> k_reweight_finish; gh_batch_spin launches each over all windows.
 //
 // Arithmetic contract (identical to oracle/hansel_ref.py): row/column sums accumulate
 // sequentially in the storage dtype, everything else is IEEE binary64 with NO fma
@@ -595,15 +590,6 @@ static int ensure_lt(gh_handle *h)
     if (rc) return rc;
     if (!h->dirty_lt && h->lt && h->lt_L == h->L) return GH_OK;
     if ((rc = alloc_lt(h))) return rc;
-    if (false) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->lt) hipFree(h->lt);
-        h->lt = nullptr;
-        size_t bytes = (size_t)(h->N + LT_PAD) * h->L * LT_BLK * sizeof(double);
-        hipError_t e = hipMalloc((void **)&h->lt, bytes);
-        if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
-        h->lt_L = h->L;
-    }
     const bool inc_ok = h->lt_inc_path && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
                         !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
