@@ -570,11 +570,11 @@ static int ensure_marg(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
     else
         hipLaunchKernelGGL((k_marg<float, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
     // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
     prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
     { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
@@ -593,7 +593,7 @@ static int ensure_lt(gh_handle *h)
     const bool inc_ok = h->lt_inc_path && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
                         !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
-    const size_t total = inc ? (size_t)h->N * h->L * LT_ROW : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
+    const size_t total = inc ? (size_t)h->N * h->L : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
     size_t nb = (total + block - 1) / block;
     if (nb > 256 * 16) nb = 256 * 16;
@@ -607,8 +607,8 @@ static int ensure_lt(gh_handle *h)
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
                            h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0);
     const int wl = h->W < h->L ? h->W : h->L;
-    // algorithmic bytes: full = read the band cells within reach + write G; incremental = one row per (source, lag)
-    prof_end(h, GH_K_LT, inc ? (double)h->N * ((double)wl * 7 * esize(h) + (double)h->L * LT_ROW * 8.0)
+    // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
+    prof_end(h, GH_K_LT, inc ? 8.0
                              : (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * LT_BLK * 8.0));
     { int rc_ = post_launch(h, "k_lt"); if (rc_) return rc_; }
     h->dirty_lt = false;
@@ -817,21 +817,29 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     }
     // in a spin the walker re-armed the flags when it finished; a lone reweight does it here
     if (!use_state) hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, 0);
+    // with a valid conditional table (conditional A or B, no marginal term) the kernel also rewrites the table rows
+    // this path changes; k_lt then only has to confirm that no candidate mask moved
+    const bool lt_ok = !h->dirty_lt && h->lt && h->lt_L == h->L && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
+                       !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
+    double *lt_rows = lt_ok ? h->lt : nullptr;
     prof_begin(h, GH_K_REWEIGHT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           d_path, ratio, use_state, h->partial, 0);
+                           d_path, ratio, use_state, h->partial, 0, lt_rows, h->L, h->cfg.cond_mode);
     else
         hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           d_path, ratio, use_state, h->partial, 0);
+                           d_path, ratio, use_state, h->partial, 0, lt_rows, h->L, h->cfg.cond_mode);
     hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec,
                        (const win_desc *)nullptr, 0);
     // algorithmic bytes: the reweighted elements (read+write) + the marginal pass (read cell (p,p+1), write the tables)
-    prof_end(h, GH_K_REWEIGHT, (double)(h->N + 1) * ((double)h->W * 2.0 * esize(h) + 1.0 + CELL * esize(h) + 2 * 64 + 88 + 8));
+    // (+ one band row read and L x 5 table entries written per (source, lag) when the table rows are rewritten too)
+    const int wl = h->W < h->L ? h->W : h->L;
+    prof_end(h, GH_K_REWEIGHT, (double)(h->N + 1) * ((double)h->W * 2.0 * esize(h) + 1.0 + CELL * esize(h) + 2 * 64 + 88 + 8) +
+                               (lt_ok ? (double)h->N * ((double)wl * 7 * esize(h) + (double)h->L * LT_ROW * 8.0) : 0.0));
     { int rc_ = post_launch(h, "k_marg<reweight>"); if (rc_) return rc_; }
-    h->lt_inc_path = (!h->dirty_lt && h->lt && h->lt_L == h->L) ? d_path : nullptr;
+    h->lt_inc_path = lt_ok ? d_path : nullptr;
     h->dirty_lt = true;
     h->dirty_marg = false;
     return GH_OK;
@@ -1037,7 +1045,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     walk_params P;
     P.N = N; P.L = L; P.chunk = 0; P.rearm = 1; P.G = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
     P.min_remove = min_remove;
-    size_t lt_nb_inc = ((size_t)N * L * LT_ROW + 255) / 256;
+    size_t lt_nb_inc = ((size_t)N * L + 255) / 256;
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     for (int s = 0; s < max_paths; s++) {
@@ -1048,11 +1056,11 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             if (f64)
                 hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
             else
                 hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0);
+                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
             hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, (const double *)nullptr, N, b->d_wd);
         }
         if (f64)
@@ -1069,11 +1077,13 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         if (f64)
             hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s);
+                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
+                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode);   // non-null = take G from wd
         else
             hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s);
+                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
+                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode);   // non-null = take G from wd
         hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, (int)marg_gx,
                            (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, b->d_wd, s);
     }

@@ -291,19 +291,21 @@ __global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a
 // RW = true fuses gretel/gretel.py:79-98 in front: the 8-lane group of position p first reweights the
 // cells (p, p+d), d = 1..W, on `rw_path` (same element-wise arithmetic and multiplicities as k_reweight,
 // removed mass into partial[blockIdx.x]) and then takes the marginals of the cell (p, p+1) it has just
-// updated -- one pass over the band instead of two, one launch less per path.
+// updated -- one pass over the band instead of two, one launch less per path.  With G != nullptr it also rewrites
+// the rows of the conditional table (k_lt below) that the path's cells feed, while those cells are still in cache.
 template <typename T, bool RW>
 __global__ void __launch_bounds__(256)
 k_marg(T *band, int N, int W, double *cnt, double *marg,
        int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st, const win_desc *wd,
-       const uint8_t *rw_path, double ratio_arg, int use_state_ratio, double *partial, int spin)
+       const uint8_t *rw_path, double ratio_arg, int use_state_ratio, double *partial, int spin,
+       double *G, int L, int cond_mode)
 {
     __shared__ double s_red[256];
     bool live = true;
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
         band = (T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st;
-        if (RW) { rw_path = d.paths + (size_t)spin * (N + 1); partial = d.partial; }
+        if (RW) { rw_path = d.paths + (size_t)spin * (N + 1); partial = d.partial; if (G) G = d.G; }
         live = !st->stop;
     }
     if (RW && use_state_ratio && st->stop) live = false;
@@ -386,6 +388,53 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
         }
     }
+    if (RW && G && act && p < N && rw_path[p] != 4) {
+        // the rows of the conditional table that this path's reweighting has changed: source p, symbol path[p],
+        // lags 1..L (the lane that rewrote element (p, p+l) also owns lag l, so it reads its own store back).
+        // nvalid / cmask of the targets are read while other groups rewrite them: k_lt trusts these rows only
+        // when no candidate mask moved (st->cm_same), and then old and new values are the same.
+        const int a = rw_path[p];
+        const int a6 = a6_of_sym(a);
+        const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
+        for (int l = s + 1; l <= L; l += 8) {
+            double *out = G + (((size_t)p * 6 + a6) * L + (l - 1)) * LT_ROW;
+            const int snp = p + l;
+            if (!(snp <= N && (a6 < 5 || p == 0))) {
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = 0.0;
+                continue;
+            }
+            double rowv[NSYM];
+            double sum = 0.0;
+            if (l <= W) {
+                const T *rc = band + ((size_t)p * W + (l - 1)) * CELL + a * NSYM;
+                T racc = (T)0;
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) { const T v = rc[x]; rowv[x] = (double)v; racc = racc + v; }
+                sum = (double)racc;
+            } else {
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) rowv[x] = 0.0;
+            }
+            const uint32_t cmj = cmask[snp];
+            const double den = (cond_mode == GH_COND_A) ? (double)nvalid[snp] + sum : nv_i + ca;
+            double xq[LT_ROW], v[LT_ROW];
+            bool odd = false;
+#pragma unroll
+            for (int b5 = 0; b5 < LT_ROW; b5++) {
+                xq[b5] = (1.0 + rowv[vsym(b5)]) / den;
+                odd |= !gh_log10_is_normal(xq[b5]);
+            }
+#pragma unroll
+            for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
+            if (odd) {
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
+            }
+#pragma unroll
+            for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmj >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
+        }
+    }
     if (RW) {
         // fixed-order tree so the removed mass is run-to-run reproducible
         s_red[threadIdx.x] = removed;
@@ -451,9 +500,10 @@ __device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond
 }
 
 // inc_path == nullptr: rebuild every entry.  Otherwise (conditional A or B, no marginal term, and the
-// tensor changed ONLY through reweight_hansel_from_path(inc_path)): every cell that changed is
-// H[path[i], path[j], i, j], which only enters the rows G[i][a6(path[i])][*][*] -- rebuild those
-// N*L*5 entries; if k_marg saw a candidate mask change (V(p) or the -inf masks moved), fall back to all.
+// tensor changed ONLY through a path reweight): every cell that changed is H[path[i], path[j], i, j], which
+// only enters the rows G[i][a6(path[i])][*][*], and k_marg<T, true> rewrote those N*L*5 entries in the same
+// pass that reweighted the cells.  k_lt then has nothing to do unless k_marg saw a candidate mask change
+// (V(p) or the -inf masks moved) or the path was cut short by a hole: then it rebuilds everything.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
@@ -466,19 +516,9 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
         if (st->stop) return;
         if (inc_path) inc_path = d.paths + (size_t)(spin - 1) * (N + 1);
     }
-    if (inc_path && st->cm_same && !st->stop) {       // after a hole the last path buffer is incomplete: rebuild in full
-        const size_t total = (size_t)N * L * LT_ROW;
-        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-            const int b5 = (int)(t % LT_ROW);
-            const size_t r = t / LT_ROW;
-            const int l = (int)(r % L) + 1;
-            const int i = (int)(r / L);
-            const int a6 = a6_of_sym(inc_path[i]);
-            G[(((size_t)i * 6 + a6) * L + (l - 1)) * LT_ROW + b5] =
-                lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
-        }
-        return;
-    }
+    // inc_path != null: k_marg<T, true> has already rewritten the rows the last path changed; they stand when no
+    // candidate mask moved and the path was complete -- otherwise rebuild everything
+    if (inc_path && st->cm_same && !st->stop) return;
     const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (size_t)gridDim.x * blockDim.x) {

@@ -36,9 +36,10 @@
 GH_HD uint64_t gh_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 GH_HD double gh_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 
-GH_HD double gh_log10(double x)
+/* the arithmetic of gh_log10 for a normal, positive, finite x (k0 = exponent carried in by the caller's
+ * subnormal scaling); straight-line code, so that several calls interleave on the GPU */
+GH_HD double gh_log10_normal(double x, int32_t k0)
 {
-    const double two54 = 1.80143985094819840000e+16;      /* 2^54 */
     const double ivln10hi = 4.34294481878168880939e-01;   /* 0x3fdbcb7b15200000 */
     const double ivln10lo = 2.50829467116452752298e-11;   /* 0x3dbb9438ca9aadd5 */
     const double log10_2hi = 3.01029995663611771306e-01;  /* 0x3FD34413509F6000 */
@@ -51,26 +52,11 @@ GH_HD double gh_log10(double x)
     const double Lg6 = 1.531383769920937332e-01;
     const double Lg7 = 1.479819860511658591e-01;
 
+
     uint64_t u = gh_d2u(x);
     int32_t hx = (int32_t)(u >> 32);
     uint32_t lx = (uint32_t)u;
-    int32_t k = 0;
-
-    if (hx < 0x00100000) {                       /* x < 2^-1022, zero, or negative */
-        if (((hx & 0x7fffffff) | (int32_t)(lx != 0)) == 0)
-            return -gh_u2d(0x7ff0000000000000ULL);           /* log(+-0) = -inf */
-        if (hx < 0)
-            return gh_u2d(0x7ff8000000000000ULL);            /* log(-#) = nan */
-        k -= 54;
-        x *= two54;                              /* subnormal: scale up */
-        u = gh_d2u(x);
-        hx = (int32_t)(u >> 32);
-        lx = (uint32_t)u;
-    }
-    if (hx >= 0x7ff00000)
-        return x + x;                            /* inf or nan */
-    if (hx == 0x3ff00000 && lx == 0)
-        return 0.0;                              /* log(1) = +0 */
+    int32_t k = k0;
 
     k += (hx >> 20) - 1023;
     hx &= 0x000fffff;
@@ -107,5 +93,35 @@ GH_HD double gh_log10(double x)
 
     return val_lo + val_hi;
 }
+
+/* 1 iff gh_log10(x) takes the straight-line path: 2^-1022 <= x < inf */
+GH_HD int gh_log10_is_normal(double x)
+{
+    const int32_t hx = (int32_t)(gh_d2u(x) >> 32);
+    return hx >= 0x00100000 && hx < 0x7ff00000;
+}
+
+GH_HD double gh_log10(double x)
+{
+    const double two54 = 1.80143985094819840000e+16;      /* 2^54 */
+    uint64_t u = gh_d2u(x);
+    int32_t hx = (int32_t)(u >> 32);
+    uint32_t lx = (uint32_t)u;
+    int32_t k = 0;
+
+    if (hx < 0x00100000) {                       /* x < 2^-1022, zero, or negative */
+        if (((hx & 0x7fffffff) | (int32_t)(lx != 0)) == 0)
+            return -gh_u2d(0x7ff0000000000000ULL);           /* log(+-0) = -inf */
+        if (hx < 0)
+            return gh_u2d(0x7ff8000000000000ULL);            /* log(-#) = nan */
+        k -= 54;
+        x *= two54;                              /* subnormal: scale up */
+        hx = (int32_t)(gh_d2u(x) >> 32);
+    }
+    if (hx >= 0x7ff00000)
+        return x + x;                            /* inf or nan */
+    return gh_log10_normal(x, k);                /* log10(1) comes out as +0 by itself */
+}
+
 
 #endif /* GH_DETLOG_H */
