@@ -25,6 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROF_STRIDE = 8
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -209,7 +210,9 @@ def main():
 
     for _ in range(desc["warmup"]):
         step()
-    h.profile_enable(True)
+    # HIP-event brackets on the handle's stream, on every PROF_STRIDE-th launch of each kernel: an event between
+    # two kernels costs the stream a ~10 us bubble, so bracketing every launch would slow the timed region by 4 %
+    h.profile_enable(PROF_STRIDE)
     h.profile_reset()
     fence()
     t0 = time.perf_counter()
@@ -220,7 +223,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = h.profile_get()
-    h.profile_enable(False)
+    h.profile_enable(0)
 
     tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -279,6 +282,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": walk["bytes_per_launch"],
                          "avg_launch_ms_hip_events": walk_ms,
+                         "hip_event_sampling": "every %d-th launch of each kernel inside the timed region (%d launches)"
+                                               % (PROF_STRIDE, walk["launches"]),
                          "walker_cycles_per_step": (cyc / nsteps) if nsteps else None,
                          "walker_clock_ghz": (cyc / (ticks * 10.0)) if ticks else None,
                          "note": "dependency-chain bound, not bandwidth bound: each step needs the previous step's "

@@ -64,6 +64,8 @@ struct prof_slot {
     double ms = 0.0;
     int64_t launches = 0;
     double bytes = 0.0;
+    int64_t seq = 0;              // launches seen since profiling was switched on
+    bool open = false;            // prof_begin recorded a start event for the launch in flight
 };
 
 struct gh_handle {
@@ -87,7 +89,7 @@ struct gh_handle {
     uint8_t *d_path;       // [N+1] scratch path
     gh_path_rec *d_rec;    // 1 scratch record
     gh_fill_stats stats;
-    bool prof;
+    int prof;                     // 0 = off, k = bracket every k-th launch of each kernel
     prof_slot ps[GH_K_COUNT];
 };
 
@@ -124,6 +126,8 @@ static void prof_begin(gh_handle *h, int k)
 {
     if (!h->prof) return;
     prof_slot &s = h->ps[k];
+    s.open = false;
+    if ((s.seq++ % h->prof) != 0) return;
     if (s.used + 2 > s.ev.size()) {
         for (int q = 0; q < 2; q++) {
             hipEvent_t e;
@@ -132,16 +136,18 @@ static void prof_begin(gh_handle *h, int k)
         }
     }
     hipEventRecord(s.ev[s.used], h->stream);
+    s.open = true;
 }
 
 static void prof_end(gh_handle *h, int k, double bytes)
 {
     if (!h->prof) return;
     prof_slot &s = h->ps[k];
-    if (s.used + 2 > s.ev.size()) return;
+    s.bytes = bytes;
+    if (!s.open) return;
+    s.open = false;
     hipEventRecord(s.ev[s.used + 1], h->stream);
     s.used += 2;
-    s.bytes = bytes;
 }
 
 static void prof_collect(gh_handle *h)
@@ -223,7 +229,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
-    h->prof = false;
+    h->prof = 0;
     h->partial = nullptr; h->partial_cap = 0;
     memset(&h->stats, 0, sizeof h->stats);
     h->stats.L = 1;
@@ -1166,7 +1172,8 @@ extern "C" int gh_export_dense(gh_t *h, double *out)
 extern "C" int gh_profile_enable(gh_t *h, int on)
 {
     if (!h) return fail(GH_ERR_ARG, "null handle");
-    h->prof = on != 0;
+    h->prof = on > 0 ? on : 0;
+    for (int k = 0; k < GH_K_COUNT; k++) { h->ps[k].seq = 0; h->ps[k].open = false; }
     return GH_OK;
 }
 
