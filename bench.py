@@ -237,7 +237,7 @@ def main():
 
     if rank == 0:
         n, L = table.n_snps, h.L
-        cyc, ticks, nsteps = h.walk_clock()
+        cyc, ticks, nsteps, variant = h.walk_clock()
         h.clear()
         h.fill_from_support(None, None, None, reads_handle=reads)
         cond_evals, rw_cells = edge_evals_per_path(h.candidate_masks(), n, L)
@@ -286,6 +286,8 @@ def main():
                                                % (PROF_STRIDE, walk["launches"]),
                          "walker_cycles_per_step": (cyc / nsteps) if nsteps else None,
                          "walker_clock_ghz": (cyc / (ticks * 10.0)) if ticks else None,
+                         "walker_variant": {2: "depth-2 speculation", 1: "depth-1 speculation, no '-' candidates",
+                                            0: "depth-1 speculation"}.get(variant),
                          "note": "dependency-chain bound, not bandwidth bound: each step needs the previous step's "
                                  "arg-max (gretel.py:143-187); see DESIGN.md section 4 for the cycle budget per step"},
         }

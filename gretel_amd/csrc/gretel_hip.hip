@@ -739,7 +739,7 @@ static int alloc_lt(gh_handle *h)
 }
 
 // path extension / reweight -------------------------------------------------------------------
-#define WALK_LDS_BUDGET (144 * 1024)
+#define WALK_LDS_MAX ((size_t)160 * 1024)     /* LDS one workgroup can have on gfx950 */
 static int walk_threads()
 {
     static const int n = getenv("GH_WALK_THREADS") ? atoi(getenv("GH_WALK_THREADS")) : 512;
@@ -776,20 +776,25 @@ static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, c
 // launches the path-extension kernel for `grid` windows (grid == 1: the handle's own buffers in P)
 static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int grid, const win_desc *wd, int spin)
 {
-    const size_t blk = (size_t)L * LT_BLK * sizeof(double);           // bytes per source position
-    int chunk = (int)((WALK_LDS_BUDGET / 2) / blk) - 2;                // k_walk_spec keeps two extra blocks per buffer
+    // bytes per position of an LDS buffer (raw G block, or the derived depth-2 tables when those are larger)
+    const size_t blk = (size_t)walk_pos_doubles(L) * sizeof(double);
+    const size_t words = 2 * 64 * sizeof(unsigned long long);
+    int chunk = (int)((WALK_LDS_MAX - words) / (2 * blk)) - WALK_OV;   // two buffers, WALK_OV extra positions each
     if (chunk > 64) chunk = 64;
     chunk = (chunk / L) * L;                                          // whole unrolled groups
     if (L <= WALK_MAX_LC && chunk >= L) {
         P.chunk = chunk;
-        const size_t lds = 2 * (size_t)(chunk + 2) * blk + 2 * 64 * sizeof(unsigned long long);
+        const size_t lds = 2 * (size_t)(chunk + WALK_OV) * blk + words;
         // GH_WALK=src selects the non-speculative walker (A/B measurements); default: depth-1 speculation
+        //               GH_WALK=spec1 keeps the speculative walker at depth 1 everywhere
         static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
+        static const bool deep = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "spec1"));
+        P.depth2 = deep;
         launch_walk_src(L, spec, lds, stream, P, grid, wd, spin);
     } else {
         int hl = 16;
         while (hl <= L) hl <<= 1;
-        P.chunk = 0;
+        P.chunk = 0; P.depth2 = 0;
         hipLaunchKernelGGL(k_walk_global, dim3(grid), dim3(64), (size_t)hl, stream, P, hl, wd, spin);
     }
 }
@@ -1199,14 +1204,14 @@ extern "C" int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *la
     return GH_OK;
 }
 
-extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[3])
+extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
 {
     if (!h || !out) return fail(GH_ERR_ARG, "null argument");
     if (set_dev(h)) return GH_ERR_HIP;
     dev_state hs;
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    out[0] = hs.dbg[0]; out[1] = hs.dbg[1]; out[2] = hs.dbg[2];
+    out[0] = hs.dbg[0]; out[1] = hs.dbg[1]; out[2] = hs.dbg[2]; out[3] = hs.dbg[3];
     return GH_OK;
 }
 

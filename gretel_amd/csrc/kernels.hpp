@@ -484,6 +484,9 @@ __global__ void k_snapshot(double *dst_minfo, const double *src_minfo, int N, co
 // symbol a6 has been selected there: the walker reads exactly one row per step.
 // ---------------------------------------------------------------------------------------------
 #define LT_PAD 16      /* zero source blocks behind N so the unrolled walker may overrun */
+// doubles per position of a k_walk_spec LDS buffer: the raw G block or the derived depth-2 tables, whichever is larger
+__host__ __device__ constexpr int walk_pos_doubles(int L) { return 6 * L * 5 > 64 + 16 * (L - 2) ? 6 * L * 5 : 64 + 16 * (L - 2); }
+#define WALK_OV 4      /* source blocks kept behind a chunk in LDS: the last body reads sources j+1 .. j+4 (k_walk_spec) */
 
 template <typename T>
 __device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond_mode, int marginal_term,
@@ -545,6 +548,8 @@ struct walk_params {
     int N, L;
     int chunk;                // source positions per LDS buffer (multiple of L, <= 64)
     int rearm;                // spin loops: re-arm first_hole/nodel/cm_same for the k_marg<T,true> that follows
+    int depth2;               // k_walk_spec: depth-2 speculation where the window allows it (no '-' candidate, L >= 2)
+    int _pad;
     const double *G;          // [(N+LT_PAD)][6][L][5]
     const double *minfo;      // [N+2][16]
     uint8_t *path_out;        // device [N+1]
@@ -755,25 +760,35 @@ __device__ __forceinline__ unsigned long long group_argmax(double acc)
 }
 
 // bookkeeper for k_walk_spec: word g of a chunk holds the symbols of positions j0+g*LC+1 .. j0+g*LC+LC
-__device__ __forceinline__ void book_positions(const walk_params &P, const unsigned long long *words, int LC,
-                                               int j0, int ns, int Nw, int lane, walk_totals &T)
+// (wbits bits each, the oldest highest).  Two steps per chunk, run one loop iteration apart so that the latency of
+// the gather never sits between two barriers: book_gather issues the loads of the selected symbols' marginals
+// (lane = chunk-local position), book_fold adds them up strictly in position order one iteration later.
+struct book_regs {
+    double lm, lm0, mg;
+};
+
+__device__ __forceinline__ void book_gather(const walk_params &P, const unsigned long long *words, int LC, int wbits,
+                                            int j0, int ns, int Nw, int lane, book_regs &R)
 {
-    double lm = 0.0, lm0 = 0.0, mg = INFINITY;
+    R.lm = 0.0; R.lm0 = 0.0; R.mg = INFINITY;
     const int j = j0 + lane + 1;
     if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
-        const int w = (int)((word >> (4 * (LC - 1 - lane % LC))) & 15ull);
+        const int w = (int)((word >> (wbits * (LC - 1 - lane % LC))) & ((1ull << wbits) - 1ull));
         const double *inf = P.minfo + (size_t)j * MINFO;
-        lm = inf[w];
-        mg = inf[5 + w];
-        lm0 = inf[11 + w];
+        R.lm = inf[w];
+        R.mg = inf[5 + w];
+        R.lm0 = inf[11 + w];
         P.path_out[j] = (uint8_t)vsym(w);
     }
+}
+
+__device__ __forceinline__ void book_fold(const book_regs &R, int ns, walk_totals &T, double &lane_min)
+{
+    if (R.mg < lane_min) lane_min = R.mg;               // gretel.py:182, per lane; reduced over lanes at the end (min is exact)
     for (int s = 0; s < ns; s++) {
-        const double m = readlane_f64(mg, s);           // gretel.py:182
-        if (m < T.minm) T.minm = m;
-        T.hp_cur += readlane_f64(lm, s);                // gretel.py:185 (+0.0 for unused lanes)
-        T.hp_orig += readlane_f64(lm0, s);              // gretel.py:186
+        T.hp_cur += readlane_f64(R.lm, s);              // gretel.py:185 (+0.0 for unused lanes)
+        T.hp_orig += readlane_f64(R.lm0, s);            // gretel.py:186
     }
 }
 
@@ -804,7 +819,7 @@ typedef __attribute__((address_space(3))) const double lds_cdouble;
 
 template <int LC, bool NODEL>
 __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, unsigned long long *words0,
-                                            int C, int nchunks, int lane)
+                                            int C, int RS, int nchunks, int lane)
 {
     constexpr int ROW = LC * LT_ROW;
     constexpr int BLK = 6 * ROW;
@@ -835,7 +850,7 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
     asm("v_mov_b32 %0, %1" : "=v"(rowb_v) : "i"(ROWB));
 
     for (int k = 0; k < nchunks; k++) {
-        unsigned vg = lds0 + (unsigned)(k & 1) * (unsigned)(C + 2) * BLKB;          // block of source k*C + g*LC
+        unsigned vg = lds0 + (unsigned)(k & 1) * (unsigned)(C + WALK_OV) * (unsigned)RS * 8u;   // block of source k*C + g*LC
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
         for (int g = 0; g < ngroups; g++) {
@@ -881,6 +896,98 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// spec2_walker: depth-2 speculation, for windows without a '-' candidate (4 symbols, 2 bits each).
+// A lone wavefront issues one instruction every 5 cycles whatever the dependencies (scratch/ubench7),
+// so a body costs 5 cycles x its instruction count once the dependency chain is long enough not to bind:
+// this variant is about having few instructions per step.
+// Lane = (a2 = lane>>4, a1 = (lane>>2)&3, b = lane&3): group (a2,a1) evaluates target t under the
+// hypothesis w_{t-2} == a2, w_{t-1} == a1.  The loader waves do not copy G, they derive two tables:
+//   H[t][lane]       = x1 + x2 = G[t-1][a1][lag 1][b] + G[t-2][a2][lag 2][b]   (path-independent; the first
+//                      addition of the reference's lag-ascending sum; position 0 always contributes its '_' row)
+//   Yr[i][w][b][l-3] = G[i][w][lag l][b], l = 3..L                              (read once w_i is resolved)
+// Body j holds four stages that work on four different targets and do not depend on each other:
+//   A  w_{j+1} = ffs(B_{j+1} >> 4*(4 w_{j-1} + w_j)) & 3; the shift is the low bits of the symbol history     5 SALU
+//   M  B_{j+2} = group-wise arg-max of acc_{j+2}                          (acc from the previous body)         7 VALU
+//   S  acc_{j+3} = H_{j+3} + Y_j[lag 3] + Y_{j-1}[lag 4] + ...            (rows read in earlier bodies)       L-2 VALU
+//   R  issue the row of source j+1 under w_{j+1} and H_{j+4}                                       1 VALU + LDS reads
+// The only cycles are A -> A and A -> R -> S -> M -> A, which spans three bodies.
+// Same IEEE additions in the same order as k_walk_src: bit-identical.
+// ---------------------------------------------------------------------------------------------
+template <int LC>
+struct deep_layout {
+    static constexpr int NY = LC - 2;                  // lags taken from resolved rows
+    static constexpr int HPOS = 64;                    // doubles of H per target
+    static constexpr int YPOS = 16 * (NY > 0 ? NY : 0);   // doubles of Yr per source
+    static constexpr int POS = HPOS + YPOS;
+};
+
+template <int LC>
+__device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, unsigned long long *words0,
+                                             int C, int RS, int nchunks, int lane)
+{
+    static_assert(LC >= 2, "depth-2 speculation needs two lags");
+    typedef deep_layout<LC> DL;
+    constexpr int NY = DL::NY;
+    constexpr unsigned HB = DL::HPOS * 8, YB = DL::YPOS * 8, YWB = 4 * (NY > 0 ? NY : 0) * 8;
+    const int b = lane & 3;
+    double Y[LC][LC];                       // Y[slot][l]: lag-(l+1) term of the source with index == slot (mod LC); l >= 2 used
+#pragma unroll
+    for (int u = 0; u < LC; u++)
+#pragma unroll
+        for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
+
+    const int npos = C + WALK_OV;
+    const unsigned bufB = (unsigned)npos * (unsigned)RS * 8u;
+    const unsigned h0 = (unsigned)(uintptr_t)g0 + (unsigned)lane * 8u;
+    const unsigned y0 = (unsigned)(uintptr_t)g0 + (unsigned)npos * HB + (unsigned)b * (unsigned)(NY > 0 ? NY : 0) * 8u;
+
+    // state entering body 0: targets 1 and 2 have no resolved lag yet; the row of source 0 is the '_' row in every slot
+    unsigned long long B = group_argmax<true>(*(lds_cdouble *)(h0 + HB));
+    double accP = *(lds_cdouble *)(h0 + 2 * HB);
+    double H12 = *(lds_cdouble *)(h0 + 3 * HB);
+#pragma unroll
+    for (int l = 2; l < LC; l++) Y[0][l] = *(lds_cdouble *)(y0 + (unsigned)(l - 2) * 8u);
+    unsigned hist = 0, sh = 0;
+    unsigned yw_v;
+    asm("v_mov_b32 %0, %1" : "=v"(yw_v) : "i"(YWB));
+
+    for (int k = 0; k < nchunks; k++) {
+        unsigned vh = h0 + (unsigned)(k & 1) * bufB, vy = y0 + (unsigned)(k & 1) * bufB;
+        unsigned long long *wk = words0 + (k & 1) * 64;
+        const int ngroups = C / LC;
+        for (int g = 0; g < ngroups; g++) {
+#pragma unroll
+            for (int u = 0; u < LC; u++) {
+                // A: resolve w_{j+1}   (body j = k*C + g*LC + u); hist keeps 2 bits per symbol, newest lowest
+                const unsigned w = (unsigned)__builtin_ctzll(B >> (sh & 63u)) & 3u;
+                hist = (hist << 2) + w;
+                sh = hist << 2;
+                // M: ballot of target j+2
+                B = group_argmax<true>(accP);
+                // S: target j+3, lag l+1 from source j-(l-2), l ascending
+                double acc = H12;
+#pragma unroll
+                for (int l = 2; l < LC; l++) acc += Y[(u - (l - 2) + 2 * LC) % LC][l];
+                accP = acc;
+                // R: row of source j+1 under its real symbol (lags 3..L); x1 + x2 of target j+4
+                if constexpr (NY > 0) {
+                    unsigned vrow;
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(vrow) : "s"(w), "v"(yw_v), "v"(vy));
+                    lds_cdouble *row = (lds_cdouble *)(vrow + (unsigned)(u + 1) * YB);
+#pragma unroll
+                    for (int l = 2; l < LC; l++) Y[(u + 1) % LC][l] = row[l - 2];
+                }
+                H12 = *(lds_cdouble *)(vh + (unsigned)(u + 4) * HB);
+            }
+            wk[g] = (unsigned long long)hist;
+            vh += (unsigned)LC * HB;
+            vy += (unsigned)LC * YB;
+        }
+        __syncthreads();
+    }
+}
+
 template <int LC>
 __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc *wd, int spin)
 {
@@ -892,48 +999,153 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
     }
     dev_state *st = P.st;
     if (st->stop) return;
-    constexpr int BLK = 6 * LC * LT_ROW;
+    constexpr int ROW = LC * LT_ROW;
+    constexpr int BLK = 6 * ROW;
+    constexpr int RS = walk_pos_doubles(LC);        // doubles per position in an LDS buffer (either layout fits)
     const int C = P.chunk;
     double *const g0 = smem;
-    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + 2) * BLK);
+    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + WALK_OV) * RS);
 
     const int first_hole = st->first_hole;
     const bool nodel = st->nodel != 0;
+    const bool deep = LC >= 2 && nodel && P.depth2 && blockDim.x == 512;   // uniform: which walker, loader and word format
     const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;      // positions that can be decided
     const int nchunks = (Nw + C - 1) / C;                         // bodies 0..Nw-1, chunk k = k*C..k*C+C-1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // depth-1 layout: plain copy of the G blocks of positions k*C .. k*C + C + WALK_OV - 1
     auto load_chunk = [&](int k, int t, int nt) {
         const int i0 = k * C;
+        const int npos = C + WALK_OV;        // overlap: the last body reads positions beyond its chunk
+        double *dst = g0 + (size_t)(k & 1) * npos * RS;
         int nsrc = P.N + LT_PAD - i0;
-        if (nsrc > C + 2) nsrc = C + 2;      // two blocks of overlap: the last body reads sources j+1 and j+2
+        if (nsrc > npos) nsrc = npos;
         if (nsrc < 0) nsrc = 0;
-        double *dst = g0 + (size_t)(k & 1) * (C + 2) * BLK;
         copy_to_lds(dst, P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
         // the walker always runs whole chunks: what lies behind the table must read as 0.0 (finite sums,
         // symbol 0 wins), never as stale LDS bits
-        for (int q = nsrc * BLK + t; q < (C + 2) * BLK; q += nt) dst[q] = 0.0;
+        for (int q = nsrc * BLK + t; q < npos * BLK; q += nt) dst[q] = 0.0;
     };
 
-    load_chunk(0, tid, (int)blockDim.x);
-    __syncthreads();
-
-    if (wave >= 2) {
-        for (int k = 0; k < nchunks; k++) {
-            if (k + 1 < nchunks) load_chunk(k + 1, tid - 128, (int)blockDim.x - 128);
+    if (deep) {
+        if constexpr (LC >= 2) {
+            // depth-2 layout: the 384 loader threads derive H and Yr (see spec2_walker) straight from global G.
+            // The loads of chunk k+2 are issued before the barrier that ends chunk k and stay in flight across it
+            // (their latency must not sit between two barriers, the walker waits there too); the sums and the LDS
+            // stores of chunk k+1 happen while the walker is in chunk k.
+            typedef deep_layout<LC> DL;
+            constexpr int NT = 384, MAXPOS = 64 + WALK_OV;
+            constexpr int MAXH = (MAXPOS * DL::HPOS + NT - 1) / NT;
+            constexpr int MAXY = DL::YPOS ? (MAXPOS * DL::YPOS + NT - 1) / NT : 0;
+            if (wave >= 2) {
+                const int t = tid - 128;
+                const int npos = C + WALK_OV;
+                const int nsrc_all = P.N + LT_PAD;                    // source blocks G holds (the last LT_PAD are zeros)
+                const int nh = npos * DL::HPOS, ny = npos * DL::YPOS;
+                const int bb = t & 3, a1 = (t >> 2) & 3, a2 = (t >> 4) & 3;    // NT is a multiple of 64: lane-constant
+                double x1[MAXH], x2[MAXH], yv[MAXY > 0 ? MAXY : 1];
+                auto fetch = [&](int k) {
+                    const int i0 = k * C;
+#pragma unroll
+                    for (int it = 0; it < MAXH; it++) {
+                        const int q = t + it * NT;
+                        const int tt = i0 + (q >> 6);
+                        x1[it] = 0.0; x2[it] = 0.0;
+                        if (q < nh && tt >= 1 && tt - 1 < nsrc_all) {
+                            const int s1 = tt - 1, s2 = tt - 2;
+                            x1[it] = P.G[(size_t)s1 * BLK + (s1 == 0 ? 5 : a1) * ROW + bb];
+                            if (tt >= 2) x2[it] = P.G[(size_t)s2 * BLK + (s2 == 0 ? 5 : a2) * ROW + LT_ROW + bb];
+                        }
+                    }
+                    if constexpr (MAXY > 0) {
+#pragma unroll
+                        for (int it = 0; it < MAXY; it++) {
+                            const int q = t + it * NT;
+                            yv[it] = 0.0;
+                            if (q < ny) {
+                                const int p = q / DL::YPOS, r = q % DL::YPOS, wb = r / DL::NY, l = 2 + r % DL::NY;
+                                const int sidx = i0 + p;
+                                if (sidx < nsrc_all)
+                                    yv[it] = P.G[(size_t)sidx * BLK + (sidx == 0 ? 5 : (wb >> 2)) * ROW + l * LT_ROW + (wb & 3)];
+                            }
+                        }
+                    }
+                };
+                auto store = [&](int k) {
+                    const int i0 = k * C;
+                    double *dst = g0 + (size_t)(k & 1) * npos * RS;
+#pragma unroll
+                    for (int it = 0; it < MAXH; it++) {
+                        const int q = t + it * NT;
+                        // target 1 has the single term x1 (not 0.0 + x1: the reference starts from the first addend)
+                        if (q < nh) dst[q] = (i0 + (q >> 6) >= 2) ? x1[it] + x2[it] : x1[it];
+                    }
+                    if constexpr (MAXY > 0) {
+                        double *yr = dst + (size_t)npos * DL::HPOS;
+#pragma unroll
+                        for (int it = 0; it < MAXY; it++) {
+                            const int q = t + it * NT;
+                            if (q < ny) yr[q] = yv[it];
+                        }
+                    }
+                };
+                fetch(0);
+                store(0);
+                if (nchunks > 1) fetch(1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                for (int k = 0; k < nchunks; k++) {
+                    if (k + 1 < nchunks) store(k + 1);
+                    if (k + 2 < nchunks) fetch(k + 2);
+                    // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                return;
+            }
             __syncthreads();
         }
-        return;
+    } else {
+        load_chunk(0, tid, (int)blockDim.x);
+        __syncthreads();
+        if (wave >= 2) {
+            for (int k = 0; k < nchunks; k++) {
+                if (k + 1 < nchunks) load_chunk(k + 1, tid - 128, (int)blockDim.x - 128);
+                __syncthreads();
+            }
+            return;
+        }
     }
     if (wave == 1) {
         walk_totals T = {0.0, 0.0, INFINITY};
+        const int wbits = deep ? 2 : 4;
+        double lane_min = INFINITY;
+        book_regs R0, R1;                   // chunk c lives in R[c & 1]
+        R0.lm = R0.lm0 = R1.lm = R1.lm0 = 0.0; R0.mg = R1.mg = INFINITY;
         if (lane == 0) P.path_out[0] = SYM_US;
-        for (int k = 0; k < nchunks; k++) {
-            if (k > 0) book_positions(P, words0 + ((k - 1) & 1) * 64, LC, (k - 1) * C, C, Nw, lane, T);
-            __syncthreads();
+        // iteration k (while the walker is in chunk k): gather chunk k-1, fold chunk k-2
+        auto iter = [&](int k, book_regs &Rg, book_regs &Rf) {
+            if (k >= 1 && k - 1 < nchunks) book_gather(P, words0 + ((k - 1) & 1) * 64, LC, wbits, (k - 1) * C, C, Nw, lane, Rg);
+            if (k >= 2) book_fold(Rf, C, T, lane_min);
+        };
+        for (int k = 0; k < nchunks; k += 2) {
+            iter(k, R1, R0);
+            // the word reads are done, the gather's global loads stay in flight across the barrier (no vmcnt wait)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (k + 1 < nchunks) {
+                iter(k + 1, R0, R1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
-        if (nchunks > 0) book_positions(P, words0 + ((nchunks - 1) & 1) * 64, LC, (nchunks - 1) * C, C, Nw, lane, T);
+        if (nchunks > 0) {
+            if (nchunks & 1) { iter(nchunks, R0, R1); book_fold(R0, C, T, lane_min); }
+            else { iter(nchunks, R1, R0); book_fold(R1, C, T, lane_min); }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double o = __shfl_xor(lane_min, off);
+            if (o < lane_min) lane_min = o;
+        }
+        T.minm = lane_min;
         if (lane == 0) {
             if (first_hole <= P.N) {                                  // gretel.py:176-180
                 st->stop = 1;
@@ -954,12 +1166,15 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
     }
     __builtin_amdgcn_s_setprio(3);          // the walker is the critical path; loaders and bookkeeper have slack
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    if (nodel) spec_walker<LC, true>(P, g0, words0, C, nchunks, lane);
-    else spec_walker<LC, false>(P, g0, words0, C, nchunks, lane);
+    if (deep) {
+        if constexpr (LC >= 2) spec2_walker<LC>(P, g0, words0, C, RS, nchunks, lane);
+    } else if (nodel) spec_walker<LC, true>(P, g0, words0, C, RS, nchunks, lane);
+    else spec_walker<LC, false>(P, g0, words0, C, RS, nchunks, lane);
     if (lane == 0) {
         st->dbg[0] = __builtin_amdgcn_s_memtime() - t0;          // shader cycles of the walk
         st->dbg[1] = __builtin_amdgcn_s_memrealtime() - r0;      // 100 MHz ticks of the walk
         st->dbg[2] = (unsigned long long)nchunks * C;            // steps executed
+        st->dbg[3] = deep ? 2 : (nodel ? 1 : 0);                 // variant: speculation depth 2 / 1 without '-' / 1 with '-'
     }
 }
 

@@ -366,10 +366,10 @@ class Hansel:
         return out
 
     def walk_clock(self):
-        """(shader cycles, 100 MHz ticks, steps) of the walker wave in the last path-extension launch."""
-        out = (C.c_uint64 * 3)()
+        """(shader cycles, 100 MHz ticks, steps, variant) of the walker wave in the last path-extension launch."""
+        out = (C.c_uint64 * 4)()
         check(self._lib.gh_debug_walk_clock(self._h, out))
-        return int(out[0]), int(out[1]), int(out[2])
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def sync(self):
         if self._h is not None:

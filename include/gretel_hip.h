@@ -173,8 +173,9 @@ int gh_profile_enable(gh_t *h, int on);
 int gh_profile_reset(gh_t *h);
 int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches);
 /* diagnostics of the last path-extension launch: out[0] = shader cycles (s_memtime) the walker wave spent,
- * out[1] = the same interval in 100 MHz ticks (s_memrealtime), out[2] = steps it executed */
-int gh_debug_walk_clock(gh_t *h, uint64_t out[3]);
+ * out[1] = the same interval in 100 MHz ticks (s_memrealtime), out[2] = steps it executed, out[3] = the variant
+ * that ran (2 = depth-2 speculation, 1 = depth 1 without '-' candidates, 0 = depth 1 with them) */
+int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
 /* algorithmic bytes of the last launch of each kernel */
 int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch);
 

@@ -9,5 +9,5 @@ for (n, reads, k) in [(10000, 200000, 5), (10000, 200000, 3), (10000, 200000, 8)
     h.fill_from_support(t.rank, t.off, t.bases)
     for rep in range(3):
         h.generate_path()
-    cyc, ticks, steps = h.walk_clock()
+    cyc, ticks, steps, _variant = h.walk_clock()
     print("N=%d L=%d: %.1f cycles/step, %.1f ns/step, clock %.2f GHz" % (n, h.L, cyc/steps, ticks*10.0/steps, cyc/(ticks*10.0)), flush=True)

@@ -1,4 +1,5 @@
-// standalone harness: run k_walk_spec<LC> (variant 0 and 1) on a random table, compare paths, print cycles
+// standalone harness: run k_walk_spec<LC> at speculation depth 1 (variant 0) and 2 (variant 1) on a random table,
+// compare paths, print cycles
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,9 +23,9 @@ int main(int argc, char** argv){
     double *dG, *dmi; uint8_t* dpath[2]; gh_path_rec* drec; dev_state* dst;
     hipMalloc(&dG, nG*8); hipMalloc(&dmi, minfo.size()*8); hipMalloc(&dpath[0], N+2); hipMalloc(&dpath[1], N+2); hipMalloc(&drec, sizeof(gh_path_rec)); hipMalloc(&dst, sizeof(dev_state));
     hipMemcpy(dG, G.data(), nG*8, hipMemcpyHostToDevice); hipMemcpy(dmi, minfo.data(), minfo.size()*8, hipMemcpyHostToDevice);
-    const size_t blk = (size_t)LC * LT_BLK * 8;
-    int chunk = (int)((144*1024/2)/blk) - 2; if (chunk > 64) chunk = 64; chunk = (chunk/LC)*LC;
-    const size_t lds = 2*(size_t)(chunk+2)*blk + 2*64*8;
+    const size_t blk = (size_t)walk_pos_doubles(LC) * 8;
+    int chunk = (int)((160*1024 - 1024)/(2*blk)) - WALK_OV; if (chunk > 64) chunk = 64; chunk = (chunk/LC)*LC;
+    const size_t lds = 2*(size_t)(chunk+WALK_OV)*blk + 2*64*8;
     hipFuncSetAttribute((const void*)k_walk_spec<HLC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<uint8_t> path[2]; 
     for (int v = 0; v < 2; v++) {
@@ -32,7 +33,7 @@ int main(int argc, char** argv){
         if (variant_only >= 0 && v != variant_only) continue;
         dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1;
         hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
-        walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.rearm = 0; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
+        walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.rearm = 0; P.depth2 = v; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
         hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P, (const win_desc*)nullptr, 0);
         hipError_t e = hipDeviceSynchronize();
         hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
