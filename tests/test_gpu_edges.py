@@ -20,7 +20,7 @@ class _T:
         self.n_reads = len(reads)
 
 
-def _check(t, paths=6, L=None, **kw):
+def _check(t, paths=6, L=None, want_variant=None, **kw):
     h = Hansel(t.n_snps, band=t.band, **kw)
     o = COracle(t.n_snps, t.band, kw.get("storage", "f32"), kw.get("cond_mode", "A"), kw.get("marginal_term", False))
     assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
@@ -29,6 +29,8 @@ def _check(t, paths=6, L=None, **kw):
         o.L = L
     assert h.gap_check() == o.gap_check()
     res, ref = h.spin(paths), o.spin(paths)
+    if want_variant is not None:
+        assert h.walk_clock()[3] == want_variant          # which path-extension variant the last launch took
     assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"]
     assert np.array_equal(res["paths"], ref["paths"])
     assert res["hp_current"].tolist() == ref["hp_current"].tolist()
@@ -84,6 +86,20 @@ def test_deletion_symbols_take_the_five_candidate_walker():
     t.bases = bases
     res = _check(t, paths=8)
     assert (res["paths"] == 5).any()          # '-' is actually selected somewhere
+
+
+@pytest.mark.parametrize("dels", [False, True])
+@pytest.mark.parametrize("L", [2, 3, 6, 13, 16])
+def test_many_chunks_every_walker_variant(L, dels):
+    # windows long enough for several LDS chunks at every unroll factor: without '-' the depth-2 walker on the
+    # loader-derived tables (L = 2 has no resolved lag at all), with '-' the depth-1 walker on the raw blocks
+    t = make_support_table(700, 12000, k=6, seed=10 + L)
+    if dels:
+        bases = t.bases.copy()
+        bases[np.random.default_rng(L).random(len(bases)) < 0.1] = ord('-')
+        t.bases = bases
+    res = _check(t, paths=3, L=L, want_variant=0 if dels else 2)
+    assert res["n"] == 3
 
 
 def test_n_symbols_are_counted_but_never_selected():
