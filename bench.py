@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-leg", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="throughput mode: this many independent windows per GPU in one batched launch")
-    ap.add_argument("--cpu-snps", type=int, default=1500, help="SNP prefix used for the Python CPU baseline sample")
+    ap.add_argument("--cpu-snps", type=int, default=3000, help="SNP prefix used for the Python CPU baseline sample")
     return ap.parse_args()
 
 
