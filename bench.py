@@ -288,8 +288,9 @@ def main():
                          "walker_clock_ghz": (cyc / (ticks * 10.0)) if ticks else None,
                          "walker_variant": {2: "depth-2 speculation", 1: "depth-1 speculation, no '-' candidates",
                                             0: "depth-1 speculation"}.get(variant),
-                         "note": "dependency-chain bound, not bandwidth bound: each step needs the previous step's "
-                                 "arg-max (gretel.py:143-187); see DESIGN.md section 4 for the cycle budget per step"},
+                         "note": "not bandwidth bound: each step needs the previous step's arg-max (gretel.py:143-187), so one "
+                                 "wavefront walks and its instruction issue rate (1 per 5 cycles) is the bound; "
+                                 "see DESIGN.md section 4 for the instruction budget per step"},
         }
         if world == 1 and not args.no_throughput_leg:
             # secondary figure (not `value`): the same contig replicated into 32 windows and recovered by ONE batched
