@@ -571,7 +571,7 @@ static int ensure_marg(gh_handle *h)
     const int threads = (h->N + 1) * 8;
     const int block = 256;
     // re-arm the "first SNP without a candidate" word that k_marg min-reduces into
-    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, 3 * sizeof(int), h->stream));   // first_hole, nodel, cm_same
+    HIPCHK(hipMemsetAsync(&h->dstate->first_hole, 0x7f, 4 * sizeof(int), h->stream));   // first_hole, nodel, cm_same, narrow
     prof_begin(h, GH_K_MARG);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
@@ -589,6 +589,7 @@ static int ensure_marg(gh_handle *h)
 }
 
 static int alloc_lt(gh_handle *h);
+static bool walk_depth2_ok(int L);
 
 static int ensure_lt(gh_handle *h)
 {
@@ -607,11 +608,11 @@ static int ensure_lt(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L));
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L));
     const int wl = h->W < h->L ? h->W : h->L;
     // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
     prof_end(h, GH_K_LT, inc ? 8.0
@@ -748,6 +749,26 @@ static int walk_threads()
 #define WALK_THREADS walk_threads()
 #define WALK_MAX_LC 16
 
+// LDS geometry of k_walk_spec for lag count L: positions per buffer (0 = does not fit, k_walk_global walks)
+static int walk_chunk(int L)
+{
+    if (L > WALK_MAX_LC) return 0;
+    const size_t blk = (size_t)walk_pos_doubles(L) * sizeof(double);  // raw G block, or the derived depth-2 tables if larger
+    const size_t words = 2 * 64 * sizeof(unsigned long long);
+    int chunk = (int)((WALK_LDS_MAX - words) / (2 * blk)) - WALK_OV;   // two buffers, WALK_OV extra positions each
+    if (chunk > 64) chunk = 64;
+    chunk = (chunk / L) * L;                                          // whole unrolled groups
+    return chunk >= L ? chunk : 0;
+}
+
+// Whether the depth-2 walker can run for this L: then k_lt may build G over candidate ranks (kernels.hpp).
+// GH_WALK=src selects the non-speculative walker, GH_WALK=spec1 keeps speculation at depth 1 (A/B measurements).
+static bool walk_depth2_ok(int L)
+{
+    static const bool off = getenv("GH_WALK") && (!strcmp(getenv("GH_WALK"), "src") || !strcmp(getenv("GH_WALK"), "spec1"));
+    return !off && L >= 2 && walk_chunk(L) > 0 && WALK_THREADS == 512;
+}
+
 template <int LC>
 static void launch_walk_lc(bool spec, size_t lds, hipStream_t stream, const walk_params &P, int grid, const win_desc *wd, int spin)
 {
@@ -776,20 +797,13 @@ static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, c
 // launches the path-extension kernel for `grid` windows (grid == 1: the handle's own buffers in P)
 static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int grid, const win_desc *wd, int spin)
 {
-    // bytes per position of an LDS buffer (raw G block, or the derived depth-2 tables when those are larger)
-    const size_t blk = (size_t)walk_pos_doubles(L) * sizeof(double);
-    const size_t words = 2 * 64 * sizeof(unsigned long long);
-    int chunk = (int)((WALK_LDS_MAX - words) / (2 * blk)) - WALK_OV;   // two buffers, WALK_OV extra positions each
-    if (chunk > 64) chunk = 64;
-    chunk = (chunk / L) * L;                                          // whole unrolled groups
-    if (L <= WALK_MAX_LC && chunk >= L) {
+    const int chunk = walk_chunk(L);
+    if (chunk > 0) {
+        const size_t blk = (size_t)walk_pos_doubles(L) * sizeof(double);
         P.chunk = chunk;
-        const size_t lds = 2 * (size_t)(chunk + WALK_OV) * blk + words;
-        // GH_WALK=src selects the non-speculative walker (A/B measurements); default: depth-1 speculation
-        //               GH_WALK=spec1 keeps the speculative walker at depth 1 everywhere
+        const size_t lds = 2 * (size_t)(chunk + WALK_OV) * blk + 2 * 64 * sizeof(unsigned long long);
         static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
-        static const bool deep = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "spec1"));
-        P.depth2 = deep;
+        P.depth2 = walk_depth2_ok(L);
         launch_walk_src(L, spec, lds, stream, P, grid, wd, spin);
     } else {
         int hl = 16;
@@ -1077,13 +1091,13 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         if (f64)
             hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
-                               inc, b->d_wd, s);
+                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
+                               inc, b->d_wd, s, walk_depth2_ok(L));
         else
             hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (const dev_state *)nullptr,
-                               inc, b->d_wd, s);
+                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
+                               inc, b->d_wd, s, walk_depth2_ok(L));
         launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
         if (f64)
             hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,

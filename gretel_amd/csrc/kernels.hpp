@@ -33,7 +33,8 @@ struct dev_state {
     int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish
     int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)
     int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one
-    int _pad2[2];
+    int narrow;      // stays non-zero while every position has at most 4 candidates (k_marg)
+    int ranked;      // layout of G as k_lt last built it: 1 = rows/columns are candidate RANKS (see k_lt), 0 = symbols
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
     unsigned long long dbg8[5];  // -DGH_STAMPS builds: cycles per body segment
 };
@@ -59,6 +60,20 @@ __constant__ int8_t c_sym_of_char[256];
 __device__ __forceinline__ int vsym(int b5) { return b5 < 4 ? b5 : 5; }            // b5 -> symbol
 __device__ __forceinline__ int fsym(int a6) { return a6 < 4 ? a6 : a6 + 1; }       // a6 -> symbol (4->5, 5->6)
 __device__ __forceinline__ int a6_of_sym(int s) { return s < 4 ? s : s - 1; }      // symbol -> a6 (5->4, 6->5); N invalid
+// candidate masks: cmask has one bit per SYMBOL (A0 C1 G2 T3 -5), cm5 one bit per compact index b5 (A0 C1 G2 T3 -4)
+__device__ __forceinline__ uint32_t cm5_of_cmask(uint32_t cm) { return (cm & 15u) | (((cm >> 5) & 1u) << 4); }
+// index of the r-th set bit of a 5-bit mask (r = 0 is the lowest), -1 if there are fewer
+__device__ __forceinline__ int nth_set5(uint32_t m, int r)
+{
+    int out = -1;
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        const bool set = (m >> b) & 1u;
+        if (set && r == 0) out = b;
+        r -= set ? 1 : 0;
+    }
+    return out;
+}
 
 template <typename T>
 __device__ __forceinline__ double rowsum(const T *cell, int a)
@@ -386,6 +401,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
             if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
             if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
+            if (p >= 1 && __popc(cm5) > 4) atomicAnd(&st->narrow, 0);
         }
     }
     if (RW && G && act && p < N && rw_path[p] != 4) {
@@ -396,8 +412,13 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         const int a = rw_path[p];
         const int a6 = a6_of_sym(a);
         const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
-        for (int l = s + 1; l <= L; l += 8) {
-            double *out = G + (((size_t)p * 6 + a6) * L + (l - 1)) * LT_ROW;
+        // ranked tables (k_lt): the row of symbol a is the row of its rank among the candidates of p, the columns of
+        // lag l are the candidates of p+l in ascending order; a path symbol that is no candidate has no row
+        const bool ranked = st->ranked != 0;
+        int row6 = a6;
+        if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
+        for (int l = s + 1; l <= L && row6 >= 0; l += 8) {
+            double *out = G + (((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW;
             const int snp = p + l;
             if (!(snp <= N && (a6 < 5 || p == 0))) {
 #pragma unroll
@@ -431,8 +452,20 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
 #pragma unroll
                 for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
             }
+            if (!ranked) {
 #pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmj >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
+                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmj >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
+            } else {
+                const uint32_t cj5 = cm5_of_cmask(cmj);
+#pragma unroll
+                for (int rb = 0; rb < LT_ROW; rb++) {
+                    const int b5 = nth_set5(cj5, rb);
+                    double r = -INFINITY;
+#pragma unroll
+                    for (int q = 0; q < LT_ROW; q++) r = (b5 == q) ? v[q] : r;
+                    out[rb] = r;
+                }
+            }
         }
     }
     if (RW) {
@@ -453,7 +486,7 @@ __global__ void k_rearm(dev_state *st, const win_desc *wd, int skip_if_stopped)
     if (wd) st = wd[blockIdx.x].st;
     // a window that hit a hole keeps its last flags: the k_marg that would refresh them is skipped as well
     if (skip_if_stopped && st->stop) return;
-    if (threadIdx.x == 0) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
+    if (threadIdx.x == 0) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
 }
 
 // freeze the current log-marginals as the original ones (slot [11..15] of minfo)
@@ -511,7 +544,8 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
      const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
-     const double *minfo, double *G, const dev_state *st, const uint8_t *inc_path, const win_desc *wd, int spin)
+     const double *minfo, double *G, dev_state *st, const uint8_t *inc_path, const win_desc *wd, int spin,
+     int allow_ranked)
 {
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
@@ -522,15 +556,35 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
     // inc_path != null: k_marg<T, true> has already rewritten the rows the last path changed; they stand when no
     // candidate mask moved and the path was complete -- otherwise rebuild everything
     if (inc_path && st->cm_same && !st->stop) return;
+    // Ranked layout (every position has at most 4 candidates and the caller's walker can use it): row r < 4 of
+    // source i is the r-th candidate of i in ascending symbol order, column c < 4 of lag l the c-th candidate of
+    // i+l; missing ranks get a row of zeros / a column of -inf, row 5 stays the '_' row of position 0.  First-wins
+    // tie-breaking over ranks is first-wins over symbols, so the depth-2 walker (4 symbols) also serves windows
+    // with '-' candidates; its bookkeeper maps ranks back through the candidate bits of minfo.
+    const bool ranked = allow_ranked && st->narrow != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->ranked = ranked ? 1 : 0;
     const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (size_t)gridDim.x * blockDim.x) {
-        const int b5 = (int)(t % LT_ROW);
+        int b5 = (int)(t % LT_ROW);
         size_t r = t / LT_ROW;
         const int l = (int)(r % L) + 1;
         r /= L;
-        const int a6 = (int)(r % 6);
+        int a6 = (int)(r % 6);
         const int i = (int)(r / 6);
+        if (ranked) {
+            const int snp = i + l;
+            double v = 0.0;
+            if (i < N && snp <= N && a6 != 4) {
+                if (a6 < 4) a6 = nth_set5(cm5_of_cmask(cmask[i]), a6);
+                if (a6 >= 0) {
+                    b5 = nth_set5(cm5_of_cmask(cmask[snp]), b5);
+                    v = b5 >= 0 ? lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5) : -INFINITY;
+                }
+            }
+            G[t] = v;
+            continue;
+        }
         G[t] = lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
     }
 }
@@ -548,7 +602,7 @@ struct walk_params {
     int N, L;
     int chunk;                // source positions per LDS buffer (multiple of L, <= 64)
     int rearm;                // spin loops: re-arm first_hole/nodel/cm_same for the k_marg<T,true> that follows
-    int depth2;               // k_walk_spec: depth-2 speculation where the window allows it (no '-' candidate, L >= 2)
+    int depth2;               // k_walk_spec: depth-2 speculation where the window allows it (<= 4 candidates per position, L >= 2)
     int _pad;
     const double *G;          // [(N+LT_PAD)][6][L][5]
     const double *minfo;      // [N+2][16]
@@ -697,7 +751,7 @@ __global__ void __launch_bounds__(512) k_walk_src(walk_params P, const win_desc 
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
-                if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
+                if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
             }
         }
         return;
@@ -765,16 +819,28 @@ __device__ __forceinline__ unsigned long long group_argmax(double acc)
 // (lane = chunk-local position), book_fold adds them up strictly in position order one iteration later.
 struct book_regs {
     double lm, lm0, mg;
+    double cm;              // ranked tables: the candidate bits of the position (minfo[10]), loaded one iteration ahead
 };
 
+__device__ __forceinline__ void book_pregather(const walk_params &P, int j0, int ns, int Nw, int lane, book_regs &R)
+{
+    const int j = j0 + lane + 1;
+    R.cm = 0.0;
+    if (lane < ns && j <= Nw) R.cm = P.minfo[(size_t)j * MINFO + 10];
+}
+
 __device__ __forceinline__ void book_gather(const walk_params &P, const unsigned long long *words, int LC, int wbits,
-                                            int j0, int ns, int Nw, int lane, book_regs &R)
+                                            bool ranked, int j0, int ns, int Nw, int lane, book_regs &R)
 {
     R.lm = 0.0; R.lm0 = 0.0; R.mg = INFINITY;
     const int j = j0 + lane + 1;
     if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
-        const int w = (int)((word >> (wbits * (LC - 1 - lane % LC))) & ((1ull << wbits) - 1ull));
+        int w = (int)((word >> (wbits * (LC - 1 - lane % LC))) & ((1ull << wbits) - 1ull));
+        if (ranked) {
+            w = nth_set5((uint32_t)__double_as_longlong(R.cm), w);
+            if (w < 0) w = 0;           // cannot happen for a resolved position (it has a candidate of that rank)
+        }
         const double *inf = P.minfo + (size_t)j * MINFO;
         R.lm = inf[w];
         R.mg = inf[5 + w];
@@ -897,7 +963,8 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 }
 
 // ---------------------------------------------------------------------------------------------
-// spec2_walker: depth-2 speculation, for windows without a '-' candidate (4 symbols, 2 bits each).
+// spec2_walker: depth-2 speculation, for windows whose positions have at most 4 candidates each: k_lt then
+// builds G over candidate ranks (2 bits each), so '-' may be among them.
 // A lone wavefront issues one instruction every 5 cycles whatever the dependencies (scratch/ubench7),
 // so a body costs 5 cycles x its instruction count once the dependency chain is long enough not to bind:
 // this variant is about having few instructions per step.
@@ -1008,7 +1075,9 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
 
     const int first_hole = st->first_hole;
     const bool nodel = st->nodel != 0;
-    const bool deep = LC >= 2 && nodel && P.depth2 && blockDim.x == 512;   // uniform: which walker, loader and word format
+    // uniform: which walker, loader and word format.  G is ranked (k_lt) exactly when the host allowed it (same
+    // condition as P.depth2) and no position has more than 4 candidates: then the 4-symbol depth-2 walker applies.
+    const bool deep = LC >= 2 && st->ranked != 0 && P.depth2 && blockDim.x == 512;
     const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;      // positions that can be decided
     const int nchunks = (Nw + C - 1) / C;                         // bodies 0..Nw-1, chunk k = k*C..k*C+C-1
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1120,11 +1189,12 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
         const int wbits = deep ? 2 : 4;
         double lane_min = INFINITY;
         book_regs R0, R1;                   // chunk c lives in R[c & 1]
-        R0.lm = R0.lm0 = R1.lm = R1.lm0 = 0.0; R0.mg = R1.mg = INFINITY;
+        R0.lm = R0.lm0 = R1.lm = R1.lm0 = 0.0; R0.mg = R1.mg = INFINITY; R0.cm = R1.cm = 0.0;
         if (lane == 0) P.path_out[0] = SYM_US;
         // iteration k (while the walker is in chunk k): gather chunk k-1, fold chunk k-2
         auto iter = [&](int k, book_regs &Rg, book_regs &Rf) {
-            if (k >= 1 && k - 1 < nchunks) book_gather(P, words0 + ((k - 1) & 1) * 64, LC, wbits, (k - 1) * C, C, Nw, lane, Rg);
+            if (deep && k < nchunks) book_pregather(P, k * C, C, Nw, lane, Rf);     // chunk k shares its set with chunk k-2
+            if (k >= 1 && k - 1 < nchunks) book_gather(P, words0 + ((k - 1) & 1) * 64, LC, wbits, deep, (k - 1) * C, C, Nw, lane, Rg);
             if (k >= 2) book_fold(Rf, C, T, lane_min);
         };
         for (int k = 0; k < nchunks; k += 2) {
@@ -1159,7 +1229,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
-                if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
+                if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
             }
         }
         return;
@@ -1245,7 +1315,7 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
             P.rec->magnitude = 0.0;
             st->ratio = r;
             st->n_done += 1;
-            if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; }
+            if (P.rearm) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
         }
     }
 }

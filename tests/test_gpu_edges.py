@@ -102,6 +102,18 @@ def test_many_chunks_every_walker_variant(L, dels):
     assert res["n"] == 3
 
 
+@pytest.mark.parametrize("L", [2, 5, 9])
+def test_deletions_with_at_most_four_candidates_take_the_depth2_walker(L):
+    # three haplotypes, no sequencing errors, '-' sprinkled in: every position has <= 4 candidates, so the conditional
+    # table is built over candidate RANKS and the 4-symbol depth-2 walker serves the window although '-' is selected
+    t = make_support_table(500, 9000, k=6, n_haps=3, err=0.0, seed=40 + L)
+    bases = t.bases.copy()
+    bases[np.random.default_rng(L).random(len(bases)) < 0.2] = ord('-')
+    t.bases = bases
+    res = _check(t, paths=4, L=L, want_variant=2)
+    assert (res["paths"] == 5).any()          # '-' is actually selected somewhere
+
+
 def test_n_symbols_are_counted_but_never_selected():
     t = make_support_table(60, 2000, k=4, seed=6)
     bases = t.bases.copy()
