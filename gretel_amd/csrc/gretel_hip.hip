@@ -740,7 +740,6 @@ static int alloc_lt(gh_handle *h)
 }
 
 // path extension / reweight -------------------------------------------------------------------
-#define WALK_LDS_MAX ((size_t)160 * 1024)     /* LDS one workgroup can have on gfx950 */
 static int walk_threads()
 {
     static const int n = getenv("GH_WALK_THREADS") ? atoi(getenv("GH_WALK_THREADS")) : 512;
@@ -749,24 +748,12 @@ static int walk_threads()
 #define WALK_THREADS walk_threads()
 #define WALK_MAX_LC 16
 
-// LDS geometry of k_walk_spec for lag count L: positions per buffer (0 = does not fit, k_walk_global walks)
-static int walk_chunk(int L)
-{
-    if (L > WALK_MAX_LC) return 0;
-    const size_t blk = (size_t)walk_pos_doubles(L) * sizeof(double);  // raw G block, or the derived depth-2 tables if larger
-    const size_t words = 2 * 64 * sizeof(unsigned long long);
-    int chunk = (int)((WALK_LDS_MAX - words) / (2 * blk)) - WALK_OV;   // two buffers, WALK_OV extra positions each
-    if (chunk > 64) chunk = 64;
-    chunk = (chunk / L) * L;                                          // whole unrolled groups
-    return chunk >= L ? chunk : 0;
-}
-
 // Whether the depth-2 walker can run for this L: then k_lt may build G over candidate ranks (kernels.hpp).
 // GH_WALK=src selects the non-speculative walker, GH_WALK=spec1 keeps speculation at depth 1 (A/B measurements).
 static bool walk_depth2_ok(int L)
 {
     static const bool off = getenv("GH_WALK") && (!strcmp(getenv("GH_WALK"), "src") || !strcmp(getenv("GH_WALK"), "spec1"));
-    return !off && L >= 2 && walk_chunk(L) > 0 && WALK_THREADS == 512;
+    return !off && L >= 2 && L <= WALK_MAX_LC && walk_chunk(L, false) > 0 && walk_chunk(L, true) > 0 && WALK_THREADS == 512;
 }
 
 template <int LC>
@@ -797,11 +784,11 @@ static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, c
 // launches the path-extension kernel for `grid` windows (grid == 1: the handle's own buffers in P)
 static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int grid, const win_desc *wd, int spin)
 {
-    const int chunk = walk_chunk(L);
+    const int chunk = L <= WALK_MAX_LC ? walk_chunk(L, false) : 0;
     if (chunk > 0) {
-        const size_t blk = (size_t)walk_pos_doubles(L) * sizeof(double);
-        P.chunk = chunk;
-        const size_t lds = 2 * (size_t)(chunk + WALK_OV) * blk + 2 * 64 * sizeof(unsigned long long);
+        P.chunk = chunk;                    // k_walk_src; k_walk_spec takes walk_chunk(L, variant) itself
+        size_t lds = walk_lds_bytes(L, false);
+        if (walk_depth2_ok(L) && walk_lds_bytes(L, true) > lds) lds = walk_lds_bytes(L, true);
         static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
         P.depth2 = walk_depth2_ok(L);
         launch_walk_src(L, spec, lds, stream, P, grid, wd, spin);

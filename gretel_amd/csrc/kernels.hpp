@@ -517,9 +517,24 @@ __global__ void k_snapshot(double *dst_minfo, const double *src_minfo, int N, co
 // symbol a6 has been selected there: the walker reads exactly one row per step.
 // ---------------------------------------------------------------------------------------------
 #define LT_PAD 16      /* zero source blocks behind N so the unrolled walker may overrun */
-// doubles per position of a k_walk_spec LDS buffer: the raw G block or the derived depth-2 tables, whichever is larger
-__host__ __device__ constexpr int walk_pos_doubles(int L) { return 6 * L * 5 > 64 + 16 * (L - 2) ? 6 * L * 5 : 64 + 16 * (L - 2); }
+// doubles per position of a k_walk_spec LDS buffer: the raw G block (depth 1), or the derived tables H + Yr (depth 2)
+__host__ __device__ constexpr int walk_pos_doubles(int L, bool deep) { return deep ? 64 + 16 * (L > 2 ? L - 2 : 0) : 6 * L * 5; }
+#define WALK_LDS_MAX (160 * 1024)   /* LDS one workgroup can have on gfx950 */
 #define WALK_OV 4      /* source blocks kept behind a chunk in LDS: the last body reads sources j+1 .. j+4 (k_walk_spec) */
+// positions per LDS buffer of k_walk_spec for lag count L (two buffers of chunk + WALK_OV positions and the two
+// word buffers must fit WALK_LDS_MAX; whole unrolled groups; at most 64 = the bookkeeper's lanes); 0 = does not fit.
+// The variant is chosen on the device (it depends on the window's candidate masks), the chunk follows from it.
+__host__ __device__ constexpr int walk_chunk(int L, bool deep)
+{
+    int c = (WALK_LDS_MAX - 2 * 64 * 8) / (2 * walk_pos_doubles(L, deep) * 8) - WALK_OV;
+    if (c > 64) c = 64;
+    c = (c / L) * L;
+    return c >= L ? c : 0;
+}
+__host__ __device__ constexpr size_t walk_lds_bytes(int L, bool deep)
+{
+    return 2 * (size_t)(walk_chunk(L, deep) + WALK_OV) * walk_pos_doubles(L, deep) * 8 + 2 * 64 * 8;
+}
 
 template <typename T>
 __device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond_mode, int marginal_term,
@@ -588,6 +603,7 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
         G[t] = lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // k_walk_src: gretel/gretel.py:143-189 as one workgroup of 8 wavefronts:
@@ -1006,8 +1022,9 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
 
     const int npos = C + WALK_OV;
     const unsigned bufB = (unsigned)npos * (unsigned)RS * 8u;
-    const unsigned h0 = (unsigned)(uintptr_t)g0 + (unsigned)lane * 8u;
-    const unsigned y0 = (unsigned)(uintptr_t)g0 + (unsigned)npos * HB + (unsigned)b * (unsigned)(NY > 0 ? NY : 0) * 8u;
+    unsigned h0 = (unsigned)(uintptr_t)g0 + (unsigned)lane * 8u;
+    unsigned y0 = (unsigned)(uintptr_t)g0 + (unsigned)npos * HB + (unsigned)b * (unsigned)(NY > 0 ? NY : 0) * 8u;
+    asm("" : "+v"(h0), "+v"(y0));          // opaque: otherwise hipcc rematerialises the LDS base (a null-check select) in every group
 
     // state entering body 0: targets 1 and 2 have no resolved lag yet; the row of source 0 is the '_' row in every slot
     unsigned long long B = group_argmax<true>(*(lds_cdouble *)(h0 + HB));
@@ -1068,16 +1085,18 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
     if (st->stop) return;
     constexpr int ROW = LC * LT_ROW;
     constexpr int BLK = 6 * ROW;
-    constexpr int RS = walk_pos_doubles(LC);        // doubles per position in an LDS buffer (either layout fits)
-    const int C = P.chunk;
     double *const g0 = smem;
-    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + WALK_OV) * RS);
 
-    const int first_hole = st->first_hole;
-    const bool nodel = st->nodel != 0;
-    // uniform: which walker, loader and word format.  G is ranked (k_lt) exactly when the host allowed it (same
+    // (readfirstlane: the flags are the same for every lane, but loaded from memory the kernel also writes, so the
+    // compiler would treat everything derived from them -- chunk size, loop bounds, the scalar resolve -- as divergent)
+    const int first_hole = __builtin_amdgcn_readfirstlane(st->first_hole);
+    const bool nodel = __builtin_amdgcn_readfirstlane(st->nodel) != 0;
+    // which walker, loader and word format.  G is ranked (k_lt) exactly when the host allowed it (same
     // condition as P.depth2) and no position has more than 4 candidates: then the 4-symbol depth-2 walker applies.
-    const bool deep = LC >= 2 && st->ranked != 0 && P.depth2 && blockDim.x == 512;
+    const bool deep = LC >= 2 && __builtin_amdgcn_readfirstlane(st->ranked) != 0 && P.depth2 && blockDim.x == 512;
+    const int RS = walk_pos_doubles(LC, deep);      // doubles per position in an LDS buffer
+    const int C = walk_chunk(LC, deep);             // positions per chunk (the host sized the LDS for either variant)
+    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)(C + WALK_OV) * RS);
     const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;      // positions that can be decided
     const int nchunks = (Nw + C - 1) / C;                         // bodies 0..Nw-1, chunk k = k*C..k*C+C-1
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1104,7 +1123,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
             // (their latency must not sit between two barriers, the walker waits there too); the sums and the LDS
             // stores of chunk k+1 happen while the walker is in chunk k.
             typedef deep_layout<LC> DL;
-            constexpr int NT = 384, MAXPOS = 64 + WALK_OV;
+            constexpr int NT = 384, MAXPOS = walk_chunk(LC, true) + WALK_OV;      // = C + WALK_OV
             constexpr int MAXH = (MAXPOS * DL::HPOS + NT - 1) / NT;
             constexpr int MAXY = DL::YPOS ? (MAXPOS * DL::YPOS + NT - 1) / NT : 0;
             if (wave >= 2) {

@@ -23,15 +23,14 @@ int main(int argc, char** argv){
     double *dG, *dmi; uint8_t* dpath[2]; gh_path_rec* drec; dev_state* dst;
     hipMalloc(&dG, nG*8); hipMalloc(&dmi, minfo.size()*8); hipMalloc(&dpath[0], N+2); hipMalloc(&dpath[1], N+2); hipMalloc(&drec, sizeof(gh_path_rec)); hipMalloc(&dst, sizeof(dev_state));
     hipMemcpy(dG, G.data(), nG*8, hipMemcpyHostToDevice); hipMemcpy(dmi, minfo.data(), minfo.size()*8, hipMemcpyHostToDevice);
-    const size_t blk = (size_t)walk_pos_doubles(LC) * 8;
-    int chunk = (int)((160*1024 - 1024)/(2*blk)) - WALK_OV; if (chunk > 64) chunk = 64; chunk = (chunk/LC)*LC;
-    const size_t lds = 2*(size_t)(chunk+WALK_OV)*blk + 2*64*8;
+    const int chunk = walk_chunk(LC, false);
+    const size_t lds = walk_lds_bytes(LC, false) > walk_lds_bytes(LC, true) ? walk_lds_bytes(LC, false) : walk_lds_bytes(LC, true);
     hipFuncSetAttribute((const void*)k_walk_spec<HLC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     std::vector<uint8_t> path[2]; 
     for (int v = 0; v < 2; v++) {
         path[v].assign(N+1, 255);
         if (variant_only >= 0 && v != variant_only) continue;
-        dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1;
+        dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1; hs.narrow = 1; hs.ranked = v;   // ranked tables <=> depth-2 walker
         hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
         walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.rearm = 0; P.depth2 = v; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
         hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P, (const win_desc*)nullptr, 0);
