@@ -518,7 +518,9 @@ __global__ void k_snapshot(double *dst_minfo, const double *src_minfo, int N, co
 // ---------------------------------------------------------------------------------------------
 #define LT_PAD 16      /* zero source blocks behind N so the unrolled walker may overrun */
 // doubles per position of a k_walk_spec LDS buffer: the raw G block (depth 1), or the derived tables H + Yr (depth 2)
-__host__ __device__ constexpr int walk_pos_doubles(int L, bool deep) { return deep ? 64 + 16 * (L > 2 ? L - 2 : 0) : 6 * L * 5; }
+// (depth 2: 64 doubles of H per target + 16 rows of Yr per source, each L-2 lags padded to an even count so that a
+// lane reads its row with 16-byte LDS loads)
+__host__ __device__ constexpr int walk_pos_doubles(int L, bool deep) { return deep ? 64 + 16 * (L > 2 ? ((L - 2 + 1) & ~1) : 0) : 6 * L * 5; }
 #define WALK_LDS_MAX (160 * 1024)   /* LDS one workgroup can have on gfx950 */
 #define WALK_OV 4      /* source blocks kept behind a chunk in LDS: the last body reads sources j+1 .. j+4 (k_walk_spec) */
 // positions per LDS buffer of k_walk_spec for lag count L (two buffers of chunk + WALK_OV positions and the two
@@ -882,6 +884,7 @@ __device__ __forceinline__ void book_fold(const book_regs &R, int ns, walk_total
 //   M  B = group-wise arg-max of acc_{j+2}                               independent of R
 // so the LDS latency of R is covered by M and by the next body's A and S.
 typedef __attribute__((address_space(3))) const double lds_cdouble;
+typedef double lds_v2d __attribute__((ext_vector_type(2), aligned(16)));
 
 // diagnostic builds only (-DGH_STAMPS): s_memtime stamps between the segments of a walker body, summed per
 // segment in scalar registers and stored once at the end into st->dbg[4..8]; never defined in the product build
@@ -1000,8 +1003,9 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 template <int LC>
 struct deep_layout {
     static constexpr int NY = LC - 2;                  // lags taken from resolved rows
+    static constexpr int NYP = NY > 0 ? ((NY + 1) & ~1) : 0;   // ... padded to an even count: rows are 16-byte aligned
     static constexpr int HPOS = 64;                    // doubles of H per target
-    static constexpr int YPOS = 16 * (NY > 0 ? NY : 0);   // doubles of Yr per source
+    static constexpr int YPOS = 16 * NYP;              // doubles of Yr per source
     static constexpr int POS = HPOS + YPOS;
 };
 
@@ -1012,7 +1016,7 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
     static_assert(LC >= 2, "depth-2 speculation needs two lags");
     typedef deep_layout<LC> DL;
     constexpr int NY = DL::NY;
-    constexpr unsigned HB = DL::HPOS * 8, YB = DL::YPOS * 8, YWB = 4 * (NY > 0 ? NY : 0) * 8;
+    constexpr unsigned HB = DL::HPOS * 8, YB = DL::YPOS * 8, YWB = 4 * DL::NYP * 8;
     const int b = lane & 3;
     double Y[LC][LC];                       // Y[slot][l]: lag-(l+1) term of the source with index == slot (mod LC); l >= 2 used
 #pragma unroll
@@ -1023,7 +1027,7 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
     const int npos = C + WALK_OV;
     const unsigned bufB = (unsigned)npos * (unsigned)RS * 8u;
     unsigned h0 = (unsigned)(uintptr_t)g0 + (unsigned)lane * 8u;
-    unsigned y0 = (unsigned)(uintptr_t)g0 + (unsigned)npos * HB + (unsigned)b * (unsigned)(NY > 0 ? NY : 0) * 8u;
+    unsigned y0 = (unsigned)(uintptr_t)g0 + (unsigned)npos * HB + (unsigned)b * (unsigned)DL::NYP * 8u;
     asm("" : "+v"(h0), "+v"(y0));          // opaque: otherwise hipcc rematerialises the LDS base (a null-check select) in every group
 
     // state entering body 0: targets 1 and 2 have no resolved lag yet; the row of source 0 is the '_' row in every slot
@@ -1058,9 +1062,16 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
                 if constexpr (NY > 0) {
                     unsigned vrow;
                     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(vrow) : "s"(w), "v"(yw_v), "v"(vy));
-                    lds_cdouble *row = (lds_cdouble *)(vrow + (unsigned)(u + 1) * YB);
+                    // 16-byte reads (their offset field is 16 bits wide; ds_read2_b64 would need an address add per read
+                    // once (u + 1) * YB passes 2040 bytes)
+                    const unsigned rb = vrow + (unsigned)(u + 1) * YB;
 #pragma unroll
-                    for (int l = 2; l < LC; l++) Y[(u + 1) % LC][l] = row[l - 2];
+                    for (int l = 2; l + 1 < LC; l += 2) {
+                        const lds_v2d pr = *(const __attribute__((address_space(3))) lds_v2d *)(rb + (unsigned)(l - 2) * 8u);
+                        Y[(u + 1) % LC][l] = pr.x;
+                        Y[(u + 1) % LC][l + 1] = pr.y;
+                    }
+                    if constexpr (NY & 1) Y[(u + 1) % LC][LC - 1] = *(lds_cdouble *)(rb + (unsigned)(NY - 1) * 8u);
                 }
                 H12 = *(lds_cdouble *)(vh + (unsigned)(u + 4) * HB);
             }
@@ -1152,9 +1163,9 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                             const int q = t + it * NT;
                             yv[it] = 0.0;
                             if (q < ny) {
-                                const int p = q / DL::YPOS, r = q % DL::YPOS, wb = r / DL::NY, l = 2 + r % DL::NY;
+                                const int p = q / DL::YPOS, r = q % DL::YPOS, wb = r / DL::NYP, l = 2 + r % DL::NYP;
                                 const int sidx = i0 + p;
-                                if (sidx < nsrc_all)
+                                if (sidx < nsrc_all && l < LC)
                                     yv[it] = P.G[(size_t)sidx * BLK + (sidx == 0 ? 5 : (wb >> 2)) * ROW + l * LT_ROW + (wb & 3)];
                             }
                         }

@@ -30,14 +30,20 @@ int main(int argc, char** argv){
     for (int v = 0; v < 2; v++) {
         path[v].assign(N+1, 255);
         if (variant_only >= 0 && v != variant_only) continue;
-        dev_state hs; memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1; hs.narrow = 1; hs.ranked = v;   // ranked tables <=> depth-2 walker
-        hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
-        walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.rearm = 0; P.depth2 = v; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
-        hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P, (const win_desc*)nullptr, 0);
-        hipError_t e = hipDeviceSynchronize();
-        hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
+        dev_state hs;
+        double best = 1e30;
+        hipError_t e = hipSuccess;
+        for (int rep = 0; rep < 4; rep++) {         // first launch is cold: report the best of four
+            memset(&hs, 0, sizeof hs); hs.first_hole = 0x7f7f7f7f; hs.nodel = 1; hs.narrow = 1; hs.ranked = v;   // ranked tables <=> depth-2 walker
+            hipMemcpy(dst, &hs, sizeof hs, hipMemcpyHostToDevice);
+            walk_params P; P.N = N; P.L = LC; P.chunk = chunk; P.rearm = 0; P.depth2 = v; P.G = dG; P.minfo = dmi; P.path_out = dpath[v]; P.rec = drec; P.st = dst; P.min_remove = 0.01;
+            hipLaunchKernelGGL((k_walk_spec<HLC>), dim3(1), dim3(512), lds, 0, P, (const win_desc*)nullptr, 0);
+            e = hipDeviceSynchronize();
+            hipMemcpy(&hs, dst, sizeof hs, hipMemcpyDeviceToHost);
+            if (hs.dbg[2] && (double)hs.dbg[0]/hs.dbg[2] < best) best = (double)hs.dbg[0]/hs.dbg[2];
+        }
         hipMemcpy(path[v].data(), dpath[v], N+1, hipMemcpyDeviceToHost);
-        printf("variant %d: %s  cycles/step %.1f  n_done %d\n", v, hipGetErrorString(e), hs.dbg[2] ? (double)hs.dbg[0]/hs.dbg[2] : 0.0, hs.n_done); fflush(stdout);
+        printf("variant %d: %s  cycles/step %.1f  n_done %d\n", v, hipGetErrorString(e), best, hs.n_done); fflush(stdout);
 #ifdef GH_STAMPS
         { const char* nm[5] = {"loop/M-tail->A", "A resolve+pack", "S adds", "R reads issue", "M argmax"}; for (int q = 0; q < 5; q++) printf("   seg %d %-16s %.1f cycles/step (incl. ~stamp cost)\n", q, nm[q], (double)hs.dbg8[q]/hs.dbg[2]); }
 #endif
