@@ -254,6 +254,20 @@ def main():
                 traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("k_walk"))
         except Exception:
             traffic = None
+        # what does bound the walker: one wavefront issues an instruction every 5 cycles (scratch/ubench6/7.hip), so the
+        # floor is 5 x the instructions per step of the inner loop as compiled (profiles/walker_isa_count.py, no GPU needed)
+        issue_model = None
+        try:
+            isa = json.load(open(os.path.join(ROOT, "profiles", "r1_walker_isa.json")))
+            ent = isa["L"].get(str(L))
+            if ent and variant == 2 and nsteps:
+                floor = ent["issue_floor_cycles_per_step"]
+                issue_model = {"instructions_per_step": ent["instructions_per_step"],
+                               "cycles_per_instruction_lone_wave": isa["cycles_per_instruction_lone_wave"],
+                               "floor_cycles_per_step": floor, "measured_cycles_per_step": cyc / nsteps,
+                               "frac": floor / (cyc / nsteps)}
+        except Exception:
+            issue_model = None
         out = {
             "metric": "haplotypes/sec + SNP-edge-evals/sec on 10k-SNP synthetic contig",
             "value": hap_s,
@@ -286,6 +300,7 @@ def main():
                                                % (PROF_STRIDE, walk["launches"]),
                          "walker_cycles_per_step": (cyc / nsteps) if nsteps else None,
                          "walker_clock_ghz": (cyc / (ticks * 10.0)) if ticks else None,
+                         "issue_model": issue_model,
                          "walker_variant": {2: "depth-2 speculation", 1: "depth-1 speculation, no '-' candidates",
                                             0: "depth-1 speculation"}.get(variant),
                          "note": "not bandwidth bound: each step needs the previous step's arg-max (gretel.py:143-187), so one "
