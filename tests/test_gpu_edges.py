@@ -114,6 +114,19 @@ def test_deletions_with_at_most_four_candidates_take_the_depth2_walker(L):
     assert (res["paths"] == 5).any()          # '-' is actually selected somewhere
 
 
+@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(marginal_term=True), dict(storage="f64", cond_mode="C"),
+                                dict(storage="f64", cond_mode="B", marginal_term=True)])
+def test_ranked_tables_under_every_switch(kw):
+    # the rank layout with '-' among the candidates, for the other conditionals / the marginal term (full k_lt each
+    # path) / f64 storage
+    t = make_support_table(300, 6000, k=5, n_haps=3, err=0.0, seed=77)
+    bases = t.bases.copy()
+    bases[np.random.default_rng(7).random(len(bases)) < 0.2] = ord('-')
+    t.bases = bases
+    res = _check(t, paths=4, L=4, want_variant=2, **kw)
+    assert (res["paths"] == 5).any()
+
+
 def test_n_symbols_are_counted_but_never_selected():
     t = make_support_table(60, 2000, k=4, seed=6)
     bases = t.bases.copy()
