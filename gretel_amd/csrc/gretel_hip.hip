@@ -815,18 +815,29 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
 }
 
 // reweight along d_path AND refresh the marginal tables in one pass (k_marg<T, true>)
-static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec)
+// room for `slots` sets of per-block partial sums of the removed mass
+static int ensure_partial(gh_handle *h, int nb, int slots)
+{
+    const size_t need = (size_t)nb * (slots > 0 ? slots : 1);
+    if (need > (size_t)h->partial_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->partial) hipFree(h->partial);
+        h->partial = nullptr; h->partial_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->partial, need * sizeof(double)));
+        h->partial_cap = (int)need;
+    }
+    return GH_OK;
+}
+
+// slot < 0: reduce the removed mass right behind the pass (k_reweight_finish).  slot >= 0 (gh_spin): keep this
+// path's partial sums in their own slot, the caller reduces all paths with one k_reweight_finish_all at the end.
+static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec, int slot = -1)
 {
     const int threads = (h->N + 1) * 8;
     const int block = 256;
     const int nb = (threads + block - 1) / block;
-    if (nb > h->partial_cap) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->partial) hipFree(h->partial);
-        h->partial = nullptr;
-        HIPCHK(hipMalloc((void **)&h->partial, (size_t)nb * sizeof(double)));
-        h->partial_cap = nb;
-    }
+    if (slot < 0) { int rc_ = ensure_partial(h, nb, 1); if (rc_) return rc_; }
+    double *partial = h->partial + (slot > 0 ? (size_t)slot * nb : 0);
     // in a spin the walker re-armed the flags when it finished; a lone reweight does it here
     if (!use_state) hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, 0);
     // with a valid conditional table (conditional A or B, no marginal term) the kernel also rewrites the table rows
@@ -838,13 +849,14 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           d_path, ratio, use_state, h->partial, 0, lt_rows, h->L, h->cfg.cond_mode);
+                           d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode);
     else
         hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           d_path, ratio, use_state, h->partial, 0, lt_rows, h->L, h->cfg.cond_mode);
-    hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, h->partial, nb, h->dstate, use_state, d_rec,
-                       (const win_desc *)nullptr, 0);
+                           d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode);
+    if (slot < 0)
+        hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, partial, nb, h->dstate, use_state, d_rec,
+                           (const win_desc *)nullptr, 0);
     // algorithmic bytes: the reweighted elements (read+write) + the marginal pass (read cell (p,p+1), write the tables)
     // (+ one band row read and L x 5 table entries written per (source, lag) when the table rows are rewritten too)
     const int wl = h->W < h->L ? h->W : h->L;
@@ -933,10 +945,19 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     hipError_t e = hipMalloc((void **)&d_recs, sizeof(gh_path_rec) * max_paths);
     if (e != hipSuccess) { hipFree(d_paths); return fail(GH_ERR_NOMEM, "hipMalloc failed"); }
     rc = reset_spin_state(h);
+    const int nb = ((h->N + 1) * 8 + 255) / 256;
+    if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);
+    int launched = 0;
     for (int s = 0; s < max_paths && rc == GH_OK; s++) {
         if ((rc = ensure_lt(h))) break;
         if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1))) break;
-        if ((rc = launch_reweight_marg(h, d_paths + n1 * s, 0.0, 1, d_recs + s))) break;
+        if ((rc = launch_reweight_marg(h, d_paths + n1 * s, 0.0, 1, d_recs + s, s))) break;
+        launched = s + 1;
+    }
+    // the removed mass of every path in one launch (it is only ever read by the host)
+    if (rc == GH_OK && launched > 0) {
+        hipLaunchKernelGGL(k_reweight_finish_all, dim3(launched), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
+        rc = post_launch(h, "k_reweight_finish_all");
     }
     dev_state hs;
     memset(&hs, 0, sizeof hs);

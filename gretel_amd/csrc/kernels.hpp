@@ -765,7 +765,7 @@ __global__ void __launch_bounds__(512) k_walk_src(walk_params P, const win_desc 
                 if (r < P.min_remove) r = P.min_remove;               // cmd.py:157-160
                 P.rec->hp_current = T.hp_cur;
                 P.rec->hp_original = T.hp_orig;
-                P.rec->ratio = T.minm;
+                P.rec->ratio = r;                                     // the ratio the reweight will use (clamped)
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
@@ -1255,7 +1255,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                 if (r < P.min_remove) r = P.min_remove;               // cmd.py:157-160
                 P.rec->hp_current = T.hp_cur;
                 P.rec->hp_original = T.hp_orig;
-                P.rec->ratio = T.minm;
+                P.rec->ratio = r;                                     // the ratio the reweight will use (clamped)
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
@@ -1341,7 +1341,7 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
             if (r < P.min_remove) r = P.min_remove;
             P.rec->hp_current = hp_cur;
             P.rec->hp_original = hp_orig;
-            P.rec->ratio = minm;
+            P.rec->ratio = r;
             P.rec->magnitude = 0.0;
             st->ratio = r;
             st->n_done += 1;
@@ -1380,6 +1380,26 @@ k_reweight_finish(const double *partial, int nb, dev_state *st, int use_state,
         rec->magnitude = s_red[0];
         if (use_state) rec->ratio = st->ratio;
     }
+}
+
+// the same reduction for every path of a spin at once (block s = path s, partial sums kept per path): the removed
+// mass is only read by the host, so gh_spin defers it to one launch behind the loop instead of one per path
+__global__ void __launch_bounds__(256)
+k_reweight_finish_all(const double *partial, int nb, const dev_state *st, gh_path_rec *recs)
+{
+    __shared__ double s_red[256];
+    const int s = blockIdx.x;
+    if (s >= st->n_done) return;            // a hole ended the recovery before this path
+    const double *part = partial + (size_t)s * nb;
+    double acc = 0.0;
+    for (int q = threadIdx.x; q < nb; q += 256) acc += part[q];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) recs[s].magnitude = s_red[0];
 }
 
 // one-cell helpers ----------------------------------------------------------------------------
