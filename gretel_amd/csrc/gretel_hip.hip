@@ -6,10 +6,12 @@
 //   cnt, marg  f64[(N+2)][8]       c_s(p) = sum_t H[s,t,p,p+1] (+ total), c_s/total          (lookup API)
 //   nvalid, cmask                  V(p), candidate bitmask
 //   minfo   f64[(N+2)][16]         log10 marginal x5, marginal x5, candidate bits, log10 ORIGINAL marginal x5
-//   G (lt)  f64[(N+16)][6][L][5]   source-major log10 conditionals
+//   G (lt)  f64[(N+16)][6][L][5]   source-major log10 conditionals, over symbols or over candidate ranks (k_lt)
 //
-// Launch sequence of one spin (gretel/cmd.py:148-179):  k_lt (row-wise after the first) -> k_walk_spec ->
-// k_marg<T,true> (reweight + marginals) -> k_reweight_finish; gh_batch_spin launches each over all windows.
+// Launch sequence of one path of a spin (gretel/cmd.py:148-179):  k_lt (full build for the first path, then only a
+// check of the candidate-mask flags) -> k_walk_spec -> k_marg<T,true> (reweight + marginals + the table rows the path
+// changed); gh_spin reduces the removed mass of all paths with one k_reweight_finish_all at the end, gh_batch_spin
+// launches each kernel over all windows (k_reweight_finish per path).
 //
 // Arithmetic contract (identical to oracle/hansel_ref.py): row/column sums accumulate
 // sequentially in the storage dtype, everything else is IEEE binary64 with NO fma
