@@ -103,7 +103,9 @@ struct gh_reads {
     uint8_t *bases;
     int max_k;
     bool sorted;      // ranks ascend: k_fill_sorted applies
+    int span_pos;     // sorted tables: widest run of positions one workgroup of k_fill_sorted (FILL_RPB reads) covers
 };
+#define FILL_RPB 2048     /* reads per workgroup of k_fill_sorted */
 
 static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STORAGE_F64 ? 8 : 4; }
 
@@ -368,6 +370,13 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
         if (k > r->max_k) r->max_k = (int)k;
         if (q > 0 && rank[q] < rank[q - 1]) r->sorted = false;
     }
+    r->span_pos = 0;
+    if (r->sorted)
+        for (int64_t q0 = 0; q0 < n_reads; q0 += FILL_RPB) {
+            const int64_t q1 = q0 + FILL_RPB < n_reads ? q0 + FILL_RPB : n_reads;
+            const int span = rank[q1 - 1] - rank[q0] + r->max_k + 1;      // the slice k_fill_sorted counts in LDS
+            if (span > r->span_pos) r->span_pos = span;
+        }
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void **)&r->rank, (size_t)(n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->off, (size_t)(n_reads + 1) * 8);
@@ -426,12 +435,15 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         prof_begin(h, GH_K_FILL);
         // sorted tables: LDS-privatised counting when a run of reads stays inside a slice that fits in LDS
         static const bool no_sorted = getenv("GH_FILL_SCATTER") && atoi(getenv("GH_FILL_SCATTER"));
-        const int rpb = 2048;                                     // reads per workgroup
+        const int rpb = FILL_RPB;                                 // reads per workgroup
         int max_pos = 0;
         if (r->sorted && !no_sorted) {
+            // LDS for the widest slice any workgroup needs (known from the upload), at most 96 KB: several
+            // workgroups per CU when the slices are narrow; what falls outside a slice goes to global atomics
             const size_t per_pos = (size_t)h->W * CELL * sizeof(unsigned);
             max_pos = (int)((96 * 1024) / per_pos);
             if (max_pos > 1024) max_pos = 1024;
+            if (r->span_pos > 0 && r->span_pos < max_pos) max_pos = r->span_pos > r->max_k + 8 ? r->span_pos : r->max_k + 8;
         }
         if (max_pos >= r->max_k + 8) {
             const unsigned gb = (unsigned)((r->n_reads + rpb - 1) / rpb);
