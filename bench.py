@@ -295,6 +295,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": walk["bytes_per_launch"],
+                         "algorithmic_bytes_definition": "SURVEY 8(d) path extension: N*((1+L)*196+28) per path",
                          "avg_launch_ms_hip_events": walk_ms,
                          "hip_event_sampling": "every %d-th launch of each kernel inside the timed region (%d launches)"
                                                % (PROF_STRIDE, walk["launches"]),

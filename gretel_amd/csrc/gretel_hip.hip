@@ -822,8 +822,9 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
     prof_begin(h, GH_K_WALK);
     launch_walk_any(h->N, h->L, P, h->stream, 1, nullptr, 0);
-    // algorithmic bytes: per step one table row (L x 5 doubles) + the selected symbol's 3 marginal words + 1 path byte
-    prof_end(h, GH_K_WALK, (double)h->N * ((double)h->L * 40.0 + 24.0 + 1.0));
+    // algorithmic bytes, SURVEY 8(d): per step the marginal cell + L history cells (49 elements each) + the original
+    // marginals (7 x 4 B).  What this build's layout needs per step is one table row: N * (L * 40 + 25) bytes.
+    prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
     { int rc_ = post_launch(h, "k_walk"); if (rc_) return rc_; }
     return GH_OK;
 }
