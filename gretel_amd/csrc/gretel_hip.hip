@@ -83,8 +83,9 @@ struct gh_handle {
     double *lt;
     int lt_L;
     bool dirty_marg, dirty_lt, have_orig;
-    const uint8_t *lt_inc_path;   // device path of the ONLY mutation since G was last built (a path reweight), else null
-    uint8_t *d_rw_path;           // [N+1] the path of gh_reweight_path (kept for the incremental table update)
+    const uint8_t *lt_inc_path;   // non-null: the ONLY mutation since G was last built is a path reweight whose fused
+                                  // kernel has rewritten the rows it changed (k_lt then only checks the mask flags)
+    uint8_t *d_rw_path;           // [N+1] device copy of the path of gh_reweight_path
     dev_state *dstate;
     double *partial;       // reweight block partial sums
     int partial_cap;
@@ -1035,7 +1036,7 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     b->hs.assign(handles, handles + n);
     b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
     b->cap_paths = 0;
-    b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_reweight and of k_marg<.., true>
+    b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_marg<.., true>
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_wd, sizeof(win_desc) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_partial, sizeof(double) * (size_t)b->nb * n);
@@ -1097,7 +1098,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     for (int s = 0; s < max_paths; s++) {
-        // any non-null pointer switches k_lt to the row-wise update; the kernel takes the path of spin s-1 from wd
+        // any non-null pointer tells k_lt that the fused reweight of spin s-1 has already rewritten the rows it changed
         const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
         if (s == 0) {
             hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, (dev_state *)nullptr, b->d_wd, 0);

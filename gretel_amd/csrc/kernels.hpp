@@ -304,7 +304,7 @@ __global__ void k_add_batch(T *__restrict__ band, int N, int W, const uint8_t *a
 // (hansel get_counts_at + get_marginal_of_at, call sites gretel/cmd.py:86, gretel/gretel.py:182)
 // ---------------------------------------------------------------------------------------------
 // RW = true fuses gretel/gretel.py:79-98 in front: the 8-lane group of position p first reweights the
-// cells (p, p+d), d = 1..W, on `rw_path` (same element-wise arithmetic and multiplicities as k_reweight,
+// cells (p, p+d), d = 1..W, on `rw_path` (the element-wise arithmetic and the multiplicities of gretel/gretel.py:79-98,
 // removed mass into partial[blockIdx.x]) and then takes the marginals of the cell (p, p+1) it has just
 // updated -- one pass over the band instead of two, one launch less per path.  With G != nullptr it also rewrites
 // the rows of the conditional table (k_lt below) that the path's cells feed, while those cells are still in cache.
