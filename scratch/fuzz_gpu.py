@@ -1,0 +1,59 @@
+"""Randomised parity fuzz: HIP path vs the C oracle on random windows, switches and lag counts (not part of the
+default suite; run on the GPU box: python scratch/fuzz_gpu.py [seconds] [seed])."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from gretel_amd.hansel import Hansel
+from gretel_amd.synth import make_support_table
+from oracle.c_oracle import COracle
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed0)
+t_end = time.time() + budget
+n_cases = 0
+variants = {}
+while time.time() < t_end:
+    n = int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
+    k = int(rng.integers(2, min(n, 12) + 1)) if rng.random() < 0.7 else None
+    n_haps = int(rng.integers(1, 9))
+    err = float(rng.choice([0.0, 0.0, 0.01, 0.05]))
+    reads = int(max(20, n * rng.integers(4, 40)))
+    t = make_support_table(n, reads, k=k, n_haps=n_haps, err=err, seed=int(rng.integers(0, 1 << 30)), k_max=min(21, n))
+    if rng.random() < 0.4:
+        bases = t.bases.copy()
+        bases[rng.random(len(bases)) < rng.choice([0.02, 0.1, 0.3])] = ord('-')
+        if rng.random() < 0.3:
+            bases[rng.random(len(bases)) < 0.03] = ord('N')
+        t.bases = bases
+    storage = str(rng.choice(["f32", "f32", "f64"]))
+    mode = str(rng.choice(["A", "A", "B", "C"]))
+    mt = bool(rng.random() < 0.25)
+    L = None if rng.random() < 0.4 else int(rng.integers(1, 21))
+    paths = int(rng.integers(1, 9))
+    desc = dict(n=n, reads=reads, k=k, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths)
+    h = Hansel(t.n_snps, band=t.band, storage=storage, cond_mode=mode, marginal_term=mt)
+    o = COracle(t.n_snps, t.band, storage, mode, mt)
+    try:
+        assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t), "fill stats"
+        if L is not None:
+            h.L = L; o.L = L
+        assert h.gap_check() == o.gap_check(), "gap"
+        res, ref = h.spin(paths), o.spin(paths)
+        assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"], "n/hole %s %s" % ((res["n"], res["hole_at"]), (ref["n"], ref["hole_at"]))
+        assert np.array_equal(res["paths"], ref["paths"]), "paths"
+        assert res["hp_current"].tolist() == ref["hp_current"].tolist(), "hp_current"
+        assert res["hp_original"].tolist() == ref["hp_original"].tolist(), "hp_original"
+        assert res["ratio"].tolist() == ref["ratio"].tolist(), "ratio"
+        assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0), "magnitude"
+        assert np.array_equal(h.export_band(), o.export_band()), "band"
+        # a second spin on the reweighted tensor (tables rebuilt / reused)
+        res2, ref2 = h.spin(2), o.spin(2)
+        assert res2["n"] == ref2["n"] and np.array_equal(res2["paths"], ref2["paths"]), "second spin"
+        v = h.walk_clock()[3] if res["n"] else -1
+        variants[v] = variants.get(v, 0) + 1
+    except AssertionError as e:
+        print("MISMATCH", e, desc, flush=True)
+        sys.exit(1)
+    n_cases += 1
+print("fuzz ok: %d cases, walker variants %s" % (n_cases, variants))
