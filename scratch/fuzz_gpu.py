@@ -3,7 +3,7 @@ default suite; run on the GPU box: python scratch/fuzz_gpu.py [seconds] [seed]).
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
-from gretel_amd.hansel import Hansel
+from gretel_amd.hansel import Hansel, HanselBatch
 from gretel_amd.synth import make_support_table
 from oracle.c_oracle import COracle
 
@@ -12,6 +12,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed0)
 t_end = time.time() + budget
 n_cases = 0
+n_batch = 0
 variants = {}
 while time.time() < t_end:
     n = int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
@@ -32,6 +33,26 @@ while time.time() < t_end:
     L = None if rng.random() < 0.4 else int(rng.integers(1, 21))
     paths = int(rng.integers(1, 9))
     desc = dict(n=n, reads=reads, k=k, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths)
+    if k is not None and rng.random() < 0.12:
+        # batched launch over 3 windows of one shape (same N, band, switches, L)
+        ts = [t] + [make_support_table(n, reads, k=k, n_haps=int(rng.integers(1, 9)), err=err, seed=int(rng.integers(0, 1 << 30)))
+                    for _ in range(2)]
+        if len({x.band for x in ts}) == 1:
+            hs, os_ = [], []
+            for x in ts:
+                hh = Hansel(x.n_snps, band=x.band, storage=storage, cond_mode=mode, marginal_term=mt)
+                oo = COracle(x.n_snps, x.band, storage, mode, mt)
+                assert hh.fill_from_support(x.rank, x.off, x.bases) == oo.fill(x)
+                hh.L = L if L is not None else 3; oo.L = hh.L
+                hs.append(hh); os_.append(oo)
+            for res, oo in zip(HanselBatch(hs).spin(paths), os_):
+                ref = oo.spin(paths)
+                if not (res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"] and np.array_equal(res["paths"], ref["paths"])
+                        and res["hp_current"].tolist() == ref["hp_current"].tolist()):
+                    print("MISMATCH batch", desc, flush=True)
+                    sys.exit(1)
+            n_batch += 1
+            continue
     h = Hansel(t.n_snps, band=t.band, storage=storage, cond_mode=mode, marginal_term=mt)
     o = COracle(t.n_snps, t.band, storage, mode, mt)
     try:
@@ -56,4 +77,4 @@ while time.time() < t_end:
         print("MISMATCH", e, desc, flush=True)
         sys.exit(1)
     n_cases += 1
-print("fuzz ok: %d cases, walker variants %s" % (n_cases, variants))
+print("fuzz ok: %d cases + %d batched triples, walker variants %s" % (n_cases, n_batch, variants))
