@@ -81,6 +81,7 @@ struct gh_handle {
     int32_t *nvalid;
     uint32_t *cmask;
     double *lt;
+    double *ht, *yt;              // depth-2 walker tables derived from lt (k_lt), when walk_depth2_ok(L)
     int lt_L;
     bool dirty_marg, dirty_lt, have_orig;
     const uint8_t *lt_inc_path;   // non-null: the ONLY mutation since G was last built is a path reweight whose fused
@@ -195,7 +196,7 @@ static void free_handle(gh_handle *h)
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
-    hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->dstate); hipFree(h->partial);
+    hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
@@ -230,7 +231,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->W = cfg->band;
     h->L = 1;
     h->n_cells = (size_t)(h->N + 2) * h->W;
-    h->lt = nullptr; h->lt_L = 0;
+    h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
@@ -615,7 +616,7 @@ static int ensure_lt(gh_handle *h)
     const bool inc_ok = h->lt_inc_path && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
                         !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
-    const size_t total = inc ? (size_t)h->N * h->L : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
+    const size_t total = inc ? (size_t)h->N * 4 : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
     size_t nb = (total + block - 1) / block;
     if (nb > 256 * 16) nb = 256 * 16;
@@ -623,11 +624,11 @@ static int ensure_lt(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L));
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L), h->ht, h->yt);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L));
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L), h->ht, h->yt);
     const int wl = h->W < h->L ? h->W : h->L;
     // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
     prof_end(h, GH_K_LT, inc ? 8.0
@@ -745,9 +746,17 @@ static int alloc_lt(gh_handle *h)
     if (h->lt && h->lt_L == h->L) return GH_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->lt) hipFree(h->lt);
-    h->lt = nullptr;
+    if (h->ht) hipFree(h->ht);
+    if (h->yt) hipFree(h->yt);
+    h->lt = nullptr; h->ht = nullptr; h->yt = nullptr;
     size_t bytes = (size_t)(h->N + LT_PAD) * h->L * LT_BLK * sizeof(double);
     hipError_t e = hipMalloc((void **)&h->lt, bytes);
+    if (e == hipSuccess && walk_depth2_ok(h->L)) {
+        // the tables the depth-2 walker's loaders copy (k_lt keeps them in step with lt)
+        e = hipMalloc((void **)&h->ht, (size_t)(h->N + WALK_TPAD) * 64 * sizeof(double));
+        const size_t ypos = (size_t)16 * deep_nyp(h->L);
+        if (e == hipSuccess && ypos) e = hipMalloc((void **)&h->yt, (size_t)(h->N + WALK_TPAD) * ypos * sizeof(double));
+    }
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc(%zu) for the conditional table failed", bytes);
     h->lt_L = h->L;
     h->dirty_lt = true; h->lt_inc_path = nullptr;
@@ -819,7 +828,7 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
 {
     walk_params P;
     P.N = h->N; P.L = h->L; P.chunk = 0; P.rearm = rearm;
-    P.G = h->lt; P.minfo = h->minfo;
+    P.G = h->lt; P.Ht = h->ht; P.Yt = h->yt; P.minfo = h->minfo;
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
     prof_begin(h, GH_K_WALK);
     launch_walk_any(h->N, h->L, P, h->stream, 1, nullptr, 0);
@@ -970,6 +979,9 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         if ((rc = launch_reweight_marg(h, d_paths + n1 * s, 0.0, 1, d_recs + s, s))) break;
         launched = s + 1;
     }
+    // bring the walker tables in step with the last reweight while its path is still allocated (the next call would
+    // otherwise refresh them from a freed buffer)
+    if (rc == GH_OK && launched > 0) rc = ensure_lt(h);
     // the removed mass of every path in one launch (it is only ever read by the host)
     if (rc == GH_OK && launched > 0) {
         hipLaunchKernelGGL(k_reweight_finish_all, dim3(launched), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
@@ -1074,7 +1086,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     for (int w = 0; w < n; w++) {
         gh_handle *h = b->hs[w];
         wd[w].band = h->band; wd[w].cnt = h->cnt; wd[w].marg = h->marg; wd[w].minfo = h->minfo;
-        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].G = h->lt; wd[w].st = h->dstate;
+        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
         wd[w].partial = b->d_partial + (size_t)w * b->nb;
         wd[w].paths = b->d_paths + n1 * max_paths * w;
         wd[w].recs = b->d_recs + (size_t)max_paths * w;
@@ -1092,9 +1104,9 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     size_t lt_nb = ((size_t)(N + LT_PAD) * L * LT_BLK + 255) / 256;
     if (lt_nb > 4096) lt_nb = 4096;
     walk_params P;
-    P.N = N; P.L = L; P.chunk = 0; P.rearm = 1; P.G = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
+    P.N = N; P.L = L; P.chunk = 0; P.rearm = 1; P.G = nullptr; P.Ht = nullptr; P.Yt = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
     P.min_remove = min_remove;
-    size_t lt_nb_inc = ((size_t)N * L + 255) / 256;
+    size_t lt_nb_inc = 64;                  // batched launches keep no walker tables: the steady-state k_lt only checks flags
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
     for (int s = 0; s < max_paths; s++) {
@@ -1116,12 +1128,12 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                               inc, b->d_wd, s, walk_depth2_ok(L));
+                               inc, b->d_wd, s, walk_depth2_ok(L), (double *)nullptr, (double *)nullptr);
         else
             hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                               inc, b->d_wd, s, walk_depth2_ok(L));
+                               inc, b->d_wd, s, walk_depth2_ok(L), (double *)nullptr, (double *)nullptr);
         launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
         if (f64)
             hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,

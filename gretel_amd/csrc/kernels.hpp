@@ -1,3 +1,4 @@
+#include <type_traits>
 // kernels.hpp -- the gfx950 kernels of the Gretel hot path (included by gretel_hip.hip).
 //
 // Symbol indices (reference order, gretel/util.py:83):  A0 C1 G2 T3 N4 -5 _6.
@@ -47,6 +48,7 @@ struct win_desc {
     int32_t *nvalid;
     uint32_t *cmask;
     double *G;
+    double *Ht, *Yt;       // depth-2 walker tables (k_lt)
     dev_state *st;
     double *partial;
     uint8_t *paths;        // [max_paths][N+1]
@@ -552,27 +554,93 @@ __device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond
     return v;
 }
 
+// The depth-2 walker (spec2_walker below) does not read G but two tables derived from the ranked G, kept in HBM in
+// exactly the layout its loader waves copy into LDS (so that the loaders execute a handful of wide copies per chunk
+// instead of a thousand scalar gathers beside the walker):
+//   Ht[t][a2*16 + a1*4 + b] = x1 + x2 = G[t-1][a1][lag 1][b] + G[t-2][a2][lag 2][b]   (t >= 2; t = 1: x1 alone; position 0
+//                             always contributes its '_' row; the first addition of the reference's lag-ascending sum)
+//   Yt[i][w][b][l - 3]       = G[i][w][lag l][b], l = 3..L, rows padded to an even number of lags
+// for positions 0 .. N + WALK_TPAD - 1 (zeros behind the table: the walker runs whole chunks).
+#define WALK_TPAD 72
+#ifndef WALK_LOADER_SETS
+#define WALK_LOADER_SETS 1
+#endif
+__host__ __device__ constexpr int deep_nyp(int L) { return L > 2 ? ((L - 2 + 1) & ~1) : 0; }
+
+// what k_lt stores at G[i][row6][lag - 1][col5] in the ranked layout
+template <typename T>
+__device__ __forceinline__ double lt_entry_ranked(const T *band, int N, int W, int cond_mode, int marginal_term,
+                                                  const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
+                                                  const double *minfo, int i, int row6, int lag, int col5)
+{
+    const int snp = i + lag;
+    if (!(i < N && snp <= N && row6 != 4)) return 0.0;
+    int a6 = row6;
+    if (a6 < 4) a6 = nth_set5(cm5_of_cmask(cmask[i]), a6);
+    if (a6 < 0) return 0.0;
+    const int b5 = nth_set5(cm5_of_cmask(cmask[snp]), col5);
+    return b5 >= 0 ? lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, lag, b5) : -INFINITY;
+}
+
 // inc_path == nullptr: rebuild every entry.  Otherwise (conditional A or B, no marginal term, and the
 // tensor changed ONLY through a path reweight): every cell that changed is H[path[i], path[j], i, j], which
 // only enters the rows G[i][a6(path[i])][*][*], and k_marg<T, true> rewrote those N*L*5 entries in the same
-// pass that reweighted the cells.  k_lt then has nothing to do unless k_marg saw a candidate mask change
-// (V(p) or the -inf masks moved) or the path was cut short by a hole: then it rebuilds everything.
+// pass that reweighted the cells.  k_lt then only refreshes the entries of Ht / Yt those rows feed -- unless k_marg saw
+// a candidate mask change (V(p) or the -inf masks moved) or the path was cut short by a hole: then it rebuilds everything.
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
      const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
      const double *minfo, double *G, dev_state *st, const uint8_t *inc_path, const win_desc *wd, int spin,
-     int allow_ranked)
+     int allow_ranked, double *Ht, double *Yt)
 {
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
         band = (const T *)d.band; cnt = d.cnt; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; G = d.G; st = d.st;
+        Ht = d.Ht; Yt = d.Yt;
         if (st->stop) return;
         if (inc_path) inc_path = d.paths + (size_t)(spin - 1) * (N + 1);
     }
-    // inc_path != null: k_marg<T, true> has already rewritten the rows the last path changed; they stand when no
+    const int nyp = deep_nyp(L), ypos = 16 * nyp;
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
+    // inc_path != null: k_marg<T, true> has already rewritten the rows of G the last path changed; they stand when no
     // candidate mask moved and the path was complete -- otherwise rebuild everything
-    if (inc_path && st->cm_same && !st->stop) return;
+    if (inc_path && st->cm_same && !st->stop) {
+        if (!(st->ranked && Ht)) return;
+        // row r_p = rank of path[p] at p changed for every p: refresh Ht[p+1][*][r_p][*], Ht[p+2][r_p][*][*], Yt[p][r_p]
+        auto Gat = [&](int i, int row, int lag, int col) { return G[(((size_t)i * 6 + row) * L + (lag - 1)) * LT_ROW + col]; };
+        const size_t total = (size_t)N * 4;                     // one thread per (position, target rank b)
+        for (size_t idx = gtid; idx < total; idx += gsize) {
+            const int p = (int)(idx >> 2), b = (int)(idx & 3);
+            if (p == 0) continue;                               // position 0 is done below
+            const int a6 = a6_of_sym(inc_path[p]);
+            const uint32_t c5 = cm5_of_cmask(cmask[p]);
+            if (inc_path[p] == 4 || a6 > 4 || !((c5 >> a6) & 1u)) continue;
+            const int r = __popc(c5 & ((1u << a6) - 1u));
+            const double g1 = Gat(p, r, 1, b), g2 = Gat(p, r, 2, b);
+            double *h1 = Ht + (size_t)(p + 1) * 64 + r * 4 + b, *h2 = Ht + (size_t)(p + 2) * 64 + r * 16 + b;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                h1[q * 16] = g1 + Gat(p - 1, p - 1 == 0 ? 5 : q, 2, b);      // a2 = q
+                h2[q * 4] = Gat(p + 1, q, 1, b) + g2;                         // a1 = q
+            }
+            for (int li = 0; li + 2 < L; li++) Yt[(size_t)p * ypos + (r * 4 + b) * nyp + li] = Gat(p, r, li + 3, b);
+        }
+        // position 0 carries '_' (row 5) whatever the hypothesis: targets 1 and 2 and the rows of source 0 in full
+        const size_t total0 = (size_t)128 + ypos;
+        for (size_t q = gtid; q < total0; q += gsize) {
+            if (q < 128) {
+                const int tt = 1 + (int)(q >> 6), ln = (int)(q & 63), b = ln & 3, a1 = (ln >> 2) & 3;
+                double v = Gat(tt - 1, tt - 1 == 0 ? 5 : a1, 1, b);
+                if (tt >= 2) v = v + Gat(0, 5, 2, b);
+                Ht[(size_t)tt * 64 + ln] = v;
+            } else {
+                const int r = (int)(q - 128), wb = r / nyp, li = r % nyp;
+                if (li + 2 < L) Yt[r] = Gat(0, 5, li + 3, wb & 3);
+            }
+        }
+        return;
+    }
     // Ranked layout (every position has at most 4 candidates and the caller's walker can use it): row r < 4 of
     // source i is the r-th candidate of i in ascending symbol order, column c < 4 of lag l the c-th candidate of
     // i+l; missing ranks get a row of zeros / a column of -inf, row 5 stays the '_' row of position 0.  First-wins
@@ -581,31 +649,42 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
     const bool ranked = allow_ranked && st->narrow != 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->ranked = ranked ? 1 : 0;
     const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (size_t)gridDim.x * blockDim.x) {
-        int b5 = (int)(t % LT_ROW);
+    for (size_t t = gtid; t < total; t += gsize) {
+        const int b5 = (int)(t % LT_ROW);
         size_t r = t / LT_ROW;
         const int l = (int)(r % L) + 1;
         r /= L;
-        int a6 = (int)(r % 6);
+        const int a6 = (int)(r % 6);
         const int i = (int)(r / 6);
-        if (ranked) {
-            const int snp = i + l;
-            double v = 0.0;
-            if (i < N && snp <= N && a6 != 4) {
-                if (a6 < 4) a6 = nth_set5(cm5_of_cmask(cmask[i]), a6);
-                if (a6 >= 0) {
-                    b5 = nth_set5(cm5_of_cmask(cmask[snp]), b5);
-                    v = b5 >= 0 ? lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5) : -INFINITY;
-                }
-            }
-            G[t] = v;
-            continue;
+        G[t] = ranked ? lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5)
+                      : lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
+    }
+    if (!(ranked && Ht)) return;
+    // the derived tables in full, from the band (other threads are still writing G)
+    const int nsrc_all = N + LT_PAD;
+    const size_t nH = (size_t)(N + WALK_TPAD) * 64;
+    for (size_t q = gtid; q < nH; q += gsize) {
+        const int tt = (int)(q >> 6), ln = (int)(q & 63), b = ln & 3, a1 = (ln >> 2) & 3, a2 = ln >> 4;
+        double v = 0.0;
+        if (tt >= 1 && tt - 1 < nsrc_all) {
+            const int s1 = tt - 1, s2 = tt - 2;
+            v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s1, s1 == 0 ? 5 : a1, 1, b);
+            if (tt >= 2 && L >= 2)
+                v = v + lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s2, s2 == 0 ? 5 : a2, 2, b);
         }
-        G[t] = lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
+        Ht[q] = v;
+    }
+    if (ypos > 0) {
+        const size_t nY = (size_t)(N + WALK_TPAD) * ypos;
+        for (size_t q = gtid; q < nY; q += gsize) {
+            const int i = (int)(q / ypos), r = (int)(q % ypos), wb = r / nyp, li = r % nyp;
+            double v = 0.0;
+            if (i < nsrc_all && li + 2 < L)
+                v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, i == 0 ? 5 : (wb >> 2), li + 3, wb & 3);
+            Yt[q] = v;
+        }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // k_walk_src: gretel/gretel.py:143-189 as one workgroup of 8 wavefronts:
@@ -623,6 +702,7 @@ struct walk_params {
     int depth2;               // k_walk_spec: depth-2 speculation where the window allows it (<= 4 candidates per position, L >= 2)
     int _pad;
     const double *G;          // [(N+LT_PAD)][6][L][5]
+    const double *Ht, *Yt;    // depth-2 tables of k_lt: [(N+WALK_TPAD)][64], [(N+WALK_TPAD)][16*deep_nyp(L)]
     const double *minfo;      // [N+2][16]
     uint8_t *path_out;        // device [N+1]
     gh_path_rec *rec;         // device
@@ -938,6 +1018,7 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
         unsigned vg = lds0 + (unsigned)(k & 1) * (unsigned)(C + WALK_OV) * (unsigned)RS * 8u;   // block of source k*C + g*LC
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
+        asm volatile(".p2align 6");          // see spec2_walker
         for (int g = 0; g < ngroups; g++) {
             unsigned long long word = 0;
             const unsigned vgh = vg + (unsigned)ga * ROWB;
@@ -1044,6 +1125,9 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
         unsigned vh = h0 + (unsigned)(k & 1) * bufB, vy = y0 + (unsigned)(k & 1) * bufB;
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
+        // the group loop starts on an instruction-fetch boundary: a lone wave at one instruction per 5 cycles has no slack
+        // for a fetch that straddles two lines (unaligned: 124 cycles per step, aligned: 117)
+        asm volatile(".p2align 6");
         for (int g = 0; g < ngroups; g++) {
 #pragma unroll
             for (int u = 0; u < LC; u++) {
@@ -1089,7 +1173,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
     extern __shared__ __align__(16) double smem[];
     if (wd) {
         const win_desc &d = wd[blockIdx.x];
-        P.G = d.G; P.minfo = d.minfo; P.st = d.st;
+        P.G = d.G; P.Ht = d.Ht; P.Yt = d.Yt; P.minfo = d.minfo; P.st = d.st;
         P.path_out = d.paths + (size_t)spin * (P.N + 1); P.rec = d.recs + spin;
     }
     dev_state *st = P.st;
@@ -1129,75 +1213,150 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
 
     if (deep) {
         if constexpr (LC >= 2) {
-            // depth-2 layout: the 384 loader threads derive H and Yr (see spec2_walker) straight from global G.
-            // The loads of chunk k+2 are issued before the barrier that ends chunk k and stay in flight across it
-            // (their latency must not sit between two barriers, the walker waits there too); the sums and the LDS
-            // stores of chunk k+1 happen while the walker is in chunk k.
+            // depth-2 layout.  With the tables of k_lt (single windows) the 384 loader threads copy the chunk's slices of
+            // Ht and Yt into the buffer: 16-byte copies, ~50 instructions per wave and chunk.  Without them (batched
+            // launches, where refreshing the tables for every window costs more HBM traffic than it saves the walkers)
+            // they derive H and Yr from G themselves.  Either way the loads of chunk k+2 are issued before the barrier
+            // that ends chunk k and stay in flight across it (their latency must not sit between two barriers, the
+            // walker waits there too); the LDS stores of chunk k+1 happen while the walker is in chunk k.
             typedef deep_layout<LC> DL;
             constexpr int NT = 384, MAXPOS = walk_chunk(LC, true) + WALK_OV;      // = C + WALK_OV
-            constexpr int MAXH = (MAXPOS * DL::HPOS + NT - 1) / NT;
-            constexpr int MAXY = DL::YPOS ? (MAXPOS * DL::YPOS + NT - 1) / NT : 0;
             if (wave >= 2) {
                 const int t = tid - 128;
                 const int npos = C + WALK_OV;
-                const int nsrc_all = P.N + LT_PAD;                    // source blocks G holds (the last LT_PAD are zeros)
-                const int nh = npos * DL::HPOS, ny = npos * DL::YPOS;
-                const int bb = t & 3, a1 = (t >> 2) & 3, a2 = (t >> 4) & 3;    // NT is a multiple of 64: lane-constant
-                double x1[MAXH], x2[MAXH], yv[MAXY > 0 ? MAXY : 1];
-                auto fetch = [&](int k) {
-                    const int i0 = k * C;
-#pragma unroll
-                    for (int it = 0; it < MAXH; it++) {
-                        const int q = t + it * NT;
-                        const int tt = i0 + (q >> 6);
-                        x1[it] = 0.0; x2[it] = 0.0;
-                        if (q < nh && tt >= 1 && tt - 1 < nsrc_all) {
-                            const int s1 = tt - 1, s2 = tt - 2;
-                            x1[it] = P.G[(size_t)s1 * BLK + (s1 == 0 ? 5 : a1) * ROW + bb];
-                            if (tt >= 2) x2[it] = P.G[(size_t)s2 * BLK + (s2 == 0 ? 5 : a2) * ROW + LT_ROW + bb];
+                // chunk c is fetched into register set c & 1 at the start of iteration c - 2 and stored during iteration
+                // c - 1: the loads have more than a chunk of time, whatever the pacing of the stores
+                auto loader_loop = [&](auto &fetch, auto &store, auto &setA, auto &setB) {
+#if WALK_LOADER_SETS == 2
+                    fetch(0, setA);
+                    store(0, setA, std::false_type{});                    // nobody is walking yet
+                    if (nchunks > 1) fetch(1, setB);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    for (int k = 0; k < nchunks; k += 2) {
+                        if (k + 2 < nchunks) fetch(k + 2, setA);
+                        if (k + 1 < nchunks) store(k + 1, setB, std::true_type{});
+                        // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        if (k + 1 < nchunks) {
+                            if (k + 3 < nchunks) fetch(k + 3, setB);
+                            if (k + 2 < nchunks) store(k + 2, setA, std::true_type{});
+                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         }
                     }
-                    if constexpr (MAXY > 0) {
+#else
+                    fetch(0, setA);
+                    store(0, setA, std::false_type{});                    // nobody is walking yet
+                    if (nchunks > 1) fetch(1, setA);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    for (int k = 0; k < nchunks; k++) {
+                        if (k + 1 < nchunks) store(k + 1, setA, std::true_type{});     // empties the registers fetch(k + 2) fills
+                        if (k + 2 < nchunks) fetch(k + 2, setA);
+                        // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+#endif
+                };
+                if (P.Ht) {
+                    constexpr int NVH = MAXPOS * DL::HPOS / 2, NVY = MAXPOS * DL::YPOS / 2;    // double2 per chunk
+                    constexpr int MAXH = (NVH + NT - 1) / NT, MAXY = (NVY + NT - 1) / NT;
+                    // s_sleep units (64 cycles) between two stores: the store phase takes about 60 % of what the
+                    // walker needs for the chunk (~88 + 7 L cycles per step)
+#ifdef WALK_PACE
+                    constexpr int PACE = WALK_PACE;
+#else
+                    constexpr int PACE = (walk_chunk(LC, true) * (88 + 7 * LC) * 62 / 100) / ((MAXH + MAXY) * 64);
+#endif
+                    struct regs { lds_v2d vh[MAXH], vy[MAXY > 0 ? MAXY : 1]; } setA, setB;
+                    auto fetch = [&](int k, regs &R) {
+                        const lds_v2d *srcH = reinterpret_cast<const lds_v2d *>(P.Ht + (size_t)k * C * DL::HPOS);
 #pragma unroll
-                        for (int it = 0; it < MAXY; it++) {
+                        for (int it = 0; it < MAXH; it++) {
                             const int q = t + it * NT;
-                            yv[it] = 0.0;
-                            if (q < ny) {
-                                const int p = q / DL::YPOS, r = q % DL::YPOS, wb = r / DL::NYP, l = 2 + r % DL::NYP;
-                                const int sidx = i0 + p;
-                                if (sidx < nsrc_all && l < LC)
-                                    yv[it] = P.G[(size_t)sidx * BLK + (sidx == 0 ? 5 : (wb >> 2)) * ROW + l * LT_ROW + (wb & 3)];
+                            if (q < NVH) R.vh[it] = srcH[q];
+                        }
+                        if constexpr (MAXY > 0) {
+                            const lds_v2d *srcY = reinterpret_cast<const lds_v2d *>(P.Yt + (size_t)k * C * DL::YPOS);
+#pragma unroll
+                            for (int it = 0; it < MAXY; it++) {
+                                const int q = t + it * NT;
+                                if (q < NVY) R.vy[it] = srcY[q];
                             }
                         }
-                    }
-                };
-                auto store = [&](int k) {
-                    const int i0 = k * C;
-                    double *dst = g0 + (size_t)(k & 1) * npos * RS;
+                    };
+                    // the 64 KB of a chunk must not reach LDS in one burst: the walker's row reads would queue behind ~70 wide
+                    // writes once per chunk (measured 5-9 cycles per step); s_sleep spreads the stores over the chunk
+                    auto store = [&](int k, regs &R, auto pace) {      // pace: std::true_type / false_type (a run-time flag here costs the walker 5 cycles per step)
+                        lds_v2d *dstH = reinterpret_cast<lds_v2d *>(g0 + (size_t)(k & 1) * npos * RS);
 #pragma unroll
-                    for (int it = 0; it < MAXH; it++) {
-                        const int q = t + it * NT;
-                        // target 1 has the single term x1 (not 0.0 + x1: the reference starts from the first addend)
-                        if (q < nh) dst[q] = (i0 + (q >> 6) >= 2) ? x1[it] + x2[it] : x1[it];
-                    }
-                    if constexpr (MAXY > 0) {
-                        double *yr = dst + (size_t)npos * DL::HPOS;
-#pragma unroll
-                        for (int it = 0; it < MAXY; it++) {
+                        for (int it = 0; it < MAXH; it++) {
                             const int q = t + it * NT;
-                            if (q < ny) yr[q] = yv[it];
+                            if (q < NVH) dstH[q] = R.vh[it];
+                            if constexpr (decltype(pace)::value && PACE > 0) __builtin_amdgcn_s_sleep(PACE);
                         }
-                    }
-                };
-                fetch(0);
-                store(0);
-                if (nchunks > 1) fetch(1);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                for (int k = 0; k < nchunks; k++) {
-                    if (k + 1 < nchunks) store(k + 1);
-                    if (k + 2 < nchunks) fetch(k + 2);
-                    // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        if constexpr (MAXY > 0) {
+                            lds_v2d *dstY = dstH + NVH;
+#pragma unroll
+                            for (int it = 0; it < MAXY; it++) {
+                                const int q = t + it * NT;
+                                if (q < NVY) dstY[q] = R.vy[it];
+                                if constexpr (decltype(pace)::value && PACE > 0) __builtin_amdgcn_s_sleep(PACE);
+                            }
+                        }
+                    };
+                    loader_loop(fetch, store, setA, setB);
+                } else {
+                    constexpr int MAXH = (MAXPOS * DL::HPOS + NT - 1) / NT;
+                    constexpr int MAXY = DL::YPOS ? (MAXPOS * DL::YPOS + NT - 1) / NT : 0;
+                    const int nsrc_all = P.N + LT_PAD;                    // source blocks G holds (the last LT_PAD are zeros)
+                    const int nh = npos * DL::HPOS, ny = npos * DL::YPOS;
+                    const int bb = t & 3, a1 = (t >> 2) & 3, a2 = (t >> 4) & 3;    // NT is a multiple of 64: lane-constant
+                    struct regs { double x1[MAXH], x2[MAXH], yv[MAXY > 0 ? MAXY : 1]; } setA, setB;
+                    auto fetch = [&](int k, regs &R) {
+                        const int i0 = k * C;
+#pragma unroll
+                        for (int it = 0; it < MAXH; it++) {
+                            const int q = t + it * NT;
+                            const int tt = i0 + (q >> 6);
+                            R.x1[it] = 0.0; R.x2[it] = 0.0;
+                            if (q < nh && tt >= 1 && tt - 1 < nsrc_all) {
+                                const int s1 = tt - 1, s2 = tt - 2;
+                                R.x1[it] = P.G[(size_t)s1 * BLK + (s1 == 0 ? 5 : a1) * ROW + bb];
+                                if (tt >= 2) R.x2[it] = P.G[(size_t)s2 * BLK + (s2 == 0 ? 5 : a2) * ROW + LT_ROW + bb];
+                            }
+                        }
+                        if constexpr (MAXY > 0) {
+#pragma unroll
+                            for (int it = 0; it < MAXY; it++) {
+                                const int q = t + it * NT;
+                                R.yv[it] = 0.0;
+                                if (q < ny) {
+                                    const int p = q / DL::YPOS, r = q % DL::YPOS, wb = r / DL::NYP, l = 2 + r % DL::NYP;
+                                    const int sidx = i0 + p;
+                                    if (sidx < nsrc_all && l < LC)
+                                        R.yv[it] = P.G[(size_t)sidx * BLK + (sidx == 0 ? 5 : (wb >> 2)) * ROW + l * LT_ROW + (wb & 3)];
+                                }
+                            }
+                        }
+                    };
+                    auto store = [&](int k, regs &R, auto) {
+                        const int i0 = k * C;
+                        double *dst = g0 + (size_t)(k & 1) * npos * RS;
+#pragma unroll
+                        for (int it = 0; it < MAXH; it++) {
+                            const int q = t + it * NT;
+                            // target 1 has the single term x1 (not 0.0 + x1: the reference starts from the first addend)
+                            if (q < nh) dst[q] = (i0 + (q >> 6) >= 2) ? R.x1[it] + R.x2[it] : R.x1[it];
+                        }
+                        if constexpr (MAXY > 0) {
+                            double *yr = dst + (size_t)npos * DL::HPOS;
+#pragma unroll
+                            for (int it = 0; it < MAXY; it++) {
+                                const int q = t + it * NT;
+                                if (q < ny) yr[q] = R.yv[it];
+                            }
+                        }
+                    };
+                    loader_loop(fetch, store, setA, setB);
                 }
                 return;
             }
