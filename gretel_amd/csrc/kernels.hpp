@@ -950,9 +950,17 @@ __device__ __forceinline__ void book_gather(const walk_params &P, const unsigned
 __device__ __forceinline__ void book_fold(const book_regs &R, int ns, walk_totals &T, double &lane_min)
 {
     if (R.mg < lane_min) lane_min = R.mg;               // gretel.py:182, per lane; reduced over lanes at the end (min is exact)
-    for (int s = 0; s < ns; s++) {
-        T.hp_cur += readlane_f64(R.lm, s);              // gretel.py:185 (+0.0 for unused lanes)
-        T.hp_orig += readlane_f64(R.lm0, s);            // gretel.py:186
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {                       // four positions per trip: less loop overhead beside the walker
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            T.hp_cur += readlane_f64(R.lm, s + q);      // gretel.py:185 (+0.0 for unused lanes)
+            T.hp_orig += readlane_f64(R.lm0, s + q);    // gretel.py:186
+        }
+    }
+    for (; s < ns; s++) {
+        T.hp_cur += readlane_f64(R.lm, s);
+        T.hp_orig += readlane_f64(R.lm0, s);
     }
 }
 
