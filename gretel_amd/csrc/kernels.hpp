@@ -1135,8 +1135,9 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
         const int ngroups = C / LC;
         // the group loop starts on an instruction-fetch boundary: a lone wave at one instruction per 5 cycles has no slack
         // for a fetch that straddles two lines (unaligned: 124 cycles per step, aligned: 117)
-        asm volatile(".p2align 6");
-        for (int g = 0; g < ngroups; g++) {
+        constexpr int UG = LC <= 8 ? 2 : 1;    // groups (of LC bodies, the register rotation period) per loop trip
+        auto group = [&](int g, auto gg_) {
+            constexpr int gg = decltype(gg_)::value;
 #pragma unroll
             for (int u = 0; u < LC; u++) {
                 // A: resolve w_{j+1}   (body j = k*C + g*LC + u); hist keeps 2 bits per symbol, newest lowest
@@ -1156,7 +1157,7 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
                     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(vrow) : "s"(w), "v"(yw_v), "v"(vy));
                     // 16-byte reads (their offset field is 16 bits wide; ds_read2_b64 would need an address add per read
                     // once (u + 1) * YB passes 2040 bytes)
-                    const unsigned rb = vrow + (unsigned)(u + 1) * YB;
+                    const unsigned rb = vrow + (unsigned)(gg * LC + u + 1) * YB;
 #pragma unroll
                     for (int l = 2; l + 1 < LC; l += 2) {
                         const lds_v2d pr = *(const __attribute__((address_space(3))) lds_v2d *)(rb + (unsigned)(l - 2) * 8u);
@@ -1165,9 +1166,20 @@ __device__ __forceinline__ void spec2_walker(const walk_params &P, double *g0, u
                     }
                     if constexpr (NY & 1) Y[(u + 1) % LC][LC - 1] = *(lds_cdouble *)(rb + (unsigned)(NY - 1) * 8u);
                 }
-                H12 = *(lds_cdouble *)(vh + (unsigned)(u + 4) * HB);
-            }
+                H12 = *(lds_cdouble *)(vh + (unsigned)(gg * LC + u + 4) * HB);
+                        }
             wk[g] = (unsigned long long)hist;
+        };
+        int g = 0;
+        asm volatile(".p2align 6");
+        for (; g + UG <= ngroups; g += UG) {
+            group(g, std::integral_constant<int, 0>{});
+            if constexpr (UG > 1) group(g + 1, std::integral_constant<int, 1>{});
+            vh += (unsigned)(UG * LC) * HB;
+            vy += (unsigned)(UG * LC) * YB;
+        }
+        for (; g < ngroups; g++) {
+            group(g, std::integral_constant<int, 0>{});
             vh += (unsigned)LC * HB;
             vy += (unsigned)LC * YB;
         }
