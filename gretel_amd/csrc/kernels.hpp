@@ -1077,7 +1077,8 @@ __device__ __forceinline__ void spec_walker(const walk_params &P, double *g0, un
 // so a body costs 5 cycles x its instruction count once the dependency chain is long enough not to bind:
 // this variant is about having few instructions per step.
 // Lane = (a2 = lane>>4, a1 = (lane>>2)&3, b = lane&3): group (a2,a1) evaluates target t under the
-// hypothesis w_{t-2} == a2, w_{t-1} == a1.  The loader waves do not copy G, they derive two tables:
+// hypothesis w_{t-2} == a2, w_{t-1} == a1.  The loader waves do not stage G in LDS but two tables derived from it
+// (copied from the Ht / Yt that k_lt maintains, or derived on the fly in batched launches):
 //   H[t][lane]       = x1 + x2 = G[t-1][a1][lag 1][b] + G[t-2][a2][lag 2][b]   (path-independent; the first
 //                      addition of the reference's lag-ascending sum; position 0 always contributes its '_' row)
 //   Yr[i][w][b][l-3] = G[i][w][lag l][b], l = 3..L                              (read once w_i is resolved)
