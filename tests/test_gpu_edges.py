@@ -31,7 +31,7 @@ def _check(t, paths=6, L=None, want_variant=None, **kw):
         o.L = L
     assert h.gap_check() == o.gap_check()
     res, ref = h.spin(paths), o.spin(paths)
-    if want_variant is not None and not os.environ.get("GH_WALK"):      # GH_WALK pins a variant for A/B measurements
+    if want_variant is not None and not (os.environ.get("GH_WALK") or os.environ.get("GH_WALK_THREADS")):   # A/B knobs pin a variant
         assert h.walk_clock()[3] == want_variant          # which path-extension variant the last launch took
     assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"]
     assert np.array_equal(res["paths"], ref["paths"])
