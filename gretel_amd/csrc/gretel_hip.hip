@@ -82,6 +82,9 @@ struct gh_handle {
     uint32_t *cmask;
     double *lt;
     double *ht, *yt;              // depth-2 walker tables derived from lt (k_lt), when walk_depth2_ok(L)
+    uint8_t *spin_paths;          // gh_spin's device results, kept between calls: [spin_cap][N+1]
+    gh_path_rec *spin_recs;       // [spin_cap]
+    int spin_cap;
     int lt_L;
     bool dirty_marg, dirty_lt, have_orig;
     const uint8_t *lt_inc_path;   // non-null: the ONLY mutation since G was last built is a path reweight whose fused
@@ -197,6 +200,7 @@ static void free_handle(gh_handle *h)
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
+    hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
@@ -232,6 +236,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->L = 1;
     h->n_cells = (size_t)(h->N + 2) * h->W;
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
+    h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
@@ -964,11 +969,21 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     int rc;
     if (!h->have_orig && (rc = gh_snapshot_original(h))) return rc;
     const size_t n1 = (size_t)h->N + 1;
-    uint8_t *d_paths = nullptr;
-    gh_path_rec *d_recs = nullptr;
-    HIPCHK(hipMalloc((void **)&d_paths, n1 * max_paths));
-    hipError_t e = hipMalloc((void **)&d_recs, sizeof(gh_path_rec) * max_paths);
-    if (e != hipSuccess) { hipFree(d_paths); return fail(GH_ERR_NOMEM, "hipMalloc failed"); }
+    if (max_paths > h->spin_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(h->spin_paths); hipFree(h->spin_recs);
+        h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
+        hipError_t ea = hipMalloc((void **)&h->spin_paths, n1 * max_paths);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_recs, sizeof(gh_path_rec) * max_paths);
+        if (ea != hipSuccess) {
+            hipFree(h->spin_paths); h->spin_paths = nullptr;
+            return fail(GH_ERR_NOMEM, "hipMalloc failed");
+        }
+        h->spin_cap = max_paths;
+    }
+    uint8_t *d_paths = h->spin_paths;
+    gh_path_rec *d_recs = h->spin_recs;
+    hipError_t e = hipSuccess;
     rc = reset_spin_state(h);
     const int nb = ((h->N + 1) * 8 + 255) / 256;
     if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);
@@ -998,7 +1013,6 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         }
         if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
     }
-    hipFree(d_paths); hipFree(d_recs);
     if (rc) return rc;
     *n_out = hs.n_done;
     *hole_at = hs.stop ? hs.hole_at : 0;
