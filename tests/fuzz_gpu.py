@@ -1,5 +1,6 @@
 """Randomised parity fuzz: HIP path vs the C oracle on random windows, switches and lag counts (not part of the
-default suite; run on the GPU box: python scratch/fuzz_gpu.py [seconds] [seed])."""
+default suite; run on the GPU box from the repo root: python tests/fuzz_gpu.py [seconds] [seed]).  Test infrastructure:
+it is the only place outside tests/test_*.py, smoke() and bench.py's cpu_baseline that calls the oracle."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
