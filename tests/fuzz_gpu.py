@@ -10,17 +10,18 @@ from oracle.c_oracle import COracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"      # long windows (many LDS chunks) instead of many small ones
 rng = np.random.default_rng(seed0)
 t_end = time.time() + budget
 n_cases = 0
 n_batch = 0
 variants = {}
 while time.time() < t_end:
-    n = int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
+    n = int(rng.choice([4000, 7777, 12000, 20011])) if big else int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
     k = int(rng.integers(2, min(n, 12) + 1)) if rng.random() < 0.7 else None
     n_haps = int(rng.integers(1, 9))
     err = float(rng.choice([0.0, 0.0, 0.01, 0.05]))
-    reads = int(max(20, n * rng.integers(4, 40)))
+    reads = int(max(20, n * rng.integers(4, 12 if big else 40)))
     t = make_support_table(n, reads, k=k, n_haps=n_haps, err=err, seed=int(rng.integers(0, 1 << 30)), k_max=min(21, n))
     if rng.random() < 0.4:
         bases = t.bases.copy()
