@@ -915,52 +915,63 @@ __device__ __forceinline__ unsigned long long group_argmax(double acc)
 // (wbits bits each, the oldest highest).  Two steps per chunk, run one loop iteration apart so that the latency of
 // the gather never sits between two barriers: book_gather issues the loads of the selected symbols' marginals
 // (lane = chunk-local position), book_fold adds them up strictly in position order one iteration later.
-struct book_regs {
-    double lm, lm0, mg;
-    double cm;              // ranked tables: the candidate bits of the position (minfo[10]), loaded one iteration ahead
+typedef double lds_v2d __attribute__((ext_vector_type(2), aligned(16)));     // 16-byte loads / stores
+
+// One chunk of bookkeeping, lane = chunk-local position.  book_prefetch loads the position's whole minfo row (128 bytes:
+// it does not depend on the path) while the walker is still in that chunk; book_consume, one iteration later, picks the
+// selected symbol's entries out of the registers and folds them strictly in position order.  No memory latency sits
+// between the walker's last step and the end of the kernel.
+struct book_row {
+    lds_v2d v[8];           // minfo[j][0..15]
 };
 
-__device__ __forceinline__ void book_pregather(const walk_params &P, int j0, int ns, int Nw, int lane, book_regs &R)
+__device__ __forceinline__ void book_prefetch(const walk_params &P, int j0, int ns, int Nw, int lane, book_row &R)
 {
     const int j = j0 + lane + 1;
-    R.cm = 0.0;
-    if (lane < ns && j <= Nw) R.cm = P.minfo[(size_t)j * MINFO + 10];
+    if (lane < ns && j <= Nw) {
+        const lds_v2d *src = reinterpret_cast<const lds_v2d *>(P.minfo + (size_t)j * MINFO);
+#pragma unroll
+        for (int q = 0; q < 8; q++) R.v[q] = src[q];
+    }
 }
 
-__device__ __forceinline__ void book_gather(const walk_params &P, const unsigned long long *words, int LC, int wbits,
-                                            bool ranked, int j0, int ns, int Nw, int lane, book_regs &R)
+__device__ __forceinline__ void book_consume(const walk_params &P, const unsigned long long *words, int LC, int wbits,
+                                             bool ranked, int j0, int ns, int Nw, int lane, const book_row &R,
+                                             walk_totals &T, double &lane_min)
 {
-    R.lm = 0.0; R.lm0 = 0.0; R.mg = INFINITY;
+    double lm = 0.0, lm0 = 0.0, mg = INFINITY;
     const int j = j0 + lane + 1;
     if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
         int w = (int)((word >> (wbits * (LC - 1 - lane % LC))) & ((1ull << wbits) - 1ull));
         if (ranked) {
-            w = nth_set5((uint32_t)__double_as_longlong(R.cm), w);
+            w = nth_set5((uint32_t)__double_as_longlong(R.v[5].x), w);      // minfo[10]: candidate bits; rank -> symbol
             if (w < 0) w = 0;           // cannot happen for a resolved position (it has a candidate of that rank)
         }
-        const double *inf = P.minfo + (size_t)j * MINFO;
-        R.lm = inf[w];
-        R.mg = inf[5 + w];
-        R.lm0 = inf[11 + w];
+        // minfo[w], minfo[5 + w], minfo[11 + w] out of the registers (w < 5)
+        const double row[16] = {R.v[0].x, R.v[0].y, R.v[1].x, R.v[1].y, R.v[2].x, R.v[2].y, R.v[3].x, R.v[3].y,
+                                R.v[4].x, R.v[4].y, R.v[5].x, R.v[5].y, R.v[6].x, R.v[6].y, R.v[7].x, R.v[7].y};
+        lm = row[0]; mg = row[5]; lm0 = row[11];
+#pragma unroll
+        for (int q = 1; q < 5; q++) {
+            lm = (w == q) ? row[q] : lm;
+            mg = (w == q) ? row[5 + q] : mg;
+            lm0 = (w == q) ? row[11 + q] : lm0;
+        }
         P.path_out[j] = (uint8_t)vsym(w);
     }
-}
-
-__device__ __forceinline__ void book_fold(const book_regs &R, int ns, walk_totals &T, double &lane_min)
-{
-    if (R.mg < lane_min) lane_min = R.mg;               // gretel.py:182, per lane; reduced over lanes at the end (min is exact)
+    if (mg < lane_min) lane_min = mg;                   // gretel.py:182, per lane; reduced over lanes at the end (min is exact)
     int s = 0;
     for (; s + 4 <= ns; s += 4) {                       // four positions per trip: less loop overhead beside the walker
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            T.hp_cur += readlane_f64(R.lm, s + q);      // gretel.py:185 (+0.0 for unused lanes)
-            T.hp_orig += readlane_f64(R.lm0, s + q);    // gretel.py:186
+            T.hp_cur += readlane_f64(lm, s + q);        // gretel.py:185 (+0.0 for unused lanes)
+            T.hp_orig += readlane_f64(lm0, s + q);      // gretel.py:186
         }
     }
     for (; s < ns; s++) {
-        T.hp_cur += readlane_f64(R.lm, s);
-        T.hp_orig += readlane_f64(R.lm0, s);
+        T.hp_cur += readlane_f64(lm, s);
+        T.hp_orig += readlane_f64(lm0, s);
     }
 }
 
@@ -972,7 +983,6 @@ __device__ __forceinline__ void book_fold(const book_regs &R, int ns, walk_total
 //   M  B = group-wise arg-max of acc_{j+2}                               independent of R
 // so the LDS latency of R is covered by M and by the next body's A and S.
 typedef __attribute__((address_space(3))) const double lds_cdouble;
-typedef double lds_v2d __attribute__((ext_vector_type(2), aligned(16)));
 
 // diagnostic builds only (-DGH_STAMPS): s_memtime stamps between the segments of a walker body, summed per
 // segment in scalar registers and stored once at the end into st->dbg[4..8]; never defined in the product build
@@ -1398,27 +1408,28 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
         walk_totals T = {0.0, 0.0, INFINITY};
         const int wbits = deep ? 2 : 4;
         double lane_min = INFINITY;
-        book_regs R0, R1;                   // chunk c lives in R[c & 1]
-        R0.lm = R0.lm0 = R1.lm = R1.lm0 = 0.0; R0.mg = R1.mg = INFINITY; R0.cm = R1.cm = 0.0;
+        book_row R0, R1;                    // chunk c lives in R[c & 1]
+#pragma unroll
+        for (int q = 0; q < 8; q++) { R0.v[q] = lds_v2d{0.0, 0.0}; R1.v[q] = lds_v2d{0.0, 0.0}; }
         if (lane == 0) P.path_out[0] = SYM_US;
-        // iteration k (while the walker is in chunk k): gather chunk k-1, fold chunk k-2
-        auto iter = [&](int k, book_regs &Rg, book_regs &Rf) {
-            if (deep && k < nchunks) book_pregather(P, k * C, C, Nw, lane, Rf);     // chunk k shares its set with chunk k-2
-            if (k >= 1 && k - 1 < nchunks) book_gather(P, words0 + ((k - 1) & 1) * 64, LC, wbits, deep, (k - 1) * C, C, Nw, lane, Rg);
-            if (k >= 2) book_fold(Rf, C, T, lane_min);
+        // iteration k (while the walker is in chunk k): prefetch the rows of chunk k, consume chunk k-1
+        auto consume = [&](int c, const book_row &R) {
+            book_consume(P, words0 + (c & 1) * 64, LC, wbits, deep, c * C, C, Nw, lane, R, T, lane_min);
         };
         for (int k = 0; k < nchunks; k += 2) {
-            iter(k, R1, R0);
-            // the word reads are done, the gather's global loads stay in flight across the barrier (no vmcnt wait)
+            book_prefetch(P, k * C, C, Nw, lane, R0);
+            if (k >= 1) consume(k - 1, R1);
+            // the word reads are done, the prefetch's global loads stay in flight across the barrier (no vmcnt wait)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (k + 1 < nchunks) {
-                iter(k + 1, R0, R1);
+                book_prefetch(P, (k + 1) * C, C, Nw, lane, R1);
+                consume(k, R0);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
         if (nchunks > 0) {
-            if (nchunks & 1) { iter(nchunks, R0, R1); book_fold(R0, C, T, lane_min); }
-            else { iter(nchunks, R1, R0); book_fold(R1, C, T, lane_min); }
+            if (nchunks & 1) consume(nchunks - 1, R0);
+            else consume(nchunks - 1, R1);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
