@@ -82,6 +82,7 @@ struct gh_handle {
     uint32_t *cmask;
     double *lt;
     double *ht, *yt;              // depth-2 walker tables derived from lt (k_lt), when walk_depth2_ok(L)
+    unsigned long long fill_seen[6];   // host mirror of dstate->fill as last read (the counters only move under this handle's calls)
     uint8_t *spin_paths;          // gh_spin's device results, kept between calls: [spin_cap][N+1]
     gh_path_rec *spin_recs;       // [spin_cap]
     int spin_cap;
@@ -237,6 +238,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->n_cells = (size_t)(h->N + 2) * h->W;
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
+    memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
@@ -297,6 +299,7 @@ extern "C" int gh_clear(gh_t *h)
     if (set_dev(h)) return GH_ERR_HIP;
     HIPCHK(hipMemsetAsync(h->band, 0, h->n_cells * CELL * esize(h), h->stream));
     HIPCHK(hipMemsetAsync(h->dstate, 0, sizeof(dev_state), h->stream));
+    memset(h->fill_seen, 0, sizeof h->fill_seen);
     memset(&h->stats, 0, sizeof h->stats);
     h->stats.L = 1;
     h->L = 1;
@@ -409,11 +412,14 @@ extern "C" int gh_reads_free(gh_reads_t *r)
     return GH_OK;
 }
 
-static int pull_fill_state(gh_handle *h, unsigned long long before[6], const char *what)
+static int pull_fill_state(gh_handle *h, const char *what)
 {
     dev_state hs;
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long before[6];
+    memcpy(before, h->fill_seen, sizeof before);
+    memcpy(h->fill_seen, hs.fill, sizeof before);
     h->stats.n_slices += (int64_t)(hs.fill[0] - before[0]);
     h->stats.n_crumbs += (int64_t)(hs.fill[1] - before[1]);
     h->stats.covered_snps += (int64_t)(hs.fill[2] - before[2]);
@@ -431,9 +437,6 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
     if (!h || !r) return fail(GH_ERR_ARG, "null argument");
     if (r->dev != h->dev) return fail(GH_ERR_ARG, "reads live on device %d, handle on %d", r->dev, h->dev);
     if (set_dev(h)) return GH_ERR_HIP;
-    dev_state before;
-    HIPCHK(hipMemcpyAsync(&before, h->dstate, sizeof before, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
     if (r->n_reads > 0) {
         const int block = 256;
         int64_t nb = (r->n_reads + block - 1) / block;
@@ -474,7 +477,7 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         { int rc_ = post_launch(h, "k_fill"); if (rc_) return rc_; }
     }
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
-    int rc = pull_fill_state(h, before.fill, "gh_fill");
+    int rc = pull_fill_state(h, "gh_fill");
     if (h->stats.n_slices > 0) {                                   // util.py:333
         int L = (int)std::ceil((double)h->stats.covered_snps / (double)h->stats.n_slices);
         if (L < 1) L = 1;
@@ -537,9 +540,6 @@ extern "C" int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const i
     int rc = GH_OK;
     if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_add_batch staging failed: %s", hipGetErrorString(e));
     if (rc == GH_OK) {
-        dev_state before;
-        hipMemcpyAsync(&before, h->dstate, sizeof before, hipMemcpyDeviceToHost, h->stream);
-        hipStreamSynchronize(h->stream);
         const int block = 256;
         const unsigned nb = (unsigned)((n + block - 1) / block);
         if (h->cfg.storage == GH_STORAGE_F64)
@@ -548,7 +548,7 @@ extern "C" int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const i
             hipLaunchKernelGGL(k_add_batch<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
         h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
         int64_t s0 = h->stats.n_slices, c0 = h->stats.n_crumbs, v0 = h->stats.covered_snps;
-        rc = pull_fill_state(h, before.fill, "gh_add_batch");
+        rc = pull_fill_state(h, "gh_add_batch");
         h->stats.n_slices = s0; h->stats.n_crumbs = c0; h->stats.covered_snps = v0;
     }
     hipFree(da); hipFree(db); hipFree(di); hipFree(dj);
@@ -973,6 +973,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         HIPCHK(hipStreamSynchronize(h->stream));
         hipFree(h->spin_paths); hipFree(h->spin_recs);
         h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
+    memset(h->fill_seen, 0, sizeof h->fill_seen);
         hipError_t ea = hipMalloc((void **)&h->spin_paths, n1 * max_paths);
         if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_recs, sizeof(gh_path_rec) * max_paths);
         if (ea != hipSuccess) {
