@@ -562,9 +562,6 @@ __device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond
 //   Yt[i][w][b][l - 3]       = G[i][w][lag l][b], l = 3..L, rows padded to an even number of lags
 // for positions 0 .. N + WALK_TPAD - 1 (zeros behind the table: the walker runs whole chunks).
 #define WALK_TPAD 72
-#ifndef WALK_LOADER_SETS
-#define WALK_LOADER_SETS 1
-#endif
 __host__ __device__ constexpr int deep_nyp(int L) { return L > 2 ? ((L - 2 + 1) & ~1) : 0; }
 
 // what k_lt stores at G[i][row6][lag - 1][col5] in the ranked layout
@@ -1228,18 +1225,20 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // depth-1 layout: plain copy of the G blocks of positions k*C .. k*C + C + WALK_OV - 1
-    auto load_chunk = [&](int k, int t, int nt) {
-        const int i0 = k * C;
-        const int npos = C + WALK_OV;        // overlap: the last body reads positions beyond its chunk
-        double *dst = g0 + (size_t)(k & 1) * npos * RS;
-        int nsrc = P.N + LT_PAD - i0;
-        if (nsrc > npos) nsrc = npos;
-        if (nsrc < 0) nsrc = 0;
-        copy_to_lds(dst, P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
-        // the walker always runs whole chunks: what lies behind the table must read as 0.0 (finite sums,
-        // symbol 0 wins), never as stale LDS bits
-        for (int q = nsrc * BLK + t; q < npos * BLK; q += nt) dst[q] = 0.0;
+    // The loader waves' pipeline, whatever they load: chunk k+1 goes from registers to LDS (paced) while the walker is in
+    // chunk k, then the loads of chunk k+2 are issued and stay in flight across the barrier (their latency must not sit
+    // between two barriers: the walker waits there too).
+    auto loader_loop = [&](auto &fetch, auto &store, auto &set) {
+        fetch(0, set);
+        store(0, set, std::false_type{});                    // nobody is walking yet
+        if (nchunks > 1) fetch(1, set);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int k = 0; k < nchunks; k++) {
+            if (k + 1 < nchunks) store(k + 1, set, std::true_type{});     // empties the registers fetch(k + 2) fills
+            if (k + 2 < nchunks) fetch(k + 2, set);
+            // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
     };
 
     if (deep) {
@@ -1255,38 +1254,6 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
             if (wave >= 2) {
                 const int t = tid - 128;
                 const int npos = C + WALK_OV;
-                // chunk c is fetched into register set c & 1 at the start of iteration c - 2 and stored during iteration
-                // c - 1: the loads have more than a chunk of time, whatever the pacing of the stores
-                auto loader_loop = [&](auto &fetch, auto &store, auto &setA, auto &setB) {
-#if WALK_LOADER_SETS == 2
-                    fetch(0, setA);
-                    store(0, setA, std::false_type{});                    // nobody is walking yet
-                    if (nchunks > 1) fetch(1, setB);
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    for (int k = 0; k < nchunks; k += 2) {
-                        if (k + 2 < nchunks) fetch(k + 2, setA);
-                        if (k + 1 < nchunks) store(k + 1, setB, std::true_type{});
-                        // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
-                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                        if (k + 1 < nchunks) {
-                            if (k + 3 < nchunks) fetch(k + 3, setB);
-                            if (k + 2 < nchunks) store(k + 2, setA, std::true_type{});
-                            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                        }
-                    }
-#else
-                    fetch(0, setA);
-                    store(0, setA, std::false_type{});                    // nobody is walking yet
-                    if (nchunks > 1) fetch(1, setA);
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    for (int k = 0; k < nchunks; k++) {
-                        if (k + 1 < nchunks) store(k + 1, setA, std::true_type{});     // empties the registers fetch(k + 2) fills
-                        if (k + 2 < nchunks) fetch(k + 2, setA);
-                        // LDS stores done, global loads still in flight: no vmcnt wait here (a fence would add one)
-                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    }
-#endif
-                };
                 if (P.Ht) {
                     constexpr int NVH = MAXPOS * DL::HPOS / 2, NVY = MAXPOS * DL::YPOS / 2;    // double2 per chunk
                     constexpr int MAXH = (NVH + NT - 1) / NT, MAXY = (NVY + NT - 1) / NT;
@@ -1297,7 +1264,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
 #else
                     constexpr int PACE = (walk_chunk(LC, true) * (88 + 7 * LC) * 62 / 100) / ((MAXH + MAXY) * 64);
 #endif
-                    struct regs { lds_v2d vh[MAXH], vy[MAXY > 0 ? MAXY : 1]; } setA, setB;
+                    struct regs { lds_v2d vh[MAXH], vy[MAXY > 0 ? MAXY : 1]; } set;
                     auto fetch = [&](int k, regs &R) {
                         const lds_v2d *srcH = reinterpret_cast<const lds_v2d *>(P.Ht + (size_t)k * C * DL::HPOS);
 #pragma unroll
@@ -1334,14 +1301,14 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                             }
                         }
                     };
-                    loader_loop(fetch, store, setA, setB);
+                    loader_loop(fetch, store, set);
                 } else {
                     constexpr int MAXH = (MAXPOS * DL::HPOS + NT - 1) / NT;
                     constexpr int MAXY = DL::YPOS ? (MAXPOS * DL::YPOS + NT - 1) / NT : 0;
                     const int nsrc_all = P.N + LT_PAD;                    // source blocks G holds (the last LT_PAD are zeros)
                     const int nh = npos * DL::HPOS, ny = npos * DL::YPOS;
                     const int bb = t & 3, a1 = (t >> 2) & 3, a2 = (t >> 4) & 3;    // NT is a multiple of 64: lane-constant
-                    struct regs { double x1[MAXH], x2[MAXH], yv[MAXY > 0 ? MAXY : 1]; } setA, setB;
+                    struct regs { double x1[MAXH], x2[MAXH], yv[MAXY > 0 ? MAXY : 1]; } set;
                     auto fetch = [&](int k, regs &R) {
                         const int i0 = k * C;
 #pragma unroll
@@ -1387,21 +1354,70 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                             }
                         }
                     };
-                    loader_loop(fetch, store, setA, setB);
+                    loader_loop(fetch, store, set);
                 }
                 return;
             }
             __syncthreads();
         }
     } else {
-        load_chunk(0, tid, (int)blockDim.x);
-        __syncthreads();
-        if (wave >= 2) {
-            for (int k = 0; k < nchunks; k++) {
-                if (k + 1 < nchunks) load_chunk(k + 1, tid - 128, (int)blockDim.x - 128);
-                __syncthreads();
-            }
+        // depth-1 layout: the G blocks of positions k*C .. k*C + C + WALK_OV - 1, copied as they are (16-byte copies)
+        constexpr int NT = 384, MAXPOS = walk_chunk(LC, false) + WALK_OV;
+        constexpr int NV = MAXPOS * BLK / 2, MAXV = (NV + NT - 1) / NT;          // double2 per chunk / per thread
+        constexpr int PACE = (walk_chunk(LC, false) * (110 + 9 * LC) * 62 / 100) / (MAXV * 64);
+        if (wave >= 2 && blockDim.x == 512) {
+            const int t = tid - 128;
+            const int npos = C + WALK_OV;
+            struct regs { lds_v2d v[MAXV]; } set;
+            auto fetch = [&](int k, regs &R) {
+                const int i0 = k * C;
+                int nsrc = P.N + LT_PAD - i0;                // what lies behind the table must read as 0.0 (finite sums,
+                if (nsrc > npos) nsrc = npos;                // symbol 0 wins): the walker always runs whole chunks
+                if (nsrc < 0) nsrc = 0;
+                const int nv = nsrc * BLK / 2;
+                const lds_v2d *src = reinterpret_cast<const lds_v2d *>(P.G + (size_t)i0 * BLK);
+#pragma unroll
+                for (int it = 0; it < MAXV; it++) {
+                    const int q = t + it * NT;
+                    R.v[it] = lds_v2d{0.0, 0.0};
+                    if (q < nv) R.v[it] = src[q];
+                }
+            };
+            auto store = [&](int k, regs &R, auto pace) {
+                lds_v2d *dst = reinterpret_cast<lds_v2d *>(g0 + (size_t)(k & 1) * npos * RS);
+#pragma unroll
+                for (int it = 0; it < MAXV; it++) {
+                    const int q = t + it * NT;
+                    if (q < NV) dst[q] = R.v[it];
+                    if constexpr (decltype(pace)::value && PACE > 0) __builtin_amdgcn_s_sleep(PACE);
+                }
+            };
+            loader_loop(fetch, store, set);
             return;
+        }
+        if (blockDim.x != 512) {
+            // other workgroup sizes (GH_WALK_THREADS, A/B measurements): every thread copies, no pipelining
+            auto load_chunk = [&](int k, int t, int nt) {
+                const int i0 = k * C;
+                const int npos = C + WALK_OV;
+                double *dst = g0 + (size_t)(k & 1) * npos * RS;
+                int nsrc = P.N + LT_PAD - i0;
+                if (nsrc > npos) nsrc = npos;
+                if (nsrc < 0) nsrc = 0;
+                copy_to_lds(dst, P.G + (size_t)i0 * BLK, (size_t)nsrc * BLK, t, nt);
+                for (int q = nsrc * BLK + t; q < npos * BLK; q += nt) dst[q] = 0.0;
+            };
+            load_chunk(0, tid, (int)blockDim.x);
+            __syncthreads();
+            if (wave >= 2) {
+                for (int k = 0; k < nchunks; k++) {
+                    if (k + 1 < nchunks) load_chunk(k + 1, tid - 128, (int)blockDim.x - 128);
+                    __syncthreads();
+                }
+                return;
+            }
+        } else {
+            __syncthreads();        // the loaders' first barrier
         }
     }
     if (wave == 1) {
