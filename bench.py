@@ -40,7 +40,30 @@ def parse():
     ap.add_argument("--no-throughput-leg", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="throughput mode: this many independent windows per GPU in one batched launch")
     ap.add_argument("--cpu-snps", type=int, default=3000, help="SNP prefix used for the Python CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="control-plane backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host sockets "
+                         "(lets several ranks share one GPU: --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="ranks take GPU (rank mod visible GPUs) instead of one each (gloo only)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one per rank, BEFORE this process
+    touches the GPU (a process that has initialised HIP must never be re-exec'ed or forked), and wait for them.
+    Rank 0's stdout carries the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    sys.exit(max(abs(rc) for rc in rcs))
 
 
 def edge_evals_per_path(cmask, n, L):
@@ -163,20 +186,33 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                   # never returns
+    args.gpus = world
 
     import torch
     import torch.distributed as dist
+    ndev = torch.cuda.device_count()        # does not initialise HIP
+    if ndev < 1:
+        sys.exit("bench.py needs a GPU (no CPU fallback for the hot path)")
+    if args.share_gpu:
+        if args.backend != "gloo":
+            sys.exit("--share-gpu needs --backend gloo (RCCL wants one GPU per rank)")
+        local = local % ndev
+    elif local >= ndev:
+        sys.exit("rank %d wants GPU %d but only %d are visible (use --backend gloo --share-gpu to share)" % (rank, local, ndev))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback for the hot path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the control records live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from gretel_amd.hansel import Hansel, DeviceReads
     from gretel_amd.synth import make_config
@@ -184,12 +220,12 @@ def main():
 
     # rank 0 decides the run, everybody learns it over RCCL
     desc = broadcast_descriptor(dict(paths=args.paths, steps=args.steps, warmup=args.warmup,
-                                     config={"C2": 2, "C3": 3, "C5": 5}[args.config]), dev, world, rank)
+                                     config={"C2": 2, "C3": 3, "C5": 5}[args.config]), comm_dev, world, rank)
     cfg_name = "C%d" % desc["config"]
     paths = desc["paths"]
 
     if args.batch > 0:
-        return bench_batch(args, cfg_name, paths, desc, rank, world, local, dev)
+        return bench_batch(args, cfg_name, paths, desc, rank, world, local, comm_dev)
 
     table = make_config(cfg_name, seed=rank)               # one independent window per GPU
     h = Hansel(table.n_snps, band=table.band, device=local)
@@ -199,7 +235,7 @@ def main():
         h.clear()
         stats = h.fill_from_support(None, None, None, reads_handle=reads)
         res = h.spin(paths)
-        gathered = gather_results(res, table.n_snps, paths, dev, world, rank)
+        gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank)
         return stats, res, gathered
 
     def fence():
@@ -225,7 +261,7 @@ def main():
     prof = h.profile_get()
     h.profile_enable(0)
 
-    tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=comm_dev)
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -284,7 +320,9 @@ def main():
             "config": {"workload": "%s: %d-SNP / %d-read synthetic contig per GPU, k=%s SNPs/read, L=%d, %d paths per step "
                                    "(fill + spins), seed=rank" % (cfg_name, n, table.n_reads, table.max_k, L, paths),
                        "n_snps": n, "n_reads": table.n_reads, "L": L, "band": table.band, "paths": paths,
-                       "parallelism": "%d independent window(s), one per GPU; RCCL broadcast/gather" % world},
+                       "parallelism": "%d independent window(s), one per rank; %s broadcast/gather of control records, no data-path collective"
+                                      % (world, "RCCL" if args.backend == "nccl" else "gloo"),
+                       "backend": args.backend, "share_gpu": bool(args.share_gpu)},
             "edge_evals_per_s": hap_s * (cond_evals + rw_cells),
             "edge_evals_per_path": {"conditionals": cond_evals, "reweight_cells": rw_cells},
             "fill": {"n_slices": stats[0], "n_crumbs": stats[1],

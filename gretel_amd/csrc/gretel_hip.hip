@@ -973,7 +973,6 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         HIPCHK(hipStreamSynchronize(h->stream));
         hipFree(h->spin_paths); hipFree(h->spin_recs);
         h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
-    memset(h->fill_seen, 0, sizeof h->fill_seen);
         hipError_t ea = hipMalloc((void **)&h->spin_paths, n1 * max_paths);
         if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_recs, sizeof(gh_path_rec) * max_paths);
         if (ea != hipSuccess) {
@@ -1174,6 +1173,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         n_out[w] = hs[w].n_done;
         hole_at[w] = hs[w].stop ? hs[w].hole_at : 0;
         b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true;
+        b->hs[w]->lt_inc_path = nullptr;       // the batch reweighted many paths and maintains no walker tables: rebuild in full
     }
     return GH_OK;
 }

@@ -73,3 +73,16 @@ def test_broadcast_and_gather_world2(tmp_path):
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    # `python bench.py --gpus 2` as the driver invokes it: the parent spawns one child per rank before touching the
+    # GPU.  Without a GPU each child stops with the "needs a GPU" message -- two of them, and no request for torchrun.
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stderr.count("needs a GPU") == 2, out.stderr
+    assert "torch.distributed.run" not in out.stderr

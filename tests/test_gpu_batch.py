@@ -61,3 +61,28 @@ def test_batch_rejects_mismatched_windows():
     c.L = a.L + 1
     with pytest.raises(GretelHipError):
         HanselBatch([a, c]).spin(2)
+
+
+def test_single_path_after_a_batched_spin_sees_every_reweight():
+    # reweight_from_path leaves the "only this path's rows changed" hint on the handle; a batched spin then reweights
+    # many paths without maintaining the single-window walker tables, so the next generate_path must rebuild them
+    wins = [_window(s, n=300, reads=9000, k=5) for s in range(3)]
+    oracles = []
+    for t, h in wins:
+        o = COracle(t.n_snps, t.band)
+        o.fill(t)
+        h.snapshot_original()
+        o.snapshot_original()
+        p = h.generate_path()
+        po = o.generate_path()
+        assert np.array_equal(p[0], po[0])
+        h.reweight_from_path(p[0], 0.4)
+        o.reweight_path(po[0], 0.4)
+        oracles.append(o)
+    res = HanselBatch([h for _, h in wins]).spin(6)
+    for (t, h), o, r in zip(wins, oracles, res):
+        ref = o.spin(6)
+        assert np.array_equal(r["paths"], ref["paths"])
+        pg, po = h.generate_path(), o.generate_path()
+        assert np.array_equal(pg[0], po[0])
+        assert pg[1:] == po[1]

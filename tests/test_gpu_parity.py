@@ -282,3 +282,23 @@ def test_fill_sorted_and_shuffled_tables_agree():
     assert lib().orc_fill(o3._h, _p(np.ascontiguousarray(t.rank)), _p(np.ascontiguousarray(t.off)), _p(t.bases), t.n_reads, 1) == 0
     assert h3.fill_from_support(t.rank, t.off, t.bases, use_end_sentinels=True) == o3.stats()
     assert np.array_equal(h3.export_band(), o3.export_band())
+
+
+def test_fill_after_spin_keeps_the_fill_accounting():
+    # fill -> spin -> fill on one handle without clear(): the second fill's counters are deltas of the device
+    # totals against the host mirror, which nothing but create/clear may reset (a stray reset inside gh_spin once
+    # re-added the whole first fill)
+    t1 = make_support_table(200, 6000, k=4, seed=21)
+    t2 = make_support_table(200, 5000, k=4, seed=22)
+    h = Hansel(t1.n_snps, band=t1.band)
+    o = COracle(t1.n_snps, t1.band, use_libm=False)
+    assert h.fill_from_support(t1.rank, t1.off, t1.bases) == o.fill(t1)
+    _same_spin(h.spin(7), o.spin(7))                      # first spin allocates the result buffers
+    assert h.fill_from_support(t2.rank, t2.off, t2.bases) == o.fill(t2)
+    assert (h.n_slices, h.n_crumbs) == o.stats()[:2]
+    assert h.L == o.L
+    assert np.array_equal(h.export_band(), o.export_band())
+    _same_spin(h.spin(9), o.spin(9))                      # a larger spin re-allocates them
+    assert h.fill_from_support(t1.rank, t1.off, t1.bases) == o.fill(t1)
+    assert h.L == o.L
+    assert np.array_equal(h.export_band(), o.export_band())
