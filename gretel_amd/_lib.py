@@ -45,7 +45,7 @@ class gh_fill_stats(C.Structure):
 
 class gh_path_rec(C.Structure):
     _fields_ = [("hp_current", C.c_double), ("hp_original", C.c_double),
-                ("ratio", C.c_double), ("magnitude", C.c_double)]
+                ("ratio", C.c_double), ("magnitude", C.c_double), ("min_marginal", C.c_double)]
 
 
 _lib = None

@@ -56,6 +56,7 @@ static int fail(int code, const char *fmt, ...)
 extern "C" const char *gh_last_error(void) { return g_err; }
 
 #include "kernels.hpp"
+#include "segwalk.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // handle
@@ -96,10 +97,33 @@ struct gh_handle {
     int partial_cap;
     uint8_t *d_path;       // [N+1] scratch path
     gh_path_rec *d_rec;    // 1 scratch record
+    // segment-parallel walk (segwalk.hpp), sized for seg_L by alloc_seg
+    uint32_t *seg_hist;    // picks of every (segment, entry state)
+    uint16_t *seg_maps, *seg_pmaps, *seg_gmaps;
+    double *seg_min;       // [256]
+    double *lmsel1;        // [N+1] selected log-marginals of a lone gh_generate_path
+    double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
+    int seg_L;
+    int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
+    int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
     gh_fill_stats stats;
+    int wmode;                    // WM_*: which path extension (GH_WALK at creation)
+    bool lt_full;                 // GH_LT_FULL=1 at creation: rebuild the conditional table in full before every path (A/B)
     int prof;                     // 0 = off, k = bracket every k-th launch of each kernel
     prof_slot ps[GH_K_COUNT];
 };
+
+// GH_WALK (read when a handle is created): see the walker selection further down
+enum { WM_SEG = 0, WM_SPEC = 1, WM_SPEC1 = 2, WM_SRC = 3 };
+
+static int walk_mode_from_env()
+{
+    const char *m = getenv("GH_WALK");
+    if (!m || !*m || !strcmp(m, "seg")) return WM_SEG;
+    if (!strcmp(m, "spec1")) return WM_SPEC1;
+    if (!strcmp(m, "src")) return WM_SRC;
+    return WM_SPEC;
+}
 
 struct gh_reads {
     int dev;
@@ -203,6 +227,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
+    hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -238,11 +263,16 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->n_cells = (size_t)(h->N + 2) * h->W;
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
+    h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
+    h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0;
+    h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
     h->prof = 0;
+    h->wmode = walk_mode_from_env();
+    h->lt_full = getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL"));
     h->partial = nullptr; h->partial_cap = 0;
     memset(&h->stats, 0, sizeof h->stats);
     h->stats.L = 1;
@@ -597,11 +627,11 @@ static int ensure_marg(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
     else
         hipLaunchKernelGGL((k_marg<float, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
     // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
     prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
     { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
@@ -610,7 +640,11 @@ static int ensure_marg(gh_handle *h)
 }
 
 static int alloc_lt(gh_handle *h);
-static bool walk_depth2_ok(int L);
+// may the fused reweight keep the conditional table current (k_marg<T,true> rewrites the rows a path changes)?
+static bool lt_incremental_ok(const gh_handle *h) { return h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term && !h->lt_full; }
+static bool walk_depth2_ok(int wm, int L);
+static bool walk_ranked_ok(int wm, int L);
+static bool seg_ok(int wm, int L);
 
 static int ensure_lt(gh_handle *h)
 {
@@ -618,8 +652,7 @@ static int ensure_lt(gh_handle *h)
     if (rc) return rc;
     if (!h->dirty_lt && h->lt && h->lt_L == h->L) return GH_OK;
     if ((rc = alloc_lt(h))) return rc;
-    const bool inc_ok = h->lt_inc_path && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
-                        !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
+    const bool inc_ok = h->lt_inc_path && lt_incremental_ok(h);
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
     const size_t total = inc ? (size_t)h->N * 4 : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
@@ -629,11 +662,11 @@ static int ensure_lt(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L), h->ht, h->yt);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_depth2_ok(h->L), h->ht, h->yt);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt);
     const int wl = h->W < h->L ? h->W : h->L;
     // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
     prof_end(h, GH_K_LT, inc ? 8.0
@@ -756,7 +789,7 @@ static int alloc_lt(gh_handle *h)
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr;
     size_t bytes = (size_t)(h->N + LT_PAD) * h->L * LT_BLK * sizeof(double);
     hipError_t e = hipMalloc((void **)&h->lt, bytes);
-    if (e == hipSuccess && walk_depth2_ok(h->L)) {
+    if (e == hipSuccess && walk_depth2_ok(h->wmode, h->L) && !seg_ok(h->wmode, h->L)) {
         // the tables the depth-2 walker's loaders copy (k_lt keeps them in step with lt)
         e = hipMalloc((void **)&h->ht, (size_t)(h->N + WALK_TPAD) * 64 * sizeof(double));
         const size_t ypos = (size_t)16 * deep_nyp(h->L);
@@ -777,13 +810,21 @@ static int walk_threads()
 #define WALK_THREADS walk_threads()
 #define WALK_MAX_LC 16
 
+// Which path extension runs.  GH_WALK pins one for A/B measurements and tests; it is read when a handle is created:
+//   unset / "seg"   segment-parallel (segwalk.hpp) for L <= SEG_MAX_L, else the serial walkers below
+//   "spec"          k_walk_spec: one wavefront, speculation depth 2 where the window allows it, else depth 1
+//   "spec1"         k_walk_spec at depth 1       "src"  k_walk_src (no speculation)
+static bool seg_ok(int wm, int L) { return wm == WM_SEG && L >= 1 && L <= SEG_MAX_L; }
+
 // Whether the depth-2 walker can run for this L: then k_lt may build G over candidate ranks (kernels.hpp).
-// GH_WALK=src selects the non-speculative walker, GH_WALK=spec1 keeps speculation at depth 1 (A/B measurements).
-static bool walk_depth2_ok(int L)
+static bool walk_depth2_ok(int wm, int L)
 {
-    static const bool off = getenv("GH_WALK") && (!strcmp(getenv("GH_WALK"), "src") || !strcmp(getenv("GH_WALK"), "spec1"));
+    const bool off = wm == WM_SRC || wm == WM_SPEC1;
     return !off && L >= 2 && L <= WALK_MAX_LC && walk_chunk(L, false) > 0 && walk_chunk(L, true) > 0 && WALK_THREADS == 512;
 }
+
+// single windows: may k_lt build the ranked layout?  (the segment-parallel walk reads either layout)
+static bool walk_ranked_ok(int wm, int L) { return seg_ok(wm, L) || walk_depth2_ok(wm, L); }
 
 template <int LC>
 static void launch_walk_lc(bool spec, size_t lds, hipStream_t stream, const walk_params &P, int grid, const win_desc *wd, int spin)
@@ -811,15 +852,15 @@ static void launch_walk_src(int LC, bool spec, size_t lds, hipStream_t stream, c
 }
 
 // launches the path-extension kernel for `grid` windows (grid == 1: the handle's own buffers in P)
-static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int grid, const win_desc *wd, int spin)
+static void launch_walk_any(int wm, int N, int L, walk_params P, hipStream_t stream, int grid, const win_desc *wd, int spin)
 {
     const int chunk = L <= WALK_MAX_LC ? walk_chunk(L, false) : 0;
     if (chunk > 0) {
         P.chunk = chunk;                    // k_walk_src; k_walk_spec takes walk_chunk(L, variant) itself
         size_t lds = walk_lds_bytes(L, false);
-        if (walk_depth2_ok(L) && walk_lds_bytes(L, true) > lds) lds = walk_lds_bytes(L, true);
-        static const bool spec = !(getenv("GH_WALK") && !strcmp(getenv("GH_WALK"), "src"));
-        P.depth2 = walk_depth2_ok(L);
+        if (walk_depth2_ok(wm, L) && walk_lds_bytes(L, true) > lds) lds = walk_lds_bytes(L, true);
+        const bool spec = wm != WM_SRC;
+        P.depth2 = walk_depth2_ok(wm, L);
         launch_walk_src(L, spec, lds, stream, P, grid, wd, spin);
     } else {
         int hl = 16;
@@ -829,14 +870,84 @@ static void launch_walk_any(int N, int L, walk_params P, hipStream_t stream, int
     }
 }
 
-static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove, int rearm)
+// ---- segment-parallel walk ---------------------------------------------------------------------
+static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+static int alloc_seg(gh_handle *h)
 {
+    if (h->seg_hist && h->seg_L == h->L) return GH_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1);
+    h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
+    const seg_geom g4 = seg_geometry(h->N, h->L, 4), g5 = seg_geometry(h->N, h->L, 5);
+    // the layout is decided on the device (st->ranked): size for both
+    const size_t hist_b = max2((size_t)g4.S * g4.NW * g4.NS, (size_t)g5.S * g5.NW * g5.NS) * 4;
+    const size_t maps_b = max2((size_t)g4.S * g4.NS, (size_t)g5.S * g5.NS) * 2;
+    const size_t gmaps_b = max2((size_t)g4.G1 * g4.NS, (size_t)g5.G1 * g5.NS) * 2;
+    hipError_t e = hipMalloc((void **)&h->seg_hist, hist_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_maps, maps_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_pmaps, maps_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmaps, gmaps_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_min, 256 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->lmsel1, ((size_t)h->N + 2) * sizeof(double));
+    if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the segment-parallel walk failed: %s", hipGetErrorString(e));
+    h->seg_L = h->L;
+    return GH_OK;
+}
+
+template <int LC>
+static void launch_seg_lc(const seg_params &P, hipStream_t stream, int N, int dev)
+{
+    const seg_geom g4 = seg_geometry(N, LC, 4), g5 = seg_geometry(N, LC, 5);
+    const size_t lds_seg = max2(seg_lds_bytes(4, LC), seg_lds_bytes(5, LC));
+    const size_t lds_scan = max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5));
+    const size_t lds_emit = max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5));
+    // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
+    static size_t set_seg[64], set_scan[64], set_emit[64];
+    const int dv = dev & 63;
+    if (lds_seg > set_seg[dv]) { hipFuncSetAttribute((const void *)k_seg<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg); set_seg[dv] = lds_seg; }
+    if (lds_scan > set_scan[dv]) { hipFuncSetAttribute((const void *)k_scan<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan); set_scan[dv] = lds_scan; }
+    if (lds_emit > set_emit[dv]) { hipFuncSetAttribute((const void *)k_emit<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit); set_emit[dv] = lds_emit; }
+    const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
+    hipLaunchKernelGGL((k_seg<LC>), dim3(S), dim3(SEG_THREADS), lds_seg, stream, P);
+    hipLaunchKernelGGL((k_scan<LC>), dim3(G1), dim3(SEG_THREADS), lds_scan, stream, P);
+    hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, stream, P);
+}
+
+static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int rearm, int check_masks)
+{
+    int rc = alloc_seg(h);
+    if (rc) return rc;
+    seg_params P;
+    P.N = h->N; P.L = h->L; P.rearm = rearm; P.check_masks = check_masks;
+    P.G = h->lt; P.minfo = h->minfo; P.st = h->dstate;
+    P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
+    P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
+    prof_begin(h, GH_K_WALK);
+    switch (h->L) {
+        case 1: launch_seg_lc<1>(P, h->stream, h->N, h->dev); break;
+        case 2: launch_seg_lc<2>(P, h->stream, h->N, h->dev); break;
+        case 3: launch_seg_lc<3>(P, h->stream, h->N, h->dev); break;
+        case 4: launch_seg_lc<4>(P, h->stream, h->N, h->dev); break;
+        case 5: launch_seg_lc<5>(P, h->stream, h->N, h->dev); break;
+        default: return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L);
+    }
+    prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
+    return post_launch(h, "k_seg/k_scan/k_emit");
+}
+
+// serial walkers: the record is closed by the walker itself.  Segment-parallel: by the k_marg<T,true> that follows
+// (spins) or by k_seg_fin (lone gh_generate_path); d_lmsel receives the selected log-marginals for k_hp.
+static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove, int rearm, double *d_lmsel = nullptr,
+                       int check_masks = 0)
+{
+    if (seg_ok(h->wmode, h->L)) return launch_seg_walk(h, d_path, d_lmsel, rearm, check_masks);
     walk_params P;
     P.N = h->N; P.L = h->L; P.chunk = 0; P.rearm = rearm;
     P.G = h->lt; P.Ht = h->ht; P.Yt = h->yt; P.minfo = h->minfo;
     P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
     prof_begin(h, GH_K_WALK);
-    launch_walk_any(h->N, h->L, P, h->stream, 1, nullptr, 0);
+    launch_walk_any(h->wmode, h->N, h->L, P, h->stream, 1, nullptr, 0);
     // algorithmic bytes, SURVEY 8(d): per step the marginal cell + L history cells (49 elements each) + the original
     // marginals (7 x 4 B).  What this build's layout needs per step is one table row: N * (L * 40 + 25) bytes.
     prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
@@ -861,7 +972,10 @@ static int ensure_partial(gh_handle *h, int nb, int slots)
 
 // slot < 0: reduce the removed mass right behind the pass (k_reweight_finish).  slot >= 0 (gh_spin): keep this
 // path's partial sums in their own slot, the caller reduces all paths with one k_reweight_finish_all at the end.
-static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec, int slot = -1)
+// seg: the walk just before was segment-parallel: the kernel reduces the minimum marginal itself, clamps it to `ratio`
+// (= min_remove) and closes the record
+static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec, int slot = -1,
+                                bool seg = false, bool chained = false)
 {
     const int threads = (h->N + 1) * 8;
     const int block = 256;
@@ -872,18 +986,21 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     if (!use_state) hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, 0);
     // with a valid conditional table (conditional A or B, no marginal term) the kernel also rewrites the table rows
     // this path changes; k_lt then only has to confirm that no candidate mask moved
-    const bool lt_ok = !h->dirty_lt && h->lt && h->lt_L == h->L && h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term &&
-                       !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
+    // (chained: a spin without k_lt between its paths -- the table is current up to the rows the previous reweight rewrote, and
+    // the k_seg that ran before this reweight has checked the candidate masks)
+    const bool lt_ok = (!h->dirty_lt || chained) && h->lt && h->lt_L == h->L && lt_incremental_ok(h);
     double *lt_rows = lt_ok ? h->lt : nullptr;
     prof_begin(h, GH_K_REWEIGHT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode);
+                           d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
+                           seg ? (const double *)h->seg_min : (const double *)nullptr, d_rec);
     else
         hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode);
+                           d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
+                           seg ? (const double *)h->seg_min : (const double *)nullptr, d_rec);
     if (slot < 0)
         hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, partial, nb, h->dstate, use_state, d_rec,
                            (const win_desc *)nullptr, 0);
@@ -927,6 +1044,16 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
     }
     if ((rc = reset_spin_state(h))) return rc;
     if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0, 0))) return rc;
+    if (seg_ok(h->wmode, h->L)) {
+        // close the record (hole / minimum marginal), then the two likelihood sums
+        seg_params P;
+        memset(&P, 0, sizeof P);
+        P.N = h->N; P.L = h->L; P.st = h->dstate; P.segmin = h->seg_min;
+        hipLaunchKernelGGL(k_seg_fin, dim3(1), dim3(256), 0, h->stream, P, h->d_rec, 0.0);
+        hipLaunchKernelGGL(k_hp, dim3(1, 2), dim3(64), 0, h->stream, (const double *)h->lmsel1, (size_t)0, (const uint8_t *)h->d_path,
+                           (size_t)0, (const double *)h->minfo, h->N, (const dev_state *)h->dstate, h->d_rec);
+        if ((rc = post_launch(h, "k_seg_fin/k_hp"))) return rc;
+    }
     dev_state hs;
     gh_path_rec rec;
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
@@ -937,7 +1064,7 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
     if (!hs.stop) {
         if (hp_current) *hp_current = rec.hp_current;
         if (hp_original) *hp_original = rec.hp_original;
-        if (min_marginal) *min_marginal = rec.ratio;
+        if (min_marginal) *min_marginal = rec.min_marginal;
     }
     return GH_OK;
 }
@@ -973,10 +1100,14 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         HIPCHK(hipStreamSynchronize(h->stream));
         hipFree(h->spin_paths); hipFree(h->spin_recs);
         h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
+        hipFree(h->spin_lmsel); h->spin_lmsel = nullptr;
         hipError_t ea = hipMalloc((void **)&h->spin_paths, n1 * max_paths);
         if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_recs, sizeof(gh_path_rec) * max_paths);
+        // the selected symbols' log-marginals of every path, for the likelihood sums behind the loop (k_hp)
+        if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_lmsel, sizeof(double) * n1 * max_paths);
         if (ea != hipSuccess) {
             hipFree(h->spin_paths); h->spin_paths = nullptr;
+            hipFree(h->spin_recs); h->spin_recs = nullptr;
             return fail(GH_ERR_NOMEM, "hipMalloc failed");
         }
         h->spin_cap = max_paths;
@@ -987,31 +1118,62 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     rc = reset_spin_state(h);
     const int nb = ((h->N + 1) * 8 + 255) / 256;
     if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);
-    int launched = 0;
-    for (int s = 0; s < max_paths && rc == GH_OK; s++) {
-        if ((rc = ensure_lt(h))) break;
-        if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1))) break;
-        if ((rc = launch_reweight_marg(h, d_paths + n1 * s, 0.0, 1, d_recs + s, s))) break;
-        launched = s + 1;
-    }
-    // bring the walker tables in step with the last reweight while its path is still allocated (the next call would
-    // otherwise refresh them from a freed buffer)
-    if (rc == GH_OK && launched > 0) rc = ensure_lt(h);
-    // the removed mass of every path in one launch (it is only ever read by the host)
-    if (rc == GH_OK && launched > 0) {
-        hipLaunchKernelGGL(k_reweight_finish_all, dim3(launched), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
-        rc = post_launch(h, "k_reweight_finish_all");
+    const bool seg = seg_ok(h->wmode, h->L);       // L only changes through gh_set_L / gh_fill, never inside a spin
+    // Segment-parallel walks with a conditional table that the fused reweight keeps current (conditional A/B, no marginal
+    // term): no k_lt between two paths.  Its only job there is to notice that a candidate mask moved (a count reached
+    // zero; rare) and rebuild the table; instead the next k_seg sees the flag k_marg left, marks the table stale and the
+    // rest of the queue does nothing.  The host then rebuilds and queues the remaining paths again.
+    const bool optimistic = seg && lt_incremental_ok(h);
+    if (rc == GH_OK && seg) {
+        const int zero = 0;
+        e = hipMemcpyAsync(&h->dstate->lt_stale, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
     }
     dev_state hs;
     memset(&hs, 0, sizeof hs);
-    if (rc == GH_OK) {
+    int first = 0;
+    h->spin_requeues = 0;
+    while (rc == GH_OK) {
+        int launched = first;
+        for (int s = first; s < max_paths && rc == GH_OK; s++) {
+            if (!optimistic || s == first) { if ((rc = ensure_lt(h))) break; }
+            if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1, h->spin_lmsel + n1 * s,
+                                  !(optimistic && s > first) ? 0 : (s == h->force_stale_at && h->spin_requeues == 0 ? 2 : 1)))) break;
+            if ((rc = launch_reweight_marg(h, d_paths + n1 * s, seg ? min_remove : 0.0, 1, d_recs + s, s, seg, optimistic && s > first))) break;
+            launched = s + 1;
+        }
+        // the likelihood sums of every path in one launch (strictly sequential additions, one wavefront per sum)
+        if (rc == GH_OK && launched > 0 && seg) {
+            hipLaunchKernelGGL(k_hp, dim3(launched, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
+                               (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
+            rc = post_launch(h, "k_hp");
+        }
+        // bring the table in step with the last reweight while its path is still allocated (the next call would
+        // otherwise refresh it from a freed buffer); rebuilds it in full when a candidate mask moved
+        if (rc == GH_OK && launched > 0) rc = ensure_lt(h);
+        // the removed mass of every path in one launch (it is only ever read by the host)
+        if (rc == GH_OK && launched > 0) {
+            hipLaunchKernelGGL(k_reweight_finish_all, dim3(launched), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
+            rc = post_launch(h, "k_reweight_finish_all");
+        }
+        if (rc != GH_OK) break;
         e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (getenv("GH_PRINT_STATE"))
+            fprintf(stderr, "gh_spin: stop %d hole_at %d n_done %d first_hole %d cur_hole %d lt_stale %d cm_same %d narrow %d ranked %d\n", hs.stop, hs.hole_at,
+                    hs.n_done, hs.first_hole, hs.cur_hole, hs.lt_stale, hs.cm_same, hs.narrow, hs.ranked);
+        if (e == hipSuccess && optimistic && hs.lt_stale && !hs.stop && hs.n_done < max_paths) {
+            // paths 0 .. n_done-1 are complete; the table has just been rebuilt by the ensure_lt above
+            const int zero = 0;
+            e = hipMemcpyAsync(&h->dstate->lt_stale, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
+            if (e == hipSuccess) { first = hs.n_done; h->spin_requeues++; continue; }
+        }
         if (e == hipSuccess && hs.n_done > 0) {
             e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
         }
         if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+        break;
     }
     if (rc) return rc;
     *n_out = hs.n_done;
@@ -1114,6 +1276,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     gh_handle *h0 = b->hs[0];
     const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
     const int N = b->N, W = b->W, L = b->L;
+    const int bwm = h0->wmode == WM_SEG ? WM_SPEC : h0->wmode;     // batched launches: one serial walker per window
     const unsigned marg_gx = (unsigned)(((N + 1) * 8 + 255) / 256);
     size_t lt_nb = ((size_t)(N + LT_PAD) * L * LT_BLK + 255) / 256;
     if (lt_nb > 4096) lt_nb = 4096;
@@ -1122,7 +1285,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     P.min_remove = min_remove;
     size_t lt_nb_inc = 64;                  // batched launches keep no walker tables: the steady-state k_lt only checks flags
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
-    const bool inc_mode = h0->cfg.cond_mode != GH_COND_C && !h0->cfg.marginal_term && !(getenv("GH_LT_FULL") && atoi(getenv("GH_LT_FULL")));
+    const bool inc_mode = lt_incremental_ok(h0);
     for (int s = 0; s < max_paths; s++) {
         // any non-null pointer tells k_lt that the fused reweight of spin s-1 has already rewritten the rows it changed
         const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
@@ -1131,34 +1294,34 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             if (f64)
                 hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
+                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
             else
                 hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0);
+                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
             hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, (const double *)nullptr, N, b->d_wd);
         }
         if (f64)
             hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                               inc, b->d_wd, s, walk_depth2_ok(L), (double *)nullptr, (double *)nullptr);
+                               inc, b->d_wd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
         else
             hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
                                h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                               inc, b->d_wd, s, walk_depth2_ok(L), (double *)nullptr, (double *)nullptr);
-        launch_walk_any(N, L, P, b->stream, n, b->d_wd, s);
+                               inc, b->d_wd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
+        launch_walk_any(bwm, N, L, P, b->stream, n, b->d_wd, s);
         if (f64)
             hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
-                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode);   // non-null = take G from wd
+                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
         else
             hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
                                (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
-                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode);   // non-null = take G from wd
+                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
         hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, (int)marg_gx,
                            (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, b->d_wd, s);
     }
@@ -1277,6 +1440,9 @@ extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     out[0] = hs.dbg[0]; out[1] = hs.dbg[1]; out[2] = hs.dbg[2]; out[3] = hs.dbg[3];
+    if (out[3] == 3) { out[0] = (uint64_t)h->spin_requeues; out[1] = 0; out[2] = 0; }
+    if (getenv("GH_PRINT_STAMPS"))      // diagnostic builds (-DSEG_STAMPS / -DGH_STAMPS)
+        fprintf(stderr, "stamps: %llu %llu %llu %llu\n", hs.dbg8[1] - hs.dbg8[0], hs.dbg8[2] - hs.dbg8[1], hs.dbg8[3] - hs.dbg8[2], hs.dbg8[4] - hs.dbg8[3]);
     return GH_OK;
 }
 

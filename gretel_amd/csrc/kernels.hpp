@@ -38,6 +38,8 @@ struct dev_state {
     int ranked;      // layout of G as k_lt last built it: 1 = rows/columns are candidate RANKS (see k_lt), 0 = symbols
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
     unsigned long long dbg8[5];  // -DGH_STAMPS builds: cycles per body segment
+    int cur_hole;    // segment-parallel walk (segwalk.hpp): first_hole as k_seg found it (k_scan re-arms the flag itself)
+    int lt_stale;    // set by k_seg when a candidate mask moved under the last reweight and no k_lt ran since (gh_spin)
 };
 
 // Batched launches (gh_batch_*): one entry per window; a kernel launched with `wd != nullptr` takes its
@@ -58,6 +60,10 @@ struct win_desc {
 };
 
 __constant__ int8_t c_sym_of_char[256];
+
+// segwalk.hpp (segment-parallel path extension); k_marg<T,true> closes the path record behind it
+__device__ __forceinline__ int seg_count(const dev_state *st, int N, int L);
+__device__ __forceinline__ void seg_finish(dev_state *st, gh_path_rec *rec, int N, double minm, double min_remove);
 
 __device__ __forceinline__ int vsym(int b5) { return b5 < 4 ? b5 : 5; }            // b5 -> symbol
 __device__ __forceinline__ int fsym(int a6) { return a6 < 4 ? a6 : a6 + 1; }       // a6 -> symbol (4->5, 5->6)
@@ -315,17 +321,36 @@ __global__ void __launch_bounds__(256)
 k_marg(T *band, int N, int W, double *cnt, double *marg,
        int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st, const win_desc *wd,
        const uint8_t *rw_path, double ratio_arg, int use_state_ratio, double *partial, int spin,
-       double *G, int L, int cond_mode)
+       double *G, int L, int cond_mode, const double *segmin, gh_path_rec *seg_rec)
 {
     __shared__ double s_red[256];
     bool live = true;
+    double seg_ratio = 0.0;
+    if (RW && segmin) {
+        // behind a segment-parallel walk (segwalk.hpp): the path's minimum marginal is still spread over the segments.
+        // Every workgroup reduces it for itself (<= 256 values, exact in any order); workgroup 0 closes the record the
+        // way the serial walkers' bookkeeper does.  ratio_arg carries the clamp (cmd.py:157-160).
+        const int nseg = seg_count(st, N, L);
+        s_red[threadIdx.x] = (int)threadIdx.x < nseg ? segmin[threadIdx.x] : INFINITY;
+        __syncthreads();
+        for (int q = 128; q > 0; q >>= 1) {
+            if ((int)threadIdx.x < q && s_red[threadIdx.x + q] < s_red[threadIdx.x]) s_red[threadIdx.x] = s_red[threadIdx.x + q];
+            __syncthreads();
+        }
+        const double minm = s_red[0];
+        __syncthreads();
+        seg_ratio = minm < ratio_arg ? ratio_arg : minm;
+        const bool dead = st->stop != 0 || st->lt_stale != 0 || st->cur_hole <= N;      // (workgroup 0 may set stop meanwhile: cur_hole says the same)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !st->stop && !st->lt_stale) seg_finish(st, seg_rec, N, minm, ratio_arg);
+        if (dead) live = false;
+    }
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
         band = (T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st;
         if (RW) { rw_path = d.paths + (size_t)spin * (N + 1); partial = d.partial; if (G) G = d.G; }
         live = !st->stop;
     }
-    if (RW && use_state_ratio && st->stop) live = false;
+    if (RW && use_state_ratio && !segmin && st->stop) live = false;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 3, s = t & 7;
     const bool act = live && p <= N;
@@ -334,7 +359,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
     int na = -1, nb = -1;
     T nval = (T)0;
     if (RW && act) {
-        const double ratio = use_state_ratio ? st->ratio : ratio_arg;
+        const double ratio = segmin ? seg_ratio : (use_state_ratio ? st->ratio : ratio_arg);
         for (int d = s + 1; d <= W; d += 8) {
             const int j = p + d;
             int mult = 0;
@@ -843,6 +868,7 @@ __global__ void __launch_bounds__(512) k_walk_src(walk_params P, const win_desc 
                 P.rec->hp_current = T.hp_cur;
                 P.rec->hp_original = T.hp_orig;
                 P.rec->ratio = r;                                     // the ratio the reweight will use (clamped)
+                P.rec->min_marginal = T.minm;
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
@@ -1463,6 +1489,7 @@ __global__ void __launch_bounds__(512) k_walk_spec(walk_params P, const win_desc
                 P.rec->hp_current = T.hp_cur;
                 P.rec->hp_original = T.hp_orig;
                 P.rec->ratio = r;                                     // the ratio the reweight will use (clamped)
+                P.rec->min_marginal = T.minm;
                 P.rec->magnitude = 0.0;
                 st->ratio = r;
                 st->n_done += 1;
@@ -1549,6 +1576,7 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
             P.rec->hp_current = hp_cur;
             P.rec->hp_original = hp_orig;
             P.rec->ratio = r;
+            P.rec->min_marginal = minm;
             P.rec->magnitude = 0.0;
             st->ratio = r;
             st->n_done += 1;

@@ -319,7 +319,8 @@ class Hansel:
                     hp_current=np.array([recs[q].hp_current for q in range(k)]),
                     hp_original=np.array([recs[q].hp_original for q in range(k)]),
                     ratio=np.array([recs[q].ratio for q in range(k)]),
-                    magnitude=np.array([recs[q].magnitude for q in range(k)]))
+                    magnitude=np.array([recs[q].magnitude for q in range(k)]),
+                    min_marginal=np.array([recs[q].min_marginal for q in range(k)]))
 
     def path_symbols(self, indices):
         return [self.symbols[int(q)] for q in indices]
@@ -405,7 +406,7 @@ class HanselBatch:
         n = len(self.hansels)
         n1 = self.hansels[0].n + 1
         paths = np.zeros((n, max_paths, n1), dtype=np.uint8)
-        recs = np.zeros((n, max_paths, 4), dtype=np.float64)
+        recs = np.zeros((n, max_paths, 5), dtype=np.float64)
         n_out = np.zeros(n, dtype=np.int32)
         hole = np.zeros(n, dtype=np.int32)
         check(self._lib.gh_batch_spin(self._b, int(max_paths), float(min_remove), _p(paths), _p(recs), _p(n_out), _p(hole)))
@@ -415,7 +416,8 @@ class HanselBatch:
             if k:
                 self.hansels[w].is_weighted = True
             out.append(dict(n=k, hole_at=int(hole[w]), paths=paths[w, :k], hp_current=recs[w, :k, 0].copy(),
-                            hp_original=recs[w, :k, 1].copy(), ratio=recs[w, :k, 2].copy(), magnitude=recs[w, :k, 3].copy()))
+                            hp_original=recs[w, :k, 1].copy(), ratio=recs[w, :k, 2].copy(), magnitude=recs[w, :k, 3].copy(),
+                            min_marginal=recs[w, :k, 4].copy()))
         return out
 
 

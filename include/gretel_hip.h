@@ -74,6 +74,7 @@ typedef struct {
     double hp_original;     /* gretel/gretel.py:186,189 */
     double ratio;           /* min marginal after the 1% clamp, gretel/cmd.py:157-160 */
     double magnitude;       /* reweight_hansel_from_path return, gretel/cmd.py:161 */
+    double min_marginal;    /* generate_path's third return value before the clamp (the "%.10f too small" note, cmd.py:158-160) */
 } gh_path_rec;
 
 const char *gh_last_error(void);
@@ -174,7 +175,9 @@ int gh_profile_reset(gh_t *h);
 int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches);
 /* diagnostics of the last path-extension launch: out[0] = shader cycles (s_memtime) the walker wave spent,
  * out[1] = the same interval in 100 MHz ticks (s_memrealtime), out[2] = steps it executed, out[3] = the variant
- * that ran (2 = depth-2 speculation, 1 = depth 1 without '-' candidates, 0 = depth 1 with them) */
+ * that ran (2 = depth-2 speculation, 1 = depth 1 without '-' candidates, 0 = depth 1 with them; 3 = segment-parallel
+ * walk, which has no single walker wave: then out[0] = how often the last gh_spin rebuilt the conditional table and
+ * queued its remaining paths again because a candidate mask moved, out[1] = out[2] = 0) */
 int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
 /* algorithmic bytes of the last launch of each kernel */
 int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch);

@@ -22,8 +22,32 @@ class _T:
         self.n_reads = len(reads)
 
 
-def _check(t, paths=6, L=None, want_variant=None, **kw):
-    h = Hansel(t.n_snps, band=t.band, **kw)
+class _walk_mode:
+    """GH_WALK is read when a handle is created: pin a path-extension variant for the handles made inside the block."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("GH_WALK")
+        if self.mode is None:
+            os.environ.pop("GH_WALK", None)
+        else:
+            os.environ["GH_WALK"] = self.mode
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("GH_WALK", None)
+        else:
+            os.environ["GH_WALK"] = self.old
+
+
+PINNED = bool(os.environ.get("GH_WALK") or os.environ.get("GH_WALK_THREADS"))      # A/B knobs pin a variant from outside
+
+
+def _check_one(t, paths, L, want_variant, walk, **kw):
+    with _walk_mode(walk):
+        h = Hansel(t.n_snps, band=t.band, **kw)
     o = COracle(t.n_snps, t.band, kw.get("storage", "f32"), kw.get("cond_mode", "A"), kw.get("marginal_term", False))
     assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
     if L is not None:
@@ -31,14 +55,29 @@ def _check(t, paths=6, L=None, want_variant=None, **kw):
         o.L = L
     assert h.gap_check() == o.gap_check()
     res, ref = h.spin(paths), o.spin(paths)
-    if want_variant is not None and not (os.environ.get("GH_WALK") or os.environ.get("GH_WALK_THREADS")):   # A/B knobs pin a variant
+    if want_variant is not None and res["n"]:
         assert h.walk_clock()[3] == want_variant          # which path-extension variant the last launch took
     assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"]
     assert np.array_equal(res["paths"], ref["paths"])
     assert res["hp_current"].tolist() == ref["hp_current"].tolist()
     assert res["hp_original"].tolist() == ref["hp_original"].tolist()
+    assert res["ratio"].tolist() == ref["ratio"].tolist()
     assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-12, atol=0)
     assert np.array_equal(h.export_band(), o.export_band())
+    return res, h.L
+
+
+def _check(t, paths=6, L=None, want_variant=None, **kw):
+    """The window through the default path extension (segment-parallel for L <= 5: variant 3) and, where a test names a
+    serial-walker variant (0, 1, 2), through GH_WALK=spec as well -- each against a fresh oracle."""
+    if PINNED:
+        return _check_one(t, paths, L, None, os.environ.get("GH_WALK"), **kw)[0]
+    res, eff_L = _check_one(t, paths, L, None, None, **kw)
+    if eff_L <= 5 and res["n"]:
+        _check_one(t, paths, L, 3, None, **kw)
+    if want_variant is not None or eff_L <= 5:
+        res2, _ = _check_one(t, paths, L, want_variant, "spec", **kw)
+        assert np.array_equal(res["paths"], res2["paths"]) and res["hp_current"].tolist() == res2["hp_current"].tolist()
     return res
 
 

@@ -1,0 +1,131 @@
+"""The segment-parallel path extension (gretel_amd/csrc/segwalk.hpp) against the C oracle and against the serial
+walker it replaces: every L it serves (1..5), both state radices (ranked 4-candidate layout, 5-symbol layout with '-'
+as a fifth candidate), segments longer than one LDS chunk, holes, the re-queue after a stale table, and the
+one-path API."""
+import os
+
+import numpy as np
+import pytest
+
+from gretel_amd.hansel import Hansel
+from gretel_amd.synth import make_support_table
+from oracle.c_oracle import COracle
+from test_gpu_edges import _walk_mode, PINNED
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(PINNED, reason="GH_WALK / GH_WALK_THREADS pin another variant")]
+
+
+def _with_dels(t, frac, seed):
+    bases = t.bases.copy()
+    bases[np.random.default_rng(seed).random(len(bases)) < frac] = ord('-')
+    t.bases = bases
+    return t
+
+
+def _pair(t, L=None, walk=None, **kw):
+    with _walk_mode(walk):
+        h = Hansel(t.n_snps, band=t.band, **kw)
+    o = COracle(t.n_snps, t.band, kw.get("storage", "f32"), kw.get("cond_mode", "A"), kw.get("marginal_term", False))
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    if L is not None:
+        h.L = L
+        o.L = L
+    return h, o
+
+
+def _same(res, ref):
+    assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"]
+    assert np.array_equal(res["paths"], ref["paths"])
+    assert res["hp_current"].tolist() == ref["hp_current"].tolist()
+    assert res["hp_original"].tolist() == ref["hp_original"].tolist()
+    assert res["ratio"].tolist() == ref["ratio"].tolist()
+    assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("wide", [False, True])
+def test_every_lag_count_and_both_radices(L, wide):
+    # wide: 10 % '-' on top of four bases with errors -> positions with five candidates -> the 5-symbol state space
+    t = make_support_table(900, 30000, k=6, seed=100 + L)
+    if wide:
+        t = _with_dels(t, 0.1, L)
+    h, o = _pair(t, L=L)
+    res, ref = h.spin(6), o.spin(6)
+    assert h.walk_clock()[3] == 3
+    _same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    if wide:
+        assert (h.candidate_masks()[1:] == 0x2F).any()        # some position really shows A C G T and '-'
+    # and the serial walker agrees bit for bit
+    hs, _ = _pair(t, L=L, walk="spec")
+    _same(hs.spin(6), res)
+
+
+@pytest.mark.parametrize("n,L", [(20000, 2), (30000, 1), (17000, 3)])
+def test_segments_longer_than_one_chunk(n, L):
+    # 256 segments at most: beyond 256 x 64 positions a segment spans several LDS chunks of k_seg
+    t = make_support_table(n, 12 * n, k=4, seed=7)
+    h, o = _pair(t, L=L)
+    _same(h.spin(3), o.spin(3))
+    assert h.walk_clock()[3] == 3
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 129])
+def test_window_lengths_around_the_segment_size(n):
+    t = make_support_table(max(n, 2), 200 + 40 * n, k=min(3, max(n, 2)), seed=n)
+    if n == 1:
+        return
+    h, o = _pair(t)
+    _same(h.spin(4), o.spin(4))
+
+
+def test_one_path_api_and_original_marginals():
+    t = make_support_table(400, 12000, k=5, seed=5)
+    h, o = _pair(t)
+    h.snapshot_original()
+    o.snapshot_original()
+    for _ in range(5):
+        pg, po = h.generate_path(), o.generate_path()
+        assert np.array_equal(pg[0], po[0])
+        assert pg[1:] == po[1]                         # hp_current, hp_original, min marginal (unclamped)
+        r = max(pg[3], 0.01)
+        assert abs(h.reweight_from_path(pg[0], r) - o.reweight_path(po[0], r)) <= 1e-12 * r * t.n_snps
+    assert np.array_equal(h.export_band(), o.export_band())
+
+
+def test_hole_stops_the_queue():
+    t = make_support_table(300, 2000, k=3, n_haps=1, err=0.0, seed=1)
+    h, o = _pair(t)
+    res, ref = h.spin(6), o.spin(6)
+    _same(res, ref)
+    assert res["n"] == 1 and res["hole_at"] >= 1
+    assert h.spin(3)["n"] == 0                         # and stays stopped
+
+
+def test_requeue_after_a_stale_table_changes_nothing():
+    # GH_SEG_FORCE_STALE=k: path k of the spin finds the conditional table stale (as when a candidate mask moves under
+    # a reweight): the queue behind it idles, the host rebuilds the table and queues the remaining paths again
+    t = make_support_table(600, 20000, k=5, seed=3)
+    os.environ["GH_SEG_FORCE_STALE"] = "4"
+    try:
+        h, o = _pair(t)
+    finally:
+        del os.environ["GH_SEG_FORCE_STALE"]
+    res, ref = h.spin(12), o.spin(12)
+    assert h.walk_clock()[:4] == (1, 0, 0, 3)          # one re-queue
+    _same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    h2, _ = _pair(t)
+    _same(h2.spin(12), res)
+    assert h2.walk_clock()[0] == 0
+
+
+@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(cond_mode="C"), dict(marginal_term=True), dict(storage="f64"),
+                                dict(storage="f64", cond_mode="B", marginal_term=True)])
+def test_every_switch(kw):
+    # conditional C and the marginal term rebuild the table in full before every path (no incremental rows)
+    t = _with_dels(make_support_table(500, 15000, k=5, n_haps=4, seed=21), 0.05, 2)
+    h, o = _pair(t, **kw)
+    _same(h.spin(5), o.spin(5))
+    assert h.walk_clock()[3] == 3
+    assert np.array_equal(h.export_band(), o.export_band())
