@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROF_STRIDE = 8
+PROF_STRIDE = 25       # HIP-event brackets on every 25th launch of each kernel (an event pair costs the stream ~10 us)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
@@ -280,17 +280,26 @@ def main():
         hap_s = n_paths_total / dt_max
         walk = prof["walk"]
         walk_ms = walk["ms"] / max(1, walk["launches"])
-        achieved = walk["bytes_per_launch"] / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else 0.0
+        seg = prof.get("seg", {"ms": 0.0, "launches": 0, "bytes_per_launch": 0.0})
+        segwalk = variant == 3                     # segment-parallel extension: k_seg + k_scan + k_emit per path
+        if segwalk and seg["launches"]:
+            dom, dom_name = seg, "k_seg (segment-parallel path extension: Next tables + all entry states of every segment)"
+            dom_bytes_def = "SURVEY 8(d), conditional lookups of the extension: N*L*196 per path (the marginal cell and the original marginals, N*224, belong to k_emit)"
+        else:
+            dom, dom_name = walk, "k_walk_spec (path extension: N dependent steps, one wavefront walks)"
+            dom_bytes_def = "SURVEY 8(d) path extension: N*((1+L)*196+28) per path"
+        dom_ms = dom["ms"] / max(1, dom["launches"])
+        achieved = dom["bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected per the
         # MI355X guide: separate --pmc runs, FETCH_SIZE x2 on gfx950); null when no profile matches
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if segwalk else "r1_pmc_traffic.json")))["kernels"]
             if cfg_name == "C3":
-                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("k_walk"))
+                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("k_seg" if segwalk else "k_walk"))
         except Exception:
             traffic = None
-        # what does bound the walker: one wavefront issues an instruction every 5 cycles (scratch/ubench6/7.hip), so the
+        # serial walker only: one wavefront issues an instruction every 5 cycles (scratch/ubench6/7.hip), so the
         # floor is 5 x the instructions per step of the inner loop as compiled (profiles/walker_isa_count.py, no GPU needed)
         issue_model = None
         try:
@@ -329,22 +338,26 @@ def main():
                      "crumbs_per_s": stats[1] / (prof["fill"]["ms"] / max(1, prof["fill"]["launches"]) * 1e-3) if prof["fill"]["ms"] else None},
             "kernels_ms_per_launch": {k: (v["ms"] / v["launches"] if v["launches"] else None) for k, v in prof.items()},
             "kernels_launches": {k: v["launches"] for k, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_walk_spec (path extension: N dependent steps, one wavefront walks)",
+            "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": walk["bytes_per_launch"],
-                         "algorithmic_bytes_definition": "SURVEY 8(d) path extension: N*((1+L)*196+28) per path",
-                         "avg_launch_ms_hip_events": walk_ms,
-                         "hip_event_sampling": "every %d-th launch of each kernel inside the timed region (%d launches)"
-                                               % (PROF_STRIDE, walk["launches"]),
-                         "walker_cycles_per_step": (cyc / nsteps) if nsteps else None,
-                         "walker_clock_ghz": (cyc / (ticks * 10.0)) if ticks else None,
+                         "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
+                         "algorithmic_bytes_definition": dom_bytes_def,
+                         "avg_launch_ms_hip_events": dom_ms,
+                         "hip_event_sampling": "every %d-th launch of each kernel inside the timed region (%d launches sampled)"
+                                               % (PROF_STRIDE, dom["launches"]),
+                         "extension_ms_per_path_hip_events": walk_ms,
+                         "walker_variant": {3: "segment-parallel (k_seg + k_scan + k_emit)", 2: "serial, depth-2 speculation",
+                                            1: "serial, depth-1 speculation, no '-' candidates", 0: "serial, depth-1 speculation"}.get(variant),
+                         "walker_cycles_per_step": (cyc / nsteps) if (nsteps and not segwalk) else None,
                          "issue_model": issue_model,
-                         "walker_variant": {2: "depth-2 speculation", 1: "depth-1 speculation, no '-' candidates",
-                                            0: "depth-1 speculation"}.get(variant),
-                         "note": "not bandwidth bound: each step needs the previous step's arg-max (gretel.py:143-187), so one "
-                                 "wavefront walks and its instruction issue rate (1 per 5 cycles) is the bound; "
-                                 "see DESIGN.md section 4 for the instruction budget per step"},
+                         "note": ("k_seg evaluates Next[t][state] for all R^L states of every position (binary64 adds and compares: "
+                                  "vector-ALU bound, then LDS-latency bound in the state walk), so its HBM traffic stays far below the "
+                                  "bandwidth roofline by construction; a path is 4 dependent kernels (k_seg, k_scan, k_emit, k_rw) "
+                                  "of 5-12 us each, about 4 us of which is launch + first-touch latency; see DESIGN.md section 4")
+                                 if segwalk else
+                                 ("not bandwidth bound: each step needs the previous step's arg-max (gretel.py:143-187), so one "
+                                  "wavefront walks and its instruction issue rate (1 per 5 cycles) is the bound")},
         }
         if world == 1 and not args.no_throughput_leg:
             # secondary figure (not `value`): the same contig replicated into 32 windows and recovered by ONE batched

@@ -161,7 +161,9 @@ static void prof_begin(gh_handle *h, int k)
     if (!h->prof) return;
     prof_slot &s = h->ps[k];
     s.open = false;
-    if ((s.seq++ % h->prof) != 0) return;
+    // (k_seg samples half a stride away from the bracket around the whole extension it is nested in, so that neither
+    // times the other's event bubbles)
+    if ((s.seq++ % h->prof) != (k == GH_K_SEG ? h->prof / 2 : 0)) return;
     if (s.used + 2 > s.ev.size()) {
         for (int q = 0; q < 2; q++) {
             hipEvent_t e;
@@ -896,8 +898,10 @@ static int alloc_seg(gh_handle *h)
 }
 
 template <int LC>
-static void launch_seg_lc(const seg_params &P, hipStream_t stream, int N, int dev)
+static void launch_seg_lc(gh_handle *h, const seg_params &P)
 {
+    hipStream_t stream = h->stream;
+    const int N = h->N, dev = h->dev;
     const seg_geom g4 = seg_geometry(N, LC, 4), g5 = seg_geometry(N, LC, 5);
     const size_t lds_seg = max2(seg_lds_bytes(4, LC), seg_lds_bytes(5, LC));
     const size_t lds_scan = max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5));
@@ -909,7 +913,10 @@ static void launch_seg_lc(const seg_params &P, hipStream_t stream, int N, int de
     if (lds_scan > set_scan[dv]) { hipFuncSetAttribute((const void *)k_scan<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan); set_scan[dv] = lds_scan; }
     if (lds_emit > set_emit[dv]) { hipFuncSetAttribute((const void *)k_emit<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit); set_emit[dv] = lds_emit; }
     const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
+    prof_begin(h, GH_K_SEG);
     hipLaunchKernelGGL((k_seg<LC>), dim3(S), dim3(SEG_THREADS), lds_seg, stream, P);
+    // algorithmic bytes of k_seg: the conditional lookups of the extension (L history cells per step)
+    prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
     hipLaunchKernelGGL((k_scan<LC>), dim3(G1), dim3(SEG_THREADS), lds_scan, stream, P);
     hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, stream, P);
 }
@@ -925,11 +932,11 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
     prof_begin(h, GH_K_WALK);
     switch (h->L) {
-        case 1: launch_seg_lc<1>(P, h->stream, h->N, h->dev); break;
-        case 2: launch_seg_lc<2>(P, h->stream, h->N, h->dev); break;
-        case 3: launch_seg_lc<3>(P, h->stream, h->N, h->dev); break;
-        case 4: launch_seg_lc<4>(P, h->stream, h->N, h->dev); break;
-        case 5: launch_seg_lc<5>(P, h->stream, h->N, h->dev); break;
+        case 1: launch_seg_lc<1>(h, P); break;
+        case 2: launch_seg_lc<2>(h, P); break;
+        case 3: launch_seg_lc<3>(h, P); break;
+        case 4: launch_seg_lc<4>(h, P); break;
+        case 5: launch_seg_lc<5>(h, P); break;
         default: return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L);
     }
     prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
@@ -991,16 +998,26 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     const bool lt_ok = (!h->dirty_lt || chained) && h->lt && h->lt_L == h->L && lt_incremental_ok(h);
     double *lt_rows = lt_ok ? h->lt : nullptr;
     prof_begin(h, GH_K_REWEIGHT);
-    if (h->cfg.storage == GH_STORAGE_F64)
+    if (seg) {
+        // behind a segment-parallel walk (L <= SEG_MAX_L <= 8: one table row per lane): segwalk.hpp's k_rw
+        if (h->cfg.storage == GH_STORAGE_F64)
+            hipLaunchKernelGGL((k_rw<double>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
+                               h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L,
+                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec);
+        else
+            hipLaunchKernelGGL((k_rw<float>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
+                               h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L,
+                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec);
+    } else if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
-                           seg ? (const double *)h->seg_min : (const double *)nullptr, d_rec);
+                           (const double *)nullptr, (gh_path_rec *)nullptr);
     else
         hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
-                           seg ? (const double *)h->seg_min : (const double *)nullptr, d_rec);
+                           (const double *)nullptr, (gh_path_rec *)nullptr);
     if (slot < 0)
         hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, partial, nb, h->dstate, use_state, d_rec,
                            (const win_desc *)nullptr, 0);

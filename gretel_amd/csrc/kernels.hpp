@@ -1,4 +1,5 @@
 #include <type_traits>
+#include <cstddef>
 // kernels.hpp -- the gfx950 kernels of the Gretel hot path (included by gretel_hip.hip).
 //
 // Symbol indices (reference order, gretel/util.py:83):  A0 C1 G2 T3 N4 -5 _6.
@@ -14,6 +15,7 @@
 //                                 [11..15] log10 ORIGINAL marginal of b5 (written by the snapshot)
 //   G[i][a6][l-1][b5] f64         source-major conditional table, see k_lt
 #pragma once
+#include "seg_geom.hpp"
 
 #define NSYM 7
 #define CELL 49
@@ -24,23 +26,36 @@
 #define LT_BLK 30        /* 6 from-symbols x 5 to-symbols */
 #define MINFO 16
 
+// The first 64 bytes are the control words every kernel of a path reads: one line, one (scalar) load -- each separate
+// dependent load of a word the previous kernel wrote costs a kernel about a microsecond before it can start.
 struct dev_state {
-    int stop;        // set by the walker at a hole: later launches of the spin become no-ops
+    int stop;        // set at a hole: later launches of the spin become no-ops
     int hole_at;
     int n_done;
     int scratch;
-    double ratio;    // clamped min marginal of the path just walked
-    unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
-    int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish
-    int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)
-    int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one
-    int narrow;      // stays non-zero while every position has at most 4 candidates (k_marg)
+    int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish   } contiguous:
+    int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)     } re-armed
+    int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one  } with one
+    int narrow;      // stays non-zero while every position has at most 4 candidates (k_marg)      } memset
     int ranked;      // layout of G as k_lt last built it: 1 = rows/columns are candidate RANKS (see k_lt), 0 = symbols
-    unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
-    unsigned long long dbg8[5];  // -DGH_STAMPS builds: cycles per body segment
     int cur_hole;    // segment-parallel walk (segwalk.hpp): first_hole as k_seg found it (k_scan re-arms the flag itself)
     int lt_stale;    // set by k_seg when a candidate mask moved under the last reweight and no k_lt ran since (gh_spin)
+    int _r0;
+    double ratio;    // clamped min marginal of the path just walked
+    double _r1;
+    unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
+    unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
+    unsigned long long dbg8[5];  // -DGH_STAMPS / -DSEG_STAMPS builds: cycles per segment of the code
 };
+
+struct dev_ctl {
+    int stop, hole_at, n_done, scratch, first_hole, nodel, cm_same, narrow, ranked, cur_hole, lt_stale, _r0;
+    double ratio, _r1;
+};
+static_assert(sizeof(dev_ctl) == 64 && offsetof(dev_state, fill) == 64, "control words = the first line of dev_state");
+
+// all control words at once (call before the kernel's first store)
+__device__ __forceinline__ dev_ctl load_ctl(const dev_state *st) { return *reinterpret_cast<const dev_ctl *>(st); }
 
 // Batched launches (gh_batch_*): one entry per window; a kernel launched with `wd != nullptr` takes its
 // window from blockIdx.y (blockIdx.x for the walkers) and its buffers from wd[window].
@@ -62,7 +77,6 @@ struct win_desc {
 __constant__ int8_t c_sym_of_char[256];
 
 // segwalk.hpp (segment-parallel path extension); k_marg<T,true> closes the path record behind it
-__device__ __forceinline__ int seg_count(const dev_state *st, int N, int L);
 __device__ __forceinline__ void seg_finish(dev_state *st, gh_path_rec *rec, int N, double minm, double min_remove);
 
 __device__ __forceinline__ int vsym(int b5) { return b5 < 4 ? b5 : 5; }            // b5 -> symbol
@@ -330,7 +344,8 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         // behind a segment-parallel walk (segwalk.hpp): the path's minimum marginal is still spread over the segments.
         // Every workgroup reduces it for itself (<= 256 values, exact in any order); workgroup 0 closes the record the
         // way the serial walkers' bookkeeper does.  ratio_arg carries the clamp (cmd.py:157-160).
-        const int nseg = seg_count(st, N, L);
+        const dev_ctl c = load_ctl(st);
+        const int nseg = seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
         s_red[threadIdx.x] = (int)threadIdx.x < nseg ? segmin[threadIdx.x] : INFINITY;
         __syncthreads();
         for (int q = 128; q > 0; q >>= 1) {
@@ -340,8 +355,8 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         const double minm = s_red[0];
         __syncthreads();
         seg_ratio = minm < ratio_arg ? ratio_arg : minm;
-        const bool dead = st->stop != 0 || st->lt_stale != 0 || st->cur_hole <= N;      // (workgroup 0 may set stop meanwhile: cur_hole says the same)
-        if (blockIdx.x == 0 && threadIdx.x == 0 && !st->stop && !st->lt_stale) seg_finish(st, seg_rec, N, minm, ratio_arg);
+        const bool dead = c.stop != 0 || c.lt_stale != 0 || c.cur_hole <= N;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && !c.stop && !c.lt_stale) seg_finish(st, seg_rec, N, minm, ratio_arg);
         if (dead) live = false;
     }
     if (wd) {

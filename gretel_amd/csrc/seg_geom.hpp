@@ -1,0 +1,83 @@
+// seg_geom.hpp -- how the segment-parallel path extension (segwalk.hpp) cuts a window: states, segments, groups, LDS
+// sizes.  Plain constexpr / inline functions shared by the host (buffer and grid sizes) and the kernels; the state
+// radix R is only known on the device (st->ranked), so the host sizes for both.
+#pragma once
+
+#define SEG_THREADS 1024
+// diagnostic builds only (-DSEG_STAMPS): s_memtime at the phase boundaries of k_seg's workgroup 0 into st->dbg8
+#ifdef SEG_STAMPS
+#define SEG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) P.st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEG_STAMP(i)
+#endif
+// -DRW_STAMPS: the same inside k_rw's workgroup 100 (every stamp waits for the memory operations issued before it)
+#ifdef RW_STAMPS
+#define RW_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 100 && threadIdx.x == 0) st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RW_STAMP(i)
+#endif
+#define SEG_MIN_LEN 8          /* shortest segment (positions) */
+#define SEG_MAX_L 5            /* 5^5 = 3125 states still fit; beyond that the serial walkers run */
+
+template <int R> struct seg_radix;
+template <> struct seg_radix<4> { typedef uint8_t next_t;  static constexpr int BITS = 2, DPW = 16; };   // 4 picks of 2 bits per entry
+template <> struct seg_radix<5> { typedef uint16_t next_t; static constexpr int BITS = 3, DPW = 10; };   // 5 picks of 3 bits
+// (DPW: picks per 32-bit word of hist)
+__host__ __device__ constexpr int seg_dpw(int R) { return R == 4 ? 16 : 10; }
+
+__host__ __device__ constexpr int seg_ipow(int b, int e) { int r = 1; for (int i = 0; i < e; i++) r *= b; return r; }
+
+// positions per LDS chunk of k_seg: the slice of G ((c + L - 1) sources x L lags x R x R doubles) and the chunk's
+// Next tables (c x R^(L-1) entries) within 96 KB, at most 64
+__host__ __device__ constexpr int seg_chunk(int R, int L)
+{
+    const int NI = seg_ipow(R, L - 1), sz = R == 4 ? 1 : 2;
+    int c = 64;
+    while (c > 8 && ((c + L - 1) * L * R * R * 8 + c * NI * sz) > 96 * 1024) c -= 8;
+    return c / seg_dpw(R) * seg_dpw(R);        // whole words of hist per chunk
+}
+
+struct seg_geom {
+    int NS, NI;         // states, entries per position (= NS / R: one entry holds the picks of all R oldest digits)
+    int seglen, S;      // positions per segment, segments
+    int G1, G2;         // groups, segments per group
+    int NW;             // 32-bit words of hist per (segment, entry state)
+};
+
+// the same on host and device; R is only known on the device (st->ranked), the host sizes for both
+__host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
+{
+    seg_geom g;
+    g.NS = seg_ipow(R, L);
+    g.NI = g.NS / R;
+    int g2 = 32768 / g.NS;                      // one group's maps (G2 x NS x 2 bytes) within 64 KB of LDS
+    if (g2 > 16) g2 = 16;
+    if (g2 < 1) g2 = 1;
+    const int g1max = g.NS > 2048 ? 12 : 16;
+    const int smax = g1max * g2;
+    int len = (N + smax - 1) / smax;
+    if (len < SEG_MIN_LEN) len = SEG_MIN_LEN;
+    g.seglen = len;
+    g.S = (N + len - 1) / len;
+    g.G2 = g2;
+    g.G1 = (g.S + g2 - 1) / g2;
+    // whole chunks except the last, each a whole number of words
+    g.NW = (len / seg_chunk(R, L)) * (seg_chunk(R, L) / seg_dpw(R)) + (len % seg_chunk(R, L) + seg_dpw(R) - 1) / seg_dpw(R);
+    return g;
+}
+
+__host__ __device__ constexpr size_t seg_lds_bytes(int R, int L)
+{
+    return (size_t)(seg_chunk(R, L) + L - 1) * L * R * R * 8 + (size_t)seg_chunk(R, L) * seg_ipow(R, L - 1) * (R == 4 ? 1 : 2);
+}
+__host__ __device__ inline size_t scan_lds_bytes(int N, int L, int R)
+{
+    const seg_geom g = seg_geometry(N, L, R);
+    return (size_t)g.G2 * g.NS * 2;
+}
+__host__ __device__ inline size_t emit_lds_bytes(int N, int L, int R)
+{
+    const seg_geom g = seg_geometry(N, L, R);
+    return (size_t)g.G1 * g.NS * 2;             // the group maps in front (<= G1 - 1) and the segment's prefix map
+}
+

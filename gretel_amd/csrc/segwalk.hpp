@@ -26,77 +26,7 @@
 // the serial walkers (which stay: L > 5, batched launches, GH_WALK=spec).  Work per path: N * R^L sums instead of N.
 #pragma once
 
-#define SEG_THREADS 1024
-// diagnostic builds only (-DSEG_STAMPS): s_memtime at the phase boundaries of k_seg's workgroup 0 into st->dbg8
-#ifdef SEG_STAMPS
-#define SEG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) P.st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SEG_STAMP(i)
-#endif
-#define SEG_MIN_LEN 8          /* shortest segment (positions) */
-#define SEG_MAX_L 5            /* 5^5 = 3125 states still fit; beyond that the serial walkers run */
-
-template <int R> struct seg_radix;
-template <> struct seg_radix<4> { typedef uint8_t next_t;  static constexpr int BITS = 2, DPW = 16; };   // 4 picks of 2 bits per entry
-template <> struct seg_radix<5> { typedef uint16_t next_t; static constexpr int BITS = 3, DPW = 10; };   // 5 picks of 3 bits
-// (DPW: picks per 32-bit word of hist)
-__host__ __device__ constexpr int seg_dpw(int R) { return R == 4 ? 16 : 10; }
-
-__host__ __device__ constexpr int seg_ipow(int b, int e) { int r = 1; for (int i = 0; i < e; i++) r *= b; return r; }
-
-// positions per LDS chunk of k_seg: the slice of G ((c + L - 1) sources x L lags x R x R doubles) and the chunk's
-// Next tables (c x R^(L-1) entries) within 96 KB, at most 64
-__host__ __device__ constexpr int seg_chunk(int R, int L)
-{
-    const int NI = seg_ipow(R, L - 1), sz = R == 4 ? 1 : 2;
-    int c = 64;
-    while (c > 8 && ((c + L - 1) * L * R * R * 8 + c * NI * sz) > 96 * 1024) c -= 8;
-    return c / seg_dpw(R) * seg_dpw(R);        // whole words of hist per chunk
-}
-
-struct seg_geom {
-    int NS, NI;         // states, entries per position (= NS / R: one entry holds the picks of all R oldest digits)
-    int seglen, S;      // positions per segment, segments
-    int G1, G2;         // groups, segments per group
-    int NW;             // 32-bit words of hist per (segment, entry state)
-};
-
-// the same on host and device; R is only known on the device (st->ranked), the host sizes for both
-__host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
-{
-    seg_geom g;
-    g.NS = seg_ipow(R, L);
-    g.NI = g.NS / R;
-    int g2 = 32768 / g.NS;                      // one group's maps (G2 x NS x 2 bytes) within 64 KB of LDS
-    if (g2 > 16) g2 = 16;
-    if (g2 < 1) g2 = 1;
-    const int g1max = g.NS > 2048 ? 12 : 16;
-    const int smax = g1max * g2;
-    int len = (N + smax - 1) / smax;
-    if (len < SEG_MIN_LEN) len = SEG_MIN_LEN;
-    g.seglen = len;
-    g.S = (N + len - 1) / len;
-    g.G2 = g2;
-    g.G1 = (g.S + g2 - 1) / g2;
-    // whole chunks except the last, each a whole number of words
-    g.NW = (len / seg_chunk(R, L)) * (seg_chunk(R, L) / seg_dpw(R)) + (len % seg_chunk(R, L) + seg_dpw(R) - 1) / seg_dpw(R);
-    return g;
-}
-
-__host__ __device__ constexpr size_t seg_lds_bytes(int R, int L)
-{
-    return (size_t)(seg_chunk(R, L) + L - 1) * L * R * R * 8 + (size_t)seg_chunk(R, L) * seg_ipow(R, L - 1) * (R == 4 ? 1 : 2);
-}
-__host__ __device__ inline size_t scan_lds_bytes(int N, int L, int R)
-{
-    const seg_geom g = seg_geometry(N, L, R);
-    return (size_t)g.G2 * g.NS * 2;
-}
-__host__ __device__ inline size_t emit_lds_bytes(int N, int L, int R)
-{
-    const seg_geom g = seg_geometry(N, L, R);
-    return (size_t)g.G1 * g.NS * 2;             // the group maps in front (<= G1 - 1) and the segment's prefix map
-}
+#include "seg_geom.hpp"
 
 struct seg_params {
     int N, L;
@@ -117,13 +47,25 @@ struct seg_params {
 // -------------------------------------------------------------------------------------------------------------
 // k_seg
 // -------------------------------------------------------------------------------------------------------------
+// first-wins arg-max over R sums (gretel.py:166-174: the first candidate is the incumbent, a later one wins on strict >)
+template <int R>
+__device__ __forceinline__ unsigned seg_argmax(const double (&v)[R])
+{
+    double best = v[0];
+    unsigned bi = 0;
+#pragma unroll
+    for (int b = 1; b < R; b++)
+        if (v[b] > best) { best = v[b]; bi = b; }
+    return bi;
+}
+
 template <int R, int LC>
 __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *smem)
 {
     typedef typename seg_radix<R>::next_t next_t;
     constexpr int BITS = seg_radix<R>::BITS;
     constexpr unsigned MASK = (1u << BITS) - 1u;
-    constexpr int NS = seg_ipow(R, LC), NI = NS / R, RR = R * R;
+    constexpr unsigned NS = seg_ipow(R, LC), NI = NS / R, RR = R * R;
     constexpr int CH = seg_chunk(R, LC);
     constexpr int SPT = (NS + SEG_THREADS - 1) / SEG_THREADS;      // states per thread
     const seg_geom g = seg_geometry(P.N, LC, R);
@@ -134,9 +76,9 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
     double *Gs = reinterpret_cast<double *>(smem);                 // [(CH + LC - 1)][LC][R][R]
     next_t *Nx = reinterpret_cast<next_t *>(Gs + (size_t)(CH + LC - 1) * LC * RR);   // [CH][NI]
 
-    int sigma[SPT];
+    unsigned sigma[SPT];                                           // (threads beyond NS walk state 0 and store nothing)
 #pragma unroll
-    for (int q = 0; q < SPT; q++) sigma[q] = tid + q * SEG_THREADS;
+    for (int q = 0; q < SPT; q++) sigma[q] = (unsigned)(tid + q * SEG_THREADS) < NS ? (unsigned)(tid + q * SEG_THREADS) : 0u;
 
     SEG_STAMP(0);
     for (int c0 = t0; c0 < t1; c0 += CH) {
@@ -145,7 +87,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
         // rows of the R digits and the R candidate columns.  Position 0 carries '_' whatever the digit says (row 5);
         // positions < 0 do not exist: their terms are +0.0, which leaves every partial sum as it is.
         const int nsrc = nc + LC - 1;
-        for (int e = tid; e < nsrc * LC * RR; e += SEG_THREADS) {
+        for (int e = tid; e < nsrc * LC * (int)RR; e += SEG_THREADS) {
             const int b = e % R, d = (e / R) % R, l = (e / RR) % LC, ii = e / (RR * LC);
             const int i = c0 + 1 - LC + ii;
             double v = 0.0;
@@ -154,47 +96,58 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
         }
         __syncthreads();
         SEG_STAMP(1);
-        // (1b) Next for every (target, state): entry idx holds the digits d_1 .. d_{L-1} (d_1 lowest); the R picks for the
-        // R values of the oldest digit d_L share the partial sum over lags 1 .. L-1.  Lag l of chunk-local target tl
-        // comes from slot tl + LC - l.
-        for (int task = tid; task < nc * NI; task += SEG_THREADS) {
-            const int tl = task / NI, idx = task - tl * NI;
-            double acc[R];
-            if constexpr (LC >= 2) {
-                int rem = idx;
-                {
-                    const int d = rem % R;
-                    rem /= R;
-                    const double *row = Gs + ((size_t)((tl + LC - 1) * LC + 0) * R + d) * R;
+        // (1b) Next for every (target, state).  Entry idx of a position holds the digits d_1 .. d_{L-1} (d_1 lowest) and
+        // the R picks for the R values of the oldest digit d_L.  A task takes the digits d_1 .. d_{L-1-SH} as given and
+        // loops over the SH oldest but one itself (SH = 1 for L >= 4: the partial sum over the young lags and the R x R
+        // terms of lag L are shared by R entries, a third of the LDS reads and a fifth fewer additions).  Lag l of
+        // chunk-local target tl comes from slot tl + LC - l.  Same additions, same order, for every state.
+        {
+            constexpr int SH = LC >= 4 ? 1 : 0;                    // digits looped inside a task besides d_L
+            constexpr unsigned NJ = NI / (SH ? R : 1);             // tasks per position
+            for (unsigned task = tid; task < (unsigned)nc * NJ; task += SEG_THREADS) {
+                const unsigned tl = task / NJ, j = task - tl * NJ;
+                double xl[R][R];                                   // lag L, every value of d_L
 #pragma unroll
-                    for (int b = 0; b < R; b++) acc[b] = row[b];
+                for (int dL = 0; dL < R; dL++) {
+                    const double *row = Gs + ((size_t)(tl * LC + (LC - 1)) * R + dL) * R;
+#pragma unroll
+                    for (int b = 0; b < R; b++) xl[dL][b] = row[b];
+                }
+                double acc[R];
+                unsigned rem = j;
+                constexpr int NYOUNG = LC - 1 - SH;                // lags summed before the in-task loop
+                if constexpr (NYOUNG >= 1) {
+#pragma unroll
+                    for (int l = 1; l <= NYOUNG; l++) {
+                        const unsigned d = rem % R;
+                        rem /= R;
+                        const double *row = Gs + ((size_t)((tl + LC - l) * LC + (l - 1)) * R + d) * R;
+#pragma unroll
+                        for (int b = 0; b < R; b++) acc[b] = l == 1 ? row[b] : acc[b] + row[b];
+                    }
                 }
 #pragma unroll
-                for (int l = 2; l < LC; l++) {
-                    const int d = rem % R;
-                    rem /= R;
-                    const double *row = Gs + ((size_t)((tl + LC - l) * LC + (l - 1)) * R + d) * R;
+                for (int dS = 0; dS < (SH ? R : 1); dS++) {
+                    double acc2[R];
+                    if constexpr (SH) {                            // lag L-1 under digit dS
+                        const double *row = Gs + ((size_t)((tl + 1) * LC + (LC - 2)) * R + dS) * R;
 #pragma unroll
-                    for (int b = 0; b < R; b++) acc[b] = acc[b] + row[b];
+                        for (int b = 0; b < R; b++) acc2[b] = NYOUNG >= 1 ? acc[b] + row[b] : row[b];
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < R; b++) acc2[b] = acc[b];
+                    }
+                    unsigned packed = 0;
+#pragma unroll
+                    for (int dL = 0; dL < R; dL++) {
+                        double v[R];
+#pragma unroll
+                        for (int b = 0; b < R; b++) v[b] = LC >= 2 ? acc2[b] + xl[dL][b] : xl[dL][b];
+                        packed |= seg_argmax<R>(v) << (BITS * dL);
+                    }
+                    Nx[(size_t)tl * NI + j + (SH ? dS * NJ : 0)] = (next_t)packed;
                 }
             }
-            unsigned packed = 0;
-#pragma unroll
-            for (int dL = 0; dL < R; dL++) {
-                const double *row = Gs + ((size_t)(tl * LC + (LC - 1)) * R + dL) * R;
-                double best;
-                unsigned bi = 0;
-#pragma unroll
-                for (int b = 0; b < R; b++) {
-                    double v;
-                    if constexpr (LC >= 2) v = acc[b] + row[b];
-                    else v = row[b];
-                    if (b == 0) best = v;
-                    else if (v > best) { best = v; bi = b; }          // first wins, later only on strict > (gretel.py:166-174)
-                }
-                packed |= bi << (BITS * dL);
-            }
-            Nx[task] = (next_t)packed;
         }
         __syncthreads();
         SEG_STAMP(2);
@@ -202,38 +155,41 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
         {
             constexpr int DPW = seg_radix<R>::DPW;
             const int w0 = (c0 - t0) / DPW;                        // chunks are whole words
-            for (int tw = 0; tw < nc; tw += DPW) {
+            auto walk_word = [&](int tw, int nu, auto full_) {
+                constexpr bool full = decltype(full_)::value;      // a whole word: no per-step bound checks in the chain
                 unsigned word[SPT];
 #pragma unroll
                 for (int q = 0; q < SPT; q++) word[q] = 0;
+                const next_t *rows = Nx + (size_t)tw * NI;
 #pragma unroll
                 for (int u = 0; u < DPW; u++) {
-                    const int tl = tw + u;
-                    if (tl < nc) {
-                        const next_t *row = Nx + (size_t)tl * NI;
+                    if (full || u < nu) {
 #pragma unroll
                         for (int q = 0; q < SPT; q++) {
-                            const int sg = sigma[q] < NS ? sigma[q] : 0;
-                            const int hi = sg / NI, idx = sg - hi * NI;
-                            const unsigned d = ((unsigned)row[idx] >> (BITS * hi)) & MASK;
+                            const unsigned sg = sigma[q];
+                            const unsigned hi = sg / NI, idx = sg - hi * NI;
+                            const unsigned d = ((unsigned)rows[u * NI + idx] >> (BITS * hi)) & MASK;
                             word[q] |= d << (BITS * u);
-                            sigma[q] = sigma[q] < NS ? idx * R + (int)d : sigma[q];
+                            sigma[q] = idx * R + d;
                         }
                     }
                 }
 #pragma unroll
                 for (int q = 0; q < SPT; q++) {
-                    const int s0 = tid + q * SEG_THREADS;
+                    const unsigned s0 = tid + q * SEG_THREADS;
                     if (s0 < NS) P.hist[((size_t)s * g.NW + w0 + tw / DPW) * NS + s0] = word[q];
                 }
-            }
+            };
+            int tw = 0;
+            for (; tw + DPW <= nc; tw += DPW) walk_word(tw, DPW, std::true_type{});
+            if (tw < nc) walk_word(tw, nc - tw, std::false_type{});
         }
         SEG_STAMP(3);
         __syncthreads();                                           // Gs / Nx are overwritten by the next chunk
     }
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
-        const int s0 = tid + q * SEG_THREADS;
+        const unsigned s0 = tid + q * SEG_THREADS;
         if (s0 < NS) P.maps[(size_t)s * NS + s0] = (uint16_t)sigma[q];
     }
     SEG_STAMP(4);
@@ -244,16 +200,17 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     dev_state *st = P.st;
-    if (st->stop || st->lt_stale) return;
-    if (P.check_masks == 2 || (P.check_masks && __builtin_amdgcn_readfirstlane(st->cm_same) == 0)) {      // (2: forced, tests)
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale) return;
+    if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {      // (2: forced, tests)
         // k_marg<T,true> saw a candidate mask change: V(p) and the -inf masks in G moved, the rows it rewrote are not
         // enough.  Every kernel queued behind this one returns at once; the host rebuilds G and queues the paths again.
         if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
         return;
     }
     // the flags k_marg left for this path; k_scan re-arms them for the next k_marg, k_emit reads the copy
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = st->first_hole;
-    if (__builtin_amdgcn_readfirstlane(st->ranked) != 0) seg_body<4, LC>(P, seg_smem);
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC>(P, seg_smem);
     else seg_body<5, LC>(P, seg_smem);
 }
 
@@ -288,12 +245,13 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     dev_state *st = P.st;
-    if (st->stop || st->lt_stale) return;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale) return;
     // (a path that ends in a hole is followed by no k_marg: the flags must stand, as after the serial walkers)
-    if (P.rearm && st->cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (P.rearm && c.cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
         st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f;
     }
-    if (__builtin_amdgcn_readfirstlane(st->ranked) != 0) scan_body<4, LC>(P, seg_smem);
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) scan_body<4, LC>(P, seg_smem);
     else scan_body<5, LC>(P, seg_smem);
 }
 
@@ -301,7 +259,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
 // k_emit
 // -------------------------------------------------------------------------------------------------------------
 template <int R, int LC>
-__device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *smem)
+__device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *smem, int first_hole)
 {
     constexpr int BITS = seg_radix<R>::BITS, DPW = seg_radix<R>::DPW;
     constexpr unsigned MASK = (1u << BITS) - 1u;
@@ -311,7 +269,6 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
     const seg_geom g = seg_geometry(P.N, LC, R);
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= g.S) return;
-    const int first_hole = P.st->cur_hole;
     const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;       // positions that can be decided (gretel.py:176-180)
     const int t0 = s * g.seglen;
     int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
@@ -393,10 +350,11 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit(seg_params P)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
     dev_state *st = P.st;
-    if (st->stop || st->lt_stale) return;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->dbg[3] = 3;      // gh_debug_walk_clock: variant 3 = segment-parallel
-    if (__builtin_amdgcn_readfirstlane(st->ranked) != 0) emit_body<4, LC>(P, seg_smem);
-    else emit_body<5, LC>(P, seg_smem);
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC>(P, seg_smem, c.cur_hole);
+    else emit_body<5, LC>(P, seg_smem, c.cur_hole);
 }
 
 // what the serial walkers' bookkeeper does at the end of a walk: hole -> stop, else the record and the ratio the
@@ -420,6 +378,216 @@ __device__ __forceinline__ void seg_finish(dev_state *st, gh_path_rec *rec, int 
 __device__ __forceinline__ int seg_count(const dev_state *st, int N, int L)
 {
     return seg_geometry(N, L, st->ranked != 0 ? 4 : 5).S;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_rw: what k_marg<T, true> does behind a serial walker -- reweight the path's cells (gretel/gretel.py:79-98, same
+// multiplicities), the marginals of every position from the cell (p, p+1) just updated, the rows of the conditional
+// table the path changed -- behind a segment-parallel walk, where it also reduces the minimum marginal over the
+// segments, clamps it (cmd.py:157-160) and closes the path record.  Same thread layout (8 lanes per position), same
+// arithmetic in the same order, so the same bits; what differs is the order of the MEMORY operations: a kernel this
+// small is a chain of dependent round trips (each about a microsecond), so every load whose address does not depend
+// on the path's symbols or on the ratio is issued up front, the band row a lane rewrites is read ONCE (the element it
+// reweights, the row sum of the conditional and the row's entries all come out of those registers), and nothing is
+// read back after a store.
+// -------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
+     const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
+     gh_path_rec *rec)
+{
+    __shared__ double s_red[256];
+    const int tid = threadIdx.x;
+    RW_STAMP(0);
+    const dev_ctl c = load_ctl(st);
+    const int nseg = seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
+    const double my_segmin = tid < nseg ? segmin[tid] : INFINITY;
+    if (c.stop || c.lt_stale) return;
+    if (c.cur_hole <= N) {                                  // the walk ended in a hole: nothing to reweight (gretel.py:176-180)
+        if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, 0.0, min_remove);
+        return;
+    }
+    const int t = blockIdx.x * 256 + tid;
+    const int p = t >> 3, s = t & 7;
+    const bool act = p <= N;
+    const int pp = act ? p : 0;
+    // ---- round 1 ---------------------------------------------------------------------------------------------
+    const int d0 = s + 1;                                   // this lane's distance (reweight) and lag (table row)
+    const int j0 = pp + d0;
+    int mult0 = 0;                                          // multiplicities of the reference's pair enumeration
+    if (act && d0 <= W) {
+        if (j0 <= N - 1) mult0 = (d0 == 1) ? 2 : 1;
+        else if (j0 == N) mult0 = (d0 == 1) ? 1 : 0;
+        else if (j0 == N + 1) mult0 = (pp == N) ? 1 : 0;
+    }
+    const int a = path[pp];
+    const int b0 = mult0 ? ((j0 == N + 1) ? path[0] : path[j0]) : 0;
+    const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N;       // this lane owns the table row of lag d0
+    const T *cell = band + ((size_t)pp * W) * CELL;         // cell (p, p+1)
+    T crow[NSYM];
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? cell[s * NSYM + x] : (T)0;
+    int nv_t = 0;
+    uint32_t cm_t = 0;
+    if (lag_row) { nv_t = nvalid[j0]; cm_t = cmask[j0]; }
+    const uint32_t cm_old = (act && s == 7) ? cmask[pp] : 0u;
+    // ---- the path's minimum marginal, while round 1 is in flight ----------------------------------------------
+    s_red[tid] = my_segmin;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q && s_red[tid + q] < s_red[tid]) s_red[tid] = s_red[tid + q];
+        __syncthreads();
+    }
+    const double minm = s_red[0];
+    __syncthreads();
+    RW_STAMP(1);
+    const double ratio = minm < min_remove ? min_remove : minm;
+    if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, minm, min_remove);
+    // ---- round 2: the row of cell (p, p+d0) under the path's symbol at p ---------------------------------------
+    const bool need_row = act && d0 <= W && (mult0 > 0 || lag_row);
+    T *rowp = band + ((size_t)pp * W + (d0 <= W ? d0 - 1 : 0)) * CELL + a * NSYM;
+    T rrow[NSYM];
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rowp[x] : (T)0;
+    RW_STAMP(2);
+    // ---- reweight ---------------------------------------------------------------------------------------------
+    double removed = 0.0;
+    int na = -1, nb = -1;
+    T nval = (T)0;
+    if (mult0) {
+        T cur = (T)0;
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) cur = (x == b0) ? rrow[x] : cur;
+        for (int q = 0; q < mult0; q++) {
+            const double old = (double)cur;
+            const double nw = old - ratio * old;
+            cur = (T)nw;
+            removed += old - nw;
+        }
+        rowp[b0] = cur;
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) rrow[x] = (x == b0) ? cur : rrow[x];
+        if (d0 == 1) { na = a; nb = b0; nval = cur; }
+    }
+    for (int d = d0 + 8; act && d <= W; d += 8) {           // bands wider than 8: the remaining distances, one by one
+        const int j = p + d;
+        int mult = 0;
+        if (j <= N - 1) mult = 1;
+        else if (j == N + 1) mult = (p == N) ? 1 : 0;
+        if (mult) {
+            const int b = (j == N + 1) ? path[0] : path[j];
+            T *e = band + ((size_t)p * W + (d - 1)) * CELL + a * NSYM + b;
+            const double old = (double)*e;
+            const double nw = old - ratio * old;
+            *e = (T)nw;
+            removed += old - nw;
+        }
+    }
+    na = __shfl(na, 0, 8); nb = __shfl(nb, 0, 8);
+    nval = (T)__shfl((double)nval, 0, 8);
+    // ---- marginals of position p (k_marg, same order of operations) ---------------------------------------------
+    double cs[NSYM];
+    double tot = 0.0;
+    int nv = 0;
+    uint32_t cm = 0, cm5 = 0;
+    T acc = (T)0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) {
+        T v = crow[x];
+        if (s == na && x == nb) v = nval;                   // the element this group has just rewritten
+        acc = acc + v;
+    }
+    const double mine = (double)acc;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) {
+        cs[x] = __shfl(mine, x, 8);
+        if (cs[x] > 0) {
+            tot += cs[x];
+            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; cm5 |= 1u << a6_of_sym(x); }
+        }
+    }
+    if (act) {
+        if (s < NSYM) {
+            const double m = (cs[s] > 0 && tot != 0.0) ? cs[s] / tot : 0.0;
+            cnt[(size_t)p * 8 + s] = cs[s];
+            marg[(size_t)p * 8 + s] = m;
+            if ((VALID_MASK >> s) & 1) {
+                const int b5 = a6_of_sym(s);
+                minfo[(size_t)p * MINFO + b5] = gh_log10(m);
+                minfo[(size_t)p * MINFO + 5 + b5] = m;
+            }
+        } else {
+            cnt[(size_t)p * 8 + 7] = tot;
+            marg[(size_t)p * 8 + 7] = 0.0;
+            nvalid[p] = nv;
+            if (cm_old != cm) atomicAnd(&st->cm_same, 0);         // the conditional table must then be rebuilt in full
+            cmask[p] = cm;
+            minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
+            if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
+            if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
+            if (p >= 1 && __popc(cm5) > 4) atomicAnd(&st->narrow, 0);
+        }
+    }
+    RW_STAMP(3);
+    // ---- the table row of lag d0 (k_marg: same divisions, same log10) --------------------------------------------
+    if (G && act && p < N && a != 4) {
+        const int a6 = a6_of_sym(a);
+        const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
+        const bool ranked = c.ranked != 0;
+        int row6 = a6;
+        if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
+        if (d0 <= L && row6 >= 0) {
+            double *out = G + (((size_t)p * 6 + row6) * L + (d0 - 1)) * LT_ROW;
+            if (!(j0 <= N && (a6 < 5 || p == 0))) {
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = 0.0;
+            } else {
+                double rowv[NSYM];
+                T racc = (T)0;
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) { rowv[x] = (double)rrow[x]; racc = racc + rrow[x]; }      // zeros beyond the band
+                const double sum = (double)racc;
+                const double den = (cond_mode == GH_COND_A) ? (double)nv_t + sum : nv_i + ca;
+                double xq[LT_ROW], v[LT_ROW];
+                bool odd = false;
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) {
+                    xq[b5] = (1.0 + rowv[vsym(b5)]) / den;
+                    odd |= !gh_log10_is_normal(xq[b5]);
+                }
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
+                if (odd) {
+#pragma unroll
+                    for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
+                }
+                if (!ranked) {
+#pragma unroll
+                    for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cm_t >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
+                } else {
+                    const uint32_t cj5 = cm5_of_cmask(cm_t);
+#pragma unroll
+                    for (int rb = 0; rb < LT_ROW; rb++) {
+                        const int b5 = nth_set5(cj5, rb);
+                        double r = -INFINITY;
+#pragma unroll
+                        for (int q = 0; q < LT_ROW; q++) r = (b5 == q) ? v[q] : r;
+                        out[rb] = r;
+                    }
+                }
+            }
+        }
+    }
+    RW_STAMP(4);
+    // ---- removed mass: fixed-order tree, as k_marg ----------------------------------------------------------------
+    s_red[tid] = removed;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) s_red[tid] += s_red[tid + q];
+        __syncthreads();
+    }
+    if (tid == 0) partial[blockIdx.x] = s_red[0];
 }
 
 // lone gh_generate_path: no k_marg<T,true> follows, so the record is closed here
