@@ -35,11 +35,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
-    ap.add_argument("--paths", type=int, default=100)
+    ap.add_argument("--paths", type=int, default=0, help="paths per step (default: 100; C5: 1000 = BASELINE.md's deep reweight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-throughput-leg", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="throughput mode: this many independent windows per GPU in one batched launch")
     ap.add_argument("--cpu-snps", type=int, default=3000, help="SNP prefix used for the Python CPU baseline sample")
+    ap.add_argument("--cpu-full", action="store_true", help="CPU baseline as BASELINE.md section 3 plans it: the Python oracle on the "
+                    "whole contig (C2: every path; C3: 3 paths; minutes), instead of the bounded sample of the default run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="control-plane backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host sockets "
                          "(lets several ranks share one GPU: --share-gpu)")
@@ -73,11 +75,22 @@ def edge_evals_per_path(cmask, n, L):
     return int((S * lag).sum()), n * (n + 3) // 2 + 1
 
 
-def cpu_baseline_python(table, n_prefix, n_full):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_python(table, n_prefix, n_full, n_paths=1):
     """The reference's own call structure (Python loop, one NumPy-backed call per Hansel cell:
-    oracle/hansel_ref.py + oracle/gretel_ref.py) on a bounded sample: the first `n_prefix`
-    SNPs of the same contig, ONE full spin; extrapolated to the full contig by call counts
-    (path extension ~ N, reweight = N(N+3)/2+1 calls)."""
+    oracle/hansel_ref.py + oracle/gretel_ref.py), single process like gretel/cmd.py:148-179.
+    n_prefix == n_full: the whole contig, `n_paths` spins (C2 in full, C3 3 paths).
+    n_prefix <  n_full: a bounded sample -- the first `n_prefix` SNPs of the same contig, ONE spin, extrapolated to the
+    full contig by call counts (path extension ~ N, reweight = N(N+3)/2+1 calls) -- and labelled as such."""
     from oracle import gretel_ref as G
     from oracle.hansel_ref import Hansel as PyHansel, SYMBOLS, UNSYMBOLS
     k = np.diff(table.off)
@@ -91,20 +104,31 @@ def cpu_baseline_python(table, n_prefix, n_full):
     G.fill_from_support(h, reads, n_prefix)
     t_fill = time.perf_counter() - t0
     orig = h.copy()
-    t0 = time.perf_counter()
-    path, prob, mn = G.generate_path(n_prefix, h, orig)
-    t_gen = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    G.reweight_hansel_from_path(h, path, max(mn, 0.01))
-    t_rw = time.perf_counter() - t0
+    t_gen = t_rw = 0.0
+    done = 0
+    for _ in range(n_paths):
+        t0 = time.perf_counter()
+        path, prob, mn = G.generate_path(n_prefix, h, orig)
+        t_gen += time.perf_counter() - t0
+        if path is None:
+            break
+        t0 = time.perf_counter()
+        G.reweight_hansel_from_path(h, path, max(mn, 0.01))
+        t_rw += time.perf_counter() - t0
+        done += 1
+    done = max(done, 1)
+    if n_prefix >= n_full:
+        return dict(value=done / (t_gen + t_rw), unit="haplotypes/s", cores=1, kind="port", cpu=cpu_model(),
+                    sample="Python oracle (reference call structure), the WHOLE contig (N=%d, %d reads), %d spins: "
+                           "fill %.2fs, generate_path %.2fs, reweight %.2fs; no extrapolation" % (n_full, len(reads), done, t_fill, t_gen, t_rw))
     calls_s = n_prefix * (n_prefix + 3) // 2 + 1
     calls_f = n_full * (n_full + 3) // 2 + 1
-    t_path_full = t_gen * (n_full / n_prefix) + t_rw * (calls_f / calls_s)
-    return dict(value=1.0 / t_path_full, unit="haplotypes/s", cores=1, kind="port",
-                sample="Python oracle (reference call structure), SNP prefix %d of the contig, %d reads, 1 spin: "
-                       "fill %.2fs, generate_path %.2fs, reweight %.2fs; per-path time extrapolated to N=%d by call "
-                       "counts (x%.1f extension, x%.1f reweight)" % (n_prefix, len(reads), t_fill, t_gen, t_rw, n_full,
-                                                                      n_full / n_prefix, calls_f / calls_s))
+    t_path_full = (t_gen / done) * (n_full / n_prefix) + (t_rw / done) * (calls_f / calls_s)
+    return dict(value=1.0 / t_path_full, unit="haplotypes/s", cores=1, kind="port", cpu=cpu_model(),
+                sample="EXTRAPOLATED: Python oracle (reference call structure), SNP prefix %d of the contig, %d reads, %d spin(s): "
+                       "fill %.2fs, generate_path %.2fs, reweight %.2fs; per-path time scaled to N=%d by call "
+                       "counts (x%.1f extension, x%.1f reweight); `bench.py --cpu-full` times the whole contig instead"
+                       % (n_prefix, len(reads), done, t_fill, t_gen, t_rw, n_full, n_full / n_prefix, calls_f / calls_s))
 
 
 def cpu_baseline_c(table, paths=3):
@@ -119,7 +143,7 @@ def cpu_baseline_c(table, paths=3):
     t0 = time.perf_counter()
     r = o.spin(paths)
     t_spin = time.perf_counter() - t0
-    return dict(value=r["n"] / t_spin, unit="haplotypes/s", cores=1, kind="port",
+    return dict(value=r["n"] / t_spin, unit="haplotypes/s", cores=1, kind="port", cpu=cpu_model(),
                 sample="C oracle, whole contig, %d spins with the reference's full pair enumeration: fill %.2fs, spins %.2fs"
                        % (r["n"], t_fill, t_spin))
 
@@ -219,6 +243,8 @@ def main():
     from gretel_amd.dist import broadcast_descriptor, gather_results
 
     # rank 0 decides the run, everybody learns it over RCCL
+    if args.paths <= 0:
+        args.paths = 1000 if args.config == "C5" else 100
     desc = broadcast_descriptor(dict(paths=args.paths, steps=args.steps, warmup=args.warmup,
                                      config={"C2": 2, "C3": 3, "C5": 5}[args.config]), comm_dev, world, rank)
     cfg_name = "C%d" % desc["config"]
@@ -380,7 +406,14 @@ def main():
             except Exception as exc:       # never let the secondary leg break the contract line
                 out["throughput_mode"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_python(table, min(args.cpu_snps, n), n)
+            # C2 in full, C3 three paths.  The default run stays within ~30 s of CPU work:
+            # C2 = the whole contig but 5 of its paths, C3 = a SNP prefix extrapolated by call counts (labelled).
+            if args.cpu_full:
+                out["cpu_baseline"] = cpu_baseline_python(table, n, n, paths if n <= 2000 else 3)
+            elif n <= 2000:
+                out["cpu_baseline"] = cpu_baseline_python(table, n, n, min(paths, 5))
+            else:
+                out["cpu_baseline"] = cpu_baseline_python(table, min(args.cpu_snps, n), n)
             out["cpu_baseline_c"] = cpu_baseline_c(table, 3 if n >= 5000 else 10)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out))

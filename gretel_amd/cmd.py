@@ -60,16 +60,45 @@ def read_first_fasta_record(path):
     return "".join(seq)
 
 
+FAIL_TEXT = '''[FAIL] Unable to recover pairwise evidence concerning SNP #%d at position %d
+       Gretel needs every SNP to appear on a read with at least one other SNP, at least once.
+       There is no read in your data set that bridges SNP #%d with any of its neighbours.
+
+       * If you are trying to run Gretel along an entire contig or genome, please note that
+       this is not the recommended usage for Gretel, as it was intended to uncover the
+       variation in a metahaplome: the set of haplotypes for a specific gene.
+           See our pre-print https://doi.org/10.1101/223404 for more information
+
+       Consider running a prediction tool such as `prokka` on your assembly or reference
+       and using the CDS regions in the GFF for corresponding genes of interest to
+       uncover haplotypes with Gretel instead.
+
+       * If you are already doing this, consider calling for SNPs more aggressively.
+       We use `snpper` (https://github.com/SamStudio8/gretel-test/blob/master/snpper.py)
+       to determine any site in a BAM that has at least one read in disagreement with
+       the reference as a SNP. Although this introduces noise from alignment and sequence
+       error, Gretel is fairly robust. Importantly, this naive calling method will
+       likely close gaps between SNPs and permit recovery.
+
+       * Finally, consider that the gaps are indicative that your reads do not support
+       one or more parts of your assembly or reference. You could try and find or construct
+       a more suitable reference, or reduce the size of the recovery window.
+
+       Sorry :(\n'''            # the message of cmd.py:93-117, character for character
+
+HOLE_TEXT = '''[NOTE] Unable to select next branch from SNP %d to %d
+       By design, Gretel will attempt to recover haplotypes until a hole in the graph has been found.
+       Recovery will intentionally terminate now.\n'''      # gretel.py:177-179
+
+
 def gap_report(hansel, vcf_h, out=None):
-    """cmd.py:85-118: returns True (and explains) when some SNP has no pairwise evidence."""
+    """cmd.py:85-118: returns True (and explains, in the reference's words) when some SNP has no pairwise evidence."""
     out = out or sys.stderr
     i = hansel.gap_check()
     if i < 0:
         return False
     pos = vcf_h["snp_rev"][i - 1] if i > 0 else 0
-    out.write("[FAIL] Unable to recover pairwise evidence concerning SNP #%d at position %d\n"
-              "       Gretel needs every SNP to appear on a read with at least one other SNP, at least once.\n"
-              "       There is no read in your data set that bridges SNP #%d with any of its neighbours.\n" % (i, pos, i))
+    out.write(FAIL_TEXT % (i, pos, i))
     return True
 
 
@@ -86,27 +115,54 @@ def print_snp_table(hansel, vcf_h, out=None):
         last = pos
 
 
+def _add_path(paths, i, key, hansel_path, hp_current, hp_original, magnitude):
+    """cmd.py:164-179"""
+    if key not in paths:
+        paths[key] = {"hp_current": [], "hp_original": [], "i": [], "i_0": i, "n": 0, "magnitude": 0,
+                      "hansel_path": hansel_path}
+    rec = paths[key]
+    rec["n"] += 1
+    rec["i"].append(i)
+    rec["magnitude"] += magnitude
+    rec["hp_current"].append(hp_current)
+    rec["hp_original"].append(hp_original)
+
+
 def recover(hansel, n_snps, max_paths, log=None):
-    """cmd.py:148-179 on the device; returns the PATHS table in order of discovery."""
+    """cmd.py:148-179 on the device; returns the PATHS table in order of discovery.  The spins have already
+    happened when the notes are written, but the notes are the reference's, in the reference's order."""
     log = log or sys.stderr
     res = hansel.spin(max_paths, MIN_REMOVE)
     paths = {}
     for i in range(res["n"]):
-        log.write("[NOTE] *Establishing next path\n")
-        log.write("[RWGT] Ratio %.3f, Removed %.1f\n" % (res["ratio"][i], res["magnitude"][i]))
-        key = Hansel.path_str(res["paths"][i])
-        if key not in paths:
-            paths[key] = {"hp_current": [], "hp_original": [], "i": [], "i_0": i, "n": 0, "magnitude": 0,
-                          "hansel_path": hansel.path_symbols(res["paths"][i])}
-        rec = paths[key]
-        rec["n"] += 1
-        rec["i"].append(i)
-        rec["magnitude"] += float(res["magnitude"][i])
-        rec["hp_current"].append(float(res["hp_current"][i]))
-        rec["hp_original"].append(float(res["hp_original"][i]))
+        log.write("[NOTE] *Establishing next path\n")                                   # gretel.py:142
+        if res["min_marginal"][i] < MIN_REMOVE:                                          # cmd.py:158-160
+            log.write("[RWGT] Ratio %.10f too small, adjusting to %.3f\n" % (res["min_marginal"][i], MIN_REMOVE))
+        log.write("[RWGT] Ratio %.3f, Removed %.1f\n" % (res["ratio"][i], res["magnitude"][i]))   # gretel.py:97
+        _add_path(paths, i, Hansel.path_str(res["paths"][i]), hansel.path_symbols(res["paths"][i]),
+                  float(res["hp_current"][i]), float(res["hp_original"][i]), float(res["magnitude"][i]))
     if res["hole_at"]:
-        log.write("[NOTE] Unable to select next branch from SNP %d to %d\n       Recovery will intentionally terminate now.\n"
-                  % (res["hole_at"] - 1, res["hole_at"]))
+        log.write("[NOTE] *Establishing next path\n")
+        log.write(HOLE_TEXT % (res["hole_at"] - 1, res["hole_at"]))
+    return paths
+
+
+def recover_with_debug(hansel, n_snps, max_paths, debug_hpos, log=None):
+    """The same loop one path at a time through gretel_amd.gretel (one kernel sequence and one host round trip per
+    path): what --debughpos needs, because the reference prints the branch weights of EVERY path as it walks
+    (gretel.py:147-164), each against the tensor as reweighted so far."""
+    from . import gretel
+    log = log or sys.stderr
+    paths = {}
+    for i in range(max_paths):
+        init_path, init_prob, init_min = gretel.generate_path(n_snps, hansel, hansel, debug_hpos=debug_hpos)
+        if init_path is None:
+            break
+        if init_min < MIN_REMOVE:
+            log.write("[RWGT] Ratio %.10f too small, adjusting to %.3f\n" % (init_min, MIN_REMOVE))
+            init_min = MIN_REMOVE
+        mag = gretel.reweight_hansel_from_path(hansel, init_path, init_min)
+        _add_path(paths, i, "".join(str(x) for x in init_path), init_path, init_prob["hp_current"], init_prob["hp_original"], mag)
     return paths
 
 
@@ -166,14 +222,9 @@ def main(argv=None):
         except ValueError:
             pass
     if debug_hpos:
-        # the reference prints the branch weights while it walks (gretel.py:147-164); here the spins run
-        # on the device, so the weights are shown for the first path only, before any reweighting
-        first = hansel.generate_path()
-        if first[0] is not None:
-            for snp in sorted(debug_hpos):
-                if 1 <= snp <= vcf_h["N"]:
-                    print(hansel.get_edge_weights_at(snp, first[0]))
-    paths = recover(hansel, vcf_h["N"], args.paths)
+        paths = recover_with_debug(hansel, vcf_h["N"], args.paths, debug_hpos)
+    else:
+        paths = recover(hansel, vcf_h["N"], args.paths)
     write_outputs(paths, hansel, vcf_h, args)
     return 0
 

@@ -99,3 +99,60 @@ def test_cli_on_synthetic_files_matches_oracle(tmp_path):
     assert head == "# %d\t%d\t%d\t%.2f" % (t.n_snps, st[1], st[0], o.L)
     full = (out / "out.fasta").read_text().splitlines()[1]
     assert len(full) == e and full[9] == want[0][1][0] and set(full) <= set("ACGTN")
+
+
+def test_cli_stderr_notes_are_the_references(tmp_path, capsys):
+    """The notes of gretel.py:97,142,177-179 and cmd.py:158-160, in the reference's order: per path one
+    "[NOTE] *Establishing next path", the clamp note when the minimum marginal is under 1 %, "[RWGT] Ratio ...";
+    a hole ends the run with one more establishing note and the three-line hole note."""
+    import numpy as np
+    from gretel_amd import bamio
+    from gretel_amd.synth import make_support_table
+    from oracle.c_oracle import COracle
+    # two haplotypes, no errors: recovery runs until the evidence of one of them is used up (a hole), and late paths
+    # have tiny minimum marginals (the clamp note)
+    t = make_support_table(60, 1500, k=4, n_haps=2, err=0.0, seed=5)
+    bam, vcf = str(tmp_path / "s.bam"), str(tmp_path / "s.vcf.gz")
+    contig, s, e = bamio.synth_to_files(t, bam, vcf)
+    out = tmp_path / "o"
+    out.mkdir()
+    assert cmd.main([bam, vcf, contig, "-p", "400", "--quiet", "-o", str(out)]) == 0
+    err = capsys.readouterr().err
+    o = COracle(t.n_snps, t.band)
+    o.fill(t)
+    o.snapshot_original()
+    want = []
+    n = 0
+    while n < 400:
+        p = o.generate_path()
+        want.append("[NOTE] *Establishing next path\n")
+        if p[0] is None:
+            want.append(cmd.HOLE_TEXT % (p[1] - 1, p[1]))
+            break
+        mn = p[1][2]
+        if mn < 0.01:
+            want.append("[RWGT] Ratio %.10f too small, adjusting to %.3f\n" % (mn, 0.01))
+        mag = o.reweight_path(p[0], max(mn, 0.01))
+        want.append("[RWGT] Ratio %.3f, Removed %.1f\n" % (max(mn, 0.01), mag))
+        n += 1
+    tail = err[err.index("[NOTE] *Establishing next path"):]
+    assert tail == "".join(want)
+    assert any("too small" in w for w in want) or any("Unable to select" in w for w in want)
+
+
+def test_cli_gap_message_is_the_references(tmp_path, capsys):
+    with pytest.raises(SystemExit):
+        cmd.main([BAM, VCF, "hoot", "-s", "10", "-e", "20", "--quiet", "-o", str(tmp_path)])
+    err = capsys.readouterr().err
+    assert "[FAIL] Unable to recover pairwise evidence concerning SNP #2 at position 20\n" in err
+    assert "prokka" in err and err.rstrip().endswith("Sorry :(")
+
+
+def test_cli_debughpos_prints_every_path(tmp_path, capsys):
+    # gretel.py:162-164 prints the branch weights of the listed SNPs for EVERY path, against the tensor as reweighted so far
+    rc = cmd.main([BAM, VCF, "hoot", "-s", "1", "-e", "20", "-p", "3", "--quiet", "--debughpos", "2,3", "-o", str(tmp_path)])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert out.count("{") == 3 * 2
+    fasta, snp, crumbs = _expected(3, 1, 20)
+    assert (tmp_path / "gretel.crumbs").read_text() == crumbs

@@ -108,3 +108,41 @@ def test_large_L_falls_back_to_global_walker():
     res, ref = h.spin(6), o.spin(6)
     assert np.array_equal(res["paths"], ref["paths"])
     assert res["hp_current"].tolist() == ref["hp_current"].tolist()
+
+
+def test_c5_deep_reweight_1000_paths():
+    # BASELINE config C5 as written: 1 000 paths ("deep reweight").  All 1 000 run on the GPU; the C oracle (0.3 s per
+    # path) checks the first 100 bit for bit, the rest is held to properties that do not need the oracle.
+    t = make_config("C5", seed=0)
+    h = Hansel(t.n_snps, band=t.band)
+    h.fill_from_support(t.rank, t.off, t.bases)
+    o = COracle(t.n_snps, t.band)
+    o.fill(t)
+    band0 = h.export_band()
+    masks0 = h.candidate_masks()
+    res = h.spin(1000)
+    ref = o.spin(100)
+    assert res["n"] == 1000 and res["hole_at"] == 0 and ref["n"] == 100
+    assert np.array_equal(res["paths"][:100], ref["paths"])
+    assert res["hp_current"][:100].tolist() == ref["hp_current"].tolist()
+    assert res["hp_original"][:100].tolist() == ref["hp_original"].tolist()
+    assert res["ratio"][:100].tolist() == ref["ratio"].tolist()
+    # every selected symbol was a candidate of its position in the original tensor (reweighting never adds evidence)
+    paths = res["paths"]
+    assert (paths[:, 0] == 6).all()
+    assert ((masks0[None, 1:] >> paths[:, 1:]) & 1).all()
+    # hp_original is the sum of log10 ORIGINAL marginals of the selected symbols: recompute it from the exported tensor
+    c = band0[:, 0].sum(axis=2)                                   # c_s(p) = sum_t H[s,t,p,p+1]
+    tot = np.where(c > 0, c, 0).sum(axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        lm0 = np.log10(c / tot[:, None])
+    pos = np.arange(1, t.n_snps + 1)
+    for k in (0, 99, 100, 500, 999):
+        assert abs(lm0[pos, paths[k, 1:]].sum() - res["hp_original"][k]) < 1e-6
+    assert np.all(np.isfinite(res["hp_current"])) and np.all(res["hp_current"] < 0)
+    assert np.all((res["ratio"] >= 0.01) & (res["ratio"] <= 1.0))
+    assert np.all(res["min_marginal"] <= res["ratio"])
+    # conservation: what the paths report as removed is what left the tensor (f32 cells: compare to f32 precision)
+    band1 = h.export_band()
+    assert np.all(band1 <= band0) and np.all(band1 >= 0)
+    assert abs((band0 - band1).sum() - res["magnitude"].sum()) <= 1e-5 * res["magnitude"].sum()
