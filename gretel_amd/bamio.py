@@ -31,11 +31,75 @@ def _bgzf_block(payload):
     return head + cdata + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
 
 
-def bgzf_write(path, data):
+BGZF_PAYLOAD = 0xff00
+
+
+def bgzf_write(path, data, level=6):
+    """Writes `data` as BGZF blocks of BGZF_PAYLOAD bytes; returns the file offset of every block (for write_bai)."""
+    offs = []
+    pos = 0
     with open(path, "wb") as fh:
-        for o in range(0, len(data), 0xff00):
-            fh.write(_bgzf_block(data[o:o + 0xff00]))
+        for o in range(0, len(data), BGZF_PAYLOAD):
+            payload = bytes(data[o:o + BGZF_PAYLOAD])
+            comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+            cdata = comp.compress(payload) + comp.flush()
+            head = struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, ord('B'), ord('C'), 2, len(cdata) + 25)
+            blk = head + cdata + struct.pack("<II", zlib.crc32(payload) & 0xffffffff, len(payload))
+            offs.append(pos)
+            fh.write(blk)
+            pos += len(blk)
+        offs.append(pos)
         fh.write(_bgzf_block(b""))          # EOF marker
+    return offs
+
+
+def write_bai(path, n_ref, rec_ref, rec_beg, rec_end, rec_uoff, rec_ulen, block_offs):
+    """A .bai for a BAM written by bgzf_write: per record its reference index, 0-based [beg, end), and where its bytes
+    sit in the uncompressed stream (offset of its block_size field, total length).  Bins with merged chunks and the
+    16 kb linear index, as the SAM specification (section 5.2) lays them out."""
+    rec_ref = np.asarray(rec_ref, dtype=np.int64)
+    rec_beg = np.asarray(rec_beg, dtype=np.int64)
+    rec_end = np.maximum(np.asarray(rec_end, dtype=np.int64), rec_beg + 1)
+    u0 = np.asarray(rec_uoff, dtype=np.int64)
+    u1 = u0 + np.asarray(rec_ulen, dtype=np.int64)
+    offs = np.asarray(block_offs, dtype=np.int64)
+
+    def voff(u):
+        b = u // BGZF_PAYLOAD
+        return (offs[b] << 16) | (u - b * BGZF_PAYLOAD)
+    v0, v1 = voff(u0), voff(u1)
+    e = rec_end - 1
+    bins = np.zeros(len(rec_beg), dtype=np.int64)
+    done = np.zeros(len(rec_beg), dtype=bool)
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        hit = ~done & ((rec_beg >> shift) == (e >> shift))
+        bins[hit] = base + (rec_beg[hit] >> shift)
+        done |= hit
+    out = [b"BAI\x01", struct.pack("<i", n_ref)]
+    for r in range(n_ref):
+        sel = np.flatnonzero(rec_ref == r)
+        chunks = {}
+        for q in sel:                        # records are in file order: adjacent ones of a bin merge into one chunk
+            c = chunks.setdefault(int(bins[q]), [])
+            if c and c[-1][1] == int(v0[q]):
+                c[-1][1] = int(v1[q])
+            else:
+                c.append([int(v0[q]), int(v1[q])])
+        out.append(struct.pack("<i", len(chunks)))
+        for b in sorted(chunks):
+            out.append(struct.pack("<Ii", b, len(chunks[b])))
+            out += [struct.pack("<QQ", c0, c1) for c0, c1 in chunks[b]]
+        n_intv = int((rec_end[sel].max() - 1 >> 14) + 1) if len(sel) else 0
+        lin = np.zeros(n_intv, dtype=np.uint64)
+        for q in sel:
+            w0, w1 = int(rec_beg[q] >> 14), int((rec_end[q] - 1) >> 14)
+            for w in range(w0, w1 + 1):
+                if lin[w] == 0 or int(v0[q]) < int(lin[w]):
+                    lin[w] = int(v0[q])
+        out.append(struct.pack("<i", n_intv))
+        out.append(lin.astype("<u8").tobytes())
+    with open(path, "wb") as fh:
+        fh.write(b"".join(out))
 
 
 def _parse_cigar(cigar):
@@ -57,13 +121,15 @@ def _reg2bin(beg, end):
     return 0
 
 
-def write_bam(path, refs, reads):
+def write_bam(path, refs, reads, index=True):
     """refs: [(name, length)]; reads: iterable of (qname, flag, ref_index, pos0, mapq, cigar_str, seq_str),
-    already coordinate sorted."""
+    already coordinate sorted.  With index=True a <path>.bai is written next to it."""
     text = "@HD\tVN:1.0\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs)
     out = [b"BAM\x01", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(refs))]
     for name, ln in refs:
         out += [struct.pack("<i", len(name) + 1), name.encode() + b"\x00", struct.pack("<i", ln)]
+    upos = sum(len(x) for x in out)
+    meta = []
     for qname, flag, rid, pos, mapq, cigar, seq in reads:
         cg = _parse_cigar(cigar)
         reflen = sum(n for op, n in cg if op in (0, 2, 3, 7, 8))
@@ -76,7 +142,12 @@ def write_bam(path, refs, reads):
                            l_seq, -1, -1, 0)
         body += name + b"".join(struct.pack("<I", (n << 4) | op) for op, n in cg) + bytes(packed) + b"\x7e" * l_seq
         out.append(struct.pack("<i", len(body)) + body)
-    bgzf_write(path, b"".join(out))
+        meta.append((rid, pos, pos + max(1, reflen), upos, len(body) + 4))
+        upos += len(body) + 4
+    offs = bgzf_write(path, b"".join(out))
+    if index:
+        m = np.array(meta, dtype=np.int64).reshape(-1, 5)
+        write_bai(path + ".bai", len(refs), m[:, 0], m[:, 1], m[:, 2], m[:, 3], m[:, 4], offs)
 
 
 def write_vcf_gz(path, contig, positions):
@@ -87,23 +158,122 @@ def write_vcf_gz(path, contig, positions):
 
 def synth_to_files(table, bam_path, vcf_path, contig="synth", spacing=10):
     """A support table as real files: SNP s (0-based) sits at 1-based position spacing*(s+1); every read is one
-    all-M alignment from its first to its last SNP with 'A' between the SNPs."""
+    all-M alignment from its first to its last SNP with 'A' between the SNPs; a .bai goes with it.
+    Tables whose reads all cover the same number of SNPs (C2, C3) are assembled with NumPy -- a million records in
+    seconds; the others go through write_bam record by record."""
     n = table.n_snps
     length = spacing * n + spacing
-    reads = []
-    bases = table.bases.tobytes()
-    for r in range(table.n_reads):
-        k = int(table.off[r + 1] - table.off[r])
-        rk = int(table.rank[r])
-        seq = bytearray(b"A" * ((k - 1) * spacing + 1))
-        for q in range(k):
-            seq[q * spacing] = bases[table.off[r] + q]
-        pos0 = spacing * (rk + 1) - 1
-        reads.append(("r%d" % r, 0, 0, pos0, 42, "%dM" % len(seq), seq.decode()))
-    reads.sort(key=lambda x: x[3])
-    write_bam(bam_path, [(contig, length)], reads)
+    ks = np.diff(table.off)
+    if table.n_reads > 1000 and (ks == ks[0]).all() and spacing % 2 == 0 and (np.diff(table.rank) >= 0).all():
+        _synth_bam_fixed_k(table, bam_path, contig, length, int(ks[0]), spacing)
+    else:
+        reads = []
+        bases = table.bases.tobytes()
+        for r in range(table.n_reads):
+            k = int(table.off[r + 1] - table.off[r])
+            rk = int(table.rank[r])
+            seq = bytearray(b"A" * ((k - 1) * spacing + 1))
+            for q in range(k):
+                seq[q * spacing] = bases[table.off[r] + q]
+            pos0 = spacing * (rk + 1) - 1
+            reads.append(("r%d" % r, 0, 0, pos0, 42, "%dM" % len(seq), seq.decode()))
+        reads.sort(key=lambda x: x[3])
+        write_bam(bam_path, [(contig, length)], reads)
     write_vcf_gz(vcf_path, contig, [spacing * (s + 1) for s in range(n)])
     return contig, 1, length
+
+
+def _synth_bam_fixed_k(table, bam_path, contig, length, k, spacing):
+    """write_bam for reads of one shape: every record has the same size, so the file body is one uint8 matrix."""
+    nr = table.n_reads
+    l_seq = (k - 1) * spacing + 1
+    l_name = 10                                            # "r%08d" + NUL
+    rec = 4 + 32 + l_name + 4 + (l_seq + 1) // 2 + l_seq
+    M = np.zeros((nr, rec), dtype=np.uint8)
+    pos0 = (spacing * (table.rank.astype(np.int64) + 1) - 1)
+    beg, end = pos0, pos0 + l_seq
+    bins = np.zeros(nr, dtype=np.int64)
+    done = np.zeros(nr, dtype=bool)
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        hit = ~done & ((beg >> shift) == ((end - 1) >> shift))
+        bins[hit] = base + (beg[hit] >> shift)
+        done |= hit
+
+    def put(col, arr, dt):
+        M[:, col:col + np.dtype(dt).itemsize] = np.ascontiguousarray(arr.astype(dt)).view(np.uint8).reshape(nr, -1)
+    put(0, np.full(nr, rec - 4), "<i4")
+    put(4, np.zeros(nr), "<i4")                            # refID
+    put(8, pos0, "<i4")
+    M[:, 12] = l_name
+    M[:, 13] = 42                                          # MAPQ
+    put(14, bins, "<u2")
+    put(16, np.full(nr, 1), "<u2")                         # n_cigar_op
+    put(18, np.zeros(nr), "<u2")                           # flag
+    put(20, np.full(nr, l_seq), "<i4")
+    put(24, np.full(nr, -1), "<i4")
+    put(28, np.full(nr, -1), "<i4")
+    put(32, np.zeros(nr), "<i4")
+    ids = np.arange(nr)
+    M[:, 36] = ord('r')
+    for d in range(8):
+        M[:, 37 + d] = ord('0') + (ids // 10 ** (7 - d)) % 10
+    c0 = 36 + l_name
+    put(c0, np.full(nr, (l_seq << 4) | 0), "<u4")          # <l_seq>M
+    s0 = c0 + 4
+    M[:, s0:s0 + (l_seq + 1) // 2] = 0x11                  # 'A','A'
+    if l_seq & 1:
+        M[:, s0 + (l_seq - 1) // 2] = 0x10
+    code = np.zeros(256, dtype=np.uint8)
+    for ch, v in _SEQ_CODE.items():
+        code[ord(ch)] = v
+    b = table.bases.reshape(nr, k)
+    for q in range(k):
+        i = q * spacing                                    # even query offset: the high nibble of byte i/2
+        M[:, s0 + i // 2] = (code[b[:, q]] << 4) | (M[:, s0 + i // 2] & 0x0f)
+    M[:, s0 + (l_seq + 1) // 2:] = 0x7e                    # qualities
+    text = "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:%s\tLN:%d\n" % (contig, length)
+    head = b"".join([b"BAM\x01", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", 1),
+                     struct.pack("<i", len(contig) + 1), contig.encode() + b"\x00", struct.pack("<i", length)])
+    offs = bgzf_write(bam_path, head + M.tobytes(), level=1)
+    write_bai_sorted(bam_path + ".bai", beg, end, len(head) + np.arange(nr, dtype=np.int64) * rec, rec, offs)
+
+
+def write_bai_sorted(path, beg, end, uoff, ulen, block_offs):
+    """write_bai for one reference and coordinate-sorted records, without a Python loop over the records: one chunk per
+    bin (first to last record of the bin -- a superset of the exact chunks, which the format allows) and the exact
+    linear index."""
+    offs = np.asarray(block_offs, dtype=np.int64)
+
+    def voff(u):
+        b = u // BGZF_PAYLOAD
+        return (offs[b] << 16) | (u - b * BGZF_PAYLOAD)
+    v0, v1 = voff(uoff), voff(uoff + ulen)
+    e = end - 1
+    bins = np.zeros(len(beg), dtype=np.int64)
+    done = np.zeros(len(beg), dtype=bool)
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        hit = ~done & ((beg >> shift) == (e >> shift))
+        bins[hit] = base + (beg[hit] >> shift)
+        done |= hit
+    out = [b"BAI\x01", struct.pack("<i", 1)]
+    ub = np.unique(bins)
+    out.append(struct.pack("<i", len(ub)))
+    for b in ub:
+        sel = np.flatnonzero(bins == b)
+        out.append(struct.pack("<IiQQ", int(b), 1, int(v0[sel[0]]), int(v1[sel[-1]])))
+    n_intv = int((e.max() >> 14) + 1)
+    lin = np.zeros(n_intv, dtype=np.uint64)
+    w0 = beg >> 14
+    w1 = e >> 14
+    # sorted by beg: the first record overlapping window w is the first with w1 >= w
+    for w in range(n_intv):
+        q = np.flatnonzero((w0 <= w) & (w1 >= w))
+        if len(q):
+            lin[w] = int(v0[q].min())
+    out.append(struct.pack("<i", n_intv))
+    out.append(lin.astype("<u8").tobytes())
+    with open(path, "wb") as fh:
+        fh.write(b"".join(out))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -112,6 +282,19 @@ def synth_to_files(table, bam_path, vcf_path, contig="synth", spacing=10):
 class _gio_table(C.Structure):
     _fields_ = [("rank", C.POINTER(C.c_int32)), ("off", C.POINTER(C.c_int64)), ("bases", C.POINTER(C.c_uint8)),
                 ("n_reads", C.c_int64), ("n_bases", C.c_int64)]
+
+
+class gio_stats(C.Structure):
+    _fields_ = [("compressed_bytes", C.c_int64), ("blocks", C.c_int64), ("records", C.c_int64), ("reads_kept", C.c_int64),
+                ("used_index", C.c_int32), ("libdeflate", C.c_int32), ("threads", C.c_int32), ("_pad", C.c_int32),
+                ("seconds", C.c_double)]
+
+
+def native_last_stats():
+    """dict of what the last native_support_table call did (bytes, blocks, records, index use, seconds)."""
+    st = gio_stats()
+    io_lib().gio_last_stats(C.byref(st))
+    return {k: getattr(st, k) for k, _ in gio_stats._fields_ if k != "_pad"}
 
 
 def io_lib():
@@ -125,6 +308,8 @@ def io_lib():
         L.gio_support_table_from_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                                  C.POINTER(_gio_table)]
         L.gio_table_free.argtypes = [C.POINTER(_gio_table)]
+        L.gio_last_stats.argtypes = [C.POINTER(gio_stats)]
+        L.gio_last_stats.restype = None
         L.gio_count_coverage.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
         _io = L
     return _io

@@ -1,20 +1,34 @@
 // bam_support.cpp -- libgretel_io.so: BGZF/BAM decoding and per-read SNP support extraction
-// (C ABI: include/gretel_io.h).  Host-only C++ with zlib; replaces the pysam pileup of the
-// reference (gretel/util.py:120-209) for the ingest half of load_from_bam.
+// (C ABI: include/gretel_io.h).  Host-only C++; replaces the pysam pileup of the reference
+// (gretel/util.py:120-209) for the ingest half of load_from_bam.
+//
+// The file is STREAMED: compressed bytes are read in batches, the BGZF blocks of a batch are inflated in parallel
+// (libdeflate when the runtime library is present, zlib otherwise) and the records are parsed out of the batch with
+// whatever a batch cuts in two carried over to the next.  With an index next to the file (<bam>.bai or <stem>.bai) the
+// stream starts at the first block that can hold an alignment overlapping the window and stops at the first record
+// behind it (coordinate-sorted input, as the reference's pysam fetch/pileup requires as well); without one the whole
+// contig is scanned.  Every record field that is used as a length or an offset is checked against the record's size:
+// malformed input is an error (-4), never an out-of-bounds read.
+#include <dlfcn.h>
 #include <zlib.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "gretel_io.h"
 
 static thread_local char g_err[512] = "";
+static thread_local gio_stats g_stats;
 
 static int fail(int code, const char *fmt, ...)
 {
@@ -26,83 +40,301 @@ static int fail(int code, const char *fmt, ...)
 }
 
 extern "C" const char *gio_last_error(void) { return g_err; }
-
-// BGZF is a series of gzip members: inflate them one after the other
-static int read_bgzf(const char *path, std::vector<uint8_t> &out)
-{
-    FILE *fp = fopen(path, "rb");
-    if (!fp) return fail(-1, "cannot open %s", path);
-    std::vector<uint8_t> in;
-    uint8_t buf[1 << 16];
-    size_t n;
-    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) in.insert(in.end(), buf, buf + n);
-    fclose(fp);
-    if (in.size() < 18 || in[0] != 0x1f || in[1] != 0x8b) return fail(-2, "%s is not gzip/BGZF", path);
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, 15 + 32) != Z_OK) return fail(-3, "inflateInit2 failed");
-    zs.next_in = in.data();
-    zs.avail_in = (uInt)in.size();
-    out.clear();
-    std::vector<uint8_t> chunk(1 << 18);
-    for (;;) {
-        zs.next_out = chunk.data();
-        zs.avail_out = (uInt)chunk.size();
-        int rc = inflate(&zs, Z_NO_FLUSH);
-        out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
-        if (rc == Z_STREAM_END) {
-            if (zs.avail_in == 0) break;
-            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); return fail(-3, "inflateReset failed"); }
-        } else if (rc != Z_OK) {
-            inflateEnd(&zs);
-            return fail(-3, "inflate failed (%d) in %s", rc, path);
-        }
-    }
-    inflateEnd(&zs);
-    return 0;
-}
+extern "C" void gio_last_stats(gio_stats *out) { if (out) *out = g_stats; }
 
 static inline int32_t rd32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
 static inline uint32_t rdu32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 static inline uint16_t rdu16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+static inline uint64_t rdu64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
-struct bam_file {
-    std::vector<uint8_t> data;
-    std::vector<std::pair<std::string, int64_t>> refs;
-    size_t first_record;
+// ---------------------------------------------------------------------------------------------
+// raw-deflate inflation of one BGZF block: libdeflate (dlopen of the runtime library; its four entry points are a
+// stable ABI) or zlib
+// ---------------------------------------------------------------------------------------------
+struct deflate_api {
+    void *(*alloc)(void) = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*free_)(void *) = nullptr;
+    bool ok = false;
 };
 
-static int open_bam(const char *path, bam_file &b)
+static const deflate_api &libdeflate()
 {
-    int rc = read_bgzf(path, b.data);
-    if (rc) return rc;
-    const std::vector<uint8_t> &d = b.data;
-    if (d.size() < 12 || memcmp(d.data(), "BAM\1", 4) != 0) return fail(-4, "%s is not a BAM file", path);
-    size_t o = 8 + (size_t)rd32(&d[4]);
-    if (o + 4 > d.size()) return fail(-4, "truncated BAM header");
-    const int n_ref = rd32(&d[o]);
-    o += 4;
-    for (int i = 0; i < n_ref; i++) {
-        if (o + 4 > d.size()) return fail(-4, "truncated BAM header");
-        const int l_name = rd32(&d[o]);
-        o += 4;
-        if (o + l_name + 4 > d.size()) return fail(-4, "truncated BAM header");
-        std::string name((const char *)&d[o], l_name > 0 ? l_name - 1 : 0);
-        o += l_name;
-        b.refs.emplace_back(name, (int64_t)rd32(&d[o]));
-        o += 4;
+    static deflate_api api = [] {
+        deflate_api a;
+        if (getenv("GIO_ZLIB") && atoi(getenv("GIO_ZLIB"))) return a;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.alloc = (void *(*)(void))dlsym(h, "libdeflate_alloc_decompressor");
+        a.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        a.free_ = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        a.ok = a.alloc && a.decompress && a.free_;
+        return a;
+    }();
+    return api;
+}
+
+struct inflater {
+    void *ld = nullptr;
+    z_stream zs;
+    bool z_init = false;
+    inflater()
+    {
+        if (libdeflate().ok) ld = libdeflate().alloc();
+        memset(&zs, 0, sizeof zs);
     }
-    b.first_record = o;
+    ~inflater()
+    {
+        if (ld) libdeflate().free_(ld);
+        if (z_init) inflateEnd(&zs);
+    }
+    // raw deflate `in` -> exactly `out_len` bytes
+    bool run(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+    {
+        if (out_len == 0) return true;
+        if (ld) {
+            size_t got = 0;
+            return libdeflate().decompress(ld, in, in_len, out, out_len, &got) == 0 && got == out_len;
+        }
+        if (!z_init) {
+            if (inflateInit2(&zs, -15) != Z_OK) return false;
+            z_init = true;
+        } else if (inflateReset(&zs) != Z_OK) return false;
+        zs.next_in = const_cast<uint8_t *>(in);
+        zs.avail_in = (uInt)in_len;
+        zs.next_out = out;
+        zs.avail_out = (uInt)out_len;
+        const int rc = inflate(&zs, Z_FINISH);
+        return rc == Z_STREAM_END && zs.avail_out == 0;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BGZF stream
+// ---------------------------------------------------------------------------------------------
+static int n_threads()
+{
+    static const int n = [] {
+        int t = getenv("GIO_THREADS") ? atoi(getenv("GIO_THREADS")) : (int)std::thread::hardware_concurrency();
+        if (t < 1) t = 1;
+        if (t > 16) t = 16;
+        return t;
+    }();
+    return n;
+}
+
+class bgzf_stream {
+public:
+    ~bgzf_stream() { if (fp_) fclose(fp_); }
+
+    int open(const char *path)
+    {
+        fp_ = fopen(path, "rb");
+        if (!fp_) return fail(-1, "cannot open %s", path);
+        path_ = path;
+        uint8_t magic[4];
+        if (fread(magic, 1, 4, fp_) != 4 || magic[0] != 0x1f || magic[1] != 0x8b)
+            return fail(-2, "%s is not gzip/BGZF", path);
+        return seek(0, 0);
+    }
+
+    // continue at virtual offset (coffset, uoffset)
+    int seek(uint64_t coffset, unsigned uoffset)
+    {
+        if (fseeko(fp_, (off_t)coffset, SEEK_SET) != 0) return fail(-1, "seek failed in %s", path_.c_str());
+        cbuf_.clear();
+        out_.clear();
+        rd_ = 0;
+        skip_ = uoffset;
+        eof_ = false;
+        return 0;
+    }
+
+    // at least `need` unread bytes in the window unless the file ends first; returns <0 on error, else bytes available
+    int64_t ensure(size_t need)
+    {
+        while (out_.size() - rd_ < need && !eof_) {
+            int rc = refill();
+            if (rc) return rc;
+        }
+        return (int64_t)(out_.size() - rd_);
+    }
+    const uint8_t *ptr() const { return out_.data() + rd_; }
+    void consume(size_t n) { rd_ += n; }
+
+private:
+    struct blk { size_t coff, clen, isize, uoff; };
+
+    int refill()
+    {
+        // keep the unread tail, read another batch of compressed bytes, inflate its complete blocks
+        if (rd_ > 0) {
+            out_.erase(out_.begin(), out_.begin() + (ptrdiff_t)rd_);
+            rd_ = 0;
+        }
+        // small first batches (the header, an index seek right behind it), then 4 MB at a time (the inflated window is reused from batch to batch: fresh pages are the expensive part)
+        const size_t BATCH = batch_;
+        if (batch_ < ((size_t)4 << 20)) batch_ *= 4;
+        const size_t have = cbuf_.size();
+        cbuf_.resize(have + BATCH);
+        const size_t got = fread(cbuf_.data() + have, 1, BATCH, fp_);
+        cbuf_.resize(have + got);
+        g_stats.compressed_bytes += (int64_t)got;
+        if (got == 0) {
+            eof_ = true;
+            if (!cbuf_.empty()) return fail(-4, "truncated BGZF block at the end of %s", path_.c_str());
+            return 0;
+        }
+        std::vector<blk> blocks;
+        size_t o = 0, total = 0;
+        while (o + 18 <= cbuf_.size()) {
+            const uint8_t *b = cbuf_.data() + o;
+            if (b[0] != 0x1f || b[1] != 0x8b || b[2] != 8 || !(b[3] & 4)) return fail(-4, "bad BGZF block header in %s", path_.c_str());
+            const size_t xlen = rdu16(b + 10);
+            if (o + 12 + xlen > cbuf_.size()) break;
+            size_t bsize = 0;
+            for (size_t x = 12; x + 4 <= 12 + xlen;) {           // extra subfields: find BC
+                const size_t slen = rdu16(b + x + 2);
+                if (b[x] == 'B' && b[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)rdu16(b + x + 4) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8) return fail(-4, "BGZF block without a valid BC field in %s", path_.c_str());
+            if (o + bsize > cbuf_.size()) break;
+            const size_t isize = rdu32(b + bsize - 4);
+            if (isize > 65536) return fail(-4, "BGZF block claims %zu bytes in %s", isize, path_.c_str());
+            blocks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, total});
+            total += isize;
+            o += bsize;
+        }
+        const size_t base = out_.size();
+        out_.resize(base + total);
+        std::atomic<size_t> next(0);
+        std::atomic<int> bad(0);
+        auto work = [&]() {
+            inflater inf;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= blocks.size()) break;
+                const blk &k = blocks[i];
+                if (!inf.run(cbuf_.data() + k.coff, k.clen, out_.data() + base + k.uoff, k.isize)) bad.store(1);
+            }
+        };
+        const int nt = (int)std::min<size_t>((size_t)n_threads(), blocks.size() / 8 + 1);
+        if (nt <= 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(work);
+            for (auto &t : th) t.join();
+        }
+        if (bad.load()) return fail(-3, "inflate failed in %s", path_.c_str());
+        g_stats.blocks += (int64_t)blocks.size();
+        cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (ptrdiff_t)o);
+        if (skip_) {                                              // first refill behind a seek: start inside the first block
+            if (skip_ > total) return fail(-4, "index offset beyond its block in %s", path_.c_str());
+            rd_ = skip_;
+            skip_ = 0;
+        }
+        return 0;
+    }
+
+    FILE *fp_ = nullptr;
+    std::string path_;
+    std::vector<uint8_t> cbuf_, out_;
+    size_t rd_ = 0, skip_ = 0, batch_ = (size_t)1 << 18;
+    bool eof_ = false;
+};
+
+// ---------------------------------------------------------------------------------------------
+// BAM header, index
+// ---------------------------------------------------------------------------------------------
+struct bam_header {
+    std::vector<std::pair<std::string, int64_t>> refs;
+};
+
+static int read_header(bgzf_stream &z, bam_header &h, const char *path)
+{
+    if (z.ensure(12) < 12 || memcmp(z.ptr(), "BAM\1", 4) != 0) return g_err[0] ? -4 : fail(-4, "%s is not a BAM file", path);
+    const int32_t l_text = rd32(z.ptr() + 4);
+    if (l_text < 0) return fail(-4, "bad BAM header");
+    z.consume(8);
+    if (z.ensure((size_t)l_text + 4) < (int64_t)l_text + 4) return fail(-4, "truncated BAM header");
+    z.consume((size_t)l_text);
+    const int32_t n_ref = rd32(z.ptr());
+    z.consume(4);
+    if (n_ref < 0) return fail(-4, "bad BAM header");
+    for (int i = 0; i < n_ref; i++) {
+        if (z.ensure(4) < 4) return fail(-4, "truncated BAM header");
+        const int32_t l_name = rd32(z.ptr());
+        z.consume(4);
+        if (l_name < 1 || l_name > (1 << 20) || z.ensure((size_t)l_name + 4) < (int64_t)l_name + 4) return fail(-4, "truncated BAM header");
+        std::string name((const char *)z.ptr(), (size_t)l_name - 1);
+        z.consume((size_t)l_name);
+        h.refs.emplace_back(name, (int64_t)rd32(z.ptr()));
+        z.consume(4);
+    }
     return 0;
+}
+
+// smallest virtual offset an alignment overlapping 0-based position `beg` of reference `tid` can start at, from the
+// linear index of a .bai (16 kb windows); false when there is no usable index
+static bool bai_start(const char *bam_path, int tid, int64_t beg, uint64_t *voff)
+{
+    if (getenv("GIO_NO_INDEX") && atoi(getenv("GIO_NO_INDEX"))) return false;
+    std::string p1 = std::string(bam_path) + ".bai", p2 = bam_path;
+    if (p2.size() > 4 && p2.compare(p2.size() - 4, 4, ".bam") == 0) p2 = p2.substr(0, p2.size() - 4) + ".bai";
+    FILE *fp = fopen(p1.c_str(), "rb");
+    if (!fp) fp = fopen(p2.c_str(), "rb");
+    if (!fp) return false;
+    std::vector<uint8_t> d;
+    uint8_t buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, fp)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(fp);
+    if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    const int32_t n_ref = rd32(&d[4]);
+    size_t o = 8;
+    for (int r = 0; r < n_ref; r++) {
+        if (o + 4 > d.size()) return false;
+        const int32_t n_bin = rd32(&d[o]);
+        o += 4;
+        for (int b = 0; b < n_bin; b++) {
+            if (o + 8 > d.size()) return false;
+            const int32_t n_chunk = rd32(&d[o + 4]);
+            o += 8;
+            if (n_chunk < 0 || o + 16 * (size_t)n_chunk > d.size()) return false;
+            o += 16 * (size_t)n_chunk;
+        }
+        if (o + 4 > d.size()) return false;
+        const int32_t n_intv = rd32(&d[o]);
+        o += 4;
+        if (n_intv < 0 || o + 8 * (size_t)n_intv > d.size()) return false;
+        if (r == tid) {
+            if (n_intv == 0) return false;
+            int64_t w = beg < 0 ? 0 : (beg >> 14);
+            if (w >= n_intv) w = n_intv - 1;
+            // windows without alignments hold 0: the nearest filled window to the left bounds the start from below
+            uint64_t v = 0;
+            for (int64_t q = w; q >= 0 && v == 0; q--) v = rdu64(&d[o + 8 * (size_t)q]);
+            if (v == 0) return false;
+            *voff = v;
+            return true;
+        }
+        o += 8 * (size_t)n_intv;
+    }
+    return false;
 }
 
 extern "C" int gio_ref_len(const char *bam_path, const char *contig, int64_t *len)
 {
     if (!bam_path || !contig || !len) return fail(-1, "null argument");
-    bam_file b;
-    int rc = open_bam(bam_path, b);
+    g_err[0] = 0;
+    bgzf_stream z;
+    int rc = z.open(bam_path);
     if (rc) return rc;
-    for (auto &r : b.refs)
+    bam_header h;
+    if ((rc = read_header(z, h, bam_path))) return rc;
+    for (auto &r : h.refs)
         if (r.first == contig) { *len = r.second; return 0; }
     return fail(-5, "contig %s not in %s", contig, bam_path);
 }
@@ -114,62 +346,170 @@ extern "C" void gio_table_free(gio_table *t)
     memset(t, 0, sizeof *t);
 }
 
+// ---------------------------------------------------------------------------------------------
+// records
+// ---------------------------------------------------------------------------------------------
+struct bam_rec {
+    int32_t ref_id, pos, l_seq;
+    int flag, n_cigar, l_read_name;
+    const char *name;
+    const uint8_t *cigar;       // n_cigar x uint32 (the CG tag's array when the core holds the placeholder)
+    const uint8_t *seq;
+};
+
+// checks every length against the record; resolves the CG:B,I tag of reads with more than 65535 CIGAR operations
+static int parse_record(const uint8_t *r, int32_t block_size, bam_rec &out)
+{
+    if (block_size < 32) return fail(-4, "BAM record shorter than its fixed fields");
+    out.ref_id = rd32(r);
+    out.pos = rd32(r + 4);
+    out.l_read_name = r[8];
+    out.n_cigar = rdu16(r + 12);
+    out.flag = rdu16(r + 14);
+    out.l_seq = rd32(r + 16);
+    if (out.l_seq < 0 || out.l_read_name < 1) return fail(-4, "BAM record with a negative sequence length or an empty name field");
+    const int64_t var = 32 + (int64_t)out.l_read_name + 4 * (int64_t)out.n_cigar + ((int64_t)out.l_seq + 1) / 2 + (int64_t)out.l_seq;
+    if (var > block_size) return fail(-4, "BAM record fields (%lld bytes) exceed its block_size %d", (long long)var, block_size);
+    out.name = (const char *)(r + 32);
+    if (out.name[out.l_read_name - 1] != 0) return fail(-4, "BAM read name is not NUL-terminated");
+    out.cigar = r + 32 + out.l_read_name;
+    out.seq = out.cigar + 4 * (size_t)out.n_cigar;
+    if (out.n_cigar == 2) {
+        // placeholder <l_seq>S<ref_len>N: the real CIGAR is in the CG:B,I tag (SAM spec 4.2.2)
+        const uint32_t c0 = rdu32(out.cigar), c1 = rdu32(out.cigar + 4);
+        if ((c0 & 15) == 4 && (int64_t)(c0 >> 4) == out.l_seq && (c1 & 15) == 3) {
+            const uint8_t *a = r + var, *end = r + block_size;
+            while (a + 3 <= end) {
+                const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+                a += 3;
+                size_t sz = 0;
+                if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+                else if (ty == 's' || ty == 'S') sz = 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+                else if (ty == 'Z' || ty == 'H') {
+                    const uint8_t *z = (const uint8_t *)memchr(a, 0, (size_t)(end - a));
+                    if (!z) return fail(-4, "unterminated string tag in a BAM record");
+                    sz = (size_t)(z - a) + 1;
+                } else if (ty == 'B') {
+                    if (a + 5 > end) return fail(-4, "truncated array tag in a BAM record");
+                    const char sub = (char)a[0];
+                    const uint32_t cnt = rdu32(a + 1);
+                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                    if ((uint64_t)cnt * es > (uint64_t)(end - a - 5)) return fail(-4, "array tag exceeds its BAM record");
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I') {
+                        out.cigar = a + 5;
+                        out.n_cigar = (int)cnt;
+                        return 0;
+                    }
+                    sz = 5 + (size_t)cnt * es;
+                } else return fail(-4, "unknown tag type '%c' in a BAM record", ty);
+                if (sz > (size_t)(end - a)) return fail(-4, "tag exceeds its BAM record");
+                a += sz;
+            }
+            return fail(-4, "placeholder CIGAR without a CG tag");
+        }
+    }
+    return 0;
+}
+
+static const char SEQ[] = "=ACMGRSVTWYHKDBN";
+
 extern "C" int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
                                           const uint8_t *region, int stepper_all, gio_table *out)
 {
     if (!bam_path || !contig || !region || !out || end_pos < 0) return fail(-1, "bad argument");
     memset(out, 0, sizeof *out);
-    bam_file b;
-    int rc = open_bam(bam_path, b);
+    memset(&g_stats, 0, sizeof g_stats);
+    g_err[0] = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    bgzf_stream z;
+    int rc = z.open(bam_path);
     if (rc) return rc;
+    bam_header hd;
+    if ((rc = read_header(z, hd, bam_path))) return rc;
     int tid = -1;
-    for (size_t i = 0; i < b.refs.size(); i++)
-        if (b.refs[i].first == contig) tid = (int)i;
+    for (size_t i = 0; i < hd.refs.size(); i++)
+        if (hd.refs[i].first == contig) tid = (int)i;
     if (tid < 0) return fail(-5, "contig %s not in %s", contig, bam_path);
+    uint64_t voff = 0;
+    if (bai_start(bam_path, tid, (int64_t)start_pos - 1, &voff)) {
+        if ((rc = z.seek(voff >> 16, (unsigned)(voff & 0xffff)))) return rc;
+        g_stats.used_index = 1;
+    }
 
     // csum[x] = number of SNPs in [0, x)
     std::vector<int32_t> csum((size_t)end_pos + 2, 0);
     for (int32_t p = 0; p <= end_pos; p++) csum[p + 1] = csum[p] + (region[p] ? 1 : 0);
 
-    static const char SEQ[] = "=ACMGRSVTWYHKDBN";
-    struct read_acc { int32_t rank; std::string seq; };
-    std::vector<read_acc> reads;
-    std::unordered_map<std::string, size_t> index;
+    // rows of the table: support characters in one arena, keys (util.py:160) in another; a key seen again (the same
+    // read met through another record) appends to its row -- rare, so the row is then moved to the arena's end
+    struct row { int32_t rank; int64_t off; int32_t len; };
+    std::vector<row> reads;
+    std::vector<uint8_t> arena;
+    std::vector<char> key_arena;                            // the keys, back to back
+    std::vector<std::pair<int64_t, int32_t>> key_at;        // per row: offset and length of its key
+    // open addressing over a 64-bit hash of the key (linear probing, at most half full): one cache line per lookup
+    // instead of a node chain; equal hashes are confirmed on the key bytes
+    struct slot { uint64_t h; uint32_t row1; };             // row1 = row + 1, 0 = empty
+    std::vector<slot> table((size_t)1 << 16, slot{0, 0});
+    size_t table_mask = table.size() - 1;
+    auto hash_key = [](const std::string &k) {
+        uint64_t h = 0xcbf29ce484222325ull;                  // FNV-1a, then a finalizer to spread the low bits
+        for (unsigned char ch : k) { h ^= ch; h *= 0x100000001b3ull; }
+        h ^= h >> 32; h *= 0x9e3779b97f4a7c15ull; h ^= h >> 29;
+        return h;
+    };
+    auto grow = [&]() {
+        std::vector<slot> nt(table.size() * 2, slot{0, 0});
+        const size_t nm = nt.size() - 1;
+        for (const slot &e : table)
+            if (e.row1) {
+                size_t i = (size_t)e.h & nm;
+                while (nt[i].row1) i = (i + 1) & nm;
+                nt[i] = e;
+            }
+        table.swap(nt);
+        table_mask = nm;
+    };
 
-    const std::vector<uint8_t> &d = b.data;
-    size_t o = b.first_record;
     std::string chars, key;
-    while (o + 4 <= d.size()) {
-        const int32_t block_size = rd32(&d[o]);
-        o += 4;
-        if (block_size < 32 || o + (size_t)block_size > d.size()) return fail(-4, "truncated BAM record");
-        const uint8_t *r = &d[o];
-        o += block_size;
-        const int32_t ref_id = rd32(r), pos = rd32(r + 4);
-        const int l_read_name = r[8];
-        const int n_cigar = rdu16(r + 12), flag = rdu16(r + 14);
-        const int32_t l_seq = rd32(r + 16);
-        if (ref_id != tid || (flag & (0x4 | 0x100 | 0x200 | 0x400))) continue;
+    for (;;) {
+        int64_t av = z.ensure(4);
+        if (av < 0) return (int)av;
+        if (av == 0) break;
+        if (av < 4) return fail(-4, "truncated BAM record");
+        const int32_t block_size = rd32(z.ptr());
+        if (block_size < 32 || block_size > (1 << 28)) return fail(-4, "bad BAM record size %d", block_size);
+        av = z.ensure(4 + (size_t)block_size);
+        if (av < 0) return (int)av;
+        if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
+        const uint8_t *r = z.ptr() + 4;
+        bam_rec b;
+        if ((rc = parse_record(r, block_size, b))) return rc;
+        z.consume(4 + (size_t)block_size);
+        g_stats.records++;
+        // coordinate-sorted: nothing behind the window, and nothing on a later reference, can matter
+        if (g_stats.used_index && (b.ref_id > tid || (b.ref_id == tid && b.pos >= end_pos))) break;
+        const int flag = b.flag;
+        if (b.ref_id != tid || (flag & (0x4 | 0x100 | 0x200 | 0x400))) continue;
         if (!stepper_all && (flag & 0x1) && !(flag & 0x2)) continue;      // orphans, stepper "samtools"
-        if (l_seq == 0) continue;
-        const char *name = (const char *)(r + 32);
-        const uint8_t *cig = r + 32 + l_read_name;
-        const uint8_t *seq = cig + 4 * (size_t)n_cigar;
+        if (b.l_seq == 0) continue;
 
         // walk the CIGAR the way htslib's pileup resolves it, column by column over the SNP positions
         chars.clear();
-        int64_t ref = pos, q = 0, qalen = 0;
+        int64_t ref = b.pos, q = 0, qalen = 0;
         const int64_t hi = end_pos;
-        for (int c = 0; c < n_cigar; c++) {
-            const uint32_t v = rdu32(cig + 4 * c);
+        for (int c = 0; c < b.n_cigar; c++) {
+            const uint32_t v = rdu32(b.cigar + 4 * (size_t)c);
             const int op = v & 15;
             const int64_t ln = v >> 4;
             if (op == 0 || op == 7 || op == 8) {                            // M = X
+                if (q + ln > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
                 int64_t lo1 = ref + 1 < 1 ? 1 : ref + 1, hi1 = ref + ln < hi ? ref + ln : hi;
                 for (int64_t p1 = lo1; p1 <= hi1; p1++)
                     if (region[p1]) {
                         const int64_t qi = q + (p1 - 1 - ref);
-                        const uint8_t byte = seq[qi >> 1];
+                        const uint8_t byte = b.seq[qi >> 1];
                         chars.push_back(SEQ[(qi & 1) ? (byte & 15) : (byte >> 4)]);      // util.py:186-189, b[0]
                     }
                 ref += ln; q += ln; qalen += ln;
@@ -180,8 +520,9 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
                 ref += ln;
             } else if (op == 1) { q += ln; qalen += ln; }                   // I
             else if (op == 4) { q += ln; }                                  // S
+            if (q > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
         }
-        int64_t leftmost = (int64_t)pos + 1;                                // util.py:162
+        int64_t leftmost = (int64_t)b.pos + 1;                              // util.py:162
         if (leftmost < start_pos) {                                         // util.py:165-171
             if (leftmost + qalen < start_pos) continue;
             leftmost = start_pos;
@@ -189,22 +530,57 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
         if (chars.empty()) continue;
         int one_or_two = 0;
         if (flag & 0x1) one_or_two = (flag & 0x40) ? 1 : ((flag & 0x80) ? 2 : 0);
-        key.assign(name);
-        key += '_'; key += std::to_string(flag); key += '_'; key += std::to_string(one_or_two);   // util.py:160
-        auto it = index.find(key);
-        if (it == index.end()) {
+        key.assign(b.name, (size_t)b.l_read_name - 1);
+        {                                                                   // "<qname>_<flag>_<1|2|0>", util.py:160
+            char tail[16];                                                  // (snprintf here was a third of the whole decode)
+            int tn = 0;
+            tail[tn++] = '_';
+            char dig[8];
+            int nd = 0, f = flag;
+            do { dig[nd++] = (char)('0' + f % 10); f /= 10; } while (f);
+            while (nd) tail[tn++] = dig[--nd];
+            tail[tn++] = '_';
+            tail[tn++] = (char)('0' + one_or_two);
+            key.append(tail, (size_t)tn);
+        }
+        const uint64_t kh = hash_key(key);
+        size_t si = (size_t)kh & table_mask;
+        int64_t found = -1;
+        while (table[si].row1) {
+            if (table[si].h == kh) {
+                const auto &ka = key_at[table[si].row1 - 1];
+                if ((size_t)ka.second == key.size() && memcmp(key_arena.data() + ka.first, key.data(), key.size()) == 0) {
+                    found = (int64_t)table[si].row1 - 1;
+                    break;
+                }
+            }
+            si = (si + 1) & table_mask;
+        }
+        if (found < 0) {
             int64_t lm = leftmost > (int64_t)end_pos + 1 ? (int64_t)end_pos + 1 : leftmost;
             const int32_t rank = lm >= 1 ? csum[lm] - csum[1] : 0;          // util.py:198
-            index.emplace(key, reads.size());
-            reads.push_back({rank, chars});
+            table[si] = slot{kh, (uint32_t)reads.size() + 1};
+            key_at.emplace_back((int64_t)key_arena.size(), (int32_t)key.size());
+            key_arena.insert(key_arena.end(), key.begin(), key.end());
+            if ((reads.size() + 1) * 2 > table.size()) grow();
+            reads.push_back({rank, (int64_t)arena.size(), (int32_t)chars.size()});
+            arena.insert(arena.end(), chars.begin(), chars.end());
         } else {
-            reads[it->second].seq += chars;
+            row &w = reads[(size_t)found];
+            if (w.off + w.len != (int64_t)arena.size()) {                   // not the last row: move it to the end
+                const size_t old = (size_t)w.off;
+                w.off = (int64_t)arena.size();
+                arena.resize(arena.size() + (size_t)w.len);
+                memcpy(arena.data() + w.off, arena.data() + old, (size_t)w.len);
+            }
+            arena.insert(arena.end(), chars.begin(), chars.end());
+            w.len += (int32_t)chars.size();
         }
     }
 
     const int64_t n = (int64_t)reads.size();
     int64_t total = 0;
-    for (auto &x : reads) total += (int64_t)x.seq.size();
+    for (auto &x : reads) total += (int64_t)x.len;
     out->rank = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
     out->off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
     out->bases = (uint8_t *)malloc((size_t)(total ? total : 1));
@@ -213,58 +589,75 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
     for (int64_t i = 0; i < n; i++) {
         out->rank[i] = reads[i].rank;
         out->off[i] = acc;
-        memcpy(out->bases + acc, reads[i].seq.data(), reads[i].seq.size());
-        acc += (int64_t)reads[i].seq.size();
+        memcpy(out->bases + acc, arena.data() + reads[i].off, (size_t)reads[i].len);
+        acc += (int64_t)reads[i].len;
     }
     out->off[n] = acc;
     out->n_reads = n;
     out->n_bases = total;
+    g_stats.reads_kept = n;
+    g_stats.libdeflate = libdeflate().ok ? 1 : 0;
+    g_stats.threads = n_threads();
+    g_stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     return 0;
 }
 
 extern "C" int gio_count_coverage(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts)
 {
     if (!bam_path || !contig || !counts || start0 < 0 || stop < start0) return fail(-1, "bad argument");
-    bam_file b;
-    int rc = open_bam(bam_path, b);
+    g_err[0] = 0;
+    bgzf_stream z;
+    int rc = z.open(bam_path);
     if (rc) return rc;
+    bam_header hd;
+    if ((rc = read_header(z, hd, bam_path))) return rc;
     int tid = -1;
-    for (size_t i = 0; i < b.refs.size(); i++)
-        if (b.refs[i].first == contig) tid = (int)i;
+    for (size_t i = 0; i < hd.refs.size(); i++)
+        if (hd.refs[i].first == contig) tid = (int)i;
     if (tid < 0) return fail(-5, "contig %s not in %s", contig, bam_path);
+    bool indexed = false;
+    uint64_t voff = 0;
+    if (bai_start(bam_path, tid, start0, &voff)) {
+        if ((rc = z.seek(voff >> 16, (unsigned)(voff & 0xffff)))) return rc;
+        indexed = true;
+    }
     const int64_t len = (int64_t)stop - start0;
     memset(counts, 0, sizeof(int32_t) * 4 * (size_t)len);
     static const int8_t code2base[16] = {-1, 0, 1, -1, 2, -1, -1, -1, 3, -1, -1, -1, -1, -1, -1, -1};   // =ACMGRSVTWYHKDBN
-    const std::vector<uint8_t> &d = b.data;
-    size_t o = b.first_record;
-    while (o + 4 <= d.size()) {
-        const int32_t block_size = rd32(&d[o]);
-        o += 4;
-        if (block_size < 32 || o + (size_t)block_size > d.size()) return fail(-4, "truncated BAM record");
-        const uint8_t *r = &d[o];
-        o += block_size;
-        if (rd32(r) != tid || (rdu16(r + 14) & 0x4)) continue;           // other contig / unmapped
-        const int32_t pos = rd32(r + 4);
-        const int n_cigar = rdu16(r + 12);
-        const uint8_t *cig = r + 32 + r[8];
-        const uint8_t *seq = cig + 4 * (size_t)n_cigar;
-        if (rd32(r + 16) == 0) continue;
-        int64_t ref = pos, q = 0;
-        for (int c = 0; c < n_cigar; c++) {
-            const uint32_t v = rdu32(cig + 4 * c);
+    for (;;) {
+        int64_t av = z.ensure(4);
+        if (av < 0) return (int)av;
+        if (av == 0) break;
+        if (av < 4) return fail(-4, "truncated BAM record");
+        const int32_t block_size = rd32(z.ptr());
+        if (block_size < 32 || block_size > (1 << 28)) return fail(-4, "bad BAM record size %d", block_size);
+        av = z.ensure(4 + (size_t)block_size);
+        if (av < 0) return (int)av;
+        if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
+        bam_rec b;
+        if ((rc = parse_record(z.ptr() + 4, block_size, b))) return rc;
+        z.consume(4 + (size_t)block_size);
+        if (indexed && (b.ref_id > tid || (b.ref_id == tid && b.pos >= stop))) break;
+        if (b.ref_id != tid || (b.flag & 0x4)) continue;                  // other contig / unmapped
+        if (b.l_seq == 0) continue;
+        int64_t ref = b.pos, q = 0;
+        for (int c = 0; c < b.n_cigar; c++) {
+            const uint32_t v = rdu32(b.cigar + 4 * (size_t)c);
             const int op = v & 15;
             const int64_t ln = v >> 4;
             if (op == 0 || op == 7 || op == 8) {
+                if (q + ln > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
                 int64_t lo = ref < start0 ? start0 : ref, hi = ref + ln < stop ? ref + ln : stop;
                 for (int64_t p = lo; p < hi; p++) {
                     const int64_t qi = q + (p - ref);
-                    const uint8_t byte = seq[qi >> 1];
+                    const uint8_t byte = b.seq[qi >> 1];
                     const int base = code2base[(qi & 1) ? (byte & 15) : (byte >> 4)];
                     if (base >= 0) counts[(size_t)base * len + (p - start0)]++;
                 }
                 ref += ln; q += ln;
             } else if (op == 2 || op == 3) ref += ln;
             else if (op == 1 || op == 4) q += ln;
+            if (q > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
         }
     }
     return 0;

@@ -15,6 +15,13 @@
  *   stepper "samtools": UNMAP/SECONDARY/QCFAIL/DUP reads and paired-but-not-proper reads are
  *   dropped; stepper "all" (--pepper, cmd.py:39,78) keeps the latter.
  * Not reproduced: pysam's max_depth cap (8000).
+ *
+ * The BAM is streamed (BGZF blocks inflated in parallel batches; libdeflate when its runtime library is present,
+ * zlib otherwise) and, like the reference's pysam fetch, uses the index next to it when there is one (<bam>.bai or
+ * <stem>.bai): the scan starts at the first block that can hold an alignment overlapping the window and ends at the
+ * first record behind it.  Without an index every record of the file is visited.  Record fields are validated
+ * against the record size (-4 on a malformed or truncated file); long-read CIGARs kept in the CG:B,I tag are resolved.
+ * Environment: GIO_THREADS (inflating threads, default = cores, <= 16), GIO_NO_INDEX=1, GIO_ZLIB=1.
  */
 #ifndef GRETEL_IO_H
 #define GRETEL_IO_H
@@ -33,7 +40,21 @@ typedef struct {
     int64_t n_bases;
 } gio_table;
 
+typedef struct {
+    int64_t compressed_bytes;   /* read from the BAM file */
+    int64_t blocks;             /* BGZF blocks inflated */
+    int64_t records;            /* BAM records parsed */
+    int64_t reads_kept;         /* rows of the support table */
+    int32_t used_index;         /* 1: started from a .bai offset and stopped behind the window */
+    int32_t libdeflate;         /* 1: libdeflate, 0: zlib */
+    int32_t threads;
+    int32_t _pad;
+    double seconds;             /* wall time of the call */
+} gio_stats;
+
 const char *gio_last_error(void);
+/* what the calling thread's last gio_support_table_from_bam did */
+void gio_last_stats(gio_stats *out);
 
 /* bam.lengths[bam.get_tid(contig)] -- gretel/util.py:27-29 */
 int gio_ref_len(const char *bam_path, const char *contig, int64_t *len);

@@ -1,0 +1,92 @@
+"""The native BAM decoder under AddressSanitizer + UBSan on the CPU: a valid BAM is damaged a few thousand ways
+(truncations, byte noise, blown-up length fields, unterminated names, shifted tails, flipped bits in the compressed
+stream) and every variant must come back as a status code.  Also: the index and the no-index scans agree, long-read
+CIGARs in the CG tag are resolved, a CIGAR that outruns its sequence is refused."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, REFDATA
+from gretel_amd import bamio, util
+from gretel_amd.synth import make_support_table
+
+
+def test_malformed_bams_never_read_out_of_bounds(tmp_path):
+    exe = str(tmp_path / "fuzz_bam")
+    src = [os.path.join(ROOT, "tests", "native", "fuzz_bam.cpp"), os.path.join(ROOT, "gretel_amd", "csrc", "bam_support.cpp")]
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                         "-I", os.path.join(ROOT, "include"), "-o", exe] + src + ["-lz", "-ldl", "-pthread"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    t = make_support_table(40, 300, k=4, seed=1)
+    bam, vcf = str(tmp_path / "v.bam"), str(tmp_path / "v.vcf.gz")
+    contig, s, e = bamio.synth_to_files(t, bam, vcf)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", GIO_THREADS="2")
+    for seed, src_bam, ctg, end in ((1, bam, contig, e), (2, os.path.join(REFDATA, "test.bam"), "hoot", 20)):
+        run = subprocess.run([exe, src_bam, ctg, str(end), "700", str(seed), str(tmp_path / "scratch.bam")],
+                             capture_output=True, text=True, env=env, timeout=600)
+        assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+        assert "fuzz_bam done" in run.stdout
+
+
+def test_index_and_full_scan_agree(tmp_path):
+    t = make_support_table(3000, 60000, k=4, seed=3)
+    bam, vcf = str(tmp_path / "s.bam"), str(tmp_path / "s.vcf.gz")
+    contig, s, e = bamio.synth_to_files(t, bam, vcf)
+    assert os.path.exists(bam + ".bai")
+    for (ws, we) in ((1, e), (9000, 12000), (25000, e), (1, 500), (e - 5, e)):
+        v = util.process_vcf(vcf, contig, ws, we)
+        a = util.support_table_from_bam(bam, contig, ws, we, v)
+        st = bamio.native_last_stats()
+        assert st["used_index"] == 1
+        os.environ["GIO_NO_INDEX"] = "1"
+        try:
+            b = util.support_table_from_bam(bam, contig, ws, we, v)
+            assert bamio.native_last_stats()["used_index"] == 0
+            assert bamio.native_last_stats()["records"] == t.n_reads
+        finally:
+            del os.environ["GIO_NO_INDEX"]
+        c = util.support_table_from_bam(bam, contig, ws, we, v, decoder="python")
+        for x, y, z in zip(a, b, c):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        if we < e // 2:
+            assert st["records"] < t.n_reads                 # the indexed scan stopped behind the window
+
+
+def _one_read_bam(path, cigar_ops, seq, aux=b"", n_cigar_field=None):
+    """BAM with one record on contig 'c' (length 100) at position 0; cigar_ops = [(op, len)]."""
+    name = b"q\x00"
+    packed = bytearray((len(seq) + 1) // 2)
+    for i, ch in enumerate(seq):
+        packed[i >> 1] |= "=ACMGRSVTWYHKDBN".index(ch) << (4 if (i & 1) == 0 else 0)
+    ncig = len(cigar_ops) if n_cigar_field is None else n_cigar_field
+    body = struct.pack("<iiBBHHHiiii", 0, 0, len(name), 42, 4681, ncig, 0, len(seq), -1, -1, 0)
+    body += name + b"".join(struct.pack("<I", (n << 4) | op) for op, n in cigar_ops) + bytes(packed) + b"\x7e" * len(seq) + aux
+    text = "@SQ\tSN:c\tLN:100\n"
+    data = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<ii", 1, 2) + b"c\x00" + struct.pack("<i", 100)
+    bamio.bgzf_write(path, data + struct.pack("<i", len(body)) + body)
+
+
+def test_long_read_cigar_in_cg_tag_and_overrunning_cigar(tmp_path):
+    vcf = str(tmp_path / "v.vcf.gz")
+    bamio.write_vcf_gz(vcf, "c", [3, 6, 9])
+    v = util.process_vcf(vcf, "c", 1, 50)
+    seq = "ACGTACGTAC"
+    real = [(0, 4), (2, 3), (0, 6)]                               # 4M3D6M: SNP 3 -> G, SNP 6 deleted, SNP 9 -> query offset 5
+    plain, tagged = str(tmp_path / "p.bam"), str(tmp_path / "t.bam")
+    _one_read_bam(plain, real, seq)
+    cg = b"CGBI" + struct.pack("<I", len(real)) + b"".join(struct.pack("<I", (n << 4) | op) for op, n in real)
+    _one_read_bam(tagged, [(4, len(seq)), (3, 13)], seq, aux=b"NMC\x01" + cg)      # placeholder <l_seq>S<ref_len>N + CG:B,I
+    a = util.support_table_from_bam(plain, "c", 1, 50, v)
+    b = util.support_table_from_bam(tagged, "c", 1, 50, v)
+    assert a[2].tobytes() == b"G-C" and b[2].tobytes() == b"G-C"
+    bad = str(tmp_path / "b.bam")
+    _one_read_bam(bad, [(0, 40)], seq)                             # 40M on a 10-base read
+    with pytest.raises(IOError):
+        util.support_table_from_bam(bad, "c", 1, 50, v)
+    _one_read_bam(bad, [(4, len(seq)), (3, 13)], seq)              # placeholder without the tag
+    with pytest.raises(IOError):
+        util.support_table_from_bam(bad, "c", 1, 50, v)
