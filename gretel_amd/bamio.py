@@ -344,6 +344,31 @@ def native_support_table(bam_path, contig, start_pos, end_pos, region, stepper="
     return rank, off, bases
 
 
+class _gio_runs(C.Structure):
+    _fields_ = [("ref_start", C.POINTER(C.c_int32)), ("off", C.POINTER(C.c_int64)), ("codes", C.POINTER(C.c_uint8)),
+                ("n_runs", C.c_int64), ("n_bases", C.c_int64)]
+
+
+def native_match_runs(bam_path, contig, start0, stop):
+    """(ref_start int32[n], off int64[n+1], codes uint8[total]): the aligned runs of the contig's records clipped to
+    [start0, stop), bases as A0 C1 G2 T3 / 4 = other -- the input of the GPU coverage histogram."""
+    L = io_lib()
+    L.gio_match_runs.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_gio_runs)]
+    L.gio_runs_free.argtypes = [C.POINTER(_gio_runs)]
+    r = _gio_runs()
+    if L.gio_match_runs(bam_path.encode(), contig.encode(), int(start0), int(stop), C.byref(r)):
+        msg = L.gio_last_error().decode()
+        raise (KeyError if "not in" in msg else IOError)(msg)
+    try:
+        n, nb = r.n_runs, r.n_bases
+        ref = np.ctypeslib.as_array(r.ref_start, shape=(max(n, 1),))[:n].copy()
+        off = np.ctypeslib.as_array(r.off, shape=(n + 1,)).copy()
+        codes = np.ctypeslib.as_array(r.codes, shape=(max(nb, 1),))[:nb].copy()
+    finally:
+        L.gio_runs_free(C.byref(r))
+    return ref, off, codes
+
+
 def native_count_coverage(bam_path, contig, start0, stop):
     """int32[4][stop-start0]: A,C,G,T counts per position, like pysam's count_coverage(..., quality_threshold=0,
     read_callback='nofilter') as gretel/snpper.py:29 calls it."""

@@ -662,3 +662,88 @@ extern "C" int gio_count_coverage(const char *bam_path, const char *contig, int3
     }
     return 0;
 }
+
+// The aligned (M/=/X) runs of every record on the contig, clipped to [start0, stop): what the coverage histogram of
+// gretel/snpper.py:29 is made of, in the form the GPU kernel takes (gh_coverage_sites, include/gretel_hip.h): per run
+// its 0-based reference start, and its bases as codes A0 C1 G2 T3, 4 = anything else (never counted).
+extern "C" void gio_runs_free(gio_runs *r)
+{
+    if (!r) return;
+    free(r->ref_start); free(r->off); free(r->codes);
+    memset(r, 0, sizeof *r);
+}
+
+extern "C" int gio_match_runs(const char *bam_path, const char *contig, int32_t start0, int32_t stop, gio_runs *out)
+{
+    if (!bam_path || !contig || !out || start0 < 0 || stop < start0) return fail(-1, "bad argument");
+    memset(out, 0, sizeof *out);
+    g_err[0] = 0;
+    bgzf_stream z;
+    int rc = z.open(bam_path);
+    if (rc) return rc;
+    bam_header hd;
+    if ((rc = read_header(z, hd, bam_path))) return rc;
+    int tid = -1;
+    for (size_t i = 0; i < hd.refs.size(); i++)
+        if (hd.refs[i].first == contig) tid = (int)i;
+    if (tid < 0) return fail(-5, "contig %s not in %s", contig, bam_path);
+    bool indexed = false;
+    uint64_t voff = 0;
+    if (bai_start(bam_path, tid, start0, &voff)) {
+        if ((rc = z.seek(voff >> 16, (unsigned)(voff & 0xffff)))) return rc;
+        indexed = true;
+    }
+    static const uint8_t code2base[16] = {4, 0, 1, 4, 2, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4};   // =ACMGRSVTWYHKDBN
+    std::vector<int32_t> ref_start;
+    std::vector<int64_t> off(1, 0);
+    std::vector<uint8_t> codes;
+    for (;;) {
+        int64_t av = z.ensure(4);
+        if (av < 0) return (int)av;
+        if (av == 0) break;
+        if (av < 4) return fail(-4, "truncated BAM record");
+        const int32_t block_size = rd32(z.ptr());
+        if (block_size < 32 || block_size > (1 << 28)) return fail(-4, "bad BAM record size %d", block_size);
+        av = z.ensure(4 + (size_t)block_size);
+        if (av < 0) return (int)av;
+        if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
+        bam_rec b;
+        if ((rc = parse_record(z.ptr() + 4, block_size, b))) return rc;
+        z.consume(4 + (size_t)block_size);
+        if (indexed && (b.ref_id > tid || (b.ref_id == tid && b.pos >= stop))) break;
+        if (b.ref_id != tid || (b.flag & 0x4) || b.l_seq == 0) continue;
+        int64_t ref = b.pos, q = 0;
+        for (int c = 0; c < b.n_cigar; c++) {
+            const uint32_t v = rdu32(b.cigar + 4 * (size_t)c);
+            const int op = v & 15;
+            const int64_t ln = v >> 4;
+            if (op == 0 || op == 7 || op == 8) {
+                if (q + ln > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
+                const int64_t lo = ref < start0 ? start0 : ref, hi = ref + ln < stop ? ref + ln : stop;
+                if (hi > lo) {
+                    ref_start.push_back((int32_t)lo);
+                    for (int64_t p = lo; p < hi; p++) {
+                        const int64_t qi = q + (p - ref);
+                        const uint8_t byte = b.seq[qi >> 1];
+                        codes.push_back(code2base[(qi & 1) ? (byte & 15) : (byte >> 4)]);
+                    }
+                    off.push_back((int64_t)codes.size());
+                }
+                ref += ln; q += ln;
+            } else if (op == 2 || op == 3) ref += ln;
+            else if (op == 1 || op == 4) q += ln;
+            if (q > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
+        }
+    }
+    const size_t n = ref_start.size();
+    out->ref_start = (int32_t *)malloc(sizeof(int32_t) * (n ? n : 1));
+    out->off = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+    out->codes = (uint8_t *)malloc(codes.size() ? codes.size() : 1);
+    if (!out->ref_start || !out->off || !out->codes) { gio_runs_free(out); return fail(-6, "out of memory"); }
+    if (n) memcpy(out->ref_start, ref_start.data(), sizeof(int32_t) * n);
+    memcpy(out->off, off.data(), sizeof(int64_t) * (n + 1));
+    if (!codes.empty()) memcpy(out->codes, codes.data(), codes.size());
+    out->n_runs = (int64_t)n;
+    out->n_bases = (int64_t)codes.size();
+    return 0;
+}

@@ -1418,6 +1418,45 @@ extern "C" int gh_export_dense(gh_t *h, double *out)
     return GH_OK;
 }
 
+// gretel-snpper -------------------------------------------------------------------------------
+extern "C" int gh_coverage_sites(int device, const int32_t *ref_start, const int64_t *off, const uint8_t *codes, int64_t n_runs,
+                                 int32_t start0, int32_t len, int32_t depth, int32_t *counts_out, uint8_t *site_out)
+{
+    if (n_runs < 0 || len < 0 || !site_out || (n_runs > 0 && (!ref_start || !off || !codes))) return fail(GH_ERR_ARG, "bad argument");
+    if (len == 0) return GH_OK;
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    const int64_t n_bases = n_runs ? off[n_runs] : 0;
+    int32_t *d_ref = nullptr;
+    int64_t *d_off = nullptr;
+    uint8_t *d_codes = nullptr, *d_site = nullptr;
+    unsigned *d_counts = nullptr;
+    hipError_t e = hipMalloc((void **)&d_counts, sizeof(unsigned) * 4 * (size_t)len);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_site, (size_t)len);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ref, sizeof(int32_t) * (size_t)(n_runs ? n_runs : 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, sizeof(int64_t) * (size_t)(n_runs + 1));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_codes, (size_t)(n_bases ? n_bases : 1));
+    if (e == hipSuccess) e = hipMemset(d_counts, 0, sizeof(unsigned) * 4 * (size_t)len);
+    if (e == hipSuccess && n_runs) {
+        e = hipMemcpy(d_ref, ref_start, sizeof(int32_t) * (size_t)n_runs, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_off, off, sizeof(int64_t) * (size_t)(n_runs + 1), hipMemcpyHostToDevice);
+        if (e == hipSuccess && n_bases) e = hipMemcpy(d_codes, codes, (size_t)n_bases, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) {
+        if (n_runs) {
+            int64_t nb = (n_runs + 3) / 4;                  // one wavefront per run, four per workgroup
+            if (nb > 256 * 16) nb = 256 * 16;
+            hipLaunchKernelGGL(k_cov, dim3((unsigned)nb), dim3(256), 0, 0, d_ref, d_off, d_codes, n_runs, start0, len, d_counts);
+        }
+        hipLaunchKernelGGL(k_sites, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, d_counts, len, (unsigned)(depth < 0 ? 0 : depth), d_site);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(site_out, d_site, (size_t)len, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && counts_out) e = hipMemcpy(counts_out, d_counts, sizeof(unsigned) * 4 * (size_t)len, hipMemcpyDeviceToHost);
+    hipFree(d_counts); hipFree(d_site); hipFree(d_ref); hipFree(d_off); hipFree(d_codes);
+    if (e != hipSuccess) return fail(GH_ERR_HIP, "gh_coverage_sites failed: %s", hipGetErrorString(e));
+    return GH_OK;
+}
+
 // profiling -----------------------------------------------------------------------------------
 extern "C" int gh_profile_enable(gh_t *h, int on)
 {

@@ -1705,3 +1705,35 @@ __global__ void k_gap(const double *cnt, int N, int *first_gap)
     if (p > N) return;
     if (cnt[(size_t)p * 8 + 7] == 0.0) atomicMin(first_gap, p);
 }
+
+// ---------------------------------------------------------------------------------------------
+// gretel-snpper (gretel/snpper.py:29-50) as a histogram: k_cov counts, per position of the window, the reads showing
+// A, C, G, T (one wavefront per aligned run, lanes stride over its bases, integer atomics); k_sites marks the
+// positions where more than one base is seen on more than `depth` reads (snpper.py:38-40).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_cov(const int32_t *__restrict__ ref_start, const int64_t *__restrict__ off, const uint8_t *__restrict__ codes,
+      int64_t n_runs, int32_t start0, int32_t len, unsigned *__restrict__ counts /* [4][len] */)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n_runs; r += nw) {
+        const int64_t o0 = off[r], o1 = off[r + 1];
+        const int32_t p0 = ref_start[r] - start0;
+        for (int64_t q = o0 + lane; q < o1; q += 64) {
+            const int c = codes[q];
+            const int64_t p = p0 + (q - o0);
+            if (c < 4 && p >= 0 && p < len) atomicAdd(&counts[(size_t)c * len + p], 1u);
+        }
+    }
+}
+
+__global__ void k_sites(const unsigned *__restrict__ counts, int32_t len, unsigned depth, uint8_t *__restrict__ site)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= len) return;
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) n += counts[(size_t)c * len + p] > depth ? 1 : 0;
+    site[p] = n > 1 ? 1 : 0;
+}

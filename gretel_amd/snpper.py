@@ -13,14 +13,36 @@ import sys
 from . import bamio
 
 
-def call_sites(bam, contig, start1=1, end=None, depth=0):
-    """1-based positions of the called sites."""
+def coverage_on_gpu(bam, contig, start0, end, depth=0, device=-1, want_counts=False):
+    """(site mask uint8[end-start0], counts int32[4][end-start0] or None) from the GPU histogram (gh_coverage_sites)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import _lib
+    ref, off, codes = bamio.native_match_runs(bam, contig, start0, end)
+    n = max(0, end - start0)
+    site = np.zeros(n, dtype=np.uint8)
+    counts = np.zeros((4, n), dtype=np.int32) if want_counts else None
+    _lib.check(_lib.load().gh_coverage_sites(int(device), ref.ctypes.data, off.ctypes.data, codes.ctypes.data, len(ref),
+                                            int(start0), int(n), int(depth),
+                                            counts.ctypes.data if want_counts else None, site.ctypes.data))
+    return site, counts
+
+
+def call_sites(bam, contig, start1=1, end=None, depth=0, host=False, device=-1):
+    """1-based positions of the called sites.  Default: the coverage histogram and the site rule run on the GPU
+    (k_cov / k_sites); host=True counts with the native decoder on the CPU instead (an explicit choice, `--host` on
+    the command line -- never a silent fallback)."""
     if not end:
         end = bamio.native_ref_len(bam, contig)                       # snpper.py:23-24
     start0 = start1 - 1                                               # snpper.py:27
-    counts = bamio.native_count_coverage(bam, contig, start0, end)    # snpper.py:29
-    sites = (counts > depth).sum(axis=0)                              # snpper.py:38
-    return [int(i) + 1 + start0 for i in (sites > 1).nonzero()[0]]    # snpper.py:39-43
+    if host:
+        counts = bamio.native_count_coverage(bam, contig, start0, end)    # snpper.py:29
+        sites = (counts > depth).sum(axis=0) > 1                          # snpper.py:38-39
+    else:
+        sites, _ = coverage_on_gpu(bam, contig, start0, end, depth, device)
+    return [int(i) + 1 + start0 for i in sites.nonzero()[0]]          # snpper.py:39-43
 
 
 def main(argv=None):
@@ -31,10 +53,11 @@ def main(argv=None):
     ap.add_argument("-s", type=int, default=1, help="start [1]")
     ap.add_argument("-e", type=int, help="end [length of the contig]")
     ap.add_argument("--depth", type=int, default=0, help="a base counts as a variant if more than this many reads show it [0]")
+    ap.add_argument("--host", action="store_true", help="count on the CPU (native decoder) instead of the GPU histogram")
     args = ap.parse_args(argv)
     out = sys.stdout
     out.write("##fileformat=VCFv4.2\n")                               # snpper.py:33-35
-    for pos in call_sites(args.bam, args.contig, args.s, args.e, args.depth):
+    for pos in call_sites(args.bam, args.contig, args.s, args.e, args.depth, host=args.host):
         out.write("\t".join([args.contig, str(pos), ".", "A", "C,T,G", "0", ".", "INFO"]) + "\n")
     return 0
 

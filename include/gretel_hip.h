@@ -166,6 +166,13 @@ int gh_export_band(gh_t *h, double *out);
 int gh_import_band(gh_t *h, const double *in);
 int gh_export_dense(gh_t *h, double *out);
 
+/* gretel-snpper's site calling -- gretel/snpper.py:29-50 -- as a GPU histogram: the aligned runs of the BAM (gio_match_runs,
+ * include/gretel_io.h: per run its 0-based reference start, bases as codes A0 C1 G2 T3, 4 = other) are counted per
+ * position of the window [start0, start0+len) and base; site_out[p] = 1 where more than one base is seen on more than
+ * `depth` reads (snpper.py:38-40).  counts_out (optional): int32[4][len], the array pysam's count_coverage returns. */
+int gh_coverage_sites(int device, const int32_t *ref_start, const int64_t *off, const uint8_t *codes, int64_t n_runs,
+                      int32_t start0, int32_t len, int32_t depth, int32_t *counts_out, uint8_t *site_out);
+
 /* Per-kernel HIP-event timing on the handle's own stream (bench.py's roofline leg).
  * gh_profile_enable(h, k): k = 0 off; k >= 1 brackets every k-th launch of each kernel with a pair of events
  * (an event between two kernels costs the stream a ~10 us bubble, so a timed region samples with k > 1). */

@@ -72,6 +72,19 @@ void gio_table_free(gio_table *t);
  * ref-skips, clips, insertions and N bases do not.  counts: int32[4][stop - start0], caller-allocated. */
 int gio_count_coverage(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts);
 
+/* The same coverage as data for the GPU histogram (gh_coverage_sites, include/gretel_hip.h): the aligned (M/=/X) runs
+ * of every record on the contig clipped to [start0, stop) -- per run its 0-based reference start and its bases as
+ * codes A0 C1 G2 T3, 4 = anything else.  Released with gio_runs_free. */
+typedef struct {
+    int32_t *ref_start;  /* [n_runs] */
+    int64_t *off;        /* [n_runs + 1]: codes[off[r] .. off[r+1]) are run r's bases */
+    uint8_t *codes;      /* [n_bases] */
+    int64_t n_runs;
+    int64_t n_bases;
+} gio_runs;
+int gio_match_runs(const char *bam_path, const char *contig, int32_t start0, int32_t stop, gio_runs *out);
+void gio_runs_free(gio_runs *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,12 +98,28 @@ def test_synthetic_files_roundtrip(tmp_path):
 def test_snpper_on_fixture_and_cigar_cases(tmp_path, capsys):
     from gretel_amd import snpper
     # fixture: hoot has A/C/T at 1,2 ; A/C at 10 ; only G at 20 -> sites 1,2,10 (what the reference's own VCF lists, plus none at 20)
-    assert snpper.call_sites(BAM, "hoot") == [1, 2, 10]
-    assert snpper.call_sites(BAM, "hoot", depth=1) == []             # no base is seen on more than one read twice
-    assert snpper.call_sites(BAM, "hoot", 2, 9) == [2]
-    assert snpper.main(["--bam", BAM, "--contig", "hoot"]) == 0
+    assert snpper.call_sites(BAM, "hoot", host=True) == [1, 2, 10]
+    assert snpper.call_sites(BAM, "hoot", depth=1, host=True) == []  # no base is seen on more than one read twice
+    assert snpper.call_sites(BAM, "hoot", 2, 9, host=True) == [2]
+    assert snpper.main(["--bam", BAM, "--contig", "hoot", "--host"]) == 0
     out = capsys.readouterr().out.splitlines()
     assert out[0] == "##fileformat=VCFv4.2" and out[1] == "hoot\t1\t.\tA\tC,T,G\t0\t.\tINFO" and len(out) == 4
     cov = bamio.native_count_coverage(BAM, "hoot", 0, 20)
     assert cov.shape == (4, 20) and cov[:, 0].tolist() == [1, 1, 0, 2] and cov[:, 19].tolist() == [0, 0, 1, 0]
     assert cov[:, 4].sum() == 0                                      # N bases are not counted
+
+
+def test_match_runs_rebuild_the_coverage_counts(tmp_path):
+    # the aligned runs handed to the GPU histogram carry exactly the coverage the host counter reports
+    t = make_support_table(200, 3000, k=4, seed=5)
+    bam, vcf = str(tmp_path / "s.bam"), str(tmp_path / "s.vcf.gz")
+    contig, s, e = bamio.synth_to_files(t, bam, vcf)
+    for (a, b) in ((0, e), (500, 1500), (0, 37)):
+        ref, off, codes = bamio.native_match_runs(bam, contig, a, b)
+        cov = np.zeros((4, b - a), dtype=np.int32)
+        for r in range(len(ref)):
+            c = codes[off[r]:off[r + 1]]
+            p = ref[r] - a + np.arange(len(c))
+            ok = c < 4
+            np.add.at(cov, (c[ok], p[ok]), 1)
+        assert np.array_equal(cov, bamio.native_count_coverage(bam, contig, a, b))

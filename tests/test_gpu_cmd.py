@@ -156,3 +156,27 @@ def test_cli_debughpos_prints_every_path(tmp_path, capsys):
     assert out.count("{") == 3 * 2
     fasta, snp, crumbs = _expected(3, 1, 20)
     assert (tmp_path / "gretel.crumbs").read_text() == crumbs
+
+
+def test_snpper_gpu_histogram_matches_the_host_counter(tmp_path, capsys):
+    """gretel-snpper (gretel/snpper.py:29-50): coverage histogram + site rule on the GPU (k_cov / k_sites) against the
+    native host counter, on the reference fixture and on a synthetic contig with errors, for several depths/windows."""
+    import numpy as np
+    from gretel_amd import bamio, snpper
+    from gretel_amd.synth import make_support_table
+    assert snpper.call_sites(BAM, "hoot") == [1, 2, 10]                    # the sites of the reference's own VCF fixture
+    assert snpper.call_sites(BAM, "hoot", depth=1) == []
+    assert snpper.call_sites(BAM, "hoot", 2, 9) == [2]
+    assert snpper.main(["--bam", BAM, "--contig", "hoot"]) == 0
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "##fileformat=VCFv4.2" and out[1] == "hoot\t1\t.\tA\tC,T,G\t0\t.\tINFO" and len(out) == 4
+    t = make_support_table(2000, 60000, k=5, seed=9, err=0.02)
+    bam, vcf = str(tmp_path / "s.bam"), str(tmp_path / "s.vcf.gz")
+    contig, s, e = bamio.synth_to_files(t, bam, vcf)
+    site, counts = snpper.coverage_on_gpu(bam, contig, 0, e, depth=0, want_counts=True)
+    assert np.array_equal(counts, bamio.native_count_coverage(bam, contig, 0, e))
+    for depth in (0, 1, 3, 10):
+        for (a, b) in ((1, None), (3000, 9000)):
+            assert snpper.call_sites(bam, contig, a, b, depth) == snpper.call_sites(bam, contig, a, b, depth, host=True)
+    got = snpper.call_sites(bam, contig, 1, None, 3)
+    assert set(got) <= {10 * (q + 1) for q in range(t.n_snps)} and len(got) > 0.9 * t.n_snps   # the planted SNPs, not the error noise
