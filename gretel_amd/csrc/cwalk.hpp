@@ -1,0 +1,455 @@
+// cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated
+// (L = 6..16: 4^L states; segwalk.hpp enumerates up to 4^5), included by gretel_hip.hip behind segwalk.hpp.
+//
+// Same decomposition -- cut the window into <= 256 segments, know for every segment what it does to the state that
+// enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states (<= 64 per
+// segment, kept from path to path), and the chain is then VERIFIED, never assumed:
+//
+//   k_cwalk   one workgroup per segment, four lanes (one per candidate rank b) per pool entry that has not been walked
+//             under the current tensor: the same lag-ascending binary64 sums and first-wins arg-max as every other
+//             walker, from the conditional table staged in LDS; records the exit state and the picks.
+//   k_clink   (behind k_cwalk, the pools stand still) where every entry's exit state sits in the next segment's pool.
+//   k_cscan   one wavefront: chains from the start state along the links.  The chain either reaches the end -- every
+//             hop an exact pool hit onto a walked entry -- or stops at a state that still has to be walked (an exit
+//             that is not in the next pool is inserted there).
+//   (repeat k_cwalk / k_cscan for the pending entries: each round walks only what is new)
+//   k_cemit   one workgroup per segment: the picks of the entry that is on the verified chain -> path symbols, selected
+//             log-marginals, minimum marginal (as k_emit).
+//
+// Nothing approximate survives: a path is emitted only when every segment's entry state equals the previous segment's
+// exit state, both produced by exact walks.  When the rounds queued for a path do not close the chain, the kernels
+// behind flag the path unresolved and idle; the host re-queues it with more rounds or hands it to the serial walker,
+// whose states then seed the pools.  The pools start from the serial walk of the spin's first path.
+#pragma once
+
+#define CW_K 64                 /* pool entries per segment */
+#define CW_THREADS (4 * CW_K)   /* four lanes per entry */
+#define CW_MIN_L 6
+#define CW_MAX_L 16             /* 2 bits per pick in a 32-bit state */
+#define CW_MAX_SEG 256
+#define CW_MIN_LEN 32
+
+struct cw_geom { int seglen, S, NW; };
+__host__ __device__ inline cw_geom cw_geometry(int N)
+{
+    cw_geom g;
+    int len = (N + CW_MAX_SEG - 1) / CW_MAX_SEG;
+    if (len < CW_MIN_LEN) len = CW_MIN_LEN;
+    g.seglen = len;
+    g.S = (N + len - 1) / len;
+    g.NW = (len + 15) / 16;
+    return g;
+}
+// positions per LDS chunk of k_cwalk: (c + L - 1) sources x 4 rows x L lags x 5 columns of doubles within 96 KB
+__host__ __device__ constexpr int cw_chunk(int L)
+{
+    int c = 64;
+    while (c > 8 && (c + L - 1) * 4 * L * 5 * 8 > 96 * 1024) c -= 1;
+    return c;
+}
+__host__ __device__ constexpr size_t cw_lds_bytes(int L) { return (size_t)(cw_chunk(L) + L - 1) * 4 * L * 5 * 8; }
+
+struct cw_params {
+    int N, L;
+    int rearm;                // spin loops: k_cemit re-arms first_hole/nodel/cm_same/narrow for the k_rw that follows
+    int check_masks;          // as seg_params
+    int round;                // 0 = first round of a path; later rounds idle once the chain has closed
+    int last_round;           // k_cscan: an open chain after this round flags the path unresolved
+    int stamp;                // path counter of the spin (pool entries remember when they were last on a chain)
+    int _pad;
+    const double *G;          // ranked layout only
+    const double *minfo;
+    dev_state *st;
+    uint32_t *keys, *exits;   // [S][CW_K]
+    int32_t *last_hit;        // [S][CW_K]
+    int32_t *npool;           // [S]
+    uint32_t *pend;           // [S][CW_K]: states waiting to join the pool (exits of the previous segment's walks)
+    int32_t *npend;           // [S]
+    uint8_t *walked;          // [S][CW_K]: walked under the current tensor
+    int8_t *nxt;              // [S][CW_K]: index of the entry's exit state in the next segment's pool, -1 = not there
+    uint32_t *hist;           // [S][NW][CW_K]
+    int32_t *true_idx;        // [S]
+    double *segmin;           // [S]
+    uint8_t *path_out;
+    double *lmsel;
+};
+
+// -------------------------------------------------------------------------------------------------------------
+// k_cwalk: quad q of workgroup s walks pool entry q of segment s (if it has not been walked under this tensor), then
+// looks its exit state up in the next segment's pool.
+// -------------------------------------------------------------------------------------------------------------
+template <int LC>
+__global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
+{
+    extern __shared__ __align__(16) unsigned char cw_smem[];
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    if (P.round > 0 && c.cw_open_at < 0) return;            // the chain closed in an earlier round
+    if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
+        return;
+    }
+    if (!c.ranked) {                                        // a position with five candidates: not this walker's layout
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;      // (the flags stand until k_cemit re-arms them)
+    const cw_geom g = cw_geometry(P.N);
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= g.S) return;
+    // (1) the states the previous segment's walks ended in, and that this pool does not hold yet, join it (only this
+    // workgroup writes pool s).  A full pool gives up the entries that were on a chain longest ago, never one of this path.
+    __shared__ int s_n;
+    if (tid < 64) {
+        int n0 = P.npool[s];
+        const int np = P.npend[s] < CW_K ? P.npend[s] : CW_K;
+        uint32_t *keys = P.keys + (size_t)s * CW_K;
+        int32_t *lh = P.last_hit + (size_t)s * CW_K;
+        for (int k = 0; k < np; k++) {
+            const uint32_t x = P.pend[(size_t)s * CW_K + k];
+            const bool dup = __builtin_amdgcn_ballot_w64(tid < n0 && keys[tid] == x) != 0;
+            if (dup) continue;
+            int slot = n0;
+            if (n0 >= CW_K) {
+                int mine = (tid == 0 && s == 0) ? 0x7fffffff : lh[tid], who = tid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int om = __shfl_xor(mine, o), ow = __shfl_xor(who, o);
+                    if (om < mine || (om == mine && ow < who)) { mine = om; who = ow; }
+                }
+                if (mine >= P.stamp) continue;              // every entry was on a chain of this path (cannot happen: one per path)
+                slot = who;
+            } else n0++;
+            if (tid == 0) { keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = 0; }
+            __builtin_amdgcn_s_waitcnt(0);                  // the next candidate's duplicate search reads keys[]
+        }
+        if (tid == 0) { P.npool[s] = n0; P.npend[s] = 0; s_n = n0; }
+    }
+    __syncthreads();
+    const int n = s_n;
+    const int q = tid >> 2, b = tid & 3;
+    const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
+    if (!__syncthreads_or(live ? 1 : 0)) return;            // nothing new to walk in this segment
+    constexpr int CH = cw_chunk(LC);
+    constexpr unsigned SMASK = LC >= 16 ? 0xffffffffu : ((1u << (2 * LC)) - 1u);
+    double *Gs = reinterpret_cast<double *>(cw_smem);       // [(CH + LC - 1)][4][LC][5]: G's own layout, rows 0..3
+    unsigned sigma = live ? P.keys[(size_t)s * CW_K + q] : 0u;
+    const int t0 = s * g.seglen;
+    const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    const unsigned shift = (unsigned)(tid & 63 & ~3);       // this quad's bits in the wave's ballot
+    int word_i = 0;
+    unsigned word = 0;
+    // The slice of G a chunk needs: sources c0+1-LC .. c0+nc-1.  Rows 0..3 of a source are one contiguous run of 4*L*5
+    // doubles in G ([i][row][lag][col]) and go to LDS as they are (16-byte copies).  The loads of chunk k+1 are issued
+    // before chunk k is walked and stay in registers under the walk: their latency is off the critical path.
+    constexpr int RUN = 4 * LC * LT_ROW, RUN2 = RUN / 2;          // doubles / double2 per source
+    constexpr int NV = ((CH + LC - 1) * RUN2 + CW_THREADS - 1) / CW_THREADS;
+    lds_v2d pre[NV];
+    auto fetch = [&](int c0) {
+        const int nc = t1 - c0 < CH ? t1 - c0 : CH;
+        const int i_lo = c0 + 1 - LC, total = (nc + LC - 1) * RUN2;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int e = tid + k * CW_THREADS;
+            pre[k] = lds_v2d{0.0, 0.0};
+            if (e < total) {
+                const int ii = e / RUN2, r2 = e - ii * RUN2;
+                const int i = i_lo + ii;
+                if (i >= 1) pre[k] = *reinterpret_cast<const lds_v2d *>(P.G + (size_t)i * 6 * LC * LT_ROW + 2 * r2);
+            }
+        }
+    };
+    auto store = [&](int c0) {
+        const int nc = t1 - c0 < CH ? t1 - c0 : CH;
+        const int i_lo = c0 + 1 - LC, total = (nc + LC - 1) * RUN2;
+        lds_v2d *dst = reinterpret_cast<lds_v2d *>(Gs);
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int e = tid + k * CW_THREADS;
+            if (e < total) dst[e] = pre[k];
+        }
+        if (i_lo <= 0) {                                          // position 0 carries '_' whatever the digit says (row 5)
+            __syncthreads();
+            const int ii0 = -i_lo;                                // its slot
+            for (int e = tid; e < RUN; e += CW_THREADS) {
+                const int l = (e / LT_ROW) % LC, bb = e % LT_ROW;
+                Gs[(size_t)ii0 * RUN + e] = P.G[(size_t)(5 * LC + l) * LT_ROW + bb];
+            }
+        }
+    };
+    fetch(t0);
+    for (int c0 = t0; c0 < t1; c0 += CH) {
+        const int nc = t1 - c0 < CH ? t1 - c0 : CH;
+        __syncthreads();                                          // the previous chunk has been walked
+        store(c0);
+        __syncthreads();
+        if (c0 + CH < t1) fetch(c0 + CH);
+        // One step: lag l of chunk-local target tl comes from slot tl + LC - l, row = the pick made l positions ago:
+        // Gs[((slot * 4 + row) * LC + (l - 1)) * 5 + b].  rowoff(l) = that pick's row offset in doubles.
+        auto step = [&](int tl, auto rowoff) {
+            const double *base = Gs + (size_t)tl * RUN + b;
+            double x[LC];
+#pragma unroll
+            for (int l = 1; l <= LC; l++) x[l - 1] = base[((LC - l) * 4 * LC + (l - 1)) * LT_ROW + rowoff(l)];
+            double acc = x[0];
+#pragma unroll
+            for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
+            double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
+            m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
+            const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+            const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & 15u);       // first wins (gretel.py:166-174)
+            sigma = ((sigma << 2) | d) & SMASK;
+            const int gt = c0 - t0 + tl;                             // position inside the segment
+            word |= d << (2 * (gt & 15));
+            if ((gt & 15) == 15 || gt == t1 - t0 - 1) {
+                if (live && b == 0) P.hist[((size_t)s * g.NW + word_i) * CW_K + q] = word;
+                word = 0;
+                word_i++;
+            }
+            return d;
+        };
+        // blocks of LC steps: the row offsets of the last LC picks sit in registers, slot k = the pick of the step that is
+        // k (mod LC) into the block, so every index below is a compile-time constant (no shuffling of registers, no
+        // bit-field extraction per lag); what is left of the chunk takes the offsets out of the state word
+        constexpr unsigned ROWD = LC * LT_ROW;                       // doubles per row
+        int tl = 0;
+        if (nc >= LC) {
+            unsigned dig[LC];
+#pragma unroll
+            for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = ((sigma >> (2 * (l - 1))) & 3u) * ROWD;
+            for (; tl + LC <= nc; tl += LC) {
+#pragma unroll
+                for (int u = 0; u < LC; u++) {
+                    const unsigned d = step(tl + u, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
+                    dig[u] = d * ROWD;
+                }
+            }
+        }
+        for (; tl < nc; tl++) step(tl, [&](int l) { return ((sigma >> (2 * (l - 1))) & 3u) * ROWD; });
+    }
+    if (live && b == 0) {
+        P.exits[(size_t)s * CW_K + q] = sigma;
+        P.walked[(size_t)s * CW_K + q] = 1;
+        // (3) closure: an exit state the next pool does not hold asks to join it.  (The next workgroup may be merging
+        // its own pending list right now: a missed match only costs a duplicate request, dropped at the merge; the hops
+        // themselves are resolved by k_clink, after this kernel.)
+        if (s + 1 < g.S) {
+            const uint32_t *kn = P.keys + (size_t)(s + 1) * CW_K;
+            bool there = false;
+            for (int k = 0; k < CW_K; k++)
+                if (kn[k] == sigma) { there = true; break; }
+            if (!there) {
+                const int slot = atomicAdd(&P.npend[s + 1], 1);
+                if (slot < CW_K) P.pend[(size_t)(s + 1) * CW_K + slot] = sigma;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_clink: behind k_cwalk the pools stand still.  Lane q of workgroup s finds where the exit state of entry (s, q) sits
+// in pool s+1:  hop >= 0: that entry, walked under this tensor;  -2: there, still to be walked;  -1: not there.
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(CW_K) k_clink(cw_params P)
+{
+    const dev_ctl c = load_ctl(P.st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    if (P.round > 0 && c.cw_open_at < 0) return;
+    const cw_geom g = cw_geometry(P.N);
+    const int s = blockIdx.x, q = threadIdx.x;
+    if (s + 1 >= g.S) return;
+    const size_t e = (size_t)s * CW_K + q;
+    const uint32_t kn = P.keys[(size_t)(s + 1) * CW_K + q];           // lane q holds key q of the next pool
+    const bool kw = P.walked[(size_t)(s + 1) * CW_K + q] != 0;
+    const int nn = P.npool[s + 1];
+    const bool mine = q < P.npool[s] && P.walked[e];
+    const uint32_t x = P.exits[e];
+    int h = -1;
+    for (int k = 0; k < nn; k++) {                                     // (uniform trip count; key k by broadcast)
+        const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)kn, k);
+        const bool ww = __builtin_amdgcn_readlane(kw ? 1 : 0, k) != 0;
+        if (h == -1 && kk == x) h = ww ? k : -2;
+    }
+    P.nxt[e] = (int8_t)(mine ? h : -1);
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_cscan: follows the hops from the start state (pool 0, entry 0).  Every hop lands on the entry that HOLDS the previous
+// entry's exit state and has been walked under this tensor (k_clink compared the keys).  Two levels, so that the longest
+// dependent chain is 16 + 16 + 16 table reads instead of 256: (1) every (group of 16 segments, entry) is carried
+// through its group -- a map per group; (2) one thread chains the groups; (3) one thread per group walks its group again
+// from the entry the chain enters it with.  Where the chain cannot hop it is open: the state waits in the next pool
+// for the next round, or is on its way there (pending list; put there now if it is not).
+// -------------------------------------------------------------------------------------------------------------
+#define CW_GRP 16
+__global__ void __launch_bounds__(1024) k_cscan(cw_params P)
+{
+    __shared__ int8_t hop[CW_MAX_SEG * CW_K];
+    __shared__ int8_t gmap[(CW_MAX_SEG / CW_GRP) * CW_K];   // entry at the group's first segment -> entry behind its last hop, -1 = stuck
+    __shared__ int tru[CW_MAX_SEG + 1];
+    __shared__ int gin[CW_MAX_SEG / CW_GRP + 1];
+    __shared__ int s_stuck;
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    if (P.round > 0 && c.cw_open_at < 0) return;
+    const cw_geom g = cw_geometry(P.N);
+    const int S = g.S, tid = threadIdx.x;
+    const int NG = (S - 1 + CW_GRP - 1) / CW_GRP;           // hops s -> s+1 for s = 0 .. S-2, in groups of 16
+    {
+        const int n4 = S * CW_K / 4;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(P.nxt);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(hop);
+        for (int e = tid; e < n4; e += 1024) dst[e] = src[e];
+    }
+    if (tid == 0) s_stuck = 0x7fffffff;
+    __syncthreads();
+    for (int e = tid; e < NG * CW_K; e += 1024) {           // (1)
+        const int gr = e / CW_K;
+        int x = e - gr * CW_K;
+        const int s1 = (gr + 1) * CW_GRP < S - 1 ? (gr + 1) * CW_GRP : S - 1;
+        for (int s = gr * CW_GRP; s < s1 && x >= 0; s++) x = hop[s * CW_K + x];
+        gmap[e] = (int8_t)(x >= 0 ? x : -1);
+    }
+    __syncthreads();
+    if (tid == 0) {                                         // (2)
+        const bool start_ok = P.npool[0] > 0 && P.walked[0] && P.keys[0] == 0u;
+        int x = start_ok ? 0 : -1;
+        for (int gr = 0; gr <= NG; gr++) {
+            gin[gr] = x;
+            if (gr < NG && x >= 0) x = gmap[gr * CW_K + x];
+        }
+        if (!start_ok) s_stuck = -1;                        // not even the start state has been walked
+    }
+    __syncthreads();
+    if (tid < NG && gin[tid] >= 0) {                        // (3)
+        int x = gin[tid];
+        const int s1 = (tid + 1) * CW_GRP < S - 1 ? (tid + 1) * CW_GRP : S - 1;
+        for (int s = tid * CW_GRP; s < s1; s++) {
+            tru[s] = x;
+            const int h = hop[s * CW_K + x];
+            if (h < 0) { atomicMin(&s_stuck, s); break; }   // the chain is open behind segment s
+            x = h;
+            if (s + 1 == S - 1) tru[S - 1] = x;
+        }
+    }
+    if (S == 1 && tid == 0 && gin[0] >= 0) tru[0] = 0;
+    __syncthreads();
+    const int stuck = s_stuck;                              // 0x7fffffff: closed; -1: at the start; else the last segment on the chain
+    const int s_end = stuck == 0x7fffffff ? S : stuck + 1;  // tru[0 .. s_end) is on the chain
+    for (int e = tid; e < s_end; e += 1024) {
+        P.true_idx[e] = tru[e];
+        P.last_hit[(size_t)e * CW_K + tru[e]] = P.stamp;
+    }
+    if (tid == 0) {
+        const bool open = stuck != 0x7fffffff;
+        if (open && stuck >= 0 && hop[stuck * CW_K + tru[stuck]] == -1) {
+            // the exit state is not in pool stuck+1: on its pending list?  (full when k_cwalk asked: first place now)
+            const uint32_t x = P.exits[(size_t)stuck * CW_K + tru[stuck]];
+            const int np = P.npend[stuck + 1] < CW_K ? P.npend[stuck + 1] : CW_K;
+            bool queued = false;
+            for (int k = 0; k < np; k++)
+                if (P.pend[(size_t)(stuck + 1) * CW_K + k] == x) queued = true;
+            if (!queued) {
+                P.pend[(size_t)(stuck + 1) * CW_K] = x;
+                if (P.npend[stuck + 1] < 1) P.npend[stuck + 1] = 1;
+            }
+        }
+        st->cw_open_at = open ? stuck + 1 : -1;
+        if (open && P.last_round) st->cw_unres = 1;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cemit(cw_params P)
+{
+    __shared__ double s_min[4];
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    const cw_geom g = cw_geometry(P.N);
+    const int s = blockIdx.x, tid = threadIdx.x;
+    if (s >= g.S) return;
+    if (s == 0 && tid == 0) {
+        st->dbg[3] = 4;                                     // gh_debug_walk_clock: variant 4 = candidate-pool segments
+        P.path_out[0] = SYM_US;
+        P.lmsel[0] = 1.0;                                   // k_hp: this path's sums are still to be taken
+        if (P.rearm && c.cur_hole > P.N) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
+    }
+    // the tensor changes behind this path: every pool entry is walked again for the next one
+    if (tid < CW_K) P.walked[(size_t)s * CW_K + tid] = 0;
+    const int Nw = c.cur_hole <= P.N ? c.cur_hole - 1 : P.N;
+    const int t0 = s * g.seglen;
+    int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    if (t1 > Nw) t1 = Nw;
+    double mn = INFINITY;
+    const int cand = P.true_idx[s];
+    for (int tl = tid; tl < t1 - t0; tl += 256) {
+        const int t = t0 + 1 + tl;
+        const double *inf = P.minfo + (size_t)t * MINFO;
+        const unsigned word = P.hist[((size_t)s * g.NW + (tl >> 4)) * CW_K + cand];
+        int b5 = nth_set5((uint32_t)__double_as_longlong(inf[10]), (int)((word >> (2 * (tl & 15))) & 3u));
+        if (b5 < 0) b5 = 0;
+        P.path_out[t] = (uint8_t)vsym(b5);
+        P.lmsel[t] = inf[b5];
+        const double m = inf[5 + b5];
+        if (m < mn) mn = m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double x = __shfl_xor(mn, o);
+        if (x < mn) mn = x;
+    }
+    if ((tid & 63) == 0) s_min[tid >> 6] = mn;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; w++)
+            if (s_min[w] < mn) mn = s_min[w];
+        P.segmin[s] = mn;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_cseed: the states of a finished path (symbols) at the segment boundaries -> pool entries.  Used behind the serial
+// walker (the spin's first path, and every path the pools could not close): merge = 0 replaces the pools, 1 adds.
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path, int merge)
+{
+    const cw_geom g = cw_geometry(P.N);
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= g.S) return;
+    const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ...
+    unsigned sigma = 0;
+    for (int l = P.L; l >= 1; l--) {                        // oldest first: the pick of lag 1 ends in bits 0..1
+        const int i = p + 1 - l;
+        unsigned d = 0;
+        if (i >= 1) {
+            const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
+            const int a6 = a6_of_sym(path[i]);
+            d = (unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u;
+        }
+        sigma = (sigma << 2) | d;
+    }
+    uint32_t *keys = P.keys + (size_t)s * CW_K;
+    int n = merge ? P.npool[s] : 0;
+    bool there = false;
+    for (int k = 0; k < n; k++)
+        if (keys[k] == sigma) { there = true; P.last_hit[(size_t)s * CW_K + k] = P.stamp; }
+    if (!there) {
+        int slot = n;
+        if (n >= CW_K) {
+            int oldest = 0x7fffffff;
+            slot = s == 0 ? 1 : 0;
+            for (int k = (s == 0 ? 1 : 0); k < CW_K; k++) {
+                const int lh = P.last_hit[(size_t)s * CW_K + k];
+                if (lh < oldest) { oldest = lh; slot = k; }
+            }
+        } else n++;
+        keys[slot] = sigma;
+        P.last_hit[(size_t)s * CW_K + slot] = P.stamp;
+    }
+    P.npool[s] = n;
+    P.npend[s] = 0;
+    for (int k = 0; k < CW_K; k++) P.walked[(size_t)s * CW_K + k] = 0;
+}

@@ -57,6 +57,7 @@ extern "C" const char *gh_last_error(void) { return g_err; }
 
 #include "kernels.hpp"
 #include "segwalk.hpp"
+#include "cwalk.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // handle
@@ -104,6 +105,17 @@ struct gh_handle {
     double *lmsel1;        // [N+1] selected log-marginals of a lone gh_generate_path
     double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
     int seg_L;
+    // candidate-pool segment walk (cwalk.hpp)
+    uint32_t *cw_keys, *cw_exits, *cw_hist, *cw_pend;
+    int32_t *cw_npend;
+    int32_t *cw_last_hit, *cw_npool, *cw_true;
+    uint8_t *cw_walked;
+    int8_t *cw_nxt;
+    bool cw_ready;         // the pools hold states of this tensor (seeded by a serial walk since the last fill / L change)
+    bool cw_off;           // the window is not narrow (a position with five candidates): serial walkers only
+    int cw_rounds;         // walk/scan rounds queued per path (adapts to how often chains stay open)
+    int cw_stamp;
+    int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
     int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
     gh_fill_stats stats;
@@ -230,6 +242,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
+    hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_hist); hipFree(h->cw_last_hit); hipFree(h->cw_npool); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true); hipFree(h->cw_pend); hipFree(h->cw_npend);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -267,6 +280,9 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0;
+    h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
+    h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_rounds = 2; h->cw_stamp = 0;
+    memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
@@ -337,6 +353,7 @@ extern "C" int gh_clear(gh_t *h)
     h->L = 1;
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
+    h->cw_ready = false; h->cw_off = false;
     return GH_OK;
 }
 
@@ -362,7 +379,7 @@ extern "C" int gh_set_L(gh_t *h, int32_t L)
     if (!h) return fail(GH_ERR_ARG, "null handle");
     if (L < 1) return fail(GH_ERR_ARG, "L must be >= 1 (got %d)", L);
     if (L > 32767) return fail(GH_ERR_ARG, "L > 32767 unsupported (got %d)", L);
-    if (L != h->L) h->dirty_lt = true;
+    if (L != h->L) { h->dirty_lt = true; h->cw_ready = false; }
     h->L = L;
     h->stats.L = L;
     return GH_OK;
@@ -509,6 +526,7 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         { int rc_ = post_launch(h, "k_fill"); if (rc_) return rc_; }
     }
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+    h->cw_ready = false; h->cw_off = false;
     int rc = pull_fill_state(h, "gh_fill");
     if (h->stats.n_slices > 0) {                                   // util.py:333
         int L = (int)std::ceil((double)h->stats.covered_snps / (double)h->stats.n_slices);
@@ -825,6 +843,9 @@ static bool walk_depth2_ok(int wm, int L)
     return !off && L >= 2 && L <= WALK_MAX_LC && walk_chunk(L, false) > 0 && walk_chunk(L, true) > 0 && WALK_THREADS == 512;
 }
 
+// candidate-pool segments (cwalk.hpp) for the lag counts above: spins only, narrow windows only (checked on the device)
+static bool cw_ok(int wm, int L) { return wm == WM_SEG && L >= CW_MIN_L && L <= CW_MAX_L; }
+
 // single windows: may k_lt build the ranked layout?  (the segment-parallel walk reads either layout)
 static bool walk_ranked_ok(int wm, int L) { return seg_ok(wm, L) || walk_depth2_ok(wm, L); }
 
@@ -982,7 +1003,7 @@ static int ensure_partial(gh_handle *h, int nb, int slots)
 // seg: the walk just before was segment-parallel: the kernel reduces the minimum marginal itself, clamps it to `ratio`
 // (= min_remove) and closes the record
 static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec, int slot = -1,
-                                bool seg = false, bool chained = false)
+                                bool seg = false, bool chained = false, int nseg_arg = 0)
 {
     const int threads = (h->N + 1) * 8;
     const int block = 256;
@@ -1003,11 +1024,11 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         if (h->cfg.storage == GH_STORAGE_F64)
             hipLaunchKernelGGL((k_rw<double>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                                h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L,
-                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec);
+                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec, nseg_arg);
         else
             hipLaunchKernelGGL((k_rw<float>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                                h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L,
-                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec);
+                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec, nseg_arg);
     } else if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
@@ -1038,6 +1059,99 @@ static int reset_spin_state(gh_handle *h)
     int zeros[3] = {0, 0, 0};
     HIPCHK(hipMemcpyAsync(h->dstate, zeros, sizeof zeros, hipMemcpyHostToDevice, h->stream));
     return GH_OK;
+}
+
+// ---- candidate-pool segment walk (cwalk.hpp): L = 6 .. 16, spins -------------------------------
+static int alloc_cw(gh_handle *h)
+{
+    if (h->cw_keys) return GH_OK;
+    const cw_geom g = cw_geometry(h->N);
+    hipError_t e = hipMalloc((void **)&h->cw_keys, sizeof(uint32_t) * g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_exits, sizeof(uint32_t) * g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_last_hit, sizeof(int32_t) * g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_hist, sizeof(uint32_t) * (size_t)g.S * g.NW * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npool, sizeof(int32_t) * g.S);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(uint32_t) * g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npend, sizeof(int32_t) * g.S);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npend, 0, sizeof(int32_t) * g.S, h->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_walked, (size_t)g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_nxt, (size_t)g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_true, sizeof(int32_t) * g.S);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npool, 0, sizeof(int32_t) * g.S, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_walked, 0, (size_t)g.S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_nxt, 0xff, (size_t)g.S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_last_hit, 0, sizeof(int32_t) * g.S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_keys, 0, sizeof(uint32_t) * g.S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_exits, 0, sizeof(uint32_t) * g.S * CW_K, h->stream);
+    if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed: %s", hipGetErrorString(e));
+    if (!h->seg_min && hipMalloc((void **)&h->seg_min, 256 * sizeof(double)) != hipSuccess)      // (alloc_seg sizes for L <= 5 only)
+        return fail(GH_ERR_NOMEM, "hipMalloc failed");
+    return GH_OK;
+}
+
+static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
+{
+    cw_params P;
+    memset(&P, 0, sizeof P);
+    P.N = h->N; P.L = h->L; P.rearm = 1; P.stamp = h->cw_stamp;
+    P.G = h->lt; P.minfo = h->minfo; P.st = h->dstate;
+    P.keys = h->cw_keys; P.exits = h->cw_exits; P.last_hit = h->cw_last_hit; P.npool = h->cw_npool; P.walked = h->cw_walked; P.nxt = h->cw_nxt; P.pend = h->cw_pend; P.npend = h->cw_npend;
+    P.hist = h->cw_hist; P.true_idx = h->cw_true; P.segmin = h->seg_min; P.path_out = d_path; P.lmsel = d_lmsel;
+    return P;
+}
+
+template <int LC>
+static void launch_cwalk_lc(const cw_params &P, hipStream_t stream, int S, int dev)
+{
+    static bool set[64];
+    if (!set[dev & 63]) {
+        hipFuncSetAttribute((const void *)k_cwalk<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cw_lds_bytes(LC));
+        set[dev & 63] = true;
+    }
+    hipLaunchKernelGGL((k_cwalk<LC>), dim3(S), dim3(CW_THREADS), cw_lds_bytes(LC), stream, P);
+}
+
+// the kernels of one path: `rounds` x (walk what is new, link + chain), emit
+static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int rounds, int check_masks, bool resume = false)
+{
+    const cw_geom g = cw_geometry(h->N);
+    cw_params P = cw_make_params(h, d_path, d_lmsel);
+    prof_begin(h, GH_K_WALK);
+    for (int r = 0; r < rounds; r++) {
+        P.round = resume ? r + 1 : r;                       // (a resumed path continues behind the rounds already run)
+        P.check_masks = (r == 0 && !resume) ? check_masks : 0;
+        P.last_round = r == rounds - 1;
+        switch (h->L) {
+#define CW_CASE(n) case n: launch_cwalk_lc<n>(P, h->stream, g.S, h->dev); break;
+            CW_CASE(6) CW_CASE(7) CW_CASE(8) CW_CASE(9) CW_CASE(10) CW_CASE(11) CW_CASE(12) CW_CASE(13) CW_CASE(14) CW_CASE(15) CW_CASE(16)
+#undef CW_CASE
+            default: return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_L);
+        }
+        hipLaunchKernelGGL(k_clink, dim3(g.S), dim3(CW_K), 0, h->stream, P);
+        hipLaunchKernelGGL(k_cscan, dim3(1), dim3(1024), 0, h->stream, P);
+    }
+    hipLaunchKernelGGL(k_cemit, dim3(g.S), dim3(256), 0, h->stream, P);
+    prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
+    return post_launch(h, "k_cwalk/k_cscan/k_cemit");
+}
+
+// one path through the serial walker, its boundary states into the pools (merge: keep what is there)
+static int cw_serial_path(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double *d_lmsel, double min_remove, int slot, int merge)
+{
+    // the serial depth-2 walker reads tables that k_lt keeps; behind pool paths (no k_lt between them) they are stale
+    h->lt_inc_path = nullptr;
+    h->dirty_lt = true;
+    int rc = ensure_lt(h);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(d_lmsel, 0, sizeof(double), h->stream));      // k_hp: the walker sums this path itself
+    if ((rc = launch_walk(h, d_path, d_rec, min_remove, 1, nullptr, 0))) return rc;
+    cw_params P = cw_make_params(h, d_path, d_lmsel);
+    const cw_geom g = cw_geometry(h->N);
+    hipLaunchKernelGGL(k_cseed, dim3((g.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)d_path, merge);
+    if ((rc = post_launch(h, "k_cseed"))) return rc;
+    rc = launch_reweight_marg(h, d_path, 0.0, 1, d_rec, slot, false, false, 0);
+    h->cw_stat[1]++;
+    return rc;
 }
 
 extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out, double *hp_current,
@@ -1150,7 +1264,120 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     memset(&hs, 0, sizeof hs);
     int first = 0;
     h->spin_requeues = 0;
-    while (rc == GH_OK) {
+    // Lag counts 6 .. 16: segments walked from candidate pools (cwalk.hpp).  The paths are queued a few at a time: a
+    // path whose chain stays open after the queued rounds idles the kernels behind it, and the host then hands that
+    // one path to the serial walker (whose states join the pools) before queueing on.
+    const bool cw = rc == GH_OK && cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h);
+    bool cw_gave_up = false;
+    if (cw) {
+        rc = alloc_cw(h);
+        const cw_geom cg = cw_geometry(h->N);
+        const int zero2[2] = {0, 0};
+        if (rc == GH_OK) {
+            e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);      // lt_stale, cw_unres
+            if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+        }
+        int done = 0;
+        int CHUNK = 8, clean = 0;        // paths queued between two looks at the device state: grows while every chain closes
+        while (rc == GH_OK && done < max_paths) {
+            if (h->cw_off) {
+                // a position with five candidates: the rest of the spin goes the serial walkers' way (the loop below)
+                cw_gave_up = true;
+                first = done;
+                if (done < max_paths) {
+                    e = hipMemset2DAsync(h->spin_lmsel + n1 * done, n1 * sizeof(double), 0, sizeof(double), (size_t)(max_paths - done), h->stream);
+                    if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+                }
+                break;
+            }
+            if (!h->cw_ready) {
+                // no pools yet for this tensor: one path through the serial walker seeds them
+                h->cw_stamp++;
+                if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 0))) break;
+                h->cw_ready = true;
+            } else {
+                const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
+                if ((rc = ensure_lt(h))) break;
+                for (int s = done; s < upto && rc == GH_OK; s++) {
+                    h->cw_stamp++;
+                    if ((rc = launch_cw_path(h, d_paths + n1 * s, h->spin_lmsel + n1 * s, h->cw_rounds, s > done ? 1 : 0))) break;
+                    rc = launch_reweight_marg(h, d_paths + n1 * s, min_remove, 1, d_recs + s, s, true, s > done, cg.S);
+                    h->cw_stat[2] += h->cw_rounds;
+                }
+                if (rc) break;
+            }
+            e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+            if (getenv("GH_PRINT_STATE"))
+                fprintf(stderr, "gh_spin(cw): n_done %d stop %d lt_stale %d cw_unres %d open_at %d rounds %d\n", hs.n_done, hs.stop, hs.lt_stale,
+                        hs.cw_unres, hs.cw_open_at, h->cw_rounds);
+            h->cw_stat[0] += hs.n_done - done;
+            done = hs.n_done;
+            if (hs.stop) break;
+            if (!hs.lt_stale && !hs.cw_unres) {
+                if (CHUNK < 64) CHUNK *= 2;
+                if (++clean >= 6 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
+            } else { CHUNK = 8; clean = 0; }
+            if (hs.lt_stale || hs.cw_unres) {
+                e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
+                if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                h->spin_requeues++;
+                h->cw_stat[3]++;
+                h->lt_inc_path = nullptr;                       // (the next ensure_lt rebuilds the table in full)
+                h->dirty_lt = true;
+                if (hs.cw_unres == 2) h->cw_off = true;         // five candidates somewhere: the serial walkers take the window
+                else if (hs.cw_unres == 1 && done < max_paths) {
+                    // the queued rounds did not close this path's chain.  Its pools keep what has been walked (the tensor
+                    // has not changed): more rounds first; if the chain is still open, the serial walker takes the path
+                    // and its states join the pools.
+                    bool closed = false;
+                    if (!hs.lt_stale) {
+                        if ((rc = ensure_lt(h))) break;
+                        if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, 12, 0, true))) break;
+                        if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+                        h->cw_stat[2] += 12;
+                        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+                        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                        if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                        closed = !hs.cw_unres && hs.n_done > done;
+                        if (hs.cw_unres) {
+                            e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
+                            if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                        }
+                    }
+                    if (!closed) {
+                        h->cw_stamp++;
+                        if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 1))) break;
+                        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+                        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                        if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                    }
+                    done = hs.n_done;
+                    if (hs.stop) break;
+                }
+            }
+        }
+        // the serial walkers' tables were not kept between pool paths: rebuild before anybody walks serially again
+        h->lt_inc_path = nullptr;
+        h->dirty_lt = true;
+        if (rc == GH_OK && done > 0 && !cw_gave_up) {
+            hipLaunchKernelGGL(k_hp, dim3(done, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
+                               (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
+            hipLaunchKernelGGL(k_reweight_finish_all, dim3(done), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
+            rc = post_launch(h, "k_hp/k_reweight_finish_all");
+            if (rc == GH_OK) {
+                e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                if (e == hipSuccess && hs.n_done > 0) {
+                    e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
+                    if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
+                }
+                if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    while ((!cw || cw_gave_up) && rc == GH_OK) {
         int launched = first;
         for (int s = first; s < max_paths && rc == GH_OK; s++) {
             if (!optimistic || s == first) { if ((rc = ensure_lt(h))) break; }
@@ -1160,7 +1387,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             launched = s + 1;
         }
         // the likelihood sums of every path in one launch (strictly sequential additions, one wavefront per sum)
-        if (rc == GH_OK && launched > 0 && seg) {
+        if (rc == GH_OK && launched > 0 && (seg || cw_gave_up)) {
             hipLaunchKernelGGL(k_hp, dim3(launched, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
                                (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
             rc = post_launch(h, "k_hp");
@@ -1497,6 +1724,7 @@ extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
     HIPCHK(hipStreamSynchronize(h->stream));
     out[0] = hs.dbg[0]; out[1] = hs.dbg[1]; out[2] = hs.dbg[2]; out[3] = hs.dbg[3];
     if (out[3] == 3) { out[0] = (uint64_t)h->spin_requeues; out[1] = 0; out[2] = 0; }
+    if (out[3] == 4) { out[0] = (uint64_t)h->spin_requeues; out[1] = (uint64_t)h->cw_stat[1]; out[2] = (uint64_t)h->cw_stat[2]; }
     if (getenv("GH_PRINT_STAMPS"))      // diagnostic builds (-DSEG_STAMPS / -DGH_STAMPS)
         fprintf(stderr, "stamps: %llu %llu %llu %llu\n", hs.dbg8[1] - hs.dbg8[0], hs.dbg8[2] - hs.dbg8[1], hs.dbg8[3] - hs.dbg8[2], hs.dbg8[4] - hs.dbg8[3]);
     return GH_OK;

@@ -40,17 +40,19 @@ struct dev_state {
     int ranked;      // layout of G as k_lt last built it: 1 = rows/columns are candidate RANKS (see k_lt), 0 = symbols
     int cur_hole;    // segment-parallel walk (segwalk.hpp): first_hole as k_seg found it (k_scan re-arms the flag itself)
     int lt_stale;    // set by k_seg when a candidate mask moved under the last reweight and no k_lt ran since (gh_spin)
-    int _r0;
+    int cw_unres;    // candidate-pool walk (cwalk.hpp): 1 = the queued rounds did not close the chain, 2 = table not ranked
     double ratio;    // clamped min marginal of the path just walked
-    double _r1;
+    int cw_open_at;  // k_cscan: -1 = chain closed, else the segment whose entry state is still to be walked
+    int _r1;
     unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
     unsigned long long dbg8[5];  // -DGH_STAMPS / -DSEG_STAMPS builds: cycles per segment of the code
 };
 
 struct dev_ctl {
-    int stop, hole_at, n_done, scratch, first_hole, nodel, cm_same, narrow, ranked, cur_hole, lt_stale, _r0;
-    double ratio, _r1;
+    int stop, hole_at, n_done, scratch, first_hole, nodel, cm_same, narrow, ranked, cur_hole, lt_stale, cw_unres;
+    double ratio;
+    int cw_open_at, _r1;
 };
 static_assert(sizeof(dev_ctl) == 64 && offsetof(dev_state, fill) == 64, "control words = the first line of dev_state");
 

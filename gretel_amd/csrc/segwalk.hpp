@@ -273,7 +273,7 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
     const int t0 = s * g.seglen;
     int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     if (t1 > Nw) t1 = Nw;
-    if (s == 0 && tid == 0) P.path_out[0] = SYM_US;                // gretel.py:138
+    if (s == 0 && tid == 0) { P.path_out[0] = SYM_US; P.lmsel[0] = 1.0; }      // gretel.py:138; k_hp: sums still to be taken
     if (t0 >= t1) {
         if (tid == 0) P.segmin[s] = INFINITY;
         return;
@@ -395,15 +395,15 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
-     gh_path_rec *rec)
+     gh_path_rec *rec, int nseg_arg)
 {
     __shared__ double s_red[256];
     const int tid = threadIdx.x;
     RW_STAMP(0);
     const dev_ctl c = load_ctl(st);
-    const int nseg = seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
+    const int nseg = nseg_arg > 0 ? nseg_arg : seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
     const double my_segmin = tid < nseg ? segmin[tid] : INFINITY;
-    if (c.stop || c.lt_stale) return;
+    if (c.stop || c.lt_stale || c.cw_unres) return;
     if (c.cur_hole <= N) {                                  // the walk ended in a hole: nothing to reweight (gretel.py:176-180)
         if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, 0.0, min_remove);
         return;
@@ -530,53 +530,71 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         }
     }
     RW_STAMP(3);
-    // ---- the table row of lag d0 (k_marg: same divisions, same log10) --------------------------------------------
+    // ---- the table rows of lags d0, d0 + 8, ... (k_marg: same divisions, same log10) --------------------------------
     if (G && act && p < N && a != 4) {
         const int a6 = a6_of_sym(a);
         const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
         const bool ranked = c.ranked != 0;
         int row6 = a6;
         if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
-        if (d0 <= L && row6 >= 0) {
-            double *out = G + (((size_t)p * 6 + row6) * L + (d0 - 1)) * LT_ROW;
-            if (!(j0 <= N && (a6 < 5 || p == 0))) {
+        auto table_row = [&](int l, const T (&rowT)[NSYM], int nvt, uint32_t cmt) {
+            double *out = G + (((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW;
+            if (!(p + l <= N && (a6 < 5 || p == 0))) {
 #pragma unroll
                 for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = 0.0;
+                return;
+            }
+            double rowv[NSYM];
+            T racc = (T)0;
+#pragma unroll
+            for (int x = 0; x < NSYM; x++) { rowv[x] = (double)rowT[x]; racc = racc + rowT[x]; }      // zeros beyond the band
+            const double sum = (double)racc;
+            const double den = (cond_mode == GH_COND_A) ? (double)nvt + sum : nv_i + ca;
+            double xq[LT_ROW], v[LT_ROW];
+            bool odd = false;
+#pragma unroll
+            for (int b5 = 0; b5 < LT_ROW; b5++) {
+                xq[b5] = (1.0 + rowv[vsym(b5)]) / den;
+                odd |= !gh_log10_is_normal(xq[b5]);
+            }
+#pragma unroll
+            for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
+            if (odd) {
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
+            }
+            if (!ranked) {
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmt >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
             } else {
-                double rowv[NSYM];
-                T racc = (T)0;
+                const uint32_t cj5 = cm5_of_cmask(cmt);
 #pragma unroll
-                for (int x = 0; x < NSYM; x++) { rowv[x] = (double)rrow[x]; racc = racc + rrow[x]; }      // zeros beyond the band
-                const double sum = (double)racc;
-                const double den = (cond_mode == GH_COND_A) ? (double)nv_t + sum : nv_i + ca;
-                double xq[LT_ROW], v[LT_ROW];
-                bool odd = false;
+                for (int rb = 0; rb < LT_ROW; rb++) {
+                    const int b5 = nth_set5(cj5, rb);
+                    double r = -INFINITY;
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) {
-                    xq[b5] = (1.0 + rowv[vsym(b5)]) / den;
-                    odd |= !gh_log10_is_normal(xq[b5]);
-                }
-#pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
-                if (odd) {
-#pragma unroll
-                    for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
-                }
-                if (!ranked) {
-#pragma unroll
-                    for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cm_t >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
-                } else {
-                    const uint32_t cj5 = cm5_of_cmask(cm_t);
-#pragma unroll
-                    for (int rb = 0; rb < LT_ROW; rb++) {
-                        const int b5 = nth_set5(cj5, rb);
-                        double r = -INFINITY;
-#pragma unroll
-                        for (int q = 0; q < LT_ROW; q++) r = (b5 == q) ? v[q] : r;
-                        out[rb] = r;
-                    }
+                    for (int q = 0; q < LT_ROW; q++) r = (b5 == q) ? v[q] : r;
+                    out[rb] = r;
                 }
             }
+        };
+        if (d0 <= L && row6 >= 0) table_row(d0, rrow, nv_t, cm_t);
+        for (int l = d0 + 8; l <= L && row6 >= 0; l += 8) {      // lag counts above 8: the remaining lags, one by one
+            T rowT[NSYM];
+#pragma unroll
+            for (int x = 0; x < NSYM; x++) rowT[x] = (T)0;
+            int nvt = 0;
+            uint32_t cmt = 0;
+            if (p + l <= N) {
+                if (l <= W) {
+                    const T *rc = band + ((size_t)p * W + (l - 1)) * CELL + a * NSYM;      // (this lane's own store included)
+#pragma unroll
+                    for (int x = 0; x < NSYM; x++) rowT[x] = rc[x];
+                }
+                nvt = nvalid[p + l];
+                cmt = cmask[p + l];
+            }
+            table_row(l, rowT, nvt, cmt);
         }
     }
     RW_STAMP(4);
@@ -619,6 +637,7 @@ k_hp(const double *lmsel, size_t lmsel_stride, const uint8_t *paths, size_t path
     const int s = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
     if (s >= st->n_done) return;
     const double *lm = lmsel + (size_t)s * lmsel_stride;
+    if (lm[0] != 1.0) return;                                      // walked by a serial walker, which summed for itself
     const uint8_t *path = paths + (size_t)s * path_stride;
     auto value = [&](int t) -> double {
         if (t > N) return 0.0;

@@ -1,0 +1,102 @@
+"""The candidate-pool segment walk (gretel_amd/csrc/cwalk.hpp: lag counts 6..16, spins) against the C oracle and the
+serial walker: every lag count, pools kept across spins and dropped by a new fill, windows it must hand back (a
+position with five candidates), holes, a stale table in the middle of a queue, the other conditionals and f64 storage."""
+import os
+
+import numpy as np
+import pytest
+
+from gretel_amd.hansel import Hansel
+from gretel_amd.synth import make_support_table
+from oracle.c_oracle import COracle
+from test_gpu_edges import _walk_mode, PINNED
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(PINNED, reason="GH_WALK / GH_WALK_THREADS pin another variant")]
+
+
+def _pair(t, L=None, walk=None, **kw):
+    with _walk_mode(walk):
+        h = Hansel(t.n_snps, band=t.band, **kw)
+    o = COracle(t.n_snps, t.band, kw.get("storage", "f32"), kw.get("cond_mode", "A"), kw.get("marginal_term", False))
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    if L is not None:
+        h.L = L
+        o.L = L
+    return h, o
+
+
+def _same(res, ref):
+    assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"]
+    assert np.array_equal(res["paths"], ref["paths"])
+    assert res["hp_current"].tolist() == ref["hp_current"].tolist()
+    assert res["hp_original"].tolist() == ref["hp_original"].tolist()
+    assert res["ratio"].tolist() == ref["ratio"].tolist()
+    assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("L", [6, 7, 8, 9, 10, 12, 13, 16])
+def test_every_lag_count(L):
+    # long-read-style reads (k ~ Poisson(10)); L = 9 and up also exercises the table rows beyond the eighth lag in k_rw
+    t = make_support_table(2500, 30000, k=None, seed=200 + L)
+    h, o = _pair(t, L=L)
+    res, ref = h.spin(24), o.spin(24)
+    assert h.walk_clock()[3] == 4
+    _same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    hs, _ = _pair(t, L=L, walk="spec")
+    _same(hs.spin(24), res)
+
+
+def test_pools_persist_across_spins_and_reset_on_fill():
+    t = make_support_table(4000, 50000, k=None, seed=31)
+    h, o = _pair(t)
+    assert 6 <= h.L <= 16
+    for n in (10, 7, 15):
+        _same(h.spin(n), o.spin(n))
+    serial_before = h.walk_clock()[1]
+    _same(h.spin(20), o.spin(20))
+    assert h.walk_clock()[1] - serial_before <= 6          # the pools know the tracks by now: few paths go serial
+    t2 = make_support_table(4000, 50000, k=None, seed=32)
+    h.clear()
+    o2 = COracle(t2.n_snps, t2.band)
+    assert h.fill_from_support(t2.rank, t2.off, t2.bases) == o2.fill(t2)
+    _same(h.spin(12), o2.spin(12))
+    assert np.array_equal(h.export_band(), o2.export_band())
+
+
+def test_window_with_five_candidates_goes_back_to_the_serial_walker():
+    t = make_support_table(1200, 30000, k=8, seed=5)
+    bases = t.bases.copy()
+    bases[np.random.default_rng(1).random(len(bases)) < 0.1] = ord('-')
+    t.bases = bases
+    h, o = _pair(t, L=7)
+    assert (h.candidate_masks()[1:] == 0x2F).any()
+    res, ref = h.spin(10), o.spin(10)
+    _same(res, ref)
+    assert h.walk_clock()[3] != 4
+    _same(h.spin(5), o.spin(5))                            # and stays there
+
+
+def test_hole_and_stale_table_inside_a_queue():
+    t = make_support_table(900, 6000, k=8, n_haps=1, err=0.0, seed=2)
+    h, o = _pair(t, L=8)
+    res, ref = h.spin(6), o.spin(6)
+    _same(res, ref)
+    assert res["n"] == 1 and res["hole_at"] >= 1
+    t = make_support_table(2000, 30000, k=None, seed=8)
+    os.environ["GH_SEG_FORCE_STALE"] = "5"
+    try:
+        h, o = _pair(t, L=9)
+    finally:
+        del os.environ["GH_SEG_FORCE_STALE"]
+    _same(h.spin(14), o.spin(14))
+    assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(storage="f64"), dict(cond_mode="C"), dict(marginal_term=True)])
+def test_switches(kw):
+    # conditional C / the marginal term rebuild the table before every path: those spins stay with the serial walker
+    t = make_support_table(1500, 20000, k=None, seed=77)
+    h, o = _pair(t, L=7, **kw)
+    _same(h.spin(12), o.spin(12))
+    assert np.array_equal(h.export_band(), o.export_band())
