@@ -256,7 +256,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     if (cfg->band < 1) return fail(GH_ERR_ARG, "band must be >= 1 (got %d)", cfg->band);
     if (cfg->storage != GH_STORAGE_F32 && cfg->storage != GH_STORAGE_F64)
         return fail(GH_ERR_ARG, "bad storage %d", cfg->storage);
-    if (cfg->cond_mode < 0 || cfg->cond_mode > 2) return fail(GH_ERR_ARG, "bad cond_mode %d", cfg->cond_mode);
+    if (cfg->cond_mode < 0 || cfg->cond_mode > 3) return fail(GH_ERR_ARG, "bad cond_mode %d", cfg->cond_mode);
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(GH_ERR_HIP, "no HIP device visible");

@@ -143,12 +143,13 @@ __device__ __forceinline__ double log_conditional(const T *__restrict__ band, in
     if (l <= W) {
         const T *cell = band + ((size_t)i * W + (l - 1)) * CELL;
         obs = (double)cell[a * NSYM + b];
-        if (cond_mode == GH_COND_A) sum = rowsum(cell, a);
+        if (cond_mode == GH_COND_A || cond_mode == GH_COND_D) sum = rowsum(cell, a);
         else if (cond_mode == GH_COND_C) sum = colsum(cell, b);
     }
     double den;
     if (cond_mode == GH_COND_A) den = (double)nvalid[j] + sum;
     else if (cond_mode == GH_COND_B) den = (double)nvalid[i] + cnt[(size_t)i * 8 + a];
+    else if (cond_mode == GH_COND_D) den = (double)nvalid[i] + sum;
     else den = (double)nvalid[i] + sum;
     return gh_log10((1.0 + obs) / den);
 }
@@ -482,7 +483,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
                 for (int x = 0; x < NSYM; x++) rowv[x] = 0.0;
             }
             const uint32_t cmj = cmask[snp];
-            const double den = (cond_mode == GH_COND_A) ? (double)nvalid[snp] + sum : nv_i + ca;
+            const double den = (cond_mode == GH_COND_A) ? (double)nvalid[snp] + sum : (cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
             double xq[LT_ROW], v[LT_ROW];
             bool odd = false;
 #pragma unroll

@@ -549,7 +549,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
 #pragma unroll
             for (int x = 0; x < NSYM; x++) { rowv[x] = (double)rowT[x]; racc = racc + rowT[x]; }      // zeros beyond the band
             const double sum = (double)racc;
-            const double den = (cond_mode == GH_COND_A) ? (double)nvt + sum : nv_i + ca;
+            const double den = (cond_mode == GH_COND_A) ? (double)nvt + sum : (cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
             double xq[LT_ROW], v[LT_ROW];
             bool odd = false;
 #pragma unroll

@@ -51,6 +51,7 @@ typedef enum {
 #define GH_COND_A 0   /* (1+H[a,b,i,j]) / (V(j) + sum_x H[a,x,i,j])   frozen default */
 #define GH_COND_B 1   /* (1+H[a,b,i,j]) / (V(i) + c_a(i))                            */
 #define GH_COND_C 2   /* (1+H[a,b,i,j]) / (V(i) + sum_x H[x,b,i,j])                  */
+#define GH_COND_D 3   /* (1+H[a,b,i,j]) / (V(i) + sum_x H[a,x,i,j])   the reading of gretel.py:10's TODO with V at pos_from */
 
 typedef struct {
     int32_t n_snps;         /* N: number of SNPs of the window (VCF_h["N"], gretel/util.py:409) */

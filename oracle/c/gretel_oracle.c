@@ -281,7 +281,8 @@ double orc_conditional(const orc_t *o, int a, int b, int i, int j)
     double den;
     if (o->cond_mode == 0) den = (double)n_valid_at(o, j) + row_sum(o, o->h, a, i, j);
     else if (o->cond_mode == 1) den = (double)n_valid_at(o, i) + row_sum(o, o->h, a, i, i + 1);
-    else den = (double)n_valid_at(o, i) + col_sum(o, o->h, b, i, j);
+    else if (o->cond_mode == 2) den = (double)n_valid_at(o, i) + col_sum(o, o->h, b, i, j);
+    else den = (double)n_valid_at(o, i) + row_sum(o, o->h, a, i, j);          /* D: V(pos_from) + row sum */
     return (1.0 + obs) / den;
 }
 

@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 SYMS = "ACGTN-_"
-COND_MODES = {"A": 0, "B": 1, "C": 2}
+COND_MODES = {"A": 0, "B": 1, "C": 2, "D": 3}
 
 
 def build():

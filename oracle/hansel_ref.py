@@ -64,7 +64,7 @@ UNSYMBOLS = ['N', '_']                             # gretel/util.py:83
 @dataclass(frozen=True)
 class HanselSpec:
     storage: str = "f32"          # "f32" | "f64"      
-    cond_mode: str = "A"          # "A" | "B" | "C"    
+    cond_mode: str = "A"          # "A" | "B" | "C" | "D"    (D = V(pos_from) + row sum)
     marginal_term: bool = False   # add log10(marginal) to edge weights (App. A-7)
 
     @property
@@ -266,6 +266,8 @@ class Hansel:
             den = float(self._n_valid_at(pos_from)) + float(self._row_sum(a, pos_from, pos_from + 1))
         elif mode == "C":
             den = float(self._n_valid_at(pos_from)) + float(self._col_sum(b, pos_from, pos_to))
+        elif mode == "D":
+            den = float(self._n_valid_at(pos_from)) + float(self._row_sum(a, pos_from, pos_to))
         else:
             raise ValueError(mode)
         num = 1.0 + obs

@@ -30,7 +30,7 @@ while time.time() < t_end:
             bases[rng.random(len(bases)) < 0.03] = ord('N')
         t.bases = bases
     storage = str(rng.choice(["f32", "f32", "f64"]))
-    mode = str(rng.choice(["A", "A", "B", "C"]))
+    mode = str(rng.choice(["A", "A", "B", "C", "D"]))
     mt = bool(rng.random() < 0.25)
     L = None if rng.random() < 0.4 else int(rng.integers(1, 21))
     paths = int(rng.integers(1, 9))

@@ -93,7 +93,7 @@ def test_hole_and_stale_table_inside_a_queue():
     assert np.array_equal(h.export_band(), o.export_band())
 
 
-@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(storage="f64"), dict(cond_mode="C"), dict(marginal_term=True)])
+@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(cond_mode="D"), dict(storage="f64"), dict(cond_mode="C"), dict(marginal_term=True)])
 def test_switches(kw):
     # conditional C / the marginal term rebuild the table before every path: those spins stay with the serial walker
     t = make_support_table(1500, 20000, k=None, seed=77)

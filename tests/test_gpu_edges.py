@@ -111,7 +111,7 @@ def test_band_wider_than_window():
     _check(t, paths=4)
 
 
-@pytest.mark.parametrize("kw", [dict(storage="f64"), dict(cond_mode="B"), dict(cond_mode="C"), dict(marginal_term=True),
+@pytest.mark.parametrize("kw", [dict(storage="f64"), dict(cond_mode="B"), dict(cond_mode="C"), dict(cond_mode="D"), dict(marginal_term=True),
                                 dict(storage="f64", cond_mode="C", marginal_term=True)])
 def test_switches_on_small_window(kw):
     t = make_support_table(25, 700, k=4, seed=9)

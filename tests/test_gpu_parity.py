@@ -135,7 +135,7 @@ def test_fill_rejects_bad_symbols_and_band_overflow():
 
 
 # -- lookups ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("storage,mode,mt", [("f32", "A", False), ("f32", "B", True), ("f32", "C", False), ("f64", "A", True)])
+@pytest.mark.parametrize("storage,mode,mt", [("f32", "A", False), ("f32", "B", True), ("f32", "C", False), ("f32", "D", False), ("f64", "A", True)])
 def test_lookups_match_oracle(storage, mode, mt):
     t = make_support_table(120, 5000, k=5, seed=3)
     h, o = _pair(t, storage, mode, mt)
@@ -164,7 +164,7 @@ def test_lookups_match_oracle(storage, mode, mt):
 
 # -- path extension + reweight ------------------------------------------------------------------------
 @pytest.mark.parametrize("storage,mode,mt,L", [("f32", "A", False, None), ("f32", "A", False, 1), ("f32", "A", False, 9),
-                                              ("f32", "B", False, None), ("f32", "C", True, None),
+                                              ("f32", "B", False, None), ("f32", "C", True, None), ("f32", "D", False, None),
                                               ("f64", "A", True, None), ("f64", "B", False, 2)])
 def test_generate_and_reweight_step_by_step(storage, mode, mt, L):
     t = make_support_table(150, 6000, k=4, seed=6)

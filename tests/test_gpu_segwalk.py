@@ -120,7 +120,7 @@ def test_requeue_after_a_stale_table_changes_nothing():
     assert h2.walk_clock()[0] == 0
 
 
-@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(cond_mode="C"), dict(marginal_term=True), dict(storage="f64"),
+@pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(cond_mode="C"), dict(cond_mode="D"), dict(marginal_term=True), dict(storage="f64"),
                                 dict(storage="f64", cond_mode="B", marginal_term=True)])
 def test_every_switch(kw):
     # conditional C and the marginal term rebuild the table in full before every path (no incremental rows)

@@ -8,7 +8,7 @@ from oracle import gretel_ref as G
 from oracle.c_oracle import COracle, paths_to_str
 from oracle.hansel_ref import Hansel, HanselSpec, SYMBOLS, UNSYMBOLS
 
-CASES = [("A", False, "f32", None), ("A", False, "f32", 3), ("B", False, "f32", None), ("C", True, "f32", None),
+CASES = [("A", False, "f32", None), ("A", False, "f32", 3), ("B", False, "f32", None), ("C", True, "f32", None), ("D", False, "f32", None),
          ("A", True, "f64", None), ("B", True, "f64", 4)]
 
 
