@@ -333,6 +333,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = h.profile_get()
     h.profile_enable(0)
+    ev_empty_ms, ev_nop_ms = h.profile_overhead(30)      # what a bracket reads with nothing / an empty kernel inside
 
     tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=comm_dev)
     if world > 1:
@@ -419,6 +420,9 @@ def main():
                          "avg_launch_ms_hip_events": dom_ms,
                          "hip_event_sampling": "every %d-th launch of each kernel inside the timed region (%d launches sampled)"
                                                % (PROF_STRIDE, dom["launches"]),
+                         "hip_event_bracket_overhead_ms": {"two_events_back_to_back": ev_empty_ms, "around_an_empty_kernel": ev_nop_ms,
+                                                           "note": "included in avg_launch_ms_hip_events and therefore in `achieved` (conservative): "
+                                                                   "rocprofv3's average for the same kernel (profiles/) lies between the raw and the net reading"},
                          "extension_ms_per_path_hip_events": walk_ms,
                          "walker_variant": {3: "segment-parallel (k_seg + k_scan + k_emit)", 2: "serial, depth-2 speculation",
                                             1: "serial, depth-1 speculation, no '-' candidates", 0: "serial, depth-1 speculation"}.get(variant),

@@ -103,6 +103,7 @@ def load():
         "gh_profile_reset": [vp],
         "gh_profile_get": [vp, i32, P(dbl), P(i64)],
         "gh_profile_bytes": [vp, i32, P(dbl)],
+        "gh_profile_overhead": [vp, i32, vp],
         "gh_debug_walk_clock": [vp, vp],
         "gh_coverage_sites": [i32, vp, vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, vp],
     }

@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1712,6 +1713,38 @@ extern "C" int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *la
     prof_collect(h);
     if (total_ms) *total_ms = h->ps[kernel].ms;
     if (launches) *launches = h->ps[kernel].launches;
+    return GH_OK;
+}
+
+__global__ void k_nop() {}
+
+// What a HIP-event bracket reads beyond the kernel inside it, on this handle's stream: out[0] = two events with nothing
+// between them, out[1] = the same around an empty one-workgroup kernel (ms, medians of `reps`).  bench.py reports them
+// next to the bracketed kernel times: for kernels of 5-15 us the bracket itself is a fifth of the reading.
+extern "C" int gh_profile_overhead(gh_t *h, int reps, double out[2])
+{
+    if (!h || !out || reps < 1) return fail(GH_ERR_ARG, "bad argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    std::vector<float> a, b;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int pass = 0; pass < 2; pass++)
+        for (int r = 0; r < reps; r++) {
+            // a kernel in front, as in the timed region (the stream is never idle there)
+            hipLaunchKernelGGL(k_nop, dim3(256), dim3(256), 0, h->stream);
+            hipEventRecord(e0, h->stream);
+            if (pass == 1) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, h->stream);
+            hipEventRecord(e1, h->stream);
+            hipLaunchKernelGGL(k_nop, dim3(256), dim3(256), 0, h->stream);
+            HIPCHK(hipStreamSynchronize(h->stream));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) (pass ? b : a).push_back(ms);
+        }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    auto med = [](std::vector<float> &v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return (double)v[v.size() / 2]; };
+    out[0] = med(a);
+    out[1] = med(b);
     return GH_OK;
 }
 

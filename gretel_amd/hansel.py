@@ -366,6 +366,12 @@ class Hansel:
             out[name] = dict(ms=ms.value, launches=n.value, bytes_per_launch=by.value)
         return out
 
+    def profile_overhead(self, reps=20):
+        """(ms of an empty HIP-event bracket, ms of a bracket around an empty kernel) on this handle's stream."""
+        out = (C.c_double * 2)()
+        check(self._lib.gh_profile_overhead(self._h, int(reps), out))
+        return float(out[0]), float(out[1])
+
     def walk_clock(self):
         """(shader cycles, 100 MHz ticks, steps, variant) of the walker wave in the last path-extension launch."""
         out = (C.c_uint64 * 4)()

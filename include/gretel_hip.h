@@ -183,6 +183,8 @@ enum { GH_K_FILL = 0, GH_K_MARG = 1, GH_K_LT = 2, GH_K_WALK = 3, GH_K_REWEIGHT =
 int gh_profile_enable(gh_t *h, int on);
 int gh_profile_reset(gh_t *h);
 int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches);
+/* what a bracket reads beyond its kernel: out[0] = two events back to back, out[1] = around an empty kernel (ms, medians) */
+int gh_profile_overhead(gh_t *h, int reps, double out[2]);
 /* diagnostics of the last path-extension launch: out[0] = shader cycles (s_memtime) the walker wave spent,
  * out[1] = the same interval in 100 MHz ticks (s_memrealtime), out[2] = steps it executed, out[3] = the variant
  * that ran (2 = depth-2 speculation, 1 = depth 1 without '-' candidates, 0 = depth 1 with them; 3 = segment-parallel
