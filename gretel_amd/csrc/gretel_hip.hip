@@ -25,7 +25,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "gretel_hip.h"
@@ -1495,6 +1498,36 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     b->L = b->hs[0]->L;
+    // (measured on C3, MI355X: 8 windows 37k haplotypes/s this way against ~16k batched; 32 windows 45k either way -- the
+    // chip is then busy with k_seg; from 48 windows on the batched serial walkers, one workgroup per window, win: 114k at 256)
+    static const int batch_cut = getenv("GH_BATCH_STREAMS_MAX") ? atoi(getenv("GH_BATCH_STREAMS_MAX")) : 47;
+    if ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || (cw_ok(b->hs[0]->wmode, b->L) && lt_incremental_ok(b->hs[0]))) {
+        // The segment-parallel extensions fill the chip poorly with ONE window (four small dependent kernels per path, most
+        // of their time launch and first-touch latency) but every window has its own stream: a few host threads each
+        // run gh_spin over their share of the windows, and the windows' kernel chains interleave on the GPU.
+        static const int nthr_env = getenv("GH_BATCH_THREADS") ? atoi(getenv("GH_BATCH_THREADS")) : 8;
+        const int nthr = nthr_env < 1 ? 1 : (nthr_env > n ? n : nthr_env);
+        std::vector<int> rcs(n, GH_OK);
+        std::vector<std::string> errs(n);
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            hipSetDevice(b->dev);
+            for (;;) {
+                const int w = next.fetch_add(1);
+                if (w >= n) break;
+                rcs[w] = gh_spin(b->hs[w], max_paths, min_remove, paths_out + n1 * max_paths * w, recs + (size_t)max_paths * w,
+                                 &n_out[w], &hole_at[w]);
+                if (rcs[w]) errs[w] = gh_last_error();
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (int w = 0; w < n; w++)
+            if (rcs[w]) return fail(rcs[w], "window %d: %s", w, errs[w].c_str());
+        return GH_OK;
+    }
     if (max_paths > b->cap_paths) {
         HIPCHK(hipStreamSynchronize(b->stream));
         hipFree(b->d_paths); hipFree(b->d_recs);
