@@ -359,6 +359,9 @@ def main():
         if segwalk and seg["launches"]:
             dom, dom_name = seg, "k_seg (segment-parallel path extension: Next tables + all entry states of every segment)"
             dom_bytes_def = "SURVEY 8(d), conditional lookups of the extension: N*L*196 per path (the marginal cell and the original marginals, N*224, belong to k_emit)"
+        elif variant == 4:
+            dom, dom_name = walk, "candidate-pool path extension (per path: rounds of k_cwalk + k_clink + k_cscan, then k_cemit; bracketed as one unit)"
+            dom_bytes_def = "SURVEY 8(d) path extension: N*((1+L)*196+28) per path"
         else:
             dom, dom_name = walk, "k_walk_spec (path extension: N dependent steps, one wavefront walks)"
             dom_bytes_def = "SURVEY 8(d) path extension: N*((1+L)*196+28) per path"
@@ -424,15 +427,20 @@ def main():
                                                            "note": "included in avg_launch_ms_hip_events and therefore in `achieved` (conservative): "
                                                                    "rocprofv3's average for the same kernel (profiles/) lies between the raw and the net reading"},
                          "extension_ms_per_path_hip_events": walk_ms,
-                         "walker_variant": {3: "segment-parallel (k_seg + k_scan + k_emit)", 2: "serial, depth-2 speculation",
+                         "walker_variant": {4: "candidate-pool segments (k_cwalk/k_clink/k_cscan rounds + k_cemit)",
+                                            3: "segment-parallel (k_seg + k_scan + k_emit)", 2: "serial, depth-2 speculation",
                                             1: "serial, depth-1 speculation, no '-' candidates", 0: "serial, depth-1 speculation"}.get(variant),
-                         "walker_cycles_per_step": (cyc / nsteps) if (nsteps and not segwalk) else None,
+                         "walker_cycles_per_step": (cyc / nsteps) if (nsteps and variant <= 2) else None,
                          "issue_model": issue_model,
                          "note": ("k_seg evaluates Next[t][state] for all R^L states of every position (binary64 adds and compares: "
                                   "vector-ALU bound, then LDS-latency bound in the state walk), so its HBM traffic stays far below the "
                                   "bandwidth roofline by construction; a path is 4 dependent kernels (k_seg, k_scan, k_emit, k_rw) "
                                   "of 5-12 us each, about 4 us of which is launch + first-touch latency; see DESIGN.md section 4")
                                  if segwalk else
+                                 ("each segment of the window is walked from a pool of candidate entry states by one wavefront per 16 "
+                                  "candidates (196 dependent steps per segment at C5), the chain of segments is verified exactly; "
+                                  "bound by one wavefront's issue rate per step, not by HBM; see DESIGN.md section 4.2")
+                                 if variant == 4 else
                                  ("not bandwidth bound: each step needs the previous step's arg-max (gretel.py:143-187), so one "
                                   "wavefront walks and its instruction issue rate (1 per 5 cycles) is the bound")},
         }

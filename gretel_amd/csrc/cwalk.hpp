@@ -237,7 +237,8 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         if (s + 1 < g.S) {
             const uint32_t *kn = P.keys + (size_t)(s + 1) * CW_K;
             bool there = false;
-            for (int k = 0; k < CW_K; k++)
+            const int nn = P.npool[s + 1];                // (entries behind the count are leftovers of earlier tensors)
+            for (int k = 0; k < nn && k < CW_K; k++)
                 if (kn[k] == sigma) { there = true; break; }
             if (!there) {
                 const int slot = atomicAdd(&P.npend[s + 1], 1);
