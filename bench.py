@@ -464,6 +464,33 @@ def main():
                 del hb, hs
             except Exception as exc:       # never let the secondary leg break the contract line
                 out["throughput_mode"] = {"error": repr(exc)}
+        if world == 1 and not args.no_throughput_leg and L <= 5:
+            # secondary figure: the same contig with 5 % of the bases read as deletions -> positions with FIVE candidates
+            # (A C G T -): the window is not "narrow", the state space of the segment-parallel extension is 5^L, not 4^L
+            try:
+                import copy
+                tw = copy.copy(table)
+                bw = table.bases.copy()
+                bw[np.random.default_rng(12345).random(len(bw)) < 0.05] = ord('-')
+                tw.bases = bw
+                hw = Hansel(n, band=table.band, device=local)
+                rw = DeviceReads(hw, tw.rank, tw.off, tw.bases)
+                hw.fill_from_support(None, None, None, reads_handle=rw)
+                hw.spin(10)
+                wide = int((hw.candidate_masks()[1:] == 0x2F).sum())
+                hw.clear()
+                hw.fill_from_support(None, None, None, reads_handle=rw)
+                torch.cuda.synchronize()
+                t0w = time.perf_counter()
+                rwres = hw.spin(paths)
+                dtw = time.perf_counter() - t0w
+                out["wide_window"] = {"value": rwres["n"] / dtw, "unit": "haplotypes/s", "ms_per_path": dtw / max(1, rwres["n"]) * 1e3,
+                                      "positions_with_5_candidates": wide, "walker_variant": hw.walk_clock()[3],
+                                      "note": "same contig, 5 %% of the bases replaced by '-': %d of %d positions show A, C, G, T and '-'; "
+                                              "one spin of %d paths (fill not included)" % (wide, n, paths)}
+                del hw, rw
+            except Exception as exc:
+                out["wide_window"] = {"error": repr(exc)}
         if world == 1 and not args.no_e2e:
             try:
                 out["end_to_end"] = end_to_end_leg(table, paths, local)
