@@ -2,7 +2,7 @@
 // of kernels.hpp (which documents every kernel and table).
 //
 // Data in HBM per window:
-//   band    T[(N+2)][W][7][7]      cell (i, j=i+d), d in 1..W, at ((i*W)+(d-1))*49 ; T = float | double
+//   band    T[(N+2)][7][W][7]      element (a, b) of cell (i, j=i+d), d in 1..W, at bidx(W, i, d, a, b) = ((i*7+a)*W+(d-1))*7+b ; T = float | double
 //   cnt, marg  f64[(N+2)][8]       c_s(p) = sum_t H[s,t,p,p+1] (+ total), c_s/total          (lookup API)
 //   nvalid, cmask                  V(p), candidate bitmask
 //   minfo   f64[(N+2)][16]         log10 marginal x5, marginal x5, candidate bits, log10 ORIGINAL marginal x5
@@ -121,6 +121,7 @@ struct gh_handle {
     int cw_stamp;
     int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
+    int spin_partial_stride;   // doubles between two paths' partial sums of the removed mass in a spin (0 outside spins)
     int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
     gh_fill_stats stats;
     int wmode;                    // WM_*: which path extension (GH_WALK at creation)
@@ -283,7 +284,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
-    h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0;
+    h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
     h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_rounds = 2; h->cw_stamp = 0;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
@@ -552,7 +553,7 @@ static int cell_index(const gh_handle *h, int a, int b, int i, int j, size_t *id
     if (a < 0 || a >= NSYM || b < 0 || b >= NSYM) return fail(GH_ERR_SYMBOL, "symbol index out of range (%d,%d)", a, b);
     int d = j - i;
     if (i < 0 || j > h->N + 1 || d < 1 || d > h->W) return 1;    // outside the band: a zero cell
-    *idx = ((size_t)i * h->W + (d - 1)) * CELL + a * NSYM + b;
+    *idx = bidx(h->W, (size_t)i, d, a, b);
     return 0;
 }
 
@@ -1004,16 +1005,23 @@ static int ensure_partial(gh_handle *h, int nb, int slots)
 
 // slot < 0: reduce the removed mass right behind the pass (k_reweight_finish).  slot >= 0 (gh_spin): keep this
 // path's partial sums in their own slot, the caller reduces all paths with one k_reweight_finish_all at the end.
+// k_rw's lane group: 32 lanes per position where the band or the lag count exceeds 8 (all distances and lags in one
+// round), else 8; blocks per path accordingly (also the stride of the per-path partial sums of the removed mass)
+static int rw_lanes(const gh_handle *h) { return (h->W > 8 || h->L > 8) ? 32 : 8; }
+static int rw_blocks(const gh_handle *h, bool seg) { return (int)(((size_t)(h->N + 1) * (seg ? rw_lanes(h) : 8) + 255) / 256); }
+
 // seg: the walk just before was segment-parallel: the kernel reduces the minimum marginal itself, clamps it to `ratio`
 // (= min_remove) and closes the record
 static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec, int slot = -1,
                                 bool seg = false, bool chained = false, int nseg_arg = 0)
 {
-    const int threads = (h->N + 1) * 8;
     const int block = 256;
-    const int nb = (threads + block - 1) / block;
+    const int nb = rw_blocks(h, seg);
+    // (a spin strides its per-path partial sums by the widest kernel it may launch: see gh_spin)
+    const int stride = (slot >= 0 && h->spin_partial_stride > nb) ? h->spin_partial_stride : nb;
     if (slot < 0) { int rc_ = ensure_partial(h, nb, 1); if (rc_) return rc_; }
-    double *partial = h->partial + (slot > 0 ? (size_t)slot * nb : 0);
+    double *partial = h->partial + (slot > 0 ? (size_t)slot * stride : 0);
+    if (slot >= 0 && stride > nb) HIPCHK(hipMemsetAsync(partial + nb, 0, sizeof(double) * (size_t)(stride - nb), h->stream));
     // in a spin the walker re-armed the flags when it finished; a lone reweight does it here
     if (!use_state) hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, 0);
     // with a valid conditional table (conditional A or B, no marginal term) the kernel also rewrites the table rows
@@ -1025,14 +1033,14 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     prof_begin(h, GH_K_REWEIGHT);
     if (seg) {
         // behind a segment-parallel walk (L <= SEG_MAX_L <= 8: one table row per lane): segwalk.hpp's k_rw
-        if (h->cfg.storage == GH_STORAGE_F64)
-            hipLaunchKernelGGL((k_rw<double>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
-                               h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L,
-                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec, nseg_arg);
-        else
-            hipLaunchKernelGGL((k_rw<float>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
-                               h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L,
-                               h->cfg.cond_mode, (const double *)h->seg_min, d_rec, nseg_arg);
+#define GH_RW_LAUNCH(T, LP)                                                                                                       \
+    hipLaunchKernelGGL((k_rw<T, LP>), dim3(nb), dim3(block), 0, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid,  \
+                       h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                    \
+                       (const double *)h->seg_min, d_rec, nseg_arg)
+        const bool wide = rw_lanes(h) == 32;
+        if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH(double, 32); else GH_RW_LAUNCH(double, 8); }
+        else { if (wide) GH_RW_LAUNCH(float, 32); else GH_RW_LAUNCH(float, 8); }
+#undef GH_RW_LAUNCH
     } else if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
@@ -1251,9 +1259,10 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     gh_path_rec *d_recs = h->spin_recs;
     hipError_t e = hipSuccess;
     rc = reset_spin_state(h);
-    const int nb = ((h->N + 1) * 8 + 255) / 256;
-    if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);
-    const bool seg = seg_ok(h->wmode, h->L);       // L only changes through gh_set_L / gh_fill, never inside a spin
+    const bool seg = seg_ok(h->wmode, h->L);
+    const int nb = rw_blocks(h, seg || cw_ok(h->wmode, h->L));       // (the widest reweight kernel this spin may launch)
+    h->spin_partial_stride = nb;
+    if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);       // L only changes through gh_set_L / gh_fill, never inside a spin
     // Segment-parallel walks with a conditional table that the fused reweight keeps current (conditional A/B, no marginal
     // term): no k_lt between two paths.  Its only job there is to notice that a candidate mask moved (a count reached
     // zero; rare) and rebuild the table; instead the next k_seg sees the flag k_marg left, marks the table stale and the
@@ -1423,6 +1432,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
         break;
     }
+    h->spin_partial_stride = 0;
     if (rc) return rc;
     *n_out = hs.n_done;
     *hole_at = hs.stop ? hs.hole_at : 0;
@@ -1629,9 +1639,9 @@ extern "C" int gh_export_band(gh_t *h, double *out)
     HIPCHK(hipMalloc((void **)&d, n * sizeof(double)));
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (h->cfg.storage == GH_STORAGE_F64)
-        hipLaunchKernelGGL(k_export<double>, dim3(nb), dim3(256), 0, h->stream, (const double *)h->band, d, n);
+        hipLaunchKernelGGL(k_export<double>, dim3(nb), dim3(256), 0, h->stream, (const double *)h->band, d, n, h->W);
     else
-        hipLaunchKernelGGL(k_export<float>, dim3(nb), dim3(256), 0, h->stream, (const float *)h->band, d, n);
+        hipLaunchKernelGGL(k_export<float>, dim3(nb), dim3(256), 0, h->stream, (const float *)h->band, d, n, h->W);
     hipError_t e = hipMemcpyAsync(out, d, n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(d);
@@ -1649,9 +1659,9 @@ extern "C" int gh_import_band(gh_t *h, const double *in)
     hipError_t e = hipMemcpyAsync(d, in, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (h->cfg.storage == GH_STORAGE_F64)
-        hipLaunchKernelGGL(k_import<double>, dim3(nb), dim3(256), 0, h->stream, (double *)h->band, d, n);
+        hipLaunchKernelGGL(k_import<double>, dim3(nb), dim3(256), 0, h->stream, (double *)h->band, d, n, h->W);
     else
-        hipLaunchKernelGGL(k_import<float>, dim3(nb), dim3(256), 0, h->stream, (float *)h->band, d, n);
+        hipLaunchKernelGGL(k_import<float>, dim3(nb), dim3(256), 0, h->stream, (float *)h->band, d, n, h->W);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(d);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;

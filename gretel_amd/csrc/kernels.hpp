@@ -76,6 +76,14 @@ struct win_desc {
     int _pad;
 };
 
+// Band layout: band[i][a][d-1][b] -- position, FROM-symbol, distance, to-symbol.  Everything a path touches at position i
+// (the elements (path[i], path[i+d]) for d = 1..W, and the rows the conditional table is rebuilt from) sits in ONE run of
+// W x 7 values, a few 32-byte sectors, instead of one sector per distance in a distance-major band.
+__host__ __device__ __forceinline__ size_t bidx(int W, size_t i, int d, int a, int b)
+{
+    return ((i * NSYM + (size_t)a) * (size_t)W + (size_t)(d - 1)) * NSYM + (size_t)b;
+}
+
 __constant__ int8_t c_sym_of_char[256];
 
 // segwalk.hpp (segment-parallel path extension); k_marg<T,true> closes the path record behind it
@@ -100,20 +108,21 @@ __device__ __forceinline__ int nth_set5(uint32_t m, int r)
 }
 
 template <typename T>
-__device__ __forceinline__ double rowsum(const T *cell, int a)
+__device__ __forceinline__ double rowsum(const T *band, int W, int i, int d, int a)
 {
+    const T *row = band + bidx(W, i, d, a, 0);
     T acc = (T)0;
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) acc = acc + cell[a * NSYM + x];
+    for (int x = 0; x < NSYM; x++) acc = acc + row[x];
     return (double)acc;
 }
 
 template <typename T>
-__device__ __forceinline__ double colsum(const T *cell, int b)
+__device__ __forceinline__ double colsum(const T *band, int W, int i, int d, int b)
 {
     T acc = (T)0;
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) acc = acc + cell[x * NSYM + b];
+    for (int x = 0; x < NSYM; x++) acc = acc + band[bidx(W, i, d, x, b)];
     return (double)acc;
 }
 
@@ -141,10 +150,9 @@ __device__ __forceinline__ double log_conditional(const T *__restrict__ band, in
     const int l = j - i;
     double obs = 0.0, sum = 0.0;
     if (l <= W) {
-        const T *cell = band + ((size_t)i * W + (l - 1)) * CELL;
-        obs = (double)cell[a * NSYM + b];
-        if (cond_mode == GH_COND_A || cond_mode == GH_COND_D) sum = rowsum(cell, a);
-        else if (cond_mode == GH_COND_C) sum = colsum(cell, b);
+        obs = (double)band[bidx(W, i, l, a, b)];
+        if (cond_mode == GH_COND_A || cond_mode == GH_COND_D) sum = rowsum(band, W, i, l, a);
+        else if (cond_mode == GH_COND_C) sum = colsum(band, W, i, l, b);
     }
     double den;
     if (cond_mode == GH_COND_A) den = (double)nvalid[j] + sum;
@@ -167,7 +175,7 @@ __device__ __forceinline__ void add_obs(T *band, int N, int W, int a, int b, int
         atomicAdd(oob, 1ULL);
         return;
     }
-    atomicAdd(&band[((size_t)i * W + (d - 1)) * CELL + a * NSYM + b], (T)1);
+    atomicAdd(&band[bidx(W, i, d, a, b)], (T)1);
 }
 
 template <typename T>
@@ -238,8 +246,8 @@ __device__ __forceinline__ void add_obs_lds(unsigned *slice, int i_lo, int n_pos
     const int d = j - i;
     if (d < 1 || d > W || i < 0 || j > N + 1) { atomicAdd(oob, 1ULL); return; }
     const int li = i - i_lo;
-    if (li >= 0 && li < n_pos) atomicAdd(&slice[(li * W + (d - 1)) * CELL + a * NSYM + b], 1u);
-    else atomicAdd(&band[((size_t)i * W + (d - 1)) * CELL + a * NSYM + b], (T)1);     // sentinel cells far from the slice
+    if (li >= 0 && li < n_pos) atomicAdd(&slice[bidx(W, li, d, a, b)], 1u);     // (the slice has the band's layout)
+    else atomicAdd(&band[bidx(W, i, d, a, b)], (T)1);     // sentinel cells far from the slice
 }
 
 template <typename T>
@@ -372,7 +380,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 3, s = t & 7;
     const bool act = live && p <= N;
-    T *cell = band + ((size_t)(act ? p : 0) * W) * CELL;       // cell (p, p+1)
+    const size_t pcell = (size_t)(act ? p : 0);                // cell (p, p+1): row s at bidx(W, p, 1, s, .)
     double removed = 0.0;
     int na = -1, nb = -1;
     T nval = (T)0;
@@ -387,7 +395,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             if (mult) {
                 const int a = rw_path[p];
                 const int b = (j == N + 1) ? rw_path[0] : rw_path[j];
-                T *e = band + ((size_t)p * W + (d - 1)) * CELL + a * NSYM + b;
+                T *e = band + bidx(W, p, d, a, b);
                 T cur = *e;
                 for (int q = 0; q < mult; q++) {
                     const double old = (double)cur;
@@ -413,7 +421,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
     if (act && s < NSYM) {
 #pragma unroll
         for (int x = 0; x < NSYM; x++) {
-            T v = cell[s * NSYM + x];
+            T v = band[bidx(W, pcell, 1, s, x)];
             if (RW && s == na && x == nb) v = nval;      // the element this group has just rewritten
             acc = acc + v;
         }
@@ -473,7 +481,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             double rowv[NSYM];
             double sum = 0.0;
             if (l <= W) {
-                const T *rc = band + ((size_t)p * W + (l - 1)) * CELL + a * NSYM;
+                const T *rc = band + bidx(W, p, l, a, 0);
                 T racc = (T)0;
 #pragma unroll
                 for (int x = 0; x < NSYM; x++) { const T v = rc[x]; rowv[x] = (double)v; racc = racc + v; }
@@ -1665,18 +1673,25 @@ __global__ void k_reweight_one(T *p, double ratio, double *removed)
     *removed = old - nw;
 }
 
+// the exported / imported tensor keeps the distance-major order [(N+2)][W][7][7] (cell (i, i+d) as 49 values)
 template <typename T>
-__global__ void k_export(const T *__restrict__ band, double *__restrict__ out, size_t n)
+__global__ void k_export(const T *__restrict__ band, double *__restrict__ out, size_t n, int W)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[t] = (double)band[t];
+    if (t >= n) return;
+    const int b = (int)(t % NSYM), a = (int)((t / NSYM) % NSYM), d = (int)((t / CELL) % W) + 1;
+    const size_t i = t / ((size_t)CELL * W);
+    out[t] = (double)band[bidx(W, i, d, a, b)];
 }
 
 template <typename T>
-__global__ void k_import(T *__restrict__ band, const double *__restrict__ in, size_t n)
+__global__ void k_import(T *__restrict__ band, const double *__restrict__ in, size_t n, int W)
 {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) band[t] = (T)in[t];
+    if (t >= n) return;
+    const int b = (int)(t % NSYM), a = (int)((t / NSYM) % NSYM), d = (int)((t / CELL) % W) + 1;
+    const size_t i = t / ((size_t)CELL * W);
+    band[bidx(W, i, d, a, b)] = (T)in[t];
 }
 
 // hansel get_edge_weights_at for an arbitrary host-supplied history (compat API; one wave,

@@ -391,7 +391,8 @@ __device__ __forceinline__ int seg_count(const dev_state *st, int N, int L)
 // reweights, the row sum of the conditional and the row's entries all come out of those registers), and nothing is
 // read back after a store.
 // -------------------------------------------------------------------------------------------------------------
-template <typename T>
+// LP lanes per position: 8, or 32 for bands / lag counts above 8 (every distance and every lag in one round)
+template <typename T, int LP>
 __global__ void __launch_bounds__(256)
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
@@ -409,7 +410,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         return;
     }
     const int t = blockIdx.x * 256 + tid;
-    const int p = t >> 3, s = t & 7;
+    const int p = t / LP, s = t % LP;
     const bool act = p <= N;
     const int pp = act ? p : 0;
     // ---- round 1 ---------------------------------------------------------------------------------------------
@@ -424,14 +425,14 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const int a = path[pp];
     const int b0 = mult0 ? ((j0 == N + 1) ? path[0] : path[j0]) : 0;
     const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N;       // this lane owns the table row of lag d0
-    const T *cell = band + ((size_t)pp * W) * CELL;         // cell (p, p+1)
     T crow[NSYM];
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? cell[s * NSYM + x] : (T)0;
+    for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? band[bidx(W, pp, 1, s, x)] : (T)0;      // cell (p, p+1), row s
     int nv_t = 0;
     uint32_t cm_t = 0;
     if (lag_row) { nv_t = nvalid[j0]; cm_t = cmask[j0]; }
     const uint32_t cm_old = (act && s == 7) ? cmask[pp] : 0u;
+    static_assert(LP == 8 || LP == 32, "lane groups of 8 or 32");
     // ---- the path's minimum marginal, while round 1 is in flight ----------------------------------------------
     s_red[tid] = my_segmin;
     __syncthreads();
@@ -446,7 +447,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, minm, min_remove);
     // ---- round 2: the row of cell (p, p+d0) under the path's symbol at p ---------------------------------------
     const bool need_row = act && d0 <= W && (mult0 > 0 || lag_row);
-    T *rowp = band + ((size_t)pp * W + (d0 <= W ? d0 - 1 : 0)) * CELL + a * NSYM;
+    T *rowp = band + bidx(W, pp, d0 <= W ? d0 : 1, a, 0);
     T rrow[NSYM];
 #pragma unroll
     for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rowp[x] : (T)0;
@@ -470,22 +471,22 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         for (int x = 0; x < NSYM; x++) rrow[x] = (x == b0) ? cur : rrow[x];
         if (d0 == 1) { na = a; nb = b0; nval = cur; }
     }
-    for (int d = d0 + 8; act && d <= W; d += 8) {           // bands wider than 8: the remaining distances, one by one
+    for (int d = d0 + LP; act && d <= W; d += LP) {         // bands wider than the lane group: the remaining distances, one by one
         const int j = p + d;
         int mult = 0;
         if (j <= N - 1) mult = 1;
         else if (j == N + 1) mult = (p == N) ? 1 : 0;
         if (mult) {
             const int b = (j == N + 1) ? path[0] : path[j];
-            T *e = band + ((size_t)p * W + (d - 1)) * CELL + a * NSYM + b;
+            T *e = band + bidx(W, p, d, a, b);
             const double old = (double)*e;
             const double nw = old - ratio * old;
             *e = (T)nw;
             removed += old - nw;
         }
     }
-    na = __shfl(na, 0, 8); nb = __shfl(nb, 0, 8);
-    nval = (T)__shfl((double)nval, 0, 8);
+    na = __shfl(na, 0, LP); nb = __shfl(nb, 0, LP);
+    nval = (T)__shfl((double)nval, 0, LP);
     // ---- marginals of position p (k_marg, same order of operations) ---------------------------------------------
     double cs[NSYM];
     double tot = 0.0;
@@ -501,7 +502,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const double mine = (double)acc;
 #pragma unroll
     for (int x = 0; x < NSYM; x++) {
-        cs[x] = __shfl(mine, x, 8);
+        cs[x] = __shfl(mine, x, LP);
         if (cs[x] > 0) {
             tot += cs[x];
             if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; cm5 |= 1u << a6_of_sym(x); }
@@ -517,7 +518,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
                 minfo[(size_t)p * MINFO + b5] = gh_log10(m);
                 minfo[(size_t)p * MINFO + 5 + b5] = m;
             }
-        } else {
+        } else if (s == 7) {
             cnt[(size_t)p * 8 + 7] = tot;
             marg[(size_t)p * 8 + 7] = 0.0;
             nvalid[p] = nv;
@@ -533,7 +534,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     // ---- the table rows of lags d0, d0 + 8, ... (k_marg: same divisions, same log10) --------------------------------
     if (G && act && p < N && a != 4) {
         const int a6 = a6_of_sym(a);
-        const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
+        const double nv_i = (double)nv, ca = __shfl(mine, a, LP);
         const bool ranked = c.ranked != 0;
         int row6 = a6;
         if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
@@ -579,7 +580,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             }
         };
         if (d0 <= L && row6 >= 0) table_row(d0, rrow, nv_t, cm_t);
-        for (int l = d0 + 8; l <= L && row6 >= 0; l += 8) {      // lag counts above 8: the remaining lags, one by one
+        for (int l = d0 + LP; l <= L && row6 >= 0; l += LP) {    // lag counts above the lane group: the remaining lags, one by one
             T rowT[NSYM];
 #pragma unroll
             for (int x = 0; x < NSYM; x++) rowT[x] = (T)0;
@@ -587,7 +588,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             uint32_t cmt = 0;
             if (p + l <= N) {
                 if (l <= W) {
-                    const T *rc = band + ((size_t)p * W + (l - 1)) * CELL + a * NSYM;      // (this lane's own store included)
+                    const T *rc = band + bidx(W, p, l, a, 0);      // (this lane's own store included)
 #pragma unroll
                     for (int x = 0; x < NSYM; x++) rowT[x] = rc[x];
                 }
