@@ -464,6 +464,26 @@ def main():
                 del hb, hs
             except Exception as exc:       # never let the secondary leg break the contract line
                 out["throughput_mode"] = {"error": repr(exc)}
+        if world == 1 and not args.no_throughput_leg and n <= 20000:
+            # secondary figure: 256 replicas of the contig in ONE batched launch per kernel (gh_batch_*: one serial
+            # path-extension workgroup per window, every CU busy) -- what `bench.py --batch 256` times with distinct windows
+            try:
+                from gretel_amd.hansel import HanselBatch
+                reps = 256
+                hs = [Hansel(n, band=table.band, device=local) for _ in range(reps)]
+                for hh in hs:
+                    hh.fill_from_support(None, None, None, reads_handle=reads)
+                hb = HanselBatch(hs)
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                rb = hb.spin(paths)
+                tb = time.perf_counter() - tb
+                out["throughput_mode_256"] = {"windows": reps, "value": sum(r["n"] for r in rb) / tb, "unit": "haplotypes/s",
+                                              "note": "256 replicas of the benchmark contig, one batched spin of %d paths each (fill not included, "
+                                                      "results copied back to the host included)" % paths}
+                del hb, hs
+            except Exception as exc:
+                out["throughput_mode_256"] = {"error": repr(exc)}
         if world == 1 and not args.no_throughput_leg and L <= 5:
             # secondary figure: the same contig with 5 % of the bases read as deletions -> positions with FIVE candidates
             # (A C G T -): the window is not "narrow", the state space of the segment-parallel extension is 5^L, not 4^L

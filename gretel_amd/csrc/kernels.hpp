@@ -412,6 +412,8 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         na = __shfl(na, 0, 8); nb = __shfl(nb, 0, 8);
         nval = (T)__shfl((double)nval, 0, 8);
     }
+    unsigned flag_bits = 0;
+    int hole_p = 0x7fffffff;
     double c[NSYM];
     double tot = 0.0;
     int nv = 0;
@@ -449,12 +451,13 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             cnt[(size_t)p * 8 + 7] = tot;
             marg[(size_t)p * 8 + 7] = 0.0;
             nvalid[p] = nv;
-            if (cmask[p] != cm) atomicAnd(&st->cm_same, 0);       // the conditional table must then be rebuilt in full
+            // (the window's flags are collected per workgroup and leave with one atomic each at the end: see k_rw)
+            if (cmask[p] != cm) flag_bits |= 1u;                  // the conditional table must then be rebuilt in full
             cmask[p] = cm;
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
-            if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
-            if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
-            if (p >= 1 && __popc(cm5) > 4) atomicAnd(&st->narrow, 0);
+            if (p >= 1 && cm == 0) hole_p = p;
+            if (p >= 1 && (cm & (1u << 5))) flag_bits |= 2u;
+            if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
         }
     }
     if (RW && G && act && p < N && rw_path[p] != 4) {
@@ -519,6 +522,22 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
                     out[rb] = r;
                 }
             }
+        }
+    }
+    {
+        __shared__ unsigned s_flags;
+        __shared__ int s_hole;
+        if (threadIdx.x == 0) { s_flags = 0; s_hole = 0x7fffffff; }
+        __syncthreads();
+        if (flag_bits) atomicOr(&s_flags, flag_bits);
+        if (hole_p != 0x7fffffff) atomicMin(&s_hole, hole_p);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned f = s_flags;
+            if (f & 1u) atomicAnd(&st->cm_same, 0);
+            if (f & 2u) atomicAnd(&st->nodel, 0);
+            if (f & 4u) atomicAnd(&st->narrow, 0);
+            if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
         }
     }
     if (RW) {

@@ -53,7 +53,8 @@ __host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
     int g2 = 32768 / g.NS;                      // one group's maps (G2 x NS x 2 bytes) within 64 KB of LDS
     if (g2 > 16) g2 = 16;
     if (g2 < 1) g2 = 1;
-    const int g1max = g.NS > 2048 ? 12 : 16;
+    // groups: k_emit keeps the maps of the groups in front of it in LDS ((G1 - 1) x NS x 2 bytes + one prefix map <= 156 KB)
+    const int g1max = g.NS > 2048 ? 25 : 16;
     const int smax = g1max * g2;
     int len = (N + smax - 1) / smax;
     if (len < SEG_MIN_LEN) len = SEG_MIN_LEN;

@@ -488,6 +488,8 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     na = __shfl(na, 0, LP); nb = __shfl(nb, 0, LP);
     nval = (T)__shfl((double)nval, 0, LP);
     // ---- marginals of position p (k_marg, same order of operations) ---------------------------------------------
+    unsigned flag_bits = 0;
+    int hole_p = 0x7fffffff;
     double cs[NSYM];
     double tot = 0.0;
     int nv = 0;
@@ -522,12 +524,14 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             cnt[(size_t)p * 8 + 7] = tot;
             marg[(size_t)p * 8 + 7] = 0.0;
             nvalid[p] = nv;
-            if (cm_old != cm) atomicAnd(&st->cm_same, 0);         // the conditional table must then be rebuilt in full
             cmask[p] = cm;
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
-            if (p >= 1 && cm == 0) atomicMin(&st->first_hole, p);
-            if (p >= 1 && (cm & (1u << 5))) atomicAnd(&st->nodel, 0);
-            if (p >= 1 && __popc(cm5) > 4) atomicAnd(&st->narrow, 0);
+            // the window's flags: collected per workgroup in LDS, one global atomic per flag and workgroup (thousands of
+            // positions and-ing the same word one by one cost 12 ns each: 0.2 ms per path in a window full of '-')
+            if (cm_old != cm) flag_bits |= 1u;                     // the conditional table must then be rebuilt in full
+            if (p >= 1 && (cm & (1u << 5))) flag_bits |= 2u;
+            if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
+            if (p >= 1 && cm == 0) hole_p = p;
         }
     }
     RW_STAMP(3);
@@ -600,13 +604,25 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     }
     RW_STAMP(4);
     // ---- removed mass: fixed-order tree, as k_marg ----------------------------------------------------------------
+    __shared__ unsigned s_flags;
+    __shared__ int s_hole;
+    if (tid == 0) { s_flags = 0; s_hole = 0x7fffffff; }
     s_red[tid] = removed;
     __syncthreads();
+    if (flag_bits) atomicOr(&s_flags, flag_bits);
+    if (hole_p != 0x7fffffff) atomicMin(&s_hole, hole_p);
     for (int q = 128; q > 0; q >>= 1) {
         if (tid < q) s_red[tid] += s_red[tid + q];
         __syncthreads();
     }
-    if (tid == 0) partial[blockIdx.x] = s_red[0];
+    if (tid == 0) {
+        partial[blockIdx.x] = s_red[0];
+        const unsigned f = s_flags;
+        if (f & 1u) atomicAnd(&st->cm_same, 0);
+        if (f & 2u) atomicAnd(&st->nodel, 0);
+        if (f & 4u) atomicAnd(&st->narrow, 0);
+        if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
+    }
 }
 
 // lone gh_generate_path: no k_marg<T,true> follows, so the record is closed here
