@@ -1,5 +1,5 @@
 // cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated
-// (L = 6..16: 4^L states; segwalk.hpp enumerates up to 4^5), included by gretel_hip.hip behind segwalk.hpp.
+// (L = 6..24: 4^L states; segwalk.hpp enumerates up to 4^5), included by gretel_hip.hip behind segwalk.hpp.
 //
 // Same decomposition -- cut the window into <= 256 segments, know for every segment what it does to the state that
 // enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states (<= 64 per
@@ -25,7 +25,8 @@
 #define CW_K 64                 /* pool entries per segment */
 #define CW_THREADS (4 * CW_K)   /* four lanes per entry */
 #define CW_MIN_L 6
-#define CW_MAX_L 16             /* 2 bits per pick in a 32-bit state */
+#define CW_MAX_L 24             /* 2 bits per pick in a 64-bit state; beyond 24 lags the table slice of a chunk outgrows the LDS */
+typedef unsigned long long cw_key;
 #define CW_MAX_SEG 256
 #define CW_MIN_LEN 32
 
@@ -41,10 +42,11 @@ __host__ __device__ inline cw_geom cw_geometry(int N)
     return g;
 }
 // positions per LDS chunk of k_cwalk: (c + L - 1) sources x 4 rows x L lags x 5 columns of doubles within 96 KB
+__host__ __device__ constexpr int cw_lds_budget(int L) { return L <= 16 ? 96 * 1024 : 150 * 1024; }
 __host__ __device__ constexpr int cw_chunk(int L)
 {
     int c = 64;
-    while (c > 8 && (c + L - 1) * 4 * L * 5 * 8 > 96 * 1024) c -= 1;
+    while (c > 2 && (c + L - 1) * 4 * L * 5 * 8 > cw_lds_budget(L)) c -= 1;
     return c;
 }
 __host__ __device__ constexpr size_t cw_lds_bytes(int L) { return (size_t)(cw_chunk(L) + L - 1) * 4 * L * 5 * 8; }
@@ -60,10 +62,10 @@ struct cw_params {
     const double *G;          // ranked layout only
     const double *minfo;
     dev_state *st;
-    uint32_t *keys, *exits;   // [S][CW_K]
+    cw_key *keys, *exits;     // [S][CW_K]
     int32_t *last_hit;        // [S][CW_K]
     int32_t *npool;           // [S]
-    uint32_t *pend;           // [S][CW_K]: states waiting to join the pool (exits of the previous segment's walks)
+    cw_key *pend;             // [S][CW_K]: states waiting to join the pool (exits of the previous segment's walks)
     int32_t *npend;           // [S]
     uint8_t *walked;          // [S][CW_K]: walked under the current tensor
     int8_t *nxt;              // [S][CW_K]: index of the entry's exit state in the next segment's pool, -1 = not there
@@ -104,10 +106,10 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
     if (tid < 64) {
         int n0 = P.npool[s];
         const int np = P.npend[s] < CW_K ? P.npend[s] : CW_K;
-        uint32_t *keys = P.keys + (size_t)s * CW_K;
+        cw_key *keys = P.keys + (size_t)s * CW_K;
         int32_t *lh = P.last_hit + (size_t)s * CW_K;
         for (int k = 0; k < np; k++) {
-            const uint32_t x = P.pend[(size_t)s * CW_K + k];
+            const cw_key x = P.pend[(size_t)s * CW_K + k];
             const bool dup = __builtin_amdgcn_ballot_w64(tid < n0 && keys[tid] == x) != 0;
             if (dup) continue;
             int slot = n0;
@@ -132,9 +134,9 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
     const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
     if (!__syncthreads_or(live ? 1 : 0)) return;            // nothing new to walk in this segment
     constexpr int CH = cw_chunk(LC);
-    constexpr unsigned SMASK = LC >= 16 ? 0xffffffffu : ((1u << (2 * LC)) - 1u);
+    constexpr cw_key SMASK = LC >= 32 ? ~0ull : ((1ull << (2 * LC)) - 1ull);
     double *Gs = reinterpret_cast<double *>(cw_smem);       // [(CH + LC - 1)][4][LC][5]: G's own layout, rows 0..3
-    unsigned sigma = live ? P.keys[(size_t)s * CW_K + q] : 0u;
+    cw_key sigma = live ? P.keys[(size_t)s * CW_K + q] : 0ull;
     const int t0 = s * g.seglen;
     const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     const unsigned shift = (unsigned)(tid & 63 & ~3);       // this quad's bits in the wave's ballot
@@ -199,7 +201,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
             m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
             const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
             const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & 15u);       // first wins (gretel.py:166-174)
-            sigma = ((sigma << 2) | d) & SMASK;
+            sigma = ((sigma << 2) | (cw_key)d) & SMASK;
             const int gt = c0 - t0 + tl;                             // position inside the segment
             word |= d << (2 * (gt & 15));
             if ((gt & 15) == 15 || gt == t1 - t0 - 1) {
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         if (nc >= LC) {
             unsigned dig[LC];
 #pragma unroll
-            for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = ((sigma >> (2 * (l - 1))) & 3u) * ROWD;
+            for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = ((unsigned)(sigma >> (2 * (l - 1))) & 3u) * ROWD;
             for (; tl + LC <= nc; tl += LC) {
 #pragma unroll
                 for (int u = 0; u < LC; u++) {
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
                 }
             }
         }
-        for (; tl < nc; tl++) step(tl, [&](int l) { return ((sigma >> (2 * (l - 1))) & 3u) * ROWD; });
+        for (; tl < nc; tl++) step(tl, [&](int l) { return ((unsigned)(sigma >> (2 * (l - 1))) & 3u) * ROWD; });
     }
     if (live && b == 0) {
         P.exits[(size_t)s * CW_K + q] = sigma;
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         // its own pending list right now: a missed match only costs a duplicate request, dropped at the merge; the hops
         // themselves are resolved by k_clink, after this kernel.)
         if (s + 1 < g.S) {
-            const uint32_t *kn = P.keys + (size_t)(s + 1) * CW_K;
+            const cw_key *kn = P.keys + (size_t)(s + 1) * CW_K;
             bool there = false;
             const int nn = P.npool[s + 1];                // (entries behind the count are leftovers of earlier tensors)
             for (int k = 0; k < nn && k < CW_K; k++)
@@ -261,14 +263,15 @@ __global__ void __launch_bounds__(CW_K) k_clink(cw_params P)
     const int s = blockIdx.x, q = threadIdx.x;
     if (s + 1 >= g.S) return;
     const size_t e = (size_t)s * CW_K + q;
-    const uint32_t kn = P.keys[(size_t)(s + 1) * CW_K + q];           // lane q holds key q of the next pool
+    const cw_key kn = P.keys[(size_t)(s + 1) * CW_K + q];             // lane q holds key q of the next pool
     const bool kw = P.walked[(size_t)(s + 1) * CW_K + q] != 0;
     const int nn = P.npool[s + 1];
     const bool mine = q < P.npool[s] && P.walked[e];
-    const uint32_t x = P.exits[e];
+    const cw_key x = P.exits[e];
     int h = -1;
     for (int k = 0; k < nn; k++) {                                     // (uniform trip count; key k by broadcast)
-        const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)kn, k);
+        const cw_key kk = ((cw_key)(unsigned)__builtin_amdgcn_readlane((int)(kn >> 32), k) << 32) |
+                          (cw_key)(unsigned)__builtin_amdgcn_readlane((int)(kn & 0xffffffffull), k);
         const bool ww = __builtin_amdgcn_readlane(kw ? 1 : 0, k) != 0;
         if (h == -1 && kk == x) h = ww ? k : -2;
     }
@@ -315,7 +318,7 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
     }
     __syncthreads();
     if (tid == 0) {                                         // (2)
-        const bool start_ok = P.npool[0] > 0 && P.walked[0] && P.keys[0] == 0u;
+        const bool start_ok = P.npool[0] > 0 && P.walked[0] && P.keys[0] == 0ull;
         int x = start_ok ? 0 : -1;
         for (int gr = 0; gr <= NG; gr++) {
             gin[gr] = x;
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
         const bool open = stuck != 0x7fffffff;
         if (open && stuck >= 0 && hop[stuck * CW_K + tru[stuck]] == -1) {
             // the exit state is not in pool stuck+1: on its pending list?  (full when k_cwalk asked: first place now)
-            const uint32_t x = P.exits[(size_t)stuck * CW_K + tru[stuck]];
+            const cw_key x = P.exits[(size_t)stuck * CW_K + tru[stuck]];
             const int np = P.npend[stuck + 1] < CW_K ? P.npend[stuck + 1] : CW_K;
             bool queued = false;
             for (int k = 0; k < np; k++)
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= g.S) return;
     const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ...
-    unsigned sigma = 0;
+    cw_key sigma = 0;
     for (int l = P.L; l >= 1; l--) {                        // oldest first: the pick of lag 1 ends in bits 0..1
         const int i = p + 1 - l;
         unsigned d = 0;
@@ -430,9 +433,9 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
             const int a6 = a6_of_sym(path[i]);
             d = (unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u;
         }
-        sigma = (sigma << 2) | d;
+        sigma = (sigma << 2) | (cw_key)d;
     }
-    uint32_t *keys = P.keys + (size_t)s * CW_K;
+    cw_key *keys = P.keys + (size_t)s * CW_K;
     int n = merge ? P.npool[s] : 0;
     bool there = false;
     for (int k = 0; k < n; k++)

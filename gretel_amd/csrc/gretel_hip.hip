@@ -110,7 +110,8 @@ struct gh_handle {
     double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
     int seg_L;
     // candidate-pool segment walk (cwalk.hpp)
-    uint32_t *cw_keys, *cw_exits, *cw_hist, *cw_pend;
+    cw_key *cw_keys, *cw_exits, *cw_pend;
+    uint32_t *cw_hist;
     int32_t *cw_npend;
     int32_t *cw_last_hit, *cw_npool, *cw_true;
     uint8_t *cw_walked;
@@ -852,7 +853,7 @@ static bool walk_depth2_ok(int wm, int L)
 static bool cw_ok(int wm, int L) { return wm == WM_SEG && L >= CW_MIN_L && L <= CW_MAX_L; }
 
 // single windows: may k_lt build the ranked layout?  (the segment-parallel walk reads either layout)
-static bool walk_ranked_ok(int wm, int L) { return seg_ok(wm, L) || walk_depth2_ok(wm, L); }
+static bool walk_ranked_ok(int wm, int L) { return seg_ok(wm, L) || cw_ok(wm, L) || walk_depth2_ok(wm, L); }
 
 template <int LC>
 static void launch_walk_lc(bool spec, size_t lds, hipStream_t stream, const walk_params &P, int grid, const win_desc *wd, int spin)
@@ -1078,12 +1079,12 @@ static int alloc_cw(gh_handle *h)
 {
     if (h->cw_keys) return GH_OK;
     const cw_geom g = cw_geometry(h->N);
-    hipError_t e = hipMalloc((void **)&h->cw_keys, sizeof(uint32_t) * g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_exits, sizeof(uint32_t) * g.S * CW_K);
+    hipError_t e = hipMalloc((void **)&h->cw_keys, sizeof(cw_key) * g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_exits, sizeof(cw_key) * g.S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_last_hit, sizeof(int32_t) * g.S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_hist, sizeof(uint32_t) * (size_t)g.S * g.NW * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npool, sizeof(int32_t) * g.S);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(uint32_t) * g.S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(cw_key) * g.S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npend, sizeof(int32_t) * g.S);
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_npend, 0, sizeof(int32_t) * g.S, h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_walked, (size_t)g.S * CW_K);
@@ -1093,8 +1094,8 @@ static int alloc_cw(gh_handle *h)
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_walked, 0, (size_t)g.S * CW_K, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_nxt, 0xff, (size_t)g.S * CW_K, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_last_hit, 0, sizeof(int32_t) * g.S * CW_K, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_keys, 0, sizeof(uint32_t) * g.S * CW_K, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_exits, 0, sizeof(uint32_t) * g.S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_keys, 0, sizeof(cw_key) * g.S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_exits, 0, sizeof(cw_key) * g.S * CW_K, h->stream);
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed: %s", hipGetErrorString(e));
     if (!h->seg_min && hipMalloc((void **)&h->seg_min, 256 * sizeof(double)) != hipSuccess)      // (alloc_seg sizes for L <= 5 only)
         return fail(GH_ERR_NOMEM, "hipMalloc failed");
@@ -1136,6 +1137,7 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
         switch (h->L) {
 #define CW_CASE(n) case n: launch_cwalk_lc<n>(P, h->stream, g.S, h->dev); break;
             CW_CASE(6) CW_CASE(7) CW_CASE(8) CW_CASE(9) CW_CASE(10) CW_CASE(11) CW_CASE(12) CW_CASE(13) CW_CASE(14) CW_CASE(15) CW_CASE(16)
+            CW_CASE(17) CW_CASE(18) CW_CASE(19) CW_CASE(20) CW_CASE(21) CW_CASE(22) CW_CASE(23) CW_CASE(24)
 #undef CW_CASE
             default: return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_L);
         }

@@ -1576,6 +1576,7 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
     const int L = P.L;
     const size_t ROW = (size_t)L * LT_ROW, BLK = 6 * ROW;
     const int first_hole = st->first_hole;
+    const bool ranked = st->ranked != 0;
     const int Nw = first_hole <= P.N ? first_hole - 1 : P.N;
     double hp_cur = 0.0, hp_orig = 0.0, minm = INFINITY;
     const int bb = (lane & 7) < 5 ? (lane & 7) : 0;
@@ -1601,13 +1602,19 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
         }
         const int w = __builtin_amdgcn_readfirstlane(argmax8(acc));
         const double *inf = P.minfo + (size_t)snp * MINFO;
-        const double mg = inf[5 + w];
+        // ranked table (k_lt): rows and columns are candidate ranks; the symbol comes back through the candidate bits
+        int b5 = w;
+        if (ranked) {
+            b5 = nth_set5((uint32_t)__double_as_longlong(inf[10]), w);
+            if (b5 < 0) b5 = 0;
+        }
+        const double mg = inf[5 + b5];
         if (mg < minm) minm = mg;
-        hp_cur += inf[w];
-        hp_orig += inf[11 + w];
+        hp_cur += inf[b5];
+        hp_orig += inf[11 + b5];
         if (lane == 0) {
             lpath[snp & hmask] = (uint8_t)w;
-            P.path_out[snp] = (uint8_t)vsym(w);
+            P.path_out[snp] = (uint8_t)vsym(b5);
         }
         __syncthreads();
     }

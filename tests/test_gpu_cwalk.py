@@ -1,4 +1,4 @@
-"""The candidate-pool segment walk (gretel_amd/csrc/cwalk.hpp: lag counts 6..16, spins) against the C oracle and the
+"""The candidate-pool segment walk (gretel_amd/csrc/cwalk.hpp: lag counts 6..24, spins) against the C oracle and the
 serial walker: every lag count, pools kept across spins and dropped by a new fill, windows it must hand back (a
 position with five candidates), holes, a stale table in the middle of a queue, the other conditionals and f64 storage."""
 import os
@@ -34,7 +34,7 @@ def _same(res, ref):
     assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("L", [6, 7, 8, 9, 10, 12, 13, 16])
+@pytest.mark.parametrize("L", [6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 24])
 def test_every_lag_count(L):
     # long-read-style reads (k ~ Poisson(10)); L = 9 and up also exercises the table rows beyond the eighth lag in k_rw
     t = make_support_table(2500, 30000, k=None, seed=200 + L)
