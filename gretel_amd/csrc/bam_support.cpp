@@ -3,15 +3,20 @@
 // (gretel/util.py:120-209) for the ingest half of load_from_bam.
 //
 // The file is STREAMED: compressed bytes are read in batches, the BGZF blocks of a batch are inflated in parallel
-// (libdeflate when the runtime library is present, zlib otherwise) and the records are parsed out of the batch with
-// whatever a batch cuts in two carried over to the next.  With an index next to the file (<bam>.bai or <stem>.bai) the
+// (libdeflate when the runtime library is present, zlib otherwise), the records of the batch are framed front to back
+// and worked on by several threads (CIGAR walk, support characters, key and its hash: functions of the record alone);
+// only the key table -- first-seen order of the rows, appends to a key seen before -- takes them one by one, in file
+// order.  What a batch cuts in two is carried over to the next.  GIO_TIMING=1 prints the time of each stage.
+// With an index next to the file (<bam>.bai or <stem>.bai) the
 // stream starts at the first block that can hold an alignment overlapping the window and stops at the first record
 // behind it (coordinate-sorted input, as the reference's pysam fetch/pileup requires as well); without one the whole
 // contig is scanned.  Every record field that is used as a length or an offset is checked against the record's size:
 // malformed input is an error (-4), never an out-of-bounds read.
+#include <sys/mman.h>
 #include <dlfcn.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
@@ -19,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -124,6 +131,77 @@ static int n_threads()
     return n;
 }
 
+// Large arrays on transparent huge pages: a million-read table touches ~200 MB of fresh memory, and at 4 KB a page the
+// faults cost more than the decoding (madvise is a hint: where THP is off nothing changes).
+static void *big_alloc(size_t bytes)
+{
+    if (bytes >= ((size_t)4 << 20)) {
+        const size_t al = (size_t)2 << 20, sz = (bytes + al - 1) / al * al;
+        void *p = aligned_alloc(al, sz);
+        if (p) madvise(p, sz, MADV_HUGEPAGE);
+        return p;
+    }
+    return malloc(bytes);
+}
+template <typename T> struct big_allocator {
+    typedef T value_type;
+    big_allocator() = default;
+    template <typename U> big_allocator(const big_allocator<U> &) {}
+    T *allocate(size_t n)
+    {
+        void *p = big_alloc(n * sizeof(T));
+        if (!p) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <typename U> bool operator==(const big_allocator<U> &) const { return true; }
+    template <typename U> bool operator!=(const big_allocator<U> &) const { return false; }
+};
+template <typename T> using bigvec = std::vector<T, big_allocator<T>>;
+
+// a byte window that grows without value-initialising what the inflaters are about to overwrite (zero-filling 100 MB
+// on one thread, and faulting its pages in there, cost more than inflating it on eight)
+// records a thread should have before another one is started (GIO_PART_RECORDS: the tests make it small)
+static size_t part_records()
+{
+    static const size_t n = [] {
+        long v = getenv("GIO_PART_RECORDS") ? atol(getenv("GIO_PART_RECORDS")) : 2048;
+        return (size_t)(v < 1 ? 1 : v);
+    }();
+    return n;
+}
+
+class rawbuf {
+public:
+    rawbuf() = default;
+    rawbuf(const rawbuf &) = delete;
+    rawbuf &operator=(const rawbuf &) = delete;
+    ~rawbuf() { free(p_); }
+    size_t size() const { return n_; }
+    uint8_t *data() { return p_; }
+    const uint8_t *data() const { return p_; }
+    void clear() { n_ = 0; }
+    void drop_front(size_t k) { if (k) { memmove(p_, p_ + k, n_ - k); n_ -= k; } }
+    bool resize_uninit(size_t n)
+    {
+        if (n > cap_) {
+            size_t c = cap_ ? cap_ : ((size_t)1 << 20);
+            while (c < n) c += c / 2;
+            uint8_t *q = (uint8_t *)big_alloc(c);
+            if (!q) return false;
+            if (n_) memcpy(q, p_, n_);
+            free(p_);
+            p_ = q;
+            cap_ = c;
+        }
+        n_ = n;
+        return true;
+    }
+private:
+    uint8_t *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+};
+
 class bgzf_stream {
 public:
     ~bgzf_stream() { if (fp_) fclose(fp_); }
@@ -133,6 +211,7 @@ public:
         fp_ = fopen(path, "rb");
         if (!fp_) return fail(-1, "cannot open %s", path);
         path_ = path;
+        if (fseeko(fp_, 0, SEEK_END) == 0) { fsize_ = (uint64_t)ftello(fp_); fseeko(fp_, 0, SEEK_SET); }
         uint8_t magic[4];
         if (fread(magic, 1, 4, fp_) != 4 || magic[0] != 0x1f || magic[1] != 0x8b)
             return fail(-2, "%s is not gzip/BGZF", path);
@@ -146,6 +225,8 @@ public:
         cbuf_.clear();
         out_.clear();
         rd_ = 0;
+        start_ = coffset;
+        taken_ = 0;
         skip_ = uoffset;
         eof_ = false;
         return 0;
@@ -161,6 +242,8 @@ public:
         return (int64_t)(out_.size() - rd_);
     }
     const uint8_t *ptr() const { return out_.data() + rd_; }
+    // share of the file behind the last seek that has been read (for sizing what grows with the records)
+    double progress() const { return fsize_ > start_ ? (double)taken_ / (double)(fsize_ - start_) : 1.0; }
     void consume(size_t n) { rd_ += n; }
 
 private:
@@ -170,7 +253,7 @@ private:
     {
         // keep the unread tail, read another batch of compressed bytes, inflate its complete blocks
         if (rd_ > 0) {
-            out_.erase(out_.begin(), out_.begin() + (ptrdiff_t)rd_);
+            out_.drop_front(rd_);
             rd_ = 0;
         }
         // small first batches (the header, an index seek right behind it), then 4 MB at a time (the inflated window is reused from batch to batch: fresh pages are the expensive part)
@@ -181,6 +264,7 @@ private:
         const size_t got = fread(cbuf_.data() + have, 1, BATCH, fp_);
         cbuf_.resize(have + got);
         g_stats.compressed_bytes += (int64_t)got;
+        taken_ += got;
         if (got == 0) {
             eof_ = true;
             if (!cbuf_.empty()) return fail(-4, "truncated BGZF block at the end of %s", path_.c_str());
@@ -208,7 +292,7 @@ private:
             o += bsize;
         }
         const size_t base = out_.size();
-        out_.resize(base + total);
+        if (!out_.resize_uninit(base + total)) return fail(-6, "out of memory");
         std::atomic<size_t> next(0);
         std::atomic<int> bad(0);
         auto work = [&]() {
@@ -240,8 +324,10 @@ private:
 
     FILE *fp_ = nullptr;
     std::string path_;
-    std::vector<uint8_t> cbuf_, out_;
+    std::vector<uint8_t> cbuf_;
+    rawbuf out_;
     size_t rd_ = 0, skip_ = 0, batch_ = (size_t)1 << 18;
+    uint64_t fsize_ = 0, start_ = 0, taken_ = 0;
     bool eof_ = false;
 };
 
@@ -440,63 +526,87 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
     // csum[x] = number of SNPs in [0, x)
     std::vector<int32_t> csum((size_t)end_pos + 2, 0);
     for (int32_t p = 0; p <= end_pos; p++) csum[p + 1] = csum[p] + (region[p] ? 1 : 0);
+    // next_snp[x] = smallest SNP position >= x (end_pos + 1 when there is none), x in [0, end_pos + 1]
+    std::vector<int32_t> next_snp((size_t)end_pos + 2, end_pos + 1);
+    for (int32_t p = end_pos; p >= 0; p--) next_snp[p] = region[p] ? p : next_snp[p + 1];
 
-    // rows of the table: support characters in one arena, keys (util.py:160) in another; a key seen again (the same
-    // read met through another record) appends to its row -- rare, so the row is then moved to the arena's end
-    struct row { int32_t rank; int64_t off; int32_t len; };
-    std::vector<row> reads;
-    std::vector<uint8_t> arena;
-    std::vector<char> key_arena;                            // the keys, back to back
-    std::vector<std::pair<int64_t, int32_t>> key_at;        // per row: offset and length of its key
-    // open addressing over a 64-bit hash of the key (linear probing, at most half full): one cache line per lookup
-    // instead of a node chain; equal hashes are confirmed on the key bytes
-    struct slot { uint64_t h; uint32_t row1; };             // row1 = row + 1, 0 = empty
-    std::vector<slot> table((size_t)1 << 16, slot{0, 0});
-    size_t table_mask = table.size() - 1;
-    auto hash_key = [](const std::string &k) {
-        uint64_t h = 0xcbf29ce484222325ull;                  // FNV-1a, then a finalizer to spread the low bits
-        for (unsigned char ch : k) { h ^= ch; h *= 0x100000001b3ull; }
-        h ^= h >> 32; h *= 0x9e3779b97f4a7c15ull; h ^= h >> 29;
-        return h;
+    // rows of the table in first-seen order (util.py:191-207).  The characters and keys stay where the threads wrote
+    // them (the parts of every batch are kept until the table is assembled); a key seen again (the same read met through
+    // another record: rare) gives its row a private copy with the new characters appended.
+    struct row { const uint8_t *ch; const char *key; int32_t rank, len, key_len; uint32_t h_lo; };
+    bigvec<row> reads;
+    std::vector<std::unique_ptr<uint8_t[]>> moved;          // the private copies
+    // open addressing (linear probing, at most half full) over a 64-bit hash of the key: the lower half says where the
+    // probe starts, a slot holds the upper half and the row -- 8 bytes, in lazily-zeroed memory; a matching tag is
+    // confirmed on the lower half and the key bytes
+    struct slot { uint32_t tag, row1; };                    // row1 = row + 1, 0 = empty
+    struct slot_table {
+        slot *p = nullptr;
+        size_t n = 0;
+        ~slot_table() { if (p) munmap(p, n * sizeof(slot)); }
+        bool alloc(size_t slots)
+        {
+            void *q = mmap(nullptr, slots * sizeof(slot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) return false;
+            madvise(q, slots * sizeof(slot), MADV_HUGEPAGE);
+            p = (slot *)q;
+            n = slots;
+            return true;
+        }
     };
-    auto grow = [&]() {
-        std::vector<slot> nt(table.size() * 2, slot{0, 0});
-        const size_t nm = nt.size() - 1;
-        for (const slot &e : table)
-            if (e.row1) {
-                size_t i = (size_t)e.h & nm;
-                while (nt[i].row1) i = (i + 1) & nm;
-                nt[i] = e;
-            }
-        table.swap(nt);
+    slot_table table;
+    if (!table.alloc((size_t)1 << 16)) return fail(-6, "out of memory");
+    size_t table_mask = table.n - 1;
+    // room for `rows` rows at half load; rehashing walks the old table front to back
+    auto table_reserve = [&](size_t rows) -> bool {
+        if (rows * 2 <= table.n) return true;
+        size_t want = table.n;
+        while (rows * 2 > want) want *= 2;
+        slot_table nt;
+        if (!nt.alloc(want)) return false;
+        const size_t nm = want - 1;
+        for (size_t i = 0; i < table.n; i++) {
+            const slot e = table.p[i];
+            if (!e.row1) continue;
+            const row &w = reads[e.row1 - 1];
+            size_t j = (size_t)w.h_lo & nm;
+            while (nt.p[j].row1) j = (j + 1) & nm;
+            nt.p[j] = e;
+        }
+        std::swap(table.p, nt.p);
+        std::swap(table.n, nt.n);
         table_mask = nm;
+        return true;
     };
 
-    std::string chars, key;
-    for (;;) {
-        int64_t av = z.ensure(4);
-        if (av < 0) return (int)av;
-        if (av == 0) break;
-        if (av < 4) return fail(-4, "truncated BAM record");
-        const int32_t block_size = rd32(z.ptr());
-        if (block_size < 32 || block_size > (1 << 28)) return fail(-4, "bad BAM record size %d", block_size);
-        av = z.ensure(4 + (size_t)block_size);
-        if (av < 0) return (int)av;
-        if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
-        const uint8_t *r = z.ptr() + 4;
+    // What one record contributes, worked out by any thread: the CIGAR walk, the key and its hash depend on nothing but
+    // the record.  Only the key table (first-seen order of the rows, util.py:191-207) is sequential: it takes the
+    // records of a batch in file order from the threads' parts.
+    struct kept { uint64_t h; int32_t rank; uint32_t key_off, key_len, ch_off, ch_len; };
+    struct part {
+        bigvec<kept> recs;
+        bigvec<uint8_t> chars;
+        bigvec<char> keys;
+        int64_t n_seen = 0;          // records of the range looked at (the one that stops the scan included)
+        bool stop = false;           // met the first record behind the window
+        int err = 0;                 // the range ended in a malformed record
+        std::string msg;
+    };
+    const bool used_index = g_stats.used_index != 0;
+    // returns 0: next record, 1: nothing behind this record can matter, < 0: malformed (g_err of the calling thread)
+    auto one_record = [&](const uint8_t *r, int32_t block_size, part &o) -> int {
         bam_rec b;
-        if ((rc = parse_record(r, block_size, b))) return rc;
-        z.consume(4 + (size_t)block_size);
-        g_stats.records++;
+        int prc = parse_record(r, block_size, b);
+        if (prc) return prc;
         // coordinate-sorted: nothing behind the window, and nothing on a later reference, can matter
-        if (g_stats.used_index && (b.ref_id > tid || (b.ref_id == tid && b.pos >= end_pos))) break;
+        if (used_index && (b.ref_id > tid || (b.ref_id == tid && b.pos >= end_pos))) return 1;
         const int flag = b.flag;
-        if (b.ref_id != tid || (flag & (0x4 | 0x100 | 0x200 | 0x400))) continue;
-        if (!stepper_all && (flag & 0x1) && !(flag & 0x2)) continue;      // orphans, stepper "samtools"
-        if (b.l_seq == 0) continue;
+        if (b.ref_id != tid || (flag & (0x4 | 0x100 | 0x200 | 0x400))) return 0;
+        if (!stepper_all && (flag & 0x1) && !(flag & 0x2)) return 0;        // orphans, stepper "samtools"
+        if (b.l_seq == 0) return 0;
 
         // walk the CIGAR the way htslib's pileup resolves it, column by column over the SNP positions
-        chars.clear();
+        const size_t ch0 = o.chars.size();
         int64_t ref = b.pos, q = 0, qalen = 0;
         const int64_t hi = end_pos;
         for (int c = 0; c < b.n_cigar; c++) {
@@ -504,35 +614,37 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
             const int op = v & 15;
             const int64_t ln = v >> 4;
             if (op == 0 || op == 7 || op == 8) {                            // M = X
-                if (q + ln > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
+                if (q + ln > b.l_seq) { o.chars.resize(ch0); return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq); }
                 int64_t lo1 = ref + 1 < 1 ? 1 : ref + 1, hi1 = ref + ln < hi ? ref + ln : hi;
-                for (int64_t p1 = lo1; p1 <= hi1; p1++)
-                    if (region[p1]) {
-                        const int64_t qi = q + (p1 - 1 - ref);
-                        const uint8_t byte = b.seq[qi >> 1];
-                        chars.push_back(SEQ[(qi & 1) ? (byte & 15) : (byte >> 4)]);      // util.py:186-189, b[0]
-                    }
+                // SNPs are sparse: from one to the next through next_snp instead of testing every column
+                for (int64_t p1 = lo1 <= hi1 ? next_snp[lo1] : hi1 + 1; p1 <= hi1; p1 = next_snp[p1 + 1]) {
+                    const int64_t qi = q + (p1 - 1 - ref);
+                    const uint8_t byte = b.seq[qi >> 1];
+                    o.chars.push_back((uint8_t)SEQ[(qi & 1) ? (byte & 15) : (byte >> 4)]);          // util.py:186-189, b[0]
+                }
                 ref += ln; q += ln; qalen += ln;
             } else if (op == 2 || op == 3) {                                // D / N -> is_del column, util.py:180-182
                 int64_t lo1 = ref + 1 < 1 ? 1 : ref + 1, hi1 = ref + ln < hi ? ref + ln : hi;
-                for (int64_t p1 = lo1; p1 <= hi1; p1++)
-                    if (region[p1]) chars.push_back('-');
+                for (int64_t p1 = lo1 <= hi1 ? next_snp[lo1] : hi1 + 1; p1 <= hi1; p1 = next_snp[p1 + 1])
+                    o.chars.push_back((uint8_t)'-');
                 ref += ln;
             } else if (op == 1) { q += ln; qalen += ln; }                   // I
             else if (op == 4) { q += ln; }                                  // S
-            if (q > b.l_seq) return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq);
+            if (q > b.l_seq) { o.chars.resize(ch0); return fail(-4, "CIGAR of read %s consumes more query than its %d bases", b.name, b.l_seq); }
         }
         int64_t leftmost = (int64_t)b.pos + 1;                              // util.py:162
         if (leftmost < start_pos) {                                         // util.py:165-171
-            if (leftmost + qalen < start_pos) continue;
+            if (leftmost + qalen < start_pos) { o.chars.resize(ch0); return 0; }
             leftmost = start_pos;
         }
-        if (chars.empty()) continue;
+        if (o.chars.size() == ch0) return 0;
         int one_or_two = 0;
         if (flag & 0x1) one_or_two = (flag & 0x40) ? 1 : ((flag & 0x80) ? 2 : 0);
-        key.assign(b.name, (size_t)b.l_read_name - 1);
-        {                                                                   // "<qname>_<flag>_<1|2|0>", util.py:160
-            char tail[16];                                                  // (snprintf here was a third of the whole decode)
+        // "<qname>_<flag>_<1|2|0>", util.py:160 (snprintf here was a third of the whole decode)
+        const size_t k0 = o.keys.size();
+        o.keys.insert(o.keys.end(), b.name, b.name + (b.l_read_name - 1));
+        {
+            char tail[16];
             int tn = 0;
             tail[tn++] = '_';
             char dig[8];
@@ -541,42 +653,145 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
             while (nd) tail[tn++] = dig[--nd];
             tail[tn++] = '_';
             tail[tn++] = (char)('0' + one_or_two);
-            key.append(tail, (size_t)tn);
+            o.keys.insert(o.keys.end(), tail, tail + tn);
         }
-        const uint64_t kh = hash_key(key);
-        size_t si = (size_t)kh & table_mask;
-        int64_t found = -1;
-        while (table[si].row1) {
-            if (table[si].h == kh) {
-                const auto &ka = key_at[table[si].row1 - 1];
-                if ((size_t)ka.second == key.size() && memcmp(key_arena.data() + ka.first, key.data(), key.size()) == 0) {
-                    found = (int64_t)table[si].row1 - 1;
-                    break;
+        uint64_t h = 0xcbf29ce484222325ull;                                 // FNV-1a, then a finalizer to spread the low bits
+        for (size_t x = k0; x < o.keys.size(); x++) { h ^= (unsigned char)o.keys[x]; h *= 0x100000001b3ull; }
+        h ^= h >> 32; h *= 0x9e3779b97f4a7c15ull; h ^= h >> 29;
+        int64_t lm = leftmost > (int64_t)end_pos + 1 ? (int64_t)end_pos + 1 : leftmost;
+        const int32_t rank = lm >= 1 ? csum[lm] - csum[1] : 0;              // util.py:198
+        o.recs.push_back(kept{h, rank, (uint32_t)k0, (uint32_t)(o.keys.size() - k0), (uint32_t)ch0, (uint32_t)(o.chars.size() - ch0)});
+        return 0;
+    };
+    // the sequential part: record by record the key into the table and the row that points at the characters
+    auto merge_part = [&](const part &o) -> bool {
+        const size_t nr = o.recs.size();
+        if (!nr) return true;
+        if (reads.capacity() < reads.size() + nr) reads.reserve(std::max(reads.size() + nr, 2 * reads.capacity()));
+        const uint8_t *cbase = o.chars.data();
+        const char *kbase = o.keys.data();
+        for (size_t i = 0; i < nr; i++) {
+            if (i + 12 < nr) __builtin_prefetch(&table.p[(size_t)(uint32_t)o.recs[i + 12].h & table_mask]);
+            const kept &k = o.recs[i];
+            const uint32_t tag = (uint32_t)(k.h >> 32);
+            size_t si = (size_t)(uint32_t)k.h & table_mask;
+            int64_t found = -1;
+            while (table.p[si].row1) {
+                if (table.p[si].tag == tag) {
+                    const row &w = reads[table.p[si].row1 - 1];
+                    if (w.h_lo == (uint32_t)k.h && (uint32_t)w.key_len == k.key_len && memcmp(w.key, kbase + k.key_off, k.key_len) == 0) {
+                        found = (int64_t)table.p[si].row1 - 1;
+                        break;
+                    }
                 }
+                si = (si + 1) & table_mask;
             }
-            si = (si + 1) & table_mask;
-        }
-        if (found < 0) {
-            int64_t lm = leftmost > (int64_t)end_pos + 1 ? (int64_t)end_pos + 1 : leftmost;
-            const int32_t rank = lm >= 1 ? csum[lm] - csum[1] : 0;          // util.py:198
-            table[si] = slot{kh, (uint32_t)reads.size() + 1};
-            key_at.emplace_back((int64_t)key_arena.size(), (int32_t)key.size());
-            key_arena.insert(key_arena.end(), key.begin(), key.end());
-            if ((reads.size() + 1) * 2 > table.size()) grow();
-            reads.push_back({rank, (int64_t)arena.size(), (int32_t)chars.size()});
-            arena.insert(arena.end(), chars.begin(), chars.end());
-        } else {
-            row &w = reads[(size_t)found];
-            if (w.off + w.len != (int64_t)arena.size()) {                   // not the last row: move it to the end
-                const size_t old = (size_t)w.off;
-                w.off = (int64_t)arena.size();
-                arena.resize(arena.size() + (size_t)w.len);
-                memcpy(arena.data() + w.off, arena.data() + old, (size_t)w.len);
+            if (found < 0) {
+                table.p[si] = slot{tag, (uint32_t)reads.size() + 1};
+                reads.push_back(row{cbase + k.ch_off, kbase + k.key_off, k.rank, (int32_t)k.ch_len, (int32_t)k.key_len, (uint32_t)k.h});
+            } else {
+                row &w = reads[(size_t)found];
+                std::unique_ptr<uint8_t[]> cp(new (std::nothrow) uint8_t[(size_t)w.len + k.ch_len]);
+                if (!cp) return false;
+                memcpy(cp.get(), w.ch, (size_t)w.len);
+                memcpy(cp.get() + w.len, cbase + k.ch_off, k.ch_len);
+                w.ch = cp.get();
+                w.len += (int32_t)k.ch_len;
+                moved.push_back(std::move(cp));
             }
-            arena.insert(arena.end(), chars.begin(), chars.end());
-            w.len += (int32_t)chars.size();
         }
+        return true;
+    };
+
+    double tm[5] = {0, 0, 0, 0, 0};
+    const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    std::vector<size_t> frames;                                             // offsets of the whole records in the window
+    std::vector<std::unique_ptr<part>> kept_parts;                         // every batch's parts: the rows point into them
+    bool done = false;
+    while (!done) {
+        auto T0 = now();
+        int64_t av = z.ensure(4);
+        if (av < 0) return (int)av;
+        if (av == 0) break;
+        if (av < 4) return fail(-4, "truncated BAM record");
+        const uint8_t *base = z.ptr();
+        frames.clear();
+        auto T1 = now(); tm[0] += secs(T0, T1);
+        size_t o = 0;
+        int32_t bad_size = 0;
+        bool bad = false;
+        while (o + 4 <= (size_t)av) {
+            const int32_t block_size = rd32(base + o);
+            if (block_size < 32 || block_size > (1 << 28)) { bad = true; bad_size = block_size; break; }
+            if (o + 4 + (size_t)block_size > (size_t)av) break;
+            frames.push_back(o);
+            o += 4 + (size_t)block_size;
+        }
+        if (frames.empty()) {
+            if (bad) return fail(-4, "bad BAM record size %d", bad_size);
+            const int32_t block_size = rd32(base);                          // a record the window does not hold yet
+            av = z.ensure(4 + (size_t)block_size);
+            tm[4] += secs(T1, now());
+            if (av < 0) return (int)av;
+            if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
+            continue;
+        }
+        const size_t nf = frames.size();
+        auto T2 = now(); tm[1] += secs(T1, T2);
+        const int nt = (int)std::min<size_t>((size_t)n_threads(), nf / part_records() + 1);
+        const size_t p0 = kept_parts.size();
+        for (int t = 0; t < nt; t++) kept_parts.emplace_back(new part());
+        auto work = [&](int t) {
+            part &P = *kept_parts[p0 + (size_t)t];
+            const size_t lo = nf * (size_t)t / (size_t)nt, hi = nf * (size_t)(t + 1) / (size_t)nt;
+            P.recs.reserve(hi - lo);
+            P.keys.reserve((hi - lo) * 24);
+            P.chars.reserve((hi - lo) * 16);
+            for (size_t f = lo; f < hi; f++) {
+                const uint8_t *r = base + frames[f];
+                P.n_seen++;
+                const int rc1 = one_record(r + 4, rd32(r), P);
+                if (rc1 == 1) { P.stop = true; break; }
+                if (rc1 < 0) { P.err = rc1; P.msg = g_err; break; }
+            }
+        };
+        if (nt <= 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+            for (auto &t : th) t.join();
+        }
+        auto T3 = now(); tm[2] += secs(T2, T3);
+        // file order: everything in front of the first record that stops the scan or is malformed counts
+        {
+            // the key table sized once for what the rest of the file will bring at this rate
+            size_t batch_rows = 0;
+            for (int t = 0; t < nt; t++) batch_rows += kept_parts[p0 + (size_t)t]->recs.size();
+            const double pr = z.progress();
+            size_t est = reads.size() + batch_rows;
+            if (pr > 0.0 && pr < 1.0) est = (size_t)((double)est / pr * 1.05) + 1024;
+            if (est < reads.size() + batch_rows || est > (size_t)1 << 31) est = reads.size() + batch_rows;
+            if (!table_reserve(est)) return fail(-6, "out of memory");
+            if (reads.capacity() < est) reads.reserve(est);
+        }
+        for (int t = 0; t < nt && !done; t++) {
+            part &P = *kept_parts[p0 + (size_t)t];
+            if (!table_reserve(reads.size() + P.recs.size() + 1) || !merge_part(P)) return fail(-6, "out of memory");
+            g_stats.records += P.n_seen;
+            if (P.err) return fail(P.err, "%s", P.msg.c_str());
+            if (P.stop) done = true;
+            bigvec<kept>().swap(P.recs);                                    // only the characters and keys are still needed
+        }
+        tm[3] += secs(T3, now());
+        if (done) break;
+        if (bad) return fail(-4, "bad BAM record size %d", bad_size);
+        z.consume(o);
     }
+    if (getenv("GIO_TIMING"))
+        fprintf(stderr, "gio: setup %.3f s, read+inflate %.3f, framing %.3f, records (%d threads) %.3f, key table %.3f, scan done at %.3f s\n",
+                t_setup, tm[0] + tm[4], tm[1], n_threads(), tm[2], tm[3], secs(t_begin, now()));
 
     const int64_t n = (int64_t)reads.size();
     int64_t total = 0;
@@ -589,10 +804,23 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
     for (int64_t i = 0; i < n; i++) {
         out->rank[i] = reads[i].rank;
         out->off[i] = acc;
-        memcpy(out->bases + acc, arena.data() + reads[i].off, (size_t)reads[i].len);
         acc += (int64_t)reads[i].len;
     }
     out->off[n] = acc;
+    {
+        // the characters: row ranges on the threads
+        const int nt = (int)std::min<int64_t>((int64_t)n_threads(), n / 65536 + 1);
+        auto copy = [&](int t) {
+            const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            for (int64_t i = lo; i < hi; i++) memcpy(out->bases + out->off[i], reads[i].ch, (size_t)reads[i].len);
+        };
+        if (nt <= 1) copy(0);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(copy, t);
+            for (auto &t : th) t.join();
+        }
+    }
     out->n_reads = n;
     out->n_bases = total;
     g_stats.reads_kept = n;

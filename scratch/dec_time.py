@@ -1,0 +1,19 @@
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from gretel_amd import bamio, util
+from gretel_amd.synth import make_config
+d = sys.argv[1] if len(sys.argv) > 1 else "/tmp/e2e"
+bam, vcf = os.path.join(d, "s.bam"), os.path.join(d, "s.vcf.gz")
+t = make_config("C3", seed=0)
+if not os.path.exists(bam):
+    bamio.synth_to_files(t, bam, vcf)
+contig, start, end = "synth", 1, 10 * t.n_snps + 10
+v = util.process_vcf(vcf, contig, start, end)
+for it in range(4):
+    t1 = time.perf_counter()
+    rank, off, bases = util.support_table_from_bam(bam, contig, start, end, v)
+    dt = time.perf_counter() - t1
+    print("decode %.3f s" % dt, bamio.native_last_stats(), flush=True)
+assert np.array_equal(rank, t.rank) and np.array_equal(off, t.off) and np.array_equal(bases, t.bases)
+print("table identical to the synthetic one")

@@ -24,7 +24,8 @@ def test_malformed_bams_never_read_out_of_bounds(tmp_path):
     t = make_support_table(40, 300, k=4, seed=1)
     bam, vcf = str(tmp_path / "v.bam"), str(tmp_path / "v.vcf.gz")
     contig, s, e = bamio.synth_to_files(t, bam, vcf)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", GIO_THREADS="2")
+    # (two threads, a new part every 16 records: the per-thread parts and their merge run under the sanitizers too)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", GIO_THREADS="2", GIO_PART_RECORDS="16")
     for seed, src_bam, ctg, end in ((1, bam, contig, e), (2, os.path.join(REFDATA, "test.bam"), "hoot", 20)):
         run = subprocess.run([exe, src_bam, ctg, str(end), "700", str(seed), str(tmp_path / "scratch.bam")],
                              capture_output=True, text=True, env=env, timeout=600)
@@ -90,3 +91,55 @@ def test_long_read_cigar_in_cg_tag_and_overrunning_cigar(tmp_path):
     _one_read_bam(bad, [(4, len(seq)), (3, 13)], seq)              # placeholder without the tag
     with pytest.raises(IOError):
         util.support_table_from_bam(bad, "c", 1, 50, v)
+
+
+def test_repeated_keys_and_errors_keep_file_order_across_threads(tmp_path):
+    """Records are worked on by several threads; the rows, the appends to a key seen before (util.py:199-207) and the
+    first error must come out as a front-to-back scan gives them."""
+    rng = np.random.default_rng(5)
+    n_snps, spacing = 400, 10
+    length = spacing * n_snps + spacing
+    reads = []
+    for r in range(30000):
+        k = int(rng.integers(2, 7))
+        first = int(rng.integers(0, n_snps - k))
+        seq = bytearray(b"A" * ((k - 1) * spacing + 1))
+        for q in range(k):
+            seq[q * spacing] = ord("ACGT"[int(rng.integers(0, 4))])
+        # one name in three is shared with other records (same flag: the same key, so the row is appended to)
+        name = "r%d" % (r if r % 3 else int(rng.integers(0, 500)))
+        reads.append((name, 0, 0, spacing * (first + 1) - 1, 42, "%dM" % len(seq), seq.decode()))
+    reads.sort(key=lambda x: x[3])
+    bam, vcf = str(tmp_path / "d.bam"), str(tmp_path / "d.vcf.gz")
+    bamio.write_bam(bam, [("c", length)], reads)
+    bamio.write_vcf_gz(vcf, "c", [spacing * (s + 1) for s in range(n_snps)])
+    for (ws, we) in ((1, length), (1200, 2600)):
+        v = util.process_vcf(vcf, "c", ws, we)
+        a = util.support_table_from_bam(bam, "c", ws, we, v)
+        assert bamio.native_last_stats()["threads"] >= 1
+        b = util.support_table_from_bam(bam, "c", ws, we, v, decoder="python")
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert len(a[0]) < (30000 if ws == 1 else 12000)           # keys were shared
+    # a record damaged in the middle of the file: the scan fails with that record's message, whatever the thread count
+    import gzip
+    with gzip.open(bam, "rb") as fh:
+        raw = bytearray(fh.read())
+    v = util.process_vcf(vcf, "c", 1, length)
+    # find the 20000th record and blow up its l_seq
+    o = raw.index(b"BAM\x01")
+    l_text = struct.unpack_from("<i", raw, o + 4)[0]
+    o += 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]
+    o += 4
+    for _ in range(n_ref):
+        l_name = struct.unpack_from("<i", raw, o)[0]
+        o += 4 + l_name + 4
+    for _ in range(20000):
+        o += 4 + struct.unpack_from("<i", raw, o)[0]
+    struct.pack_into("<i", raw, o + 4 + 16, 1 << 27)
+    bad = str(tmp_path / "bad.bam")
+    bamio.bgzf_write(bad, bytes(raw))
+    with pytest.raises(Exception) as ei:
+        util.support_table_from_bam(bad, "c", 1, length, v)
+    assert "exceed" in str(ei.value)
