@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <string>
@@ -411,7 +412,7 @@ static bool bai_start(const char *bam_path, int tid, int64_t beg, uint64_t *voff
     return false;
 }
 
-extern "C" int gio_ref_len(const char *bam_path, const char *contig, int64_t *len)
+static int gio_ref_len_impl(const char *bam_path, const char *contig, int64_t *len)
 {
     if (!bam_path || !contig || !len) return fail(-1, "null argument");
     g_err[0] = 0;
@@ -500,8 +501,8 @@ static int parse_record(const uint8_t *r, int32_t block_size, bam_rec &out)
 
 static const char SEQ[] = "=ACMGRSVTWYHKDBN";
 
-extern "C" int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
-                                          const uint8_t *region, int stepper_all, gio_table *out)
+static int gio_support_table_from_bam_impl(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                                           const uint8_t *region, int stepper_all, gio_table *out)
 {
     if (!bam_path || !contig || !region || !out || end_pos < 0) return fail(-1, "bad argument");
     memset(out, 0, sizeof *out);
@@ -746,15 +747,20 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
         auto work = [&](int t) {
             part &P = *kept_parts[p0 + (size_t)t];
             const size_t lo = nf * (size_t)t / (size_t)nt, hi = nf * (size_t)(t + 1) / (size_t)nt;
-            P.recs.reserve(hi - lo);
-            P.keys.reserve((hi - lo) * 24);
-            P.chars.reserve((hi - lo) * 16);
-            for (size_t f = lo; f < hi; f++) {
-                const uint8_t *r = base + frames[f];
-                P.n_seen++;
-                const int rc1 = one_record(r + 4, rd32(r), P);
-                if (rc1 == 1) { P.stop = true; break; }
-                if (rc1 < 0) { P.err = rc1; P.msg = g_err; break; }
+            try {
+                P.recs.reserve(hi - lo);
+                P.keys.reserve((hi - lo) * 24);
+                P.chars.reserve((hi - lo) * 16);
+                for (size_t f = lo; f < hi; f++) {
+                    const uint8_t *r = base + frames[f];
+                    P.n_seen++;
+                    const int rc1 = one_record(r + 4, rd32(r), P);
+                    if (rc1 == 1) { P.stop = true; break; }
+                    if (rc1 < 0) { P.err = rc1; P.msg = g_err; break; }
+                }
+            } catch (const std::exception &) {                              // (an exception must not leave a thread)
+                P.err = -6;
+                P.msg = "out of memory";
             }
         };
         if (nt <= 1) work(0);
@@ -830,7 +836,7 @@ extern "C" int gio_support_table_from_bam(const char *bam_path, const char *cont
     return 0;
 }
 
-extern "C" int gio_count_coverage(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts)
+static int gio_count_coverage_impl(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts)
 {
     if (!bam_path || !contig || !counts || start0 < 0 || stop < start0) return fail(-1, "bad argument");
     g_err[0] = 0;
@@ -901,7 +907,7 @@ extern "C" void gio_runs_free(gio_runs *r)
     memset(r, 0, sizeof *r);
 }
 
-extern "C" int gio_match_runs(const char *bam_path, const char *contig, int32_t start0, int32_t stop, gio_runs *out)
+static int gio_match_runs_impl(const char *bam_path, const char *contig, int32_t start0, int32_t stop, gio_runs *out)
 {
     if (!bam_path || !contig || !out || start0 < 0 || stop < start0) return fail(-1, "bad argument");
     memset(out, 0, sizeof *out);
@@ -974,4 +980,33 @@ extern "C" int gio_match_runs(const char *bam_path, const char *contig, int32_t 
     out->n_runs = (int64_t)n;
     out->n_bases = (int64_t)codes.size();
     return 0;
+}
+
+extern "C" int gio_ref_len(const char *bam_path, const char *contig, int64_t *len)
+{
+    try { return gio_ref_len_impl(bam_path, contig, len); }
+    catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
+    catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
+}
+
+extern "C" int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                                          const uint8_t *region, int stepper_all, gio_table *out)
+{
+    try { return gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, out); }
+    catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
+    catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
+}
+
+extern "C" int gio_count_coverage(const char *bam_path, const char *contig, int32_t start0, int32_t stop, int32_t *counts)
+{
+    try { return gio_count_coverage_impl(bam_path, contig, start0, stop, counts); }
+    catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
+    catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
+}
+
+extern "C" int gio_match_runs(const char *bam_path, const char *contig, int32_t start0, int32_t stop, gio_runs *out)
+{
+    try { return gio_match_runs_impl(bam_path, contig, start0, stop, out); }
+    catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
+    catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
 }

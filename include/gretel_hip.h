@@ -190,7 +190,7 @@ int gh_profile_overhead(gh_t *h, int reps, double out[2]);
  * that ran (2 = depth-2 speculation, 1 = depth 1 without '-' candidates, 0 = depth 1 with them; 3 = segment-parallel
  * walk, which has no single walker wave: then out[0] = how often the last gh_spin rebuilt the conditional table and
  * queued its remaining paths again because a candidate mask moved, out[1] = out[2] = 0; 4 = candidate-pool segments
- * (L = 6..16): out[0] = re-queues of the last gh_spin, out[1] = paths this handle handed to the serial walker so far,
+ * (L = 6..24): out[0] = re-queues of the last gh_spin, out[1] = paths this handle handed to the serial walker so far,
  * out[2] = walk/scan rounds it queued so far) */
 int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
 /* algorithmic bytes of the last launch of each kernel */
