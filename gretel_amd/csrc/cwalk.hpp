@@ -29,6 +29,7 @@
 typedef unsigned long long cw_key;
 #define CW_MAX_SEG 256
 #define CW_MIN_LEN 32
+#define CW_BOOT_ROUNDS 8        /* rounds queued for the first path of a tensor (pools started from k_cguess) */
 
 struct cw_geom { int seglen, S, NW; };
 __host__ __device__ inline cw_geom cw_geometry(int N)
@@ -456,4 +457,24 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
     P.npool[s] = n;
     P.npend[s] = 0;
     for (int k = 0; k < CW_K; k++) P.walked[(size_t)s * CW_K + k] = 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_cguess: a first guess for pools that hold nothing yet -- the symbol with the largest marginal at every position
+// (first wins).  k_cseed turns its states at the segment boundaries into one entry per pool; wherever the guess is not
+// what the walk does there, closure brings the right states in over the next rounds.  Only a guess: no result depends
+// on it (a chain is emitted when every hop is an exact hit, whatever the pools were started from).
+// -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cguess(cw_params P, uint8_t *path)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > P.N) return;
+    if (p == 0) { path[0] = SYM_US; return; }
+    const double *inf = P.minfo + (size_t)p * MINFO;
+    int best = 0;
+    double bm = inf[5];
+#pragma unroll
+    for (int b5 = 1; b5 < 5; b5++)
+        if (inf[5 + b5] > bm) { bm = inf[5 + b5]; best = b5; }
+    path[p] = (uint8_t)vsym(best);
 }

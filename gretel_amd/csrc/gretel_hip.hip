@@ -122,6 +122,7 @@ struct gh_handle {
     int cw_stamp;
     int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
+    int cw_round_cap;      // GH_CW_ROUND_CAP=k at creation (tests): never more than k rounds per launch, so that chains stay open and the serial fallback runs
     int spin_partial_stride;   // doubles between two paths' partial sums of the removed mass in a spin (0 outside spins)
     int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
     gh_fill_stats stats;
@@ -290,6 +291,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_rounds = 2; h->cw_stamp = 0;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
+    h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
@@ -1129,6 +1131,7 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
 {
     const cw_geom g = cw_geometry(h->N);
     cw_params P = cw_make_params(h, d_path, d_lmsel);
+    if (h->cw_round_cap > 0 && rounds > h->cw_round_cap) rounds = h->cw_round_cap;
     prof_begin(h, GH_K_WALK);
     for (int r = 0; r < rounds; r++) {
         P.round = resume ? r + 1 : r;                       // (a resumed path continues behind the rounds already run)
@@ -1306,9 +1309,19 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
                 break;
             }
             if (!h->cw_ready) {
-                // no pools yet for this tensor: one path through the serial walker seeds them
+                // no pools yet for this tensor: one entry per pool from the largest marginals (k_cguess), and rounds
+                // until closure has brought in what the walk really does (the serial walker costs 20 rounds at L <= 16
+                // and 400 beyond: it only takes the path if the chain is still open after CW_BOOT + the resumed rounds)
                 h->cw_stamp++;
-                if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 0))) break;
+                if ((rc = ensure_lt(h))) break;
+                uint8_t *pth = d_paths + n1 * done;
+                cw_params P = cw_make_params(h, pth, h->spin_lmsel + n1 * done);
+                hipLaunchKernelGGL(k_cguess, dim3((unsigned)((h->N + 256) / 256)), dim3(256), 0, h->stream, P, pth);
+                hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, 0);
+                if ((rc = post_launch(h, "k_cguess/k_cseed"))) break;
+                if ((rc = launch_cw_path(h, pth, h->spin_lmsel + n1 * done, CW_BOOT_ROUNDS, 0))) break;
+                if ((rc = launch_reweight_marg(h, pth, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+                h->cw_stat[2] += CW_BOOT_ROUNDS;
                 h->cw_ready = true;
             } else {
                 const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
@@ -1349,9 +1362,10 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
                     bool closed = false;
                     if (!hs.lt_stale) {
                         if ((rc = ensure_lt(h))) break;
-                        if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, 12, 0, true))) break;
+                        const int more = h->L > 16 ? 48 : 12;      // (the serial walker of L > 16 is the slow one)
+                        if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, more, 0, true))) break;
                         if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
-                        h->cw_stat[2] += 12;
+                        h->cw_stat[2] += more;
                         e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
                         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                         if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }

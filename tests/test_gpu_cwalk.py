@@ -100,3 +100,18 @@ def test_switches(kw):
     h, o = _pair(t, L=7, **kw)
     _same(h.spin(12), o.spin(12))
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [8, 18])
+def test_chains_left_open_go_to_the_serial_walker_and_change_nothing(L, monkeypatch):
+    # GH_CW_ROUND_CAP=1 (read when the handle is created): one round per launch, so most chains stay open, the host
+    # re-queues, and the serial walker takes the paths -- its states join the pools (k_cseed).  Same results.
+    t = make_support_table(3000, 36000, k=None, seed=77)
+    monkeypatch.setenv("GH_CW_ROUND_CAP", "1")
+    h, o = _pair(t, L=L)
+    monkeypatch.delenv("GH_CW_ROUND_CAP")
+    res, ref = h.spin(16), o.spin(16)
+    _same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    assert h.walk_clock()[1] >= 1                          # paths handed to the serial walker
+    _same(h.spin(5), o.spin(5))
