@@ -27,23 +27,28 @@
 #define CW_MIN_L 6
 #define CW_MAX_L 24             /* 2 bits per pick in a 64-bit state; beyond 24 lags the table slice of a chunk outgrows the LDS */
 typedef unsigned long long cw_key;
-#define CW_MAX_SEG 256
+#define CW_MAX_SEG 512
 #define CW_MIN_LEN 32
 #define CW_BOOT_ROUNDS 8        /* rounds queued for the first path of a tensor (pools started from k_cguess) */
 
+// Segments: a wavefront alone on its SIMD issues an instruction every ~5 cycles, so where the table slice of a chunk
+// leaves room for two workgroups per CU (L <= 13: 76 KB each) the window is cut into twice as many, half as long
+// segments, and every SIMD has two walkers to interleave.
+__host__ __device__ constexpr int cw_max_seg(int L) { return L <= 13 ? 512 : 256; }
 struct cw_geom { int seglen, S, NW; };
-__host__ __device__ inline cw_geom cw_geometry(int N)
+__host__ __device__ inline cw_geom cw_geometry(int N, int L)
 {
     cw_geom g;
-    int len = (N + CW_MAX_SEG - 1) / CW_MAX_SEG;
+    const int smax = cw_max_seg(L);
+    int len = (N + smax - 1) / smax;
     if (len < CW_MIN_LEN) len = CW_MIN_LEN;
     g.seglen = len;
     g.S = (N + len - 1) / len;
     g.NW = (len + 15) / 16;
     return g;
 }
-// positions per LDS chunk of k_cwalk: (c + L - 1) sources x 4 rows x L lags x 5 columns of doubles within 96 KB
-__host__ __device__ constexpr int cw_lds_budget(int L) { return L <= 16 ? 96 * 1024 : 150 * 1024; }
+// positions per LDS chunk of k_cwalk: (c + L - 1) sources x 4 rows x L lags x 5 columns of doubles within the budget
+__host__ __device__ constexpr int cw_lds_budget(int L) { return L <= 13 ? 76 * 1024 : (L <= 16 ? 96 * 1024 : 150 * 1024); }
 __host__ __device__ constexpr int cw_chunk(int L)
 {
     int c = 64;
@@ -98,7 +103,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         return;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;      // (the flags stand until k_cemit re-arms them)
-    const cw_geom g = cw_geometry(P.N);
+    const cw_geom g = cw_geometry(P.N, P.L);
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= g.S) return;
     // (1) the states the previous segment's walks ended in, and that this pool does not hold yet, join it (only this
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(CW_K) k_clink(cw_params P)
     const dev_ctl c = load_ctl(P.st);
     if (c.stop || c.lt_stale || c.cw_unres) return;
     if (P.round > 0 && c.cw_open_at < 0) return;
-    const cw_geom g = cw_geometry(P.N);
+    const cw_geom g = cw_geometry(P.N, P.L);
     const int s = blockIdx.x, q = threadIdx.x;
     if (s + 1 >= g.S) return;
     const size_t e = (size_t)s * CW_K + q;
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
     const dev_ctl c = load_ctl(st);
     if (c.stop || c.lt_stale || c.cw_unres) return;
     if (P.round > 0 && c.cw_open_at < 0) return;
-    const cw_geom g = cw_geometry(P.N);
+    const cw_geom g = cw_geometry(P.N, P.L);
     const int S = g.S, tid = threadIdx.x;
     const int NG = (S - 1 + CW_GRP - 1) / CW_GRP;           // hops s -> s+1 for s = 0 .. S-2, in groups of 16
     {
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(256) k_cemit(cw_params P)
     dev_state *st = P.st;
     const dev_ctl c = load_ctl(st);
     if (c.stop || c.lt_stale || c.cw_unres) return;
-    const cw_geom g = cw_geometry(P.N);
+    const cw_geom g = cw_geometry(P.N, P.L);
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= g.S) return;
     if (s == 0 && tid == 0) {
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(256) k_cemit(cw_params P)
 // -------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path, int merge)
 {
-    const cw_geom g = cw_geometry(P.N);
+    const cw_geom g = cw_geometry(P.N, P.L);
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= g.S) return;
     const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ...

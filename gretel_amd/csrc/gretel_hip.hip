@@ -105,7 +105,7 @@ struct gh_handle {
     // segment-parallel walk (segwalk.hpp), sized for seg_L by alloc_seg
     uint32_t *seg_hist;    // picks of every (segment, entry state)
     uint16_t *seg_maps, *seg_pmaps, *seg_gmaps;
-    double *seg_min;       // [256]
+    double *seg_min;       // [CW_MAX_SEG]
     double *lmsel1;        // [N+1] selected log-marginals of a lone gh_generate_path
     double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
     int seg_L;
@@ -919,7 +919,7 @@ static int alloc_seg(gh_handle *h)
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_maps, maps_b);
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_pmaps, maps_b);
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmaps, gmaps_b);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_min, 256 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_min, CW_MAX_SEG * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->lmsel1, ((size_t)h->N + 2) * sizeof(double));
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the segment-parallel walk failed: %s", hipGetErrorString(e));
     h->seg_L = h->L;
@@ -1080,26 +1080,29 @@ static int reset_spin_state(gh_handle *h)
 static int alloc_cw(gh_handle *h)
 {
     if (h->cw_keys) return GH_OK;
-    const cw_geom g = cw_geometry(h->N);
-    hipError_t e = hipMalloc((void **)&h->cw_keys, sizeof(cw_key) * g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_exits, sizeof(cw_key) * g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_last_hit, sizeof(int32_t) * g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_hist, sizeof(uint32_t) * (size_t)g.S * g.NW * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npool, sizeof(int32_t) * g.S);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(cw_key) * g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npend, sizeof(int32_t) * g.S);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npend, 0, sizeof(int32_t) * g.S, h->stream);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_walked, (size_t)g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_nxt, (size_t)g.S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_true, sizeof(int32_t) * g.S);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npool, 0, sizeof(int32_t) * g.S, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_walked, 0, (size_t)g.S * CW_K, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_nxt, 0xff, (size_t)g.S * CW_K, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_last_hit, 0, sizeof(int32_t) * g.S * CW_K, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_keys, 0, sizeof(cw_key) * g.S * CW_K, h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_exits, 0, sizeof(cw_key) * g.S * CW_K, h->stream);
+    // sized for whichever geometry a lag count gives this N (h->L can change between spins)
+    const cw_geom ga = cw_geometry(h->N, CW_MIN_L), gb = cw_geometry(h->N, CW_MAX_L);
+    const size_t S = (size_t)(ga.S > gb.S ? ga.S : gb.S);
+    const size_t SNW = (size_t)ga.S * ga.NW > (size_t)gb.S * gb.NW ? (size_t)ga.S * ga.NW : (size_t)gb.S * gb.NW;
+    hipError_t e = hipMalloc((void **)&h->cw_keys, sizeof(cw_key) * S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_exits, sizeof(cw_key) * S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_last_hit, sizeof(int32_t) * S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_hist, sizeof(uint32_t) * SNW * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npool, sizeof(int32_t) * S);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(cw_key) * S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npend, sizeof(int32_t) * S);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npend, 0, sizeof(int32_t) * S, h->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_walked, S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_nxt, S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_true, sizeof(int32_t) * S);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npool, 0, sizeof(int32_t) * S, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_walked, 0, S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_nxt, 0xff, S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_last_hit, 0, sizeof(int32_t) * S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_keys, 0, sizeof(cw_key) * S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_exits, 0, sizeof(cw_key) * S * CW_K, h->stream);
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed: %s", hipGetErrorString(e));
-    if (!h->seg_min && hipMalloc((void **)&h->seg_min, 256 * sizeof(double)) != hipSuccess)      // (alloc_seg sizes for L <= 5 only)
+    if (!h->seg_min && hipMalloc((void **)&h->seg_min, CW_MAX_SEG * sizeof(double)) != hipSuccess)      // (alloc_seg sizes for L <= 5 only)
         return fail(GH_ERR_NOMEM, "hipMalloc failed");
     return GH_OK;
 }
@@ -1129,7 +1132,7 @@ static void launch_cwalk_lc(const cw_params &P, hipStream_t stream, int S, int d
 // the kernels of one path: `rounds` x (walk what is new, link + chain), emit
 static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int rounds, int check_masks, bool resume = false)
 {
-    const cw_geom g = cw_geometry(h->N);
+    const cw_geom g = cw_geometry(h->N, h->L);
     cw_params P = cw_make_params(h, d_path, d_lmsel);
     if (h->cw_round_cap > 0 && rounds > h->cw_round_cap) rounds = h->cw_round_cap;
     prof_begin(h, GH_K_WALK);
@@ -1163,7 +1166,7 @@ static int cw_serial_path(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, dou
     HIPCHK(hipMemsetAsync(d_lmsel, 0, sizeof(double), h->stream));      // k_hp: the walker sums this path itself
     if ((rc = launch_walk(h, d_path, d_rec, min_remove, 1, nullptr, 0))) return rc;
     cw_params P = cw_make_params(h, d_path, d_lmsel);
-    const cw_geom g = cw_geometry(h->N);
+    const cw_geom g = cw_geometry(h->N, h->L);
     hipLaunchKernelGGL(k_cseed, dim3((g.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)d_path, merge);
     if ((rc = post_launch(h, "k_cseed"))) return rc;
     rc = launch_reweight_marg(h, d_path, 0.0, 1, d_rec, slot, false, false, 0);
@@ -1289,7 +1292,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     bool cw_gave_up = false;
     if (cw) {
         rc = alloc_cw(h);
-        const cw_geom cg = cw_geometry(h->N);
+        const cw_geom cg = cw_geometry(h->N, h->L);
         const int zero2[2] = {0, 0};
         if (rc == GH_OK) {
             e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);      // lt_stale, cw_unres
@@ -1344,7 +1347,9 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             done = hs.n_done;
             if (hs.stop) break;
             if (!hs.lt_stale && !hs.cw_unres) {
-                if (CHUNK < 64) CHUNK *= 2;
+                // (a look costs ~25 us of idle GPU; an open chain costs the ~37 us of idle launches of every path queued
+                // behind it: at one open chain in 50..100 paths the optimum is 8..16 paths per look)
+                if (CHUNK < 16) CHUNK *= 2;
                 if (++clean >= 6 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
             } else { CHUNK = 8; clean = 0; }
             if (hs.lt_stale || hs.cw_unres) {
@@ -1352,8 +1357,11 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
                 if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
                 h->spin_requeues++;
                 h->cw_stat[3]++;
-                h->lt_inc_path = nullptr;                       // (the next ensure_lt rebuilds the table in full)
-                h->dirty_lt = true;
+                // a moved candidate mask or a window for the serial walkers: the next ensure_lt rebuilds the table in
+                // full.  Behind a chain that merely stayed open the table is current: every kernel queued behind it
+                // idled, and the reweights that ran kept their rows.
+                h->lt_inc_path = nullptr;
+                h->dirty_lt = hs.lt_stale || hs.cw_unres == 2;
                 if (hs.cw_unres == 2) h->cw_off = true;         // five candidates somewhere: the serial walkers take the window
                 else if (hs.cw_unres == 1 && done < max_paths) {
                     // the queued rounds did not close this path's chain.  Its pools keep what has been walked (the tensor

@@ -403,7 +403,11 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     RW_STAMP(0);
     const dev_ctl c = load_ctl(st);
     const int nseg = nseg_arg > 0 ? nseg_arg : seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
-    const double my_segmin = tid < nseg ? segmin[tid] : INFINITY;
+    double my_segmin = INFINITY;                            // (<= 512 segments: two per thread at most)
+    for (int q = tid; q < nseg; q += 256) {
+        const double v = segmin[q];
+        if (v < my_segmin) my_segmin = v;
+    }
     if (c.stop || c.lt_stale || c.cw_unres) return;
     if (c.cur_hole <= N) {                                  // the walk ended in a hole: nothing to reweight (gretel.py:176-180)
         if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, 0.0, min_remove);
