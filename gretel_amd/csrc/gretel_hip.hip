@@ -1236,6 +1236,160 @@ extern "C" int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, doub
     return GH_OK;
 }
 
+// The spin of lag counts 6 .. 24: segments walked from candidate pools (cwalk.hpp).  The paths are queued a few at a
+// time: a path whose chain stays open after the queued rounds idles the kernels behind it; the host then queues more
+// rounds for that one path, and if its chain is still open hands it to the serial walker (whose states join the pools)
+// before queueing on.  Returns with *gave_up set when the window turned out to have a position with five candidates:
+// paths *first .. go the serial walkers' way (the caller's loop).
+struct spin_io {
+    int max_paths;
+    double min_remove;
+    size_t n1;              // bytes per path
+    int nb;                 // stride of the per-path partial sums
+    uint8_t *d_paths;
+    gh_path_rec *d_recs;
+    uint8_t *paths_out;
+    gh_path_rec *recs;
+};
+
+static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, int *first_out, bool *gave_up)
+{
+    const int max_paths = io.max_paths;
+    const double min_remove = io.min_remove;
+    const size_t n1 = io.n1;
+    const int nb = io.nb;
+    uint8_t *d_paths = io.d_paths, *paths_out = io.paths_out;
+    gh_path_rec *d_recs = io.d_recs, *recs = io.recs;
+    hipError_t e = hipSuccess;
+    int rc = GH_OK, first = 0;
+    bool cw_gave_up = false;
+    rc = alloc_cw(h);
+    const cw_geom cg = cw_geometry(h->N, h->L);
+    const int zero2[2] = {0, 0};
+    if (rc == GH_OK) {
+        e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);      // lt_stale, cw_unres
+        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+    }
+    int done = 0;
+    int CHUNK = 8, clean = 0;        // paths queued between two looks at the device state: grows while every chain closes
+    while (rc == GH_OK && done < max_paths) {
+        if (h->cw_off) {
+            // a position with five candidates: the rest of the spin goes the serial walkers' way (the loop below)
+            cw_gave_up = true;
+            first = done;
+            if (done < max_paths) {
+                e = hipMemset2DAsync(h->spin_lmsel + n1 * done, n1 * sizeof(double), 0, sizeof(double), (size_t)(max_paths - done), h->stream);
+                if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+            }
+            break;
+        }
+        if (!h->cw_ready) {
+            // no pools yet for this tensor: one entry per pool from the largest marginals (k_cguess), and rounds
+            // until closure has brought in what the walk really does (the serial walker costs 20 rounds at L <= 16
+            // and 400 beyond: it only takes the path if the chain is still open after CW_BOOT + the resumed rounds)
+            h->cw_stamp++;
+            if ((rc = ensure_lt(h))) break;
+            uint8_t *pth = d_paths + n1 * done;
+            cw_params P = cw_make_params(h, pth, h->spin_lmsel + n1 * done);
+            hipLaunchKernelGGL(k_cguess, dim3((unsigned)((h->N + 256) / 256)), dim3(256), 0, h->stream, P, pth);
+            hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, 0);
+            if ((rc = post_launch(h, "k_cguess/k_cseed"))) break;
+            if ((rc = launch_cw_path(h, pth, h->spin_lmsel + n1 * done, CW_BOOT_ROUNDS, 0))) break;
+            if ((rc = launch_reweight_marg(h, pth, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+            h->cw_stat[2] += CW_BOOT_ROUNDS;
+            h->cw_ready = true;
+        } else {
+            const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
+            if ((rc = ensure_lt(h))) break;
+            for (int s = done; s < upto && rc == GH_OK; s++) {
+                h->cw_stamp++;
+                if ((rc = launch_cw_path(h, d_paths + n1 * s, h->spin_lmsel + n1 * s, h->cw_rounds, s > done ? 1 : 0))) break;
+                rc = launch_reweight_marg(h, d_paths + n1 * s, min_remove, 1, d_recs + s, s, true, s > done, cg.S);
+                h->cw_stat[2] += h->cw_rounds;
+            }
+            if (rc) break;
+        }
+        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+        if (getenv("GH_PRINT_STATE"))
+            fprintf(stderr, "gh_spin(cw): n_done %d stop %d lt_stale %d cw_unres %d open_at %d rounds %d\n", hs.n_done, hs.stop, hs.lt_stale,
+                    hs.cw_unres, hs.cw_open_at, h->cw_rounds);
+        h->cw_stat[0] += hs.n_done - done;
+        done = hs.n_done;
+        if (hs.stop) break;
+        if (!hs.lt_stale && !hs.cw_unres) {
+            // (a look costs ~25 us of idle GPU; an open chain costs the ~37 us of idle launches of every path queued
+            // behind it: at one open chain in 50..100 paths the optimum is 8..16 paths per look)
+            if (CHUNK < 16) CHUNK *= 2;
+            if (++clean >= 6 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
+        } else { CHUNK = 8; clean = 0; }
+        if (hs.lt_stale || hs.cw_unres) {
+            e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
+            if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+            h->spin_requeues++;
+            h->cw_stat[3]++;
+            // a moved candidate mask or a window for the serial walkers: the next ensure_lt rebuilds the table in
+            // full.  Behind a chain that merely stayed open the table is current: every kernel queued behind it
+            // idled, and the reweights that ran kept their rows.
+            h->lt_inc_path = nullptr;
+            h->dirty_lt = hs.lt_stale || hs.cw_unres == 2;
+            if (hs.cw_unres == 2) h->cw_off = true;         // five candidates somewhere: the serial walkers take the window
+            else if (hs.cw_unres == 1 && done < max_paths) {
+                // the queued rounds did not close this path's chain.  Its pools keep what has been walked (the tensor
+                // has not changed): more rounds first; if the chain is still open, the serial walker takes the path
+                // and its states join the pools.
+                bool closed = false;
+                if (!hs.lt_stale) {
+                    if ((rc = ensure_lt(h))) break;
+                    const int more = h->L > 16 ? 48 : 12;      // (the serial walker of L > 16 is the slow one)
+                    if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, more, 0, true))) break;
+                    if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+                    h->cw_stat[2] += more;
+                    e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                    if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                    closed = !hs.cw_unres && hs.n_done > done;
+                    if (hs.cw_unres) {
+                        e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
+                        if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                    }
+                }
+                if (!closed) {
+                    h->cw_stamp++;
+                    if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 1))) break;
+                    e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                    if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                }
+                done = hs.n_done;
+                if (hs.stop) break;
+            }
+        }
+    }
+    // the serial walkers' tables were not kept between pool paths: rebuild before anybody walks serially again
+    h->lt_inc_path = nullptr;
+    h->dirty_lt = true;
+    if (rc == GH_OK && done > 0 && !cw_gave_up) {
+        hipLaunchKernelGGL(k_hp, dim3(done, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
+                           (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
+        hipLaunchKernelGGL(k_reweight_finish_all, dim3(done), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
+        rc = post_launch(h, "k_hp/k_reweight_finish_all");
+        if (rc == GH_OK) {
+            e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess && hs.n_done > 0) {
+                e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
+            }
+            if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+        }
+    }
+    *first_out = first;
+    *gave_up = cw_gave_up;
+    return rc;
+}
+
 extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
                        int *n_out, int *hole_at)
 {
@@ -1285,134 +1439,14 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     memset(&hs, 0, sizeof hs);
     int first = 0;
     h->spin_requeues = 0;
-    // Lag counts 6 .. 16: segments walked from candidate pools (cwalk.hpp).  The paths are queued a few at a time: a
-    // path whose chain stays open after the queued rounds idles the kernels behind it, and the host then hands that
-    // one path to the serial walker (whose states join the pools) before queueing on.
+    // lag counts 6 .. 24: segments walked from candidate pools (spin_candidate_pools above)
     const bool cw = rc == GH_OK && cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h);
     bool cw_gave_up = false;
     if (cw) {
-        rc = alloc_cw(h);
-        const cw_geom cg = cw_geometry(h->N, h->L);
-        const int zero2[2] = {0, 0};
-        if (rc == GH_OK) {
-            e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);      // lt_stale, cw_unres
-            if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
-        }
-        int done = 0;
-        int CHUNK = 8, clean = 0;        // paths queued between two looks at the device state: grows while every chain closes
-        while (rc == GH_OK && done < max_paths) {
-            if (h->cw_off) {
-                // a position with five candidates: the rest of the spin goes the serial walkers' way (the loop below)
-                cw_gave_up = true;
-                first = done;
-                if (done < max_paths) {
-                    e = hipMemset2DAsync(h->spin_lmsel + n1 * done, n1 * sizeof(double), 0, sizeof(double), (size_t)(max_paths - done), h->stream);
-                    if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
-                }
-                break;
-            }
-            if (!h->cw_ready) {
-                // no pools yet for this tensor: one entry per pool from the largest marginals (k_cguess), and rounds
-                // until closure has brought in what the walk really does (the serial walker costs 20 rounds at L <= 16
-                // and 400 beyond: it only takes the path if the chain is still open after CW_BOOT + the resumed rounds)
-                h->cw_stamp++;
-                if ((rc = ensure_lt(h))) break;
-                uint8_t *pth = d_paths + n1 * done;
-                cw_params P = cw_make_params(h, pth, h->spin_lmsel + n1 * done);
-                hipLaunchKernelGGL(k_cguess, dim3((unsigned)((h->N + 256) / 256)), dim3(256), 0, h->stream, P, pth);
-                hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, 0);
-                if ((rc = post_launch(h, "k_cguess/k_cseed"))) break;
-                if ((rc = launch_cw_path(h, pth, h->spin_lmsel + n1 * done, CW_BOOT_ROUNDS, 0))) break;
-                if ((rc = launch_reweight_marg(h, pth, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
-                h->cw_stat[2] += CW_BOOT_ROUNDS;
-                h->cw_ready = true;
-            } else {
-                const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
-                if ((rc = ensure_lt(h))) break;
-                for (int s = done; s < upto && rc == GH_OK; s++) {
-                    h->cw_stamp++;
-                    if ((rc = launch_cw_path(h, d_paths + n1 * s, h->spin_lmsel + n1 * s, h->cw_rounds, s > done ? 1 : 0))) break;
-                    rc = launch_reweight_marg(h, d_paths + n1 * s, min_remove, 1, d_recs + s, s, true, s > done, cg.S);
-                    h->cw_stat[2] += h->cw_rounds;
-                }
-                if (rc) break;
-            }
-            e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
-            if (getenv("GH_PRINT_STATE"))
-                fprintf(stderr, "gh_spin(cw): n_done %d stop %d lt_stale %d cw_unres %d open_at %d rounds %d\n", hs.n_done, hs.stop, hs.lt_stale,
-                        hs.cw_unres, hs.cw_open_at, h->cw_rounds);
-            h->cw_stat[0] += hs.n_done - done;
-            done = hs.n_done;
-            if (hs.stop) break;
-            if (!hs.lt_stale && !hs.cw_unres) {
-                // (a look costs ~25 us of idle GPU; an open chain costs the ~37 us of idle launches of every path queued
-                // behind it: at one open chain in 50..100 paths the optimum is 8..16 paths per look)
-                if (CHUNK < 16) CHUNK *= 2;
-                if (++clean >= 6 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
-            } else { CHUNK = 8; clean = 0; }
-            if (hs.lt_stale || hs.cw_unres) {
-                e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
-                if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
-                h->spin_requeues++;
-                h->cw_stat[3]++;
-                // a moved candidate mask or a window for the serial walkers: the next ensure_lt rebuilds the table in
-                // full.  Behind a chain that merely stayed open the table is current: every kernel queued behind it
-                // idled, and the reweights that ran kept their rows.
-                h->lt_inc_path = nullptr;
-                h->dirty_lt = hs.lt_stale || hs.cw_unres == 2;
-                if (hs.cw_unres == 2) h->cw_off = true;         // five candidates somewhere: the serial walkers take the window
-                else if (hs.cw_unres == 1 && done < max_paths) {
-                    // the queued rounds did not close this path's chain.  Its pools keep what has been walked (the tensor
-                    // has not changed): more rounds first; if the chain is still open, the serial walker takes the path
-                    // and its states join the pools.
-                    bool closed = false;
-                    if (!hs.lt_stale) {
-                        if ((rc = ensure_lt(h))) break;
-                        const int more = h->L > 16 ? 48 : 12;      // (the serial walker of L > 16 is the slow one)
-                        if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, more, 0, true))) break;
-                        if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
-                        h->cw_stat[2] += more;
-                        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
-                        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-                        if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
-                        closed = !hs.cw_unres && hs.n_done > done;
-                        if (hs.cw_unres) {
-                            e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
-                            if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
-                        }
-                    }
-                    if (!closed) {
-                        h->cw_stamp++;
-                        if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 1))) break;
-                        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
-                        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-                        if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
-                    }
-                    done = hs.n_done;
-                    if (hs.stop) break;
-                }
-            }
-        }
-        // the serial walkers' tables were not kept between pool paths: rebuild before anybody walks serially again
-        h->lt_inc_path = nullptr;
-        h->dirty_lt = true;
-        if (rc == GH_OK && done > 0 && !cw_gave_up) {
-            hipLaunchKernelGGL(k_hp, dim3(done, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
-                               (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
-            hipLaunchKernelGGL(k_reweight_finish_all, dim3(done), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
-            rc = post_launch(h, "k_hp/k_reweight_finish_all");
-            if (rc == GH_OK) {
-                e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-                if (e == hipSuccess && hs.n_done > 0) {
-                    e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
-                    if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
-                }
-                if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
-            }
-        }
+        spin_io io;
+        io.max_paths = max_paths; io.min_remove = min_remove; io.n1 = n1; io.nb = nb;
+        io.d_paths = d_paths; io.d_recs = d_recs; io.paths_out = paths_out; io.recs = recs;
+        rc = spin_candidate_pools(h, io, hs, &first, &cw_gave_up);
     }
     while ((!cw || cw_gave_up) && rc == GH_OK) {
         int launched = first;
