@@ -1568,8 +1568,10 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     b->L = b->hs[0]->L;
     // (measured on C3, MI355X: 8 windows 37k haplotypes/s this way against ~16k batched; 32 windows 45k either way -- the
     // chip is then busy with k_seg; from 48 windows on the batched serial walkers, one workgroup per window, win: 114k at 256)
-    static const int batch_cut = getenv("GH_BATCH_STREAMS_MAX") ? atoi(getenv("GH_BATCH_STREAMS_MAX")) : 47;
-    if ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || (cw_ok(b->hs[0]->wmode, b->L) && lt_incremental_ok(b->hs[0]))) {
+    // (read on every call: the tests switch between the two ways; -1 = always the batched kernels)
+    const int batch_cut = getenv("GH_BATCH_STREAMS_MAX") ? atoi(getenv("GH_BATCH_STREAMS_MAX")) : 47;
+    if (batch_cut >= 0 &&
+        ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || (cw_ok(b->hs[0]->wmode, b->L) && lt_incremental_ok(b->hs[0])))) {
         // The segment-parallel extensions fill the chip poorly with ONE window (four small dependent kernels per path, most
         // of their time launch and first-touch latency) but every window has its own stream: a few host threads each
         // run gh_spin over their share of the windows, and the windows' kernel chains interleave on the GPU.

@@ -1,7 +1,7 @@
 """Randomised parity fuzz: HIP path vs the C oracle on random windows, switches and lag counts (not part of the
 default suite; run on the GPU box from the repo root: python tests/fuzz_gpu.py [seconds] [seed]).  Test infrastructure:
 it is the only place outside tests/test_*.py, smoke() and bench.py's cpu_baseline that calls the oracle."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from gretel_amd.hansel import Hansel, HanselBatch
@@ -47,6 +47,11 @@ while time.time() < t_end:
                 assert hh.fill_from_support(x.rank, x.off, x.bases) == oo.fill(x)
                 hh.L = L if L is not None else 3; oo.L = hh.L
                 hs.append(hh); os_.append(oo)
+            # either way of running a batch: windows on their own streams, or kernels launched over all windows
+            if rng.random() < 0.5:
+                os.environ["GH_BATCH_STREAMS_MAX"] = "-1"
+            else:
+                os.environ.pop("GH_BATCH_STREAMS_MAX", None)
             for res, oo in zip(HanselBatch(hs).spin(paths), os_):
                 ref = oo.spin(paths)
                 if not (res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"] and np.array_equal(res["paths"], ref["paths"])

@@ -86,3 +86,31 @@ def test_single_path_after_a_batched_spin_sees_every_reweight():
         pg, po = h.generate_path(), o.generate_path()
         assert np.array_equal(pg[0], po[0])
         assert pg[1:] == po[1]
+
+
+@pytest.mark.parametrize("way", ["streams", "batched"])
+@pytest.mark.parametrize("L", [2, 5, 9, 18])
+def test_both_ways_of_running_a_batch_agree_with_the_oracle(way, L, monkeypatch):
+    # up to 47 windows run on their own streams from host threads, larger batches through kernels launched over all
+    # windows (one serial path extension per window); GH_BATCH_STREAMS_MAX = -1 sends this small batch the second way
+    if way == "batched":
+        monkeypatch.setenv("GH_BATCH_STREAMS_MAX", "-1")
+    else:
+        monkeypatch.delenv("GH_BATCH_STREAMS_MAX", raising=False)
+    wins = []
+    for s in range(5):
+        t = make_support_table(700, 14000, k=None if L > 5 else 6, seed=40 + s, n_haps=6, err=0.01, k_max=21)
+        h = Hansel(t.n_snps, band=21 if L > 5 else t.band)
+        o = COracle(t.n_snps, 21 if L > 5 else t.band)
+        assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+        h.L = L
+        o.L = L
+        wins.append((h, o))
+    res = HanselBatch([h for h, _ in wins]).spin(10)
+    for (h, o), r in zip(wins, res):
+        ref = o.spin(10)
+        assert r["n"] == ref["n"] and r["hole_at"] == ref["hole_at"]
+        assert np.array_equal(r["paths"], ref["paths"])
+        assert r["hp_current"].tolist() == ref["hp_current"].tolist()
+        assert r["ratio"].tolist() == ref["ratio"].tolist()
+        assert np.array_equal(h.export_band(), o.export_band())
