@@ -648,32 +648,57 @@ __global__ void __launch_bounds__(256) k_seg_fin(seg_params P, gh_path_rec *rec,
 // -------------------------------------------------------------------------------------------------------------
 // k_hp: running_prob += log10(marginal) over the SNPs, left to right (gretel.py:185-186).  blockIdx.x = path,
 // blockIdx.y = 0: current marginals (kept by k_emit at walk time), 1: original marginals (minfo[11..15], fixed since
-// the snapshot, looked up through the path's symbols).  One wavefront each: 64 values per load, then 64 additions in
-// lane order; an unused lane adds +0.0, which changes nothing.
+// the snapshot, looked up through the path's symbols).  A strictly sequential binary64 sum, one wavefront per sum.
+// The addends come in by vector loads, 512 at a time (the next 512 in flight under the additions), go through LDS,
+// and every addition reads its addend back with a broadcast ds_read (same address in all lanes; LDS data returns in
+// order, so the reads run ahead of the additions): ~2 instructions per addend where moving a vector register's lanes
+// through scalar registers (two v_readlane per addend, each followed by the scalar-operand hazard) took 150 us per
+// 10 000 SNPs.  An unused slot adds +0.0, which changes nothing.
 // -------------------------------------------------------------------------------------------------------------
+#define HP_CHUNK 512
+template <int WHICH>
+__device__ __forceinline__ double hp_sum(const double *lm, const uint8_t *path, const double *minfo, int N, double (*buf)[HP_CHUNK])
+{
+    const int lane = threadIdx.x;
+    // (no branches around the loads: a slot beyond the window reads position N and is replaced by +0.0)
+    auto value = [&](int t) -> double {
+        const int tt = t <= N ? t : N;
+        const double v = WHICH == 0 ? lm[tt] : minfo[(size_t)tt * MINFO + 11 + a6_of_sym(path[tt])];
+        return t <= N ? v : 0.0;
+    };
+    constexpr int PER = HP_CHUNK / 64;
+    double r[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) r[k] = value(1 + lane + 64 * k);
+    const int nchunks = (N + HP_CHUNK - 1) / HP_CHUNK;
+    double acc = 0.0;
+    for (int c = 0; c < nchunks; c++) {
+        double *b = buf[c & 1];
+#pragma unroll
+        for (int k = 0; k < PER; k++) b[lane + 64 * k] = r[k];
+        __syncthreads();
+        if (c + 1 < nchunks) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) r[k] = value(1 + (c + 1) * HP_CHUNK + lane + 64 * k);
+        }
+#pragma unroll 32
+        for (int j = 0; j < HP_CHUNK; j++) acc += b[j];
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(64)
 k_hp(const double *lmsel, size_t lmsel_stride, const uint8_t *paths, size_t path_stride, const double *minfo, int N,
      const dev_state *st, gh_path_rec *recs)
 {
-    const int s = blockIdx.x, which = blockIdx.y, lane = threadIdx.x;
+    __shared__ double buf[2][HP_CHUNK];
+    const int s = blockIdx.x, which = blockIdx.y;
     if (s >= st->n_done) return;
     const double *lm = lmsel + (size_t)s * lmsel_stride;
     if (lm[0] != 1.0) return;                                      // walked by a serial walker, which summed for itself
     const uint8_t *path = paths + (size_t)s * path_stride;
-    auto value = [&](int t) -> double {
-        if (t > N) return 0.0;
-        if (which == 0) return lm[t];
-        return minfo[(size_t)t * MINFO + 11 + a6_of_sym(path[t])];
-    };
-    double acc = 0.0;
-    double v = value(1 + lane);
-    for (int base = 1; base <= N; base += 64) {
-        const double cur = v;
-        v = value(base + 64 + lane);                                // next chunk's loads in flight under the additions
-#pragma unroll
-        for (int j = 0; j < 64; j++) acc += readlane_f64(cur, j);
-    }
-    if (lane == 0) {
+    const double acc = which == 0 ? hp_sum<0>(lm, path, minfo, N, buf) : hp_sum<1>(lm, path, minfo, N, buf);
+    if (threadIdx.x == 0) {
         if (which == 0) recs[s].hp_current = acc;
         else recs[s].hp_original = acc;
     }
