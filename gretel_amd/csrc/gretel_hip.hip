@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <string>
 #include <thread>
@@ -122,6 +123,8 @@ struct gh_handle {
     int cw_stamp;
     int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
+    uint8_t *stage;        // pinned host staging for the results of a spin
+    size_t stage_cap;
     int cw_round_cap;      // GH_CW_ROUND_CAP=k at creation (tests): never more than k rounds per launch, so that chains stay open and the serial fallback runs
     int spin_partial_stride;   // doubles between two paths' partial sums of the removed mass in a spin (0 outside spins)
     int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
@@ -249,6 +252,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
+    if (h->stage) hipHostFree(h->stage);
     hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_hist); hipFree(h->cw_last_hit); hipFree(h->cw_npool); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true); hipFree(h->cw_pend); hipFree(h->cw_npend);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
@@ -292,6 +296,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
+    h->stage = nullptr; h->stage_cap = 0;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
@@ -1236,6 +1241,34 @@ extern "C" int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, doub
     return GH_OK;
 }
 
+// results to the caller's (pageable) buffers through pinned staging: one asynchronous copy each at PCIe rate and a
+// host memcpy, instead of the runtime's chunked pageable path
+static int results_to_host(gh_handle *h, uint8_t *paths_out, const uint8_t *d_paths, size_t path_bytes, gh_path_rec *recs,
+                           const gh_path_rec *d_recs, size_t rec_bytes)
+{
+    const size_t need = path_bytes + rec_bytes;
+    if (need > h->stage_cap) {
+        if (h->stage) hipHostFree(h->stage);
+        h->stage = nullptr; h->stage_cap = 0;
+        const size_t cap = need + need / 2 + 4096;
+        if (hipHostMalloc((void **)&h->stage, cap, hipHostMallocDefault) != hipSuccess) {
+            // no pinned memory to be had: the plain copies
+            (void)hipGetLastError();
+            h->stage = nullptr;
+            HIPCHK(hipMemcpy(paths_out, d_paths, path_bytes, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(recs, d_recs, rec_bytes, hipMemcpyDeviceToHost));
+            return GH_OK;
+        }
+        h->stage_cap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(h->stage, d_paths, path_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage + path_bytes, d_recs, rec_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(paths_out, h->stage, path_bytes);
+    memcpy(recs, h->stage + path_bytes, rec_bytes);
+    return GH_OK;
+}
+
 // The spin of lag counts 6 .. 24: segments walked from candidate pools (cwalk.hpp).  The paths are queued a few at a
 // time: a path whose chain stays open after the queued rounds idles the kernels behind it; the host then queues more
 // rounds for that one path, and if its chain is still open hands it to the serial walker (whose states join the pools)
@@ -1378,11 +1411,8 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
         if (rc == GH_OK) {
             e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e == hipSuccess && hs.n_done > 0) {
-                e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
-                if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
-            }
             if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+            else if (hs.n_done > 0) rc = results_to_host(h, paths_out, d_paths, n1 * hs.n_done, recs, d_recs, sizeof(gh_path_rec) * hs.n_done);
         }
     }
     *first_out = first;
@@ -1483,11 +1513,8 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             e = hipMemcpyAsync(&h->dstate->lt_stale, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
             if (e == hipSuccess) { first = hs.n_done; h->spin_requeues++; continue; }
         }
-        if (e == hipSuccess && hs.n_done > 0) {
-            e = hipMemcpy(paths_out, d_paths, n1 * hs.n_done, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(recs, d_recs, sizeof(gh_path_rec) * hs.n_done, hipMemcpyDeviceToHost);
-        }
         if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+        else if (hs.n_done > 0) rc = results_to_host(h, paths_out, d_paths, n1 * hs.n_done, recs, d_recs, sizeof(gh_path_rec) * hs.n_done);
         break;
     }
     h->spin_partial_stride = 0;
