@@ -286,7 +286,7 @@ class _gio_table(C.Structure):
 
 class gio_stats(C.Structure):
     _fields_ = [("compressed_bytes", C.c_int64), ("blocks", C.c_int64), ("records", C.c_int64), ("reads_kept", C.c_int64),
-                ("used_index", C.c_int32), ("libdeflate", C.c_int32), ("threads", C.c_int32), ("_pad", C.c_int32),
+                ("used_index", C.c_int32), ("libdeflate", C.c_int32), ("threads", C.c_int32), ("reframed", C.c_int32),
                 ("seconds", C.c_double)]
 
 

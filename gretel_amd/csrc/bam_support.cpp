@@ -531,52 +531,88 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     std::vector<int32_t> next_snp((size_t)end_pos + 2, end_pos + 1);
     for (int32_t p = end_pos; p >= 0; p--) next_snp[p] = region[p] ? p : next_snp[p + 1];
 
-    // rows of the table in first-seen order (util.py:191-207).  The characters and keys stay where the threads wrote
-    // them (the parts of every batch are kept until the table is assembled); a key seen again (the same read met through
-    // another record: rare) gives its row a private copy with the new characters appended.
-    struct row { const uint8_t *ch; const char *key; int32_t rank, len, key_len; uint32_t h_lo; };
-    bigvec<row> reads;
-    std::vector<std::unique_ptr<uint8_t[]>> moved;          // the private copies
-    // open addressing (linear probing, at most half full) over a 64-bit hash of the key: the lower half says where the
-    // probe starts, a slot holds the upper half and the row -- 8 bytes, in lazily-zeroed memory; a matching tag is
-    // confirmed on the lower half and the key bytes
-    struct slot { uint32_t tag, row1; };                    // row1 = row + 1, 0 = empty
-    struct slot_table {
-        slot *p = nullptr;
-        size_t n = 0;
-        ~slot_table() { if (p) munmap(p, n * sizeof(slot)); }
-        bool alloc(size_t slots)
+    // One entry per KEPT RECORD in file order (its number = gid).  The rows of the table (util.py:191-207) are the records
+    // that were the first with their key, in that order; a record whose key was seen before (the same read met through
+    // another record: rare) gives the first one's row a private copy of its characters with the new ones appended.
+    // The characters and keys stay where the threads wrote them (the parts of every batch live until the table is assembled).
+    struct rinfo {
+        const uint8_t *ch;
+        const char *key;
+        int32_t rank, len, key_len;
+        uint32_t h_lo, h_hi;
+        uint32_t dup_of1;                                   // 0: opens a row; else 1 + gid of the record that opened it
+    };
+    // (grown without value-initialising: a million entries are 40 MB that the fill threads are about to write anyway)
+    struct rinfo_vec {
+        rinfo *p = nullptr;
+        size_t n = 0, cap = 0;
+        ~rinfo_vec() { free(p); }
+        size_t size() const { return n; }
+        size_t capacity() const { return cap; }
+        rinfo *data() { return p; }
+        rinfo &operator[](size_t i) { return p[i]; }
+        bool reserve(size_t c)
         {
-            void *q = mmap(nullptr, slots * sizeof(slot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (q == MAP_FAILED) return false;
-            madvise(q, slots * sizeof(slot), MADV_HUGEPAGE);
-            p = (slot *)q;
-            n = slots;
+            if (c <= cap) return true;
+            rinfo *q = (rinfo *)big_alloc(c * sizeof(rinfo));
+            if (!q) return false;
+            if (n) memcpy(q, p, n * sizeof(rinfo));
+            free(p);
+            p = q;
+            cap = c;
             return true;
         }
-    };
-    slot_table table;
-    if (!table.alloc((size_t)1 << 16)) return fail(-6, "out of memory");
-    size_t table_mask = table.n - 1;
-    // room for `rows` rows at half load; rehashing walks the old table front to back
-    auto table_reserve = [&](size_t rows) -> bool {
-        if (rows * 2 <= table.n) return true;
-        size_t want = table.n;
-        while (rows * 2 > want) want *= 2;
-        slot_table nt;
-        if (!nt.alloc(want)) return false;
-        const size_t nm = want - 1;
-        for (size_t i = 0; i < table.n; i++) {
-            const slot e = table.p[i];
-            if (!e.row1) continue;
-            const row &w = reads[e.row1 - 1];
-            size_t j = (size_t)w.h_lo & nm;
-            while (nt.p[j].row1) j = (j + 1) & nm;
-            nt.p[j] = e;
+        bool resize_uninit(size_t m)
+        {
+            if (m > cap && !reserve(std::max(m, cap + cap / 2))) return false;
+            n = m;
+            return true;
         }
-        std::swap(table.p, nt.p);
-        std::swap(table.n, nt.n);
-        table_mask = nm;
+    } info;
+    std::vector<std::unique_ptr<uint8_t[]>> moved;          // the private copies
+    // The key table is cut into PARTITIONS by bits of the key's hash, one thread each: whether a record is the first with
+    // its key only depends on the records of its own partition, taken in file order.  Per partition: open addressing
+    // (linear probing, at most half full); the hash's lower half says where the probe starts, a slot holds the upper half
+    // and the gid -- 8 bytes, lazily-zeroed memory; a matching tag is confirmed on the lower half and the key bytes.
+    struct slot { uint32_t tag, gid1; };                    // gid1 = gid + 1, 0 = empty
+    struct ptable {
+        slot *p = nullptr;
+        size_t n = 0, count = 0;
+        std::vector<uint32_t> dups;                         // this batch's records whose key was there already
+        bool oom = false;
+        ptable() = default;
+        ptable(const ptable &) = delete;
+        ptable &operator=(const ptable &) = delete;
+        ~ptable() { if (p) munmap(p, n * sizeof(slot)); }
+        static slot *alloc(size_t slots)
+        {
+            void *q = mmap(nullptr, slots * sizeof(slot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) return nullptr;
+            madvise(q, slots * sizeof(slot), MADV_HUGEPAGE);
+            return (slot *)q;
+        }
+    };
+    int n_part = 1;
+    while (n_part * 2 <= n_threads()) n_part *= 2;
+    std::vector<ptable> tabs((size_t)n_part);
+    // room for `rows` keys at half load in one partition; rehashing walks the old table front to back
+    auto ptable_reserve = [&](ptable &T, size_t rows) -> bool {
+        if (T.p && rows * 2 <= T.n) return true;
+        size_t want = T.n ? T.n : ((size_t)1 << 12);
+        while (rows * 2 > want) want *= 2;
+        slot *np = ptable::alloc(want);
+        if (!np) return false;
+        const size_t nm = want - 1;
+        for (size_t i = 0; i < T.n; i++) {
+            const slot e = T.p[i];
+            if (!e.gid1) continue;
+            size_t j = (size_t)info[e.gid1 - 1].h_lo & nm;
+            while (np[j].gid1) j = (j + 1) & nm;
+            np[j] = e;
+        }
+        if (T.p) munmap(T.p, T.n * sizeof(slot));
+        T.p = np;
+        T.n = want;
         return true;
     };
 
@@ -664,53 +700,46 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         o.recs.push_back(kept{h, rank, (uint32_t)k0, (uint32_t)(o.keys.size() - k0), (uint32_t)ch0, (uint32_t)(o.chars.size() - ch0)});
         return 0;
     };
-    // the sequential part: record by record the key into the table and the row that points at the characters
-    auto merge_part = [&](const part &o) -> bool {
-        const size_t nr = o.recs.size();
-        if (!nr) return true;
-        if (reads.capacity() < reads.size() + nr) reads.reserve(std::max(reads.size() + nr, 2 * reads.capacity()));
-        const uint8_t *cbase = o.chars.data();
-        const char *kbase = o.keys.data();
-        for (size_t i = 0; i < nr; i++) {
-            if (i + 12 < nr) __builtin_prefetch(&table.p[(size_t)(uint32_t)o.recs[i + 12].h & table_mask]);
-            const kept &k = o.recs[i];
-            const uint32_t tag = (uint32_t)(k.h >> 32);
-            size_t si = (size_t)(uint32_t)k.h & table_mask;
-            int64_t found = -1;
-            while (table.p[si].row1) {
-                if (table.p[si].tag == tag) {
-                    const row &w = reads[table.p[si].row1 - 1];
-                    if (w.h_lo == (uint32_t)k.h && (uint32_t)w.key_len == k.key_len && memcmp(w.key, kbase + k.key_off, k.key_len) == 0) {
-                        found = (int64_t)table.p[si].row1 - 1;
-                        break;
-                    }
-                }
-                si = (si + 1) & table_mask;
-            }
-            if (found < 0) {
-                table.p[si] = slot{tag, (uint32_t)reads.size() + 1};
-                reads.push_back(row{cbase + k.ch_off, kbase + k.key_off, k.rank, (int32_t)k.ch_len, (int32_t)k.key_len, (uint32_t)k.h});
-            } else {
-                row &w = reads[(size_t)found];
-                std::unique_ptr<uint8_t[]> cp(new (std::nothrow) uint8_t[(size_t)w.len + k.ch_len]);
-                if (!cp) return false;
-                memcpy(cp.get(), w.ch, (size_t)w.len);
-                memcpy(cp.get() + w.len, cbase + k.ch_off, k.ch_len);
-                w.ch = cp.get();
-                w.len += (int32_t)k.ch_len;
-                moved.push_back(std::move(cp));
-            }
-        }
-        return true;
-    };
-
     double tm[5] = {0, 0, 0, 0, 0};
     const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    std::vector<size_t> frames;                                             // offsets of the whole records in the window
     std::vector<std::unique_ptr<part>> kept_parts;                         // every batch's parts: the rows point into them
+    const int64_t n_ref = (int64_t)hd.refs.size();
+    // Does a record plausibly start at byte x of the window?  Only a guess (fixed fields in range, lengths that fit, a
+    // printable NUL-terminated name, and the same for the record behind it): a thread that starts in the middle of the
+    // window starts at such a place, and the chain of the thread in front of it must END EXACTLY THERE, or the batch
+    // is done again front to back.
+    auto plausible1 = [&](const uint8_t *w, size_t av, size_t x, size_t *next) -> bool {
+        if (x + 36 > av) return false;
+        const int32_t bs = rd32(w + x);
+        if (bs < 32 || bs > (1 << 28)) return false;
+        const int32_t refid = rd32(w + x + 4), pos = rd32(w + x + 8), l_seq = rd32(w + x + 20), nref = rd32(w + x + 24);
+        const int l_name = w[x + 12], n_cig = rdu16(w + x + 16);
+        if (refid < -1 || refid >= n_ref || nref < -1 || nref >= n_ref || pos < -1 || l_seq < 0 || l_name < 1) return false;
+        const int64_t var = 32 + (int64_t)l_name + 4 * (int64_t)n_cig + ((int64_t)l_seq + 1) / 2 + (int64_t)l_seq;
+        if (var > bs) return false;
+        if (x + 36 + (size_t)l_name <= av) {
+            const uint8_t *nm = w + x + 36;
+            if (nm[l_name - 1] != 0) return false;
+            for (int i = 0; i + 1 < l_name; i++)
+                if (nm[i] < 33 || nm[i] > 126) return false;
+        }
+        *next = x + 4 + (size_t)bs;
+        return true;
+    };
+    auto find_start = [&](const uint8_t *w, size_t av, size_t from, size_t until) -> size_t {
+        for (size_t x = from; x < until; x++) {
+            size_t n1 = 0, n2 = 0, n3 = 0;
+            if (!plausible1(w, av, x, &n1)) continue;
+            if (n1 + 36 <= av && !plausible1(w, av, n1, &n2)) continue;
+            if (n2 && n2 + 36 <= av && !plausible1(w, av, n2, &n3)) continue;
+            return x;
+        }
+        return (size_t)-1;
+    };
     bool done = false;
+    bool front_to_back = false;                                             // this batch again on one thread (a guessed start was wrong)
     while (!done) {
         auto T0 = now();
         int64_t av = z.ensure(4);
@@ -718,50 +747,49 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         if (av == 0) break;
         if (av < 4) return fail(-4, "truncated BAM record");
         const uint8_t *base = z.ptr();
-        frames.clear();
         auto T1 = now(); tm[0] += secs(T0, T1);
-        size_t o = 0;
-        int32_t bad_size = 0;
-        bool bad = false;
-        while (o + 4 <= (size_t)av) {
-            const int32_t block_size = rd32(base + o);
-            if (block_size < 32 || block_size > (1 << 28)) { bad = true; bad_size = block_size; break; }
-            if (o + 4 + (size_t)block_size > (size_t)av) break;
-            frames.push_back(o);
-            o += 4 + (size_t)block_size;
+        // Threads: each takes a byte range of the window, finds the first record that starts in it, and frames AND works on
+        // records from there until it reaches the start of the next thread's range (framing alone is a chain of dependent
+        // cache misses, one per record: 7 ms per million on one thread).
+        int nt = front_to_back ? 1 : (int)std::min<size_t>((size_t)n_threads(), (size_t)av / (part_records() * 128) + 1);
+        std::vector<size_t> start((size_t)nt + 1, (size_t)av), stop_at((size_t)nt, 0);
+        start[0] = 0;
+        for (int t = 1; t < nt; t++) {
+            start[(size_t)t] = find_start(base, (size_t)av, (size_t)av * (size_t)t / (size_t)nt, (size_t)av * (size_t)(t + 1) / (size_t)nt);
+            if (start[(size_t)t] == (size_t)-1) { nt = 1; start[1] = (size_t)av; break; }       // (no start found: one thread)
         }
-        if (frames.empty()) {
-            if (bad) return fail(-4, "bad BAM record size %d", bad_size);
-            const int32_t block_size = rd32(base);                          // a record the window does not hold yet
-            av = z.ensure(4 + (size_t)block_size);
-            tm[4] += secs(T1, now());
-            if (av < 0) return (int)av;
-            if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
-            continue;
-        }
-        const size_t nf = frames.size();
-        auto T2 = now(); tm[1] += secs(T1, T2);
-        const int nt = (int)std::min<size_t>((size_t)n_threads(), nf / part_records() + 1);
         const size_t p0 = kept_parts.size();
         for (int t = 0; t < nt; t++) kept_parts.emplace_back(new part());
         auto work = [&](int t) {
             part &P = *kept_parts[p0 + (size_t)t];
-            const size_t lo = nf * (size_t)t / (size_t)nt, hi = nf * (size_t)(t + 1) / (size_t)nt;
+            const size_t lim = start[(size_t)t + 1];
+            size_t o = start[(size_t)t];
             try {
-                P.recs.reserve(hi - lo);
-                P.keys.reserve((hi - lo) * 24);
-                P.chars.reserve((hi - lo) * 16);
-                for (size_t f = lo; f < hi; f++) {
-                    const uint8_t *r = base + frames[f];
+                const size_t guess = (lim - o) / 96 + 16;
+                P.recs.reserve(guess);
+                P.keys.reserve(guess * 24);
+                P.chars.reserve(guess * 16);
+                while (o < lim && o + 4 <= (size_t)av) {
+                    const int32_t block_size = rd32(base + o);
+                    if (block_size < 32 || block_size > (1 << 28)) {
+                        P.err = -4;
+                        char m[64];
+                        snprintf(m, sizeof m, "bad BAM record size %d", block_size);
+                        P.msg = m;
+                        break;
+                    }
+                    if (o + 4 + (size_t)block_size > (size_t)av) break;     // the window ends inside this record
                     P.n_seen++;
-                    const int rc1 = one_record(r + 4, rd32(r), P);
+                    const int rc1 = one_record(base + o + 4, block_size, P);
                     if (rc1 == 1) { P.stop = true; break; }
                     if (rc1 < 0) { P.err = rc1; P.msg = g_err; break; }
+                    o += 4 + (size_t)block_size;
                 }
             } catch (const std::exception &) {                              // (an exception must not leave a thread)
                 P.err = -6;
                 P.msg = "out of memory";
             }
+            stop_at[(size_t)t] = o;
         };
         if (nt <= 1) work(0);
         else {
@@ -769,64 +797,175 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             for (int t = 0; t < nt; t++) th.emplace_back(work, t);
             for (auto &t : th) t.join();
         }
+        // every chain must end where the next one began (then, by induction from the true start 0, every start was true)
+        bool chained = true;
+        for (int t = 0; t + 1 < nt && chained; t++) {
+            const part &P = *kept_parts[p0 + (size_t)t];
+            if (P.stop || P.err) break;                                     // (nothing behind it counts)
+            if (stop_at[(size_t)t] != start[(size_t)t + 1]) chained = false;
+        }
+        if (!chained) {
+            g_stats.reframed++;
+            kept_parts.resize(p0);
+            front_to_back = true;
+            continue;
+        }
+        front_to_back = false;
+        size_t o = stop_at[(size_t)nt - 1];
+        if (o == 0 && !kept_parts[p0]->err && !kept_parts[p0]->stop) {
+            // not one whole record in the window
+            kept_parts.resize(p0);
+            const int32_t block_size = rd32(base);
+            av = z.ensure(4 + (size_t)block_size);
+            tm[4] += secs(T1, now());
+            if (av < 0) return (int)av;
+            if (av < 4 + (int64_t)block_size) return fail(-4, "truncated BAM record");
+            continue;
+        }
+        auto T2 = T1;
         auto T3 = now(); tm[2] += secs(T2, T3);
         // file order: everything in front of the first record that stops the scan or is malformed counts
-        {
-            // the key table sized once for what the rest of the file will bring at this rate
-            size_t batch_rows = 0;
-            for (int t = 0; t < nt; t++) batch_rows += kept_parts[p0 + (size_t)t]->recs.size();
-            const double pr = z.progress();
-            size_t est = reads.size() + batch_rows;
-            if (pr > 0.0 && pr < 1.0) est = (size_t)((double)est / pr * 1.05) + 1024;
-            if (est < reads.size() + batch_rows || est > (size_t)1 << 31) est = reads.size() + batch_rows;
-            if (!table_reserve(est)) return fail(-6, "out of memory");
-            if (reads.capacity() < est) reads.reserve(est);
-        }
+        int n_valid = 0;                                                    // parts that count
         for (int t = 0; t < nt && !done; t++) {
             part &P = *kept_parts[p0 + (size_t)t];
-            if (!table_reserve(reads.size() + P.recs.size() + 1) || !merge_part(P)) return fail(-6, "out of memory");
             g_stats.records += P.n_seen;
             if (P.err) return fail(P.err, "%s", P.msg.c_str());
             if (P.stop) done = true;
-            bigvec<kept>().swap(P.recs);                                    // only the characters and keys are still needed
+            n_valid = t + 1;
         }
+        // gids of this batch: the parts' records behind one another
+        std::vector<size_t> gbase((size_t)n_valid + 1, info.size());
+        for (int t = 0; t < n_valid; t++) gbase[(size_t)t + 1] = gbase[(size_t)t] + kept_parts[p0 + (size_t)t]->recs.size();
+        const size_t g_end = gbase[(size_t)n_valid];
+        if (g_end >= 0xfffffff0ull) return fail(-6, "more than 4e9 reads in the window");
+        {
+            // sized for what the rest of the file will bring at this rate
+            const double pr = z.progress();
+            size_t est = g_end;
+            if (pr > 0.0 && pr < 1.0) est = (size_t)((double)est / pr * 1.05) + 1024;
+            if (est < g_end || est > (size_t)1 << 32) est = g_end;
+            if (!info.reserve(est) || !info.resize_uninit(g_end)) return fail(-6, "out of memory");
+            for (auto &T : tabs)
+                if (!ptable_reserve(T, est / (size_t)n_part + est / (size_t)(4 * n_part) + 1024)) return fail(-6, "out of memory");
+        }
+        // (a) the parts' records into info, each part by the thread that made it
+        auto fill = [&](int t) {
+            const part &P = *kept_parts[p0 + (size_t)t];
+            const uint8_t *cbase = P.chars.data();
+            const char *kbase = P.keys.data();
+            rinfo *dst = info.data() + gbase[(size_t)t];
+            const size_t nr = P.recs.size();
+            for (size_t i = 0; i < nr; i++) {
+                const kept &k = P.recs[i];
+                dst[i] = rinfo{cbase + k.ch_off, kbase + k.key_off, k.rank, (int32_t)k.ch_len, (int32_t)k.key_len, (uint32_t)k.h, (uint32_t)(k.h >> 32), 0u};
+            }
+        };
+        // (b) partition q takes the records whose hash says q, in file order
+        const size_t g_lo = gbase[0];
+        auto place = [&](int q) {
+            ptable &T = tabs[(size_t)q];
+            T.dups.clear();
+            const rinfo *in = info.data();
+            const uint32_t qmask = (uint32_t)n_part - 1u;
+            for (size_t g = g_lo; g < g_end; g++) {
+                const rinfo &r = in[g];
+                if (((r.h_hi >> 8) & qmask) != (uint32_t)q) continue;
+                if ((T.count + 1) * 2 > T.n && !ptable_reserve(T, T.count * 2 + 1024)) { T.oom = true; return; }
+                const size_t mask = T.n - 1;
+                size_t si = (size_t)r.h_lo & mask;
+                uint32_t found1 = 0;
+                while (T.p[si].gid1) {
+                    if (T.p[si].tag == r.h_hi) {
+                        const rinfo &w = in[T.p[si].gid1 - 1];
+                        if (w.h_lo == r.h_lo && w.key_len == r.key_len && memcmp(w.key, r.key, (size_t)r.key_len) == 0) {
+                            found1 = T.p[si].gid1;
+                            break;
+                        }
+                    }
+                    si = (si + 1) & mask;
+                }
+                if (!found1) {
+                    T.p[si] = slot{r.h_hi, (uint32_t)g + 1u};
+                    T.count++;
+                } else {
+                    info[g].dup_of1 = found1;                               // (only this partition's thread writes this entry)
+                    T.dups.push_back((uint32_t)g);
+                }
+            }
+        };
+        auto run = [&](int n, auto &&fn) {
+            if (n <= 1) { if (n == 1) fn(0); return; }
+            std::vector<std::thread> th;
+            for (int t = 0; t < n; t++) th.emplace_back([&fn, t] { fn(t); });
+            for (auto &t : th) t.join();
+        };
+        run(n_valid, fill);
+        if (g_end - g_lo < 4096) { for (int q = 0; q < n_part; q++) place(q); }
+        else run(n_part, place);
+        for (auto &T : tabs)
+            if (T.oom) return fail(-6, "out of memory");
+        // (c) the records whose key was there already, in file order: their characters behind the row's
+        {
+            std::vector<uint32_t> dups;
+            for (auto &T : tabs) dups.insert(dups.end(), T.dups.begin(), T.dups.end());
+            std::sort(dups.begin(), dups.end());
+            for (uint32_t g : dups) {
+                rinfo &w = info[info[g].dup_of1 - 1];
+                const rinfo &r = info[g];
+                std::unique_ptr<uint8_t[]> cp(new (std::nothrow) uint8_t[(size_t)w.len + (size_t)r.len]);
+                if (!cp) return fail(-6, "out of memory");
+                memcpy(cp.get(), w.ch, (size_t)w.len);
+                memcpy(cp.get() + w.len, r.ch, (size_t)r.len);
+                w.ch = cp.get();
+                w.len += r.len;
+                moved.push_back(std::move(cp));
+            }
+        }
+        for (int t = 0; t < nt; t++) bigvec<kept>().swap(kept_parts[p0 + (size_t)t]->recs);      // only the characters and keys are still needed
         tm[3] += secs(T3, now());
         if (done) break;
-        if (bad) return fail(-4, "bad BAM record size %d", bad_size);
         z.consume(o);
     }
     if (getenv("GIO_TIMING"))
-        fprintf(stderr, "gio: setup %.3f s, read+inflate %.3f, framing %.3f, records (%d threads) %.3f, key table %.3f, scan done at %.3f s\n",
-                t_setup, tm[0] + tm[4], tm[1], n_threads(), tm[2], tm[3], secs(t_begin, now()));
+        fprintf(stderr, "gio: setup %.3f s, read+inflate %.3f, framing + records (%d threads) %.3f, key table (%d partitions) %.3f, scan done at %.3f s\n",
+                t_setup, tm[0] + tm[4], n_threads(), tm[2], n_part, tm[3], secs(t_begin, now()));
 
-    const int64_t n = (int64_t)reads.size();
-    int64_t total = 0;
-    for (auto &x : reads) total += (int64_t)x.len;
+    // the table: the records that opened a row, in file order.  Ranges of gids on the threads: count, then place.
+    const int64_t n_rec = (int64_t)info.size();
+    const int nt_out = (int)std::min<int64_t>((int64_t)n_threads(), n_rec / 65536 + 1);
+    std::vector<int64_t> rows_in((size_t)nt_out + 1, 0), chars_in((size_t)nt_out + 1, 0);
+    auto run_out = [&](auto &&fn) {
+        if (nt_out <= 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt_out; t++) th.emplace_back([&fn, t] { fn(t); });
+        for (auto &t : th) t.join();
+    };
+    run_out([&](int t) {
+        int64_t r = 0, c = 0;
+        for (int64_t g = n_rec * t / nt_out, hi = n_rec * (t + 1) / nt_out; g < hi; g++)
+            if (!info[(size_t)g].dup_of1) { r++; c += (int64_t)info[(size_t)g].len; }
+        rows_in[(size_t)t + 1] = r;
+        chars_in[(size_t)t + 1] = c;
+    });
+    for (int t = 0; t < nt_out; t++) { rows_in[(size_t)t + 1] += rows_in[(size_t)t]; chars_in[(size_t)t + 1] += chars_in[(size_t)t]; }
+    const int64_t n = rows_in[(size_t)nt_out], total = chars_in[(size_t)nt_out];
     out->rank = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
     out->off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
     out->bases = (uint8_t *)malloc((size_t)(total ? total : 1));
     if (!out->rank || !out->off || !out->bases) { gio_table_free(out); return fail(-6, "out of memory"); }
-    int64_t acc = 0;
-    for (int64_t i = 0; i < n; i++) {
-        out->rank[i] = reads[i].rank;
-        out->off[i] = acc;
-        acc += (int64_t)reads[i].len;
-    }
-    out->off[n] = acc;
-    {
-        // the characters: row ranges on the threads
-        const int nt = (int)std::min<int64_t>((int64_t)n_threads(), n / 65536 + 1);
-        auto copy = [&](int t) {
-            const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
-            for (int64_t i = lo; i < hi; i++) memcpy(out->bases + out->off[i], reads[i].ch, (size_t)reads[i].len);
-        };
-        if (nt <= 1) copy(0);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++) th.emplace_back(copy, t);
-            for (auto &t : th) t.join();
+    run_out([&](int t) {
+        int64_t r = rows_in[(size_t)t], c = chars_in[(size_t)t];
+        for (int64_t g = n_rec * t / nt_out, hi = n_rec * (t + 1) / nt_out; g < hi; g++) {
+            const rinfo &x = info[(size_t)g];
+            if (x.dup_of1) continue;
+            out->rank[r] = x.rank;
+            out->off[r] = c;
+            memcpy(out->bases + c, x.ch, (size_t)x.len);
+            r++;
+            c += (int64_t)x.len;
         }
-    }
+    });
+    out->off[n] = total;
     out->n_reads = n;
     out->n_bases = total;
     g_stats.reads_kept = n;

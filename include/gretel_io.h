@@ -48,7 +48,7 @@ typedef struct {
     int32_t used_index;         /* 1: started from a .bai offset and stopped behind the window */
     int32_t libdeflate;         /* 1: libdeflate, 0: zlib */
     int32_t threads;
-    int32_t _pad;
+    int32_t reframed;           /* batches done again front to back because a thread's guessed first record was none */
     double seconds;             /* wall time of the call */
 } gio_stats;
 

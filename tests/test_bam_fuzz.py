@@ -143,3 +143,48 @@ def test_repeated_keys_and_errors_keep_file_order_across_threads(tmp_path):
     with pytest.raises(Exception) as ei:
         util.support_table_from_bam(bad, "c", 1, length, v)
     assert "exceed" in str(ei.value)
+
+
+def test_a_decoy_record_inside_a_tag_cannot_fool_the_threads(tmp_path):
+    """The decoder's threads start in the middle of the inflated window at a place that LOOKS like a record; here every
+    record carries a byte-array tag that holds three perfectly formed records.  A thread that starts on such a decoy is
+    found out (the chain of the thread in front of it does not end there) and the batch is done again front to back."""
+    rng = np.random.default_rng(11)
+    n_snps, spacing = 60, 10
+    length = spacing * n_snps + spacing
+
+    def record(name, pos0, seq, aux=b""):
+        nm = name.encode() + b"\x00"
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i >> 1] |= "=ACMGRSVTWYHKDBN".index(ch) << (4 if (i & 1) == 0 else 0)
+        body = struct.pack("<iiBBHHHiiii", 0, pos0, len(nm), 42, 4681, 1, 0, len(seq), -1, -1, 0)
+        body += nm + struct.pack("<I", (len(seq) << 4) | 0) + bytes(packed) + b"\x7e" * len(seq) + aux
+        return struct.pack("<i", len(body)) + body
+
+    decoy = b"".join(record("decoy%d" % i, 5, "ACGTACGTACGT") for i in range(3))
+    aux = b"XXBC" + struct.pack("<I", len(decoy)) + decoy
+    recs, rows = [], []
+    for r in range(1500):
+        k = int(rng.integers(2, 5))
+        first = int(rng.integers(0, n_snps - k))
+        seq = bytearray(b"A" * ((k - 1) * spacing + 1))
+        for q in range(k):
+            seq[q * spacing] = ord("ACGT"[int(rng.integers(0, 4))])
+        recs.append((spacing * (first + 1) - 1, "r%d" % r, seq.decode()))
+    recs.sort(key=lambda x: x[0])
+    text = "@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:c\tLN:%d\n" % length
+    data = b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<ii", 1, 2) + b"c\x00" + struct.pack("<i", length)
+    data += b"".join(record(nm, pos0, seq, aux) for pos0, nm, seq in recs)
+    bam, vcf = str(tmp_path / "decoy.bam"), str(tmp_path / "decoy.vcf.gz")
+    bamio.bgzf_write(bam, data)
+    bamio.write_vcf_gz(vcf, "c", [spacing * (s + 1) for s in range(n_snps)])
+    v = util.process_vcf(vcf, "c", 1, length)
+    a = util.support_table_from_bam(bam, "c", 1, length, v)
+    st = bamio.native_last_stats()
+    b = util.support_table_from_bam(bam, "c", 1, length, v, decoder="python")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert len(a[0]) == 1500 and st["records"] == 1500
+    if st["threads"] > 1:
+        assert st["reframed"] >= 1          # three quarters of the window are decoys: some thread started on one
