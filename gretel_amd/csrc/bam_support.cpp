@@ -230,6 +230,7 @@ public:
         taken_ = 0;
         skip_ = uoffset;
         eof_ = false;
+        more_ = false;
         return 0;
     }
 
@@ -260,17 +261,22 @@ private:
         // small first batches (the header, an index seek right behind it), then 4 MB at a time (the inflated window is reused from batch to batch: fresh pages are the expensive part)
         const size_t BATCH = batch_;
         if (batch_ < ((size_t)4 << 20)) batch_ *= 4;
+        // (compressed bytes a capped window left behind are inflated before more are read)
         const size_t have = cbuf_.size();
-        cbuf_.resize(have + BATCH);
-        const size_t got = fread(cbuf_.data() + have, 1, BATCH, fp_);
-        cbuf_.resize(have + got);
-        g_stats.compressed_bytes += (int64_t)got;
-        taken_ += got;
-        if (got == 0) {
-            eof_ = true;
-            if (!cbuf_.empty()) return fail(-4, "truncated BGZF block at the end of %s", path_.c_str());
-            return 0;
+        size_t got = 0;
+        if (have < ((size_t)1 << 17) || !more_) {
+            cbuf_.resize(have + BATCH);
+            got = fread(cbuf_.data() + have, 1, BATCH, fp_);
+            cbuf_.resize(have + got);
+            g_stats.compressed_bytes += (int64_t)got;
+            taken_ += got;
+            if (got == 0 && !more_) {
+                eof_ = true;
+                if (!cbuf_.empty()) return fail(-4, "truncated BGZF block at the end of %s", path_.c_str());
+                return 0;
+            }
         }
+        more_ = false;
         std::vector<blk> blocks;
         size_t o = 0, total = 0;
         while (o + 18 <= cbuf_.size()) {
@@ -288,6 +294,9 @@ private:
             if (o + bsize > cbuf_.size()) break;
             const size_t isize = rdu32(b + bsize - 4);
             if (isize > 65536) return fail(-4, "BGZF block claims %zu bytes in %s", isize, path_.c_str());
+            // the inflated window stays within WINDOW bytes (what is touched once and freed again costs page faults and
+            // unmapping: 116 MB for a million short reads in one piece); the blocks behind wait in cbuf_
+            if (total + isize > WINDOW && !blocks.empty()) { more_ = true; break; }
             blocks.push_back({o + 12 + xlen, bsize - 12 - xlen - 8, isize, total});
             total += isize;
             o += bsize;
@@ -327,6 +336,9 @@ private:
     std::string path_;
     std::vector<uint8_t> cbuf_;
     rawbuf out_;
+    // (GIO_WINDOW: the tests make it one block)
+    const size_t WINDOW = getenv("GIO_WINDOW") ? (size_t)atol(getenv("GIO_WINDOW")) : ((size_t)32 << 20);
+    bool more_ = false;                                               // whole blocks are waiting in cbuf_
     size_t rd_ = 0, skip_ = 0, batch_ = (size_t)1 << 18;
     uint64_t fsize_ = 0, start_ = 0, taken_ = 0;
     bool eof_ = false;
@@ -700,7 +712,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         o.recs.push_back(kept{h, rank, (uint32_t)k0, (uint32_t)(o.keys.size() - k0), (uint32_t)ch0, (uint32_t)(o.chars.size() - ch0)});
         return 0;
     };
-    double tm[5] = {0, 0, 0, 0, 0};
+    double tm[5] = {0, 0, 0, 0, 0}, kt[3] = {0, 0, 0};
     const double t_setup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -738,6 +750,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         }
         return (size_t)-1;
     };
+    std::vector<std::vector<uint32_t>> lists;                               // [part][partition] -> gids, per batch
     bool done = false;
     bool front_to_back = false;                                             // this batch again on one thread (a guessed start was wrong)
     while (!done) {
@@ -849,15 +862,22 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                 if (!ptable_reserve(T, est / (size_t)n_part + est / (size_t)(4 * n_part) + 1024)) return fail(-6, "out of memory");
         }
         // (a) the parts' records into info, each part by the thread that made it
+        if (lists.size() < (size_t)n_valid * (size_t)n_part) lists.resize((size_t)n_valid * (size_t)n_part);
         auto fill = [&](int t) {
             const part &P = *kept_parts[p0 + (size_t)t];
             const uint8_t *cbase = P.chars.data();
             const char *kbase = P.keys.data();
             rinfo *dst = info.data() + gbase[(size_t)t];
             const size_t nr = P.recs.size();
+            // ... and their numbers sorted by partition (a partition's thread then only touches its own records)
+            std::vector<uint32_t> *mine = lists.data() + (size_t)t * (size_t)n_part;
+            for (int q = 0; q < n_part; q++) { mine[q].clear(); mine[q].reserve(nr / (size_t)n_part + nr / (size_t)(8 * n_part) + 16); }
+            const uint32_t qmask = (uint32_t)n_part - 1u;
+            const uint32_t g0 = (uint32_t)gbase[(size_t)t];
             for (size_t i = 0; i < nr; i++) {
                 const kept &k = P.recs[i];
                 dst[i] = rinfo{cbase + k.ch_off, kbase + k.key_off, k.rank, (int32_t)k.ch_len, (int32_t)k.key_len, (uint32_t)k.h, (uint32_t)(k.h >> 32), 0u};
+                mine[(uint32_t)(k.h >> 40) & qmask].push_back(g0 + (uint32_t)i);
             }
         };
         // (b) partition q takes the records whose hash says q, in file order
@@ -866,10 +886,15 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             ptable &T = tabs[(size_t)q];
             T.dups.clear();
             const rinfo *in = info.data();
-            const uint32_t qmask = (uint32_t)n_part - 1u;
-            for (size_t g = g_lo; g < g_end; g++) {
+            for (int t = 0; t < n_valid; t++) {
+            const std::vector<uint32_t> &lst = lists[(size_t)t * (size_t)n_part + (size_t)q];
+            const size_t nl = lst.size();
+            for (size_t li = 0; li < nl; li++) {
+                // (two cache misses per record, both known ahead: its entry, then its slot)
+                if (li + 16 < nl) __builtin_prefetch(&in[lst[li + 16]]);
+                if (li + 8 < nl && T.n) __builtin_prefetch(&T.p[(size_t)in[lst[li + 8]].h_lo & (T.n - 1)]);
+                const uint32_t g = lst[li];
                 const rinfo &r = in[g];
-                if (((r.h_hi >> 8) & qmask) != (uint32_t)q) continue;
                 if ((T.count + 1) * 2 > T.n && !ptable_reserve(T, T.count * 2 + 1024)) { T.oom = true; return; }
                 const size_t mask = T.n - 1;
                 size_t si = (size_t)r.h_lo & mask;
@@ -892,6 +917,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                     T.dups.push_back((uint32_t)g);
                 }
             }
+            }
         };
         auto run = [&](int n, auto &&fn) {
             if (n <= 1) { if (n == 1) fn(0); return; }
@@ -899,9 +925,13 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             for (int t = 0; t < n; t++) th.emplace_back([&fn, t] { fn(t); });
             for (auto &t : th) t.join();
         };
+        auto K0 = now();
         run(n_valid, fill);
+        auto K1 = now();
         if (g_end - g_lo < 4096) { for (int q = 0; q < n_part; q++) place(q); }
         else run(n_part, place);
+        auto K2 = now();
+        kt[0] += secs(T3, K0); kt[1] += secs(K0, K1); kt[2] += secs(K1, K2);
         for (auto &T : tabs)
             if (T.oom) return fail(-6, "out of memory");
         // (c) the records whose key was there already, in file order: their characters behind the row's
@@ -927,8 +957,8 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         z.consume(o);
     }
     if (getenv("GIO_TIMING"))
-        fprintf(stderr, "gio: setup %.3f s, read+inflate %.3f, framing + records (%d threads) %.3f, key table (%d partitions) %.3f, scan done at %.3f s\n",
-                t_setup, tm[0] + tm[4], n_threads(), tm[2], n_part, tm[3], secs(t_begin, now()));
+        fprintf(stderr, "gio: setup %.3f s, read+inflate %.3f, framing + records (%d threads) %.3f, key table (%d partitions) %.3f = sizing %.3f + entries %.3f + placing %.3f + repeats, scan done at %.3f s\n",
+                t_setup, tm[0] + tm[4], n_threads(), tm[2], n_part, tm[3], kt[0], kt[1], kt[2], secs(t_begin, now()));
 
     // the table: the records that opened a row, in file order.  Ranges of gids on the threads: count, then place.
     const int64_t n_rec = (int64_t)info.size();

@@ -25,7 +25,7 @@ def test_malformed_bams_never_read_out_of_bounds(tmp_path):
     bam, vcf = str(tmp_path / "v.bam"), str(tmp_path / "v.vcf.gz")
     contig, s, e = bamio.synth_to_files(t, bam, vcf)
     # (two threads, a new part every 16 records: the per-thread parts and their merge run under the sanitizers too)
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", GIO_THREADS="2", GIO_PART_RECORDS="16")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", GIO_THREADS="2", GIO_PART_RECORDS="16", GIO_WINDOW="70000")
     for seed, src_bam, ctg, end in ((1, bam, contig, e), (2, os.path.join(REFDATA, "test.bam"), "hoot", 20)):
         run = subprocess.run([exe, src_bam, ctg, str(end), "700", str(seed), str(tmp_path / "scratch.bam")],
                              capture_output=True, text=True, env=env, timeout=600)
@@ -51,8 +51,13 @@ def test_index_and_full_scan_agree(tmp_path):
         finally:
             del os.environ["GIO_NO_INDEX"]
         c = util.support_table_from_bam(bam, contig, ws, we, v, decoder="python")
-        for x, y, z in zip(a, b, c):
-            assert np.array_equal(x, y) and np.array_equal(x, z)
+        os.environ["GIO_WINDOW"] = "100000"                  # the inflated window capped at one or two blocks
+        try:
+            d = util.support_table_from_bam(bam, contig, ws, we, v)
+        finally:
+            del os.environ["GIO_WINDOW"]
+        for x, y, z, w in zip(a, b, c, d):
+            assert np.array_equal(x, y) and np.array_equal(x, z) and np.array_equal(x, w)
         if we < e // 2:
             assert st["records"] < t.n_reads                 # the indexed scan stopped behind the window
 
