@@ -2,11 +2,14 @@
 // (C ABI: include/gretel_io.h).  Host-only C++; replaces the pysam pileup of the reference
 // (gretel/util.py:120-209) for the ingest half of load_from_bam.
 //
-// The file is STREAMED: compressed bytes are read in batches, the BGZF blocks of a batch are inflated in parallel
-// (libdeflate when the runtime library is present, zlib otherwise), the records of the batch are framed front to back
-// and worked on by several threads (CIGAR walk, support characters, key and its hash: functions of the record alone);
-// only the key table -- first-seen order of the rows, appends to a key seen before -- takes them one by one, in file
-// order.  What a batch cuts in two is carried over to the next.  GIO_TIMING=1 prints the time of each stage.
+// The file is STREAMED: compressed bytes are read in batches and the BGZF blocks of a batch inflated in parallel
+// (libdeflate when the runtime library is present, zlib otherwise) into a window of at most 32 MB.  Every thread then
+// takes a byte range of the window, finds where a record plausibly starts in it, and frames and works on records from
+// there (CIGAR walk from SNP to SNP, support characters, key and its hash: functions of the record alone); the chain of
+// the thread in front must end exactly on that start, or the window is done again front to back.  The key table --
+// first-seen order of the rows, appends to a key seen before -- is cut into partitions by hash bits, one thread each: a
+// record is the first with its key or not whatever the other partitions hold, and file order lives in the records'
+// numbers.  What a window cuts in two is carried over to the next.  GIO_TIMING=1 prints the time of each stage.
 // With an index next to the file (<bam>.bai or <stem>.bai) the
 // stream starts at the first block that can hold an alignment overlapping the window and stops at the first record
 // behind it (coordinate-sorted input, as the reference's pysam fetch/pileup requires as well); without one the whole
