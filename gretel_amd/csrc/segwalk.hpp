@@ -47,16 +47,24 @@ struct seg_params {
 // -------------------------------------------------------------------------------------------------------------
 // k_seg
 // -------------------------------------------------------------------------------------------------------------
-// first-wins arg-max over R sums (gretel.py:166-174: the first candidate is the incumbent, a later one wins on strict >)
+// first-wins arg-max over R sums (gretel.py:166-174: the first candidate is the incumbent, a later one wins on strict >).
+// As a tournament: the incumbent of a pair is its first member unless the second is strictly greater, and a later pair
+// (or the fifth value) only wins on strictly greater than the maximum so far -- the same index as the scan front to
+// back for every input without NaNs (the sums are finite or -inf), with v_max_f64 where the scan needs two
+// v_cndmask per value it carries along.
 template <int R>
 __device__ __forceinline__ unsigned seg_argmax(const double (&v)[R])
 {
-    double best = v[0];
-    unsigned bi = 0;
-#pragma unroll
-    for (int b = 1; b < R; b++)
-        if (v[b] > best) { best = v[b]; bi = b; }
-    return bi;
+    static_assert(R == 4 || R == 5, "four ranks or five symbols");
+    const bool c01 = v[1] > v[0], c23 = v[3] > v[2];
+    const double m01 = vmax_f64(v[0], v[1]), m23 = vmax_f64(v[2], v[3]);
+    const bool c = m23 > m01;
+    unsigned idx = c ? (c23 ? 3u : 2u) : (c01 ? 1u : 0u);
+    if constexpr (R == 5) {
+        const double m = vmax_f64(m01, m23);
+        idx = v[4] > m ? 4u : idx;
+    }
+    return idx;
 }
 
 template <int R, int LC>
