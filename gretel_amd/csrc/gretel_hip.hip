@@ -1355,7 +1355,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             // (a look costs ~25 us of idle GPU; an open chain costs the ~37 us of idle launches of every path queued
             // behind it: at one open chain in 50..100 paths the optimum is 8..16 paths per look)
             if (CHUNK < 16) CHUNK *= 2;
-            if (++clean >= 6 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
+            if (++clean >= 3 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
         } else { CHUNK = 8; clean = 0; }
         if (hs.lt_stale || hs.cw_unres) {
             e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
@@ -1367,6 +1367,9 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             // idled, and the reweights that ran kept their rows.
             h->lt_inc_path = nullptr;
             h->dirty_lt = hs.lt_stale || hs.cw_unres == 2;
+            // an open chain costs a look, the resumed rounds and the idle launches of everything queued behind it -- far
+            // more than an idle round (three empty launches) on every path: queue one round more from now on
+            if (hs.cw_unres == 1 && h->cw_rounds < 8) h->cw_rounds++;
             if (hs.cw_unres == 2) h->cw_off = true;         // five candidates somewhere: the serial walkers take the window
             else if (hs.cw_unres == 1 && done < max_paths) {
                 // the queued rounds did not close this path's chain.  Its pools keep what has been walked (the tensor
