@@ -48,7 +48,7 @@ __host__ __device__ inline cw_geom cw_geometry(int N, int L)
     return g;
 }
 // positions per LDS chunk of k_cwalk: (c + L - 1) sources x 4 rows x L lags x 5 columns of doubles within the budget
-__host__ __device__ constexpr int cw_lds_budget(int L) { return L <= 13 ? 76 * 1024 : (L <= 16 ? 96 * 1024 : 150 * 1024); }
+__host__ __device__ constexpr int cw_lds_budget(int L) { return L <= 13 ? 76 * 1024 : (L <= 17 ? 96 * 1024 : (L <= 19 ? 120 * 1024 : 150 * 1024)); }
 __host__ __device__ constexpr int cw_chunk(int L)
 {
     int c = 64;

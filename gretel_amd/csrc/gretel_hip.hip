@@ -1378,18 +1378,27 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
                 bool closed = false;
                 if (!hs.lt_stale) {
                     if ((rc = ensure_lt(h))) break;
-                    const int more = h->L > 16 ? 48 : 12;      // (the serial walker of L > 16 is the slow one)
-                    if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, more, 0, true))) break;
-                    if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
-                    h->cw_stat[2] += more;
-                    e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
-                    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-                    if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
-                    closed = !hs.cw_unres && hs.n_done > done;
-                    if (hs.cw_unres) {
-                        e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
+                    // Every round carries the verified chain at least one segment further (the state it stopped at joins
+                    // the next pool and is walked), so S rounds always close it.  Beyond 16 lags the serial walker is
+                    // k_walk_global, 3 ms per thousand SNPs: there the rounds go on until the chain is closed; up to 16
+                    // lags the depth-2 walker costs about as much as a dozen rounds, and takes over after those.
+                    const int more = h->L > 16 ? 48 : 12;
+                    const int tries = h->L > 16 ? (cg.S + 16) / more + 1 : 1;
+                    for (int a = 0; a < tries && !closed; a++) {
+                        if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, more, 0, true))) break;
+                        if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+                        h->cw_stat[2] += more;
+                        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+                        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                         if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                        closed = !hs.cw_unres && hs.n_done > done;
+                        if (hs.cw_unres) {
+                            e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
+                            if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+                        }
+                        if (hs.stop) break;
                     }
+                    if (rc != GH_OK) break;
                 }
                 if (!closed) {
                     h->cw_stamp++;
