@@ -27,6 +27,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -125,6 +126,7 @@ struct gh_handle {
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
     uint8_t *stage;        // pinned host staging for the results of a spin
     size_t stage_cap;
+    const gh_reads *last_reads;   // the table of the last gh_fill (not owned: see reads_alive)
     int cw_round_cap;      // GH_CW_ROUND_CAP=k at creation (tests): never more than k rounds per launch, so that chains stay open and the serial fallback runs
     int spin_partial_stride;   // doubles between two paths' partial sums of the removed mass in a spin (0 outside spins)
     int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
@@ -158,6 +160,16 @@ struct gh_reads {
     int span_pos;     // sorted tables: widest run of positions one workgroup of k_fill_sorted (FILL_RPB reads) covers
 };
 #define FILL_RPB 2048     /* reads per workgroup of k_fill_sorted */
+
+// The read tables that are alive: a handle remembers the table it was last filled from (the candidate pools of
+// cwalk.hpp are started from its reads) but does not own it -- the pointer is only used while it is still in this set.
+static std::mutex g_reads_mu;
+static std::vector<const gh_reads *> g_reads_live;
+static bool reads_alive(const gh_reads *r)
+{
+    std::lock_guard<std::mutex> g(g_reads_mu);
+    return std::find(g_reads_live.begin(), g_reads_live.end(), r) != g_reads_live.end();
+}
 
 static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STORAGE_F64 ? 8 : 4; }
 
@@ -297,6 +309,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
     h->stage = nullptr; h->stage_cap = 0;
+    h->last_reads = nullptr;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
@@ -461,6 +474,10 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
         delete r;
         return fail(GH_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
+    {
+        std::lock_guard<std::mutex> g(g_reads_mu);
+        g_reads_live.push_back(r);
+    }
     *out = r;
     return GH_OK;
 }
@@ -468,6 +485,10 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
 extern "C" int gh_reads_free(gh_reads_t *r)
 {
     if (!r) return GH_OK;
+    {
+        std::lock_guard<std::mutex> g(g_reads_mu);
+        g_reads_live.erase(std::remove(g_reads_live.begin(), g_reads_live.end(), (const gh_reads *)r), g_reads_live.end());
+    }
     hipSetDevice(r->dev);
     hipFree(r->rank); hipFree(r->off); hipFree(r->bases);
     delete r;
@@ -1325,7 +1346,15 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             uint8_t *pth = d_paths + n1 * done;
             cw_params P = cw_make_params(h, pth, h->spin_lmsel + n1 * done);
             hipLaunchKernelGGL(k_cguess, dim3((unsigned)((h->N + 256) / 256)), dim3(256), 0, h->stream, P, pth);
-            hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, 0);
+            // ... and, when the table the window was filled from is still there (and sorted), from the states its reads show at
+            // the segment boundaries (k_cseed_reads); the guess then only joins them
+            const gh_reads *rd = h->last_reads;
+            const bool from_reads = rd && reads_alive(rd) && rd->sorted && rd->n_reads > 0 && rd->max_k >= h->L &&
+                                    !(getenv("GH_CW_SEED_READS") && atoi(getenv("GH_CW_SEED_READS")) == 0);
+            if (from_reads)
+                hipLaunchKernelGGL(k_cseed_reads, dim3(cg.S), dim3(256), 0, h->stream, P, (const int32_t *)rd->rank, (const int64_t *)rd->off,
+                                   (const uint8_t *)rd->bases, (long long)rd->n_reads, rd->max_k);
+            hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, from_reads ? 1 : 0);
             if ((rc = post_launch(h, "k_cguess/k_cseed"))) break;
             if ((rc = launch_cw_path(h, pth, h->spin_lmsel + n1 * done, CW_BOOT_ROUNDS, 0))) break;
             if ((rc = launch_reweight_marg(h, pth, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
@@ -1346,8 +1375,8 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
         if (getenv("GH_PRINT_STATE"))
-            fprintf(stderr, "gh_spin(cw): n_done %d stop %d lt_stale %d cw_unres %d open_at %d rounds %d\n", hs.n_done, hs.stop, hs.lt_stale,
-                    hs.cw_unres, hs.cw_open_at, h->cw_rounds);
+            fprintf(stderr, "gh_spin(cw): n_done %d stop %d lt_stale %d cw_unres %d open_at %d rounds %d  closed in round 0/1/2/3/4+: %llu %llu %llu %llu %llu\n", hs.n_done, hs.stop, hs.lt_stale,
+                    hs.cw_unres, hs.cw_open_at, h->cw_rounds, hs.dbg8[0], hs.dbg8[1], hs.dbg8[2], hs.dbg8[3], hs.dbg8[4]);
         h->cw_stat[0] += hs.n_done - done;
         done = hs.n_done;
         if (hs.stop) break;
@@ -1355,7 +1384,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             // (a look costs ~25 us of idle GPU; an open chain costs the ~37 us of idle launches of every path queued
             // behind it: at one open chain in 50..100 paths the optimum is 8..16 paths per look)
             if (CHUNK < 16) CHUNK *= 2;
-            if (++clean >= 3 && h->cw_rounds > 2) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
+            if (++clean >= 3 && h->cw_rounds > 1) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
         } else { CHUNK = 8; clean = 0; }
         if (hs.lt_stale || hs.cw_unres) {
             e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);
