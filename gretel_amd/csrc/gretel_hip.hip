@@ -1570,6 +1570,8 @@ struct gh_batch {
     int n, dev, N, W, L;
     std::vector<gh_handle *> hs;
     hipStream_t stream;
+    hipStream_t gstream[3];     // window groups of the batched kernels (gh_batch_spin): created on first use
+    hipEvent_t gevent[3];
     win_desc *d_wd;
     uint8_t *d_paths;
     gh_path_rec *d_recs;
@@ -1583,6 +1585,10 @@ extern "C" int gh_batch_destroy(gh_batch_t *b)
     hipSetDevice(b->dev);
     if (b->stream) hipStreamSynchronize(b->stream);
     hipFree(b->d_wd); hipFree(b->d_paths); hipFree(b->d_recs); hipFree(b->d_partial);
+    for (int g = 0; g < 3; g++) {
+        if (b->gstream[g]) { hipStreamSynchronize(b->gstream[g]); hipStreamDestroy(b->gstream[g]); }
+        if (b->gevent[g]) hipEventDestroy(b->gevent[g]);
+    }
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
     return GH_OK;
@@ -1607,6 +1613,7 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     b->n = n; b->dev = h0->dev; b->N = h0->N; b->W = h0->W; b->L = 0;
     b->hs.assign(handles, handles + n);
     b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
+    for (int g = 0; g < 3; g++) { b->gstream[g] = nullptr; b->gevent[g] = nullptr; }
     b->cap_paths = 0;
     b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_marg<.., true>
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
@@ -1702,45 +1709,66 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     size_t lt_nb_inc = 64;                  // batched launches keep no walker tables: the steady-state k_lt only checks flags
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = lt_incremental_ok(h0);
+    // The windows go in up to three GROUPS, each on its own stream and one phase behind the group in front: a path is a
+    // serial extension (one workgroup per window, 0.6 ms for 10k SNPs whatever the number of windows: latency) followed by
+    // a reweight (HBM-bound, ~4 us per window).  In step, every group would wait out the extension with an idle memory
+    // system and then share it; staggered, one group reweights while the others extend.
+    static const int groups_env = getenv("GH_BATCH_GROUPS") ? atoi(getenv("GH_BATCH_GROUPS")) : 0;
+    int NG = groups_env > 0 ? groups_env : (n >= 96 ? 3 : (n >= 32 ? 2 : 1));
+    if (NG > 3) NG = 3;
+    if (NG > n) NG = n;
+    for (int g = 0; g < NG; g++) {
+        if (!b->gstream[g]) HIPCHK(hipStreamCreateWithFlags(&b->gstream[g], hipStreamNonBlocking));
+        if (!b->gevent[g]) HIPCHK(hipEventCreateWithFlags(&b->gevent[g], hipEventDisableTiming));
+    }
     for (int s = 0; s < max_paths; s++) {
         // any non-null pointer tells k_lt that the fused reweight of spin s-1 has already rewritten the rows it changed
         const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
-        if (s == 0) {
-            hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, b->stream, (dev_state *)nullptr, b->d_wd, 0);
+        for (int g = 0; g < NG; g++) {
+            const int w0 = (int)((long long)n * g / NG), ng = (int)((long long)n * (g + 1) / NG) - w0;
+            const win_desc *gwd = b->d_wd + w0;
+            hipStream_t st = b->gstream[g];
+            if (s == 0) {
+                // (group g starts when group g-1 has finished its first extension)
+                if (g > 0) hipStreamWaitEvent(st, b->gevent[g - 1], 0);
+                hipLaunchKernelGGL(k_rearm, dim3(ng), dim3(64), 0, st, (dev_state *)nullptr, gwd, 0);
+                if (f64)
+                    hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, N, W,
+                                       (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                                       (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                else
+                    hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, ng), dim3(256), 0, st, (float *)nullptr, N, W,
+                                       (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                                       (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, (const double *)nullptr, N, gwd);
+            }
             if (f64)
-                hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
-                                   (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), ng), dim3(256), 0, st, (const double *)nullptr, N, W, L,
+                                   h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                                   (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
+                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
             else
-                hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
+                hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), ng), dim3(256), 0, st, (const float *)nullptr, N, W, L,
+                                   h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                                   (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
+                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
+            launch_walk_any(bwm, N, L, P, st, ng, gwd, s);
+            if (s == 0 && g + 1 < NG) hipEventRecord(b->gevent[g], st);
+            if (f64)
+                hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                   (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
-            hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, (const double *)nullptr, N, b->d_wd);
+                                   (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
+                                   inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
+            else
+                hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, ng), dim3(256), 0, st, (float *)nullptr, N, W,
+                                   (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                                   (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
+                                   inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
+            hipLaunchKernelGGL(k_reweight_finish, dim3(ng), dim3(256), 0, st, (const double *)nullptr, (int)marg_gx,
+                               (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, gwd, s);
         }
-        if (f64)
-            hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const double *)nullptr, N, W, L,
-                               h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                               inc, b->d_wd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
-        else
-            hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), n), dim3(256), 0, b->stream, (const float *)nullptr, N, W, L,
-                               h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
-                               (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                               inc, b->d_wd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
-        launch_walk_any(bwm, N, L, P, b->stream, n, b->d_wd, s);
-        if (f64)
-            hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (double *)nullptr, N, W,
-                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
-                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
-        else
-            hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, n), dim3(256), 0, b->stream, (float *)nullptr, N, W,
-                               (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                               (dev_state *)nullptr, b->d_wd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
-                               inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
-        hipLaunchKernelGGL(k_reweight_finish, dim3(n), dim3(256), 0, b->stream, (const double *)nullptr, (int)marg_gx,
-                           (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, b->d_wd, s);
     }
+    for (int g = 0; g < NG; g++) HIPCHK(hipStreamSynchronize(b->gstream[g]));
     HIPCHK(hipGetLastError());
     std::vector<dev_state> hs(n);
     for (int w = 0; w < n; w++)
