@@ -126,6 +126,7 @@ struct gh_handle {
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
     uint8_t *stage;        // pinned host staging for the results of a spin
     size_t stage_cap;
+    bool seg6;             // inside a gh_spin at L = 6 whose table is ranked: every state of every segment (4^6), not pools
     const gh_reads *last_reads;   // the table of the last gh_fill (not owned: see reads_alive)
     int cw_round_cap;      // GH_CW_ROUND_CAP=k at creation (tests): never more than k rounds per launch, so that chains stay open and the serial fallback runs
     int spin_partial_stride;   // doubles between two paths' partial sums of the removed mass in a spin (0 outside spins)
@@ -310,6 +311,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
     h->stage = nullptr; h->stage_cap = 0;
     h->last_reads = nullptr;
+    h->seg6 = false;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
@@ -936,8 +938,8 @@ static int alloc_seg(gh_handle *h)
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1);
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
-    const seg_geom g4 = seg_geometry(h->N, h->L, 4), g5 = seg_geometry(h->N, h->L, 5);
-    // the layout is decided on the device (st->ranked): size for both
+    // the layout is decided on the device (st->ranked): size for both (L = 6: ranked tables only, see gh_spin)
+    const seg_geom g4 = seg_geometry(h->N, h->L, 4), g5 = seg_radix_ok(5, h->L) ? seg_geometry(h->N, h->L, 5) : g4;
     const size_t hist_b = max2((size_t)g4.S * g4.NW * g4.NS, (size_t)g5.S * g5.NW * g5.NS) * 4;
     const size_t maps_b = max2((size_t)g4.S * g4.NS, (size_t)g5.S * g5.NS) * 2;
     const size_t gmaps_b = max2((size_t)g4.G1 * g4.NS, (size_t)g5.G1 * g5.NS) * 2;
@@ -957,10 +959,11 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
 {
     hipStream_t stream = h->stream;
     const int N = h->N, dev = h->dev;
-    const seg_geom g4 = seg_geometry(N, LC, 4), g5 = seg_geometry(N, LC, 5);
-    const size_t lds_seg = max2(seg_lds_bytes(4, LC), seg_lds_bytes(5, LC));
-    const size_t lds_scan = max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5));
-    const size_t lds_emit = max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5));
+    constexpr bool five = seg_radix_ok(5, LC);
+    const seg_geom g4 = seg_geometry(N, LC, 4), g5 = five ? seg_geometry(N, LC, 5) : g4;
+    const size_t lds_seg = five ? max2(seg_lds_bytes(4, LC), seg_lds_bytes(5, LC)) : seg_lds_bytes(4, LC);
+    const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
+    const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
     // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
     static size_t set_seg[64], set_scan[64], set_emit[64];
     const int dv = dev & 63;
@@ -992,7 +995,8 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
         case 3: launch_seg_lc<3>(h, P); break;
         case 4: launch_seg_lc<4>(h, P); break;
         case 5: launch_seg_lc<5>(h, P); break;
-        default: return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L);
+        case 6: launch_seg_lc<6>(h, P); break;      // (ranked tables only: gh_spin decides)
+        default: return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L_NARROW);
     }
     prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
     return post_launch(h, "k_seg/k_scan/k_emit");
@@ -1003,7 +1007,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
 static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double min_remove, int rearm, double *d_lmsel = nullptr,
                        int check_masks = 0)
 {
-    if (seg_ok(h->wmode, h->L)) return launch_seg_walk(h, d_path, d_lmsel, rearm, check_masks);
+    if (seg_ok(h->wmode, h->L) || h->seg6) return launch_seg_walk(h, d_path, d_lmsel, rearm, check_masks);
     walk_params P;
     P.N = h->N; P.L = h->L; P.chunk = 0; P.rearm = rearm;
     P.G = h->lt; P.Ht = h->ht; P.Yt = h->yt; P.minfo = h->minfo;
@@ -1492,7 +1496,20 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     gh_path_rec *d_recs = h->spin_recs;
     hipError_t e = hipSuccess;
     rc = reset_spin_state(h);
-    const bool seg = seg_ok(h->wmode, h->L);
+    bool seg = seg_ok(h->wmode, h->L);
+    h->seg6 = false;
+    if (rc == GH_OK && !seg && h->wmode == WM_SEG && h->L == SEG_MAX_L_NARROW && !(getenv("GH_SEG6") && atoi(getenv("GH_SEG6")) == 0)) {
+        // 4^6 states can still be enumerated -- 5^6 cannot: look at the layout k_lt chose for this tensor (a window that is
+        // narrow stays narrow: candidates only ever disappear)
+        rc = ensure_lt(h);
+        dev_state look;
+        if (rc == GH_OK) {
+            e = hipMemcpyAsync(&look, h->dstate, sizeof look, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+            else if (look.ranked) { seg = true; h->seg6 = true; }
+        }
+    }
     const int nb = rw_blocks(h, seg || cw_ok(h->wmode, h->L));       // (the widest reweight kernel this spin may launch)
     h->spin_partial_stride = nb;
     if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);       // L only changes through gh_set_L / gh_fill, never inside a spin
@@ -1511,7 +1528,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     int first = 0;
     h->spin_requeues = 0;
     // lag counts 6 .. 24: segments walked from candidate pools (spin_candidate_pools above)
-    const bool cw = rc == GH_OK && cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h);
+    const bool cw = rc == GH_OK && !seg && cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h);
     bool cw_gave_up = false;
     if (cw) {
         spin_io io;
@@ -1559,6 +1576,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         break;
     }
     h->spin_partial_stride = 0;
+    h->seg6 = false;
     if (rc) return rc;
     *n_out = hs.n_done;
     *hole_at = hs.stop ? hs.hole_at : 0;

@@ -18,6 +18,9 @@
 #endif
 #define SEG_MIN_LEN 8          /* shortest segment (positions) */
 #define SEG_MAX_L 5            /* 5^5 = 3125 states still fit; beyond that the serial walkers run */
+#define SEG_MAX_L_NARROW 6     /* ... and 4^6 = 4096 in a window whose positions all have at most four candidates */
+// the five-symbol radix at this lag count?  (R = 4: always)
+__host__ __device__ constexpr bool seg_radix_ok(int R, int L) { return R == 4 ? L <= SEG_MAX_L_NARROW : L <= SEG_MAX_L; }
 
 template <int R> struct seg_radix;
 template <> struct seg_radix<4> { typedef uint8_t next_t;  static constexpr int BITS = 2, DPW = 16; };   // 4 picks of 2 bits per entry
@@ -50,11 +53,11 @@ __host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
     seg_geom g;
     g.NS = seg_ipow(R, L);
     g.NI = g.NS / R;
-    int g2 = 32768 / g.NS;                      // one group's maps (G2 x NS x 2 bytes) within 64 KB of LDS
+    int g2 = (g.NS > 3125 ? 65536 : 32768) / g.NS;      // one group's maps (G2 x NS x 2 bytes) within 64 KB of LDS (128 KB for 4^6 states)
     if (g2 > 16) g2 = 16;
     if (g2 < 1) g2 = 1;
     // groups: k_emit keeps the maps of the groups in front of it in LDS ((G1 - 1) x NS x 2 bytes + one prefix map <= 156 KB)
-    const int g1max = g.NS > 2048 ? 25 : 16;
+    const int g1max = (g.NS > 2048 && g.NS <= 3125) ? 25 : 16;
     const int smax = g1max * g2;
     int len = (N + smax - 1) / smax;
     if (len < SEG_MIN_LEN) len = SEG_MIN_LEN;

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
     // the flags k_marg left for this path; k_scan re-arms them for the next k_marg, k_emit reads the copy
     if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC>(P, seg_smem);
-    else seg_body<5, LC>(P, seg_smem);
+    else if constexpr (seg_radix_ok(5, LC)) seg_body<5, LC>(P, seg_smem);      // (beyond: the host only launches this for ranked tables)
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
         st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f;
     }
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) scan_body<4, LC>(P, seg_smem);
-    else scan_body<5, LC>(P, seg_smem);
+    else if constexpr (seg_radix_ok(5, LC)) scan_body<5, LC>(P, seg_smem);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit(seg_params P)
     if (c.stop || c.lt_stale) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->dbg[3] = 3;      // gh_debug_walk_clock: variant 3 = segment-parallel
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC>(P, seg_smem, c.cur_hole);
-    else emit_body<5, LC>(P, seg_smem, c.cur_hole);
+    else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC>(P, seg_smem, c.cur_hole);
 }
 
 // what the serial walkers' bookkeeper does at the end of a walk: hole -> stop, else the record and the ratio the

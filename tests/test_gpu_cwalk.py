@@ -34,13 +34,20 @@ def _same(res, ref):
     assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("L", [6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 24])
-def test_every_lag_count(L):
-    # long-read-style reads (k ~ Poisson(10)); L = 9 and up also exercises the table rows beyond the eighth lag in k_rw
+@pytest.mark.parametrize("L", [-6, 6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 24])
+def test_every_lag_count(L, monkeypatch):
+    # long-read-style reads (k ~ Poisson(10)); L = 9 and up also exercises the table rows beyond the eighth lag in k_rw.
+    # L = 6 in a window without a five-candidate position enumerates its 4^6 states (variant 3); -6: the pools all the same
+    if L < 0:
+        monkeypatch.setenv("GH_SEG6", "0")
+        L = -L
+        want = 4
+    else:
+        want = 3 if L == 6 else 4
     t = make_support_table(2500, 30000, k=None, seed=200 + L)
     h, o = _pair(t, L=L)
     res, ref = h.spin(24), o.spin(24)
-    assert h.walk_clock()[3] == 4
+    assert h.walk_clock()[3] == want
     _same(res, ref)
     assert np.array_equal(h.export_band(), o.export_band())
     hs, _ = _pair(t, L=L, walk="spec")
