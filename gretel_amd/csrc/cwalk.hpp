@@ -1,5 +1,5 @@
 // cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated
-// (L = 6..24: 4^L states; segwalk.hpp enumerates up to 4^5), included by gretel_hip.hip behind segwalk.hpp.
+// (L = 6..24: 4^L states; segwalk.hpp enumerates up to 5^5, and 4^6 when the table is ranked), included by gretel_hip.hip behind segwalk.hpp.
 //
 // Same decomposition -- cut the window into <= 256 segments, know for every segment what it does to the state that
 // enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states (<= 64 per
