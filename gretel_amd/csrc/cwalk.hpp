@@ -1,4 +1,5 @@
 // cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated
+// (ranked tables: 2 bits per pick, up to 24 lags; tables over the symbols -- a five-candidate position somewhere --: 3 bits, up to 21)
 // (L = 6..24: 4^L states; segwalk.hpp enumerates up to 5^5, and 4^6 when the table is ranked), included by gretel_hip.hip behind segwalk.hpp.
 //
 // Same decomposition -- cut the window into <= 256 segments, know for every segment what it does to the state that
@@ -23,7 +24,6 @@
 #pragma once
 
 #define CW_K 64                 /* pool entries per segment */
-#define CW_THREADS (4 * CW_K)   /* four lanes per entry */
 #define CW_MIN_L 6
 #define CW_MAX_L 24             /* 2 bits per pick in a 64-bit state; beyond 24 lags the table slice of a chunk outgrows the LDS */
 typedef unsigned long long cw_key;
@@ -35,7 +35,7 @@ typedef unsigned long long cw_key;
 // leaves room for two workgroups per CU (L <= 13: 76 KB each) the window is cut into twice as many, half as long
 // segments, and every SIMD has two walkers to interleave.
 __host__ __device__ constexpr int cw_max_seg(int L) { return L <= 13 ? 512 : 256; }
-struct cw_geom { int seglen, S, NW; };
+struct cw_geom { int seglen, S, NW, NW5; };               // words of picks per entry: 16 per word (ranks), 8 per word (symbols)
 __host__ __device__ inline cw_geom cw_geometry(int N, int L)
 {
     cw_geom g;
@@ -45,17 +45,31 @@ __host__ __device__ inline cw_geom cw_geometry(int N, int L)
     g.seglen = len;
     g.S = (N + len - 1) / len;
     g.NW = (len + 15) / 16;
+    g.NW5 = (len + 7) / 8;
     return g;
 }
-// positions per LDS chunk of k_cwalk: (c + L - 1) sources x 4 rows x L lags x 5 columns of doubles within the budget
-__host__ __device__ constexpr int cw_lds_budget(int L) { return L <= 13 ? 76 * 1024 : (L <= 17 ? 96 * 1024 : (L <= 19 ? 120 * 1024 : 150 * 1024)); }
-__host__ __device__ constexpr int cw_chunk(int L)
+// R = 4: the ranked table (every position has at most four candidates), 2 bits per pick, four lanes per pool entry.
+// R = 5: the table over the symbols A C G T - (a position with five candidates somewhere), 3 bits per pick -- 21 lags in a
+// 64-bit state --, eight lanes per entry (five at work), five rows per source in LDS.
+#define CW_MAX_L5 21
+__host__ __device__ constexpr int cw_lanes(int R) { return R == 4 ? 4 : 8; }
+__host__ __device__ constexpr int cw_bits(int R) { return R == 4 ? 2 : 3; }
+// rows of a source staged in LDS: 0..3 of the ranked table; all six of the symbol table (rows 0..4 are used; six keep the
+// slice one contiguous, 16-byte-divisible run of G)
+__host__ __device__ constexpr int cw_rows(int R) { return R == 4 ? 4 : 6; }
+// positions per LDS chunk of k_cwalk: (c + L - 1) sources x rows x L lags x 5 columns of doubles within the budget
+__host__ __device__ constexpr int cw_lds_budget(int L, int R)
+{
+    return R == 4 ? (L <= 13 ? 76 * 1024 : (L <= 17 ? 96 * 1024 : (L <= 19 ? 120 * 1024 : 150 * 1024)))
+                  : (L <= 12 ? 76 * 1024 : (L <= 13 ? 96 * 1024 : (L <= 15 ? 120 * 1024 : 150 * 1024)));
+}
+__host__ __device__ constexpr int cw_chunk(int L, int R)
 {
     int c = 64;
-    while (c > 2 && (c + L - 1) * 4 * L * 5 * 8 > cw_lds_budget(L)) c -= 1;
+    while (c > 2 && (c + L - 1) * cw_rows(R) * L * 5 * 8 > cw_lds_budget(L, R)) c -= 1;
     return c;
 }
-__host__ __device__ constexpr size_t cw_lds_bytes(int L) { return (size_t)(cw_chunk(L) + L - 1) * 4 * L * 5 * 8; }
+__host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)(cw_chunk(L, R) + L - 1) * cw_rows(R) * L * 5 * 8; }
 
 struct cw_params {
     int N, L;
@@ -65,7 +79,7 @@ struct cw_params {
     int last_round;           // k_cscan: an open chain after this round flags the path unresolved
     int stamp;                // path counter of the spin (pool entries remember when they were last on a chain)
     int _pad;
-    const double *G;          // ranked layout only
+    const double *G;          // ranked or over the symbols (st->ranked): k_cwalk<LC, 4> / k_cwalk<LC, 5>
     const double *minfo;
     dev_state *st;
     cw_key *keys, *exits;     // [S][CW_K]
@@ -86,9 +100,12 @@ struct cw_params {
 // k_cwalk: quad q of workgroup s walks pool entry q of segment s (if it has not been walked under this tensor), then
 // looks its exit state up in the next segment's pool.
 // -------------------------------------------------------------------------------------------------------------
-template <int LC>
-__global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
+template <int LC, int R>
+__global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
 {
+    constexpr int LPE = cw_lanes(R), BITS = cw_bits(R), NTHR = CW_K * LPE;
+    constexpr unsigned DMASK = (1u << BITS) - 1u;
+    constexpr int PPW = R == 4 ? 16 : 8, WB = R == 4 ? 2 : 4;     // picks per word of hist, bits each
     extern __shared__ __align__(16) unsigned char cw_smem[];
     dev_state *st = P.st;
     const dev_ctl c = load_ctl(st);
@@ -98,7 +115,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
         return;
     }
-    if (!c.ranked) {                                        // a position with five candidates: not this walker's layout
+    if ((c.ranked != 0) != (R == 4)) {                      // the table is not in this instantiation's layout (it was rebuilt): the host looks again
         if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
         return;
     }
@@ -136,30 +153,34 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
     }
     __syncthreads();
     const int n = s_n;
-    const int q = tid >> 2, b = tid & 3;
+    const int q = tid / LPE, b = tid & (LPE - 1);
+    const int bcol = b < R ? b : R - 1;                     // (R = 5: lanes 5..7 of the group read a valid column and carry -inf)
     const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
     if (!__syncthreads_or(live ? 1 : 0)) return;            // nothing new to walk in this segment
-    constexpr int CH = cw_chunk(LC);
-    constexpr cw_key SMASK = LC >= 32 ? ~0ull : ((1ull << (2 * LC)) - 1ull);
-    double *Gs = reinterpret_cast<double *>(cw_smem);       // [(CH + LC - 1)][4][LC][5]: G's own layout, rows 0..3
+    constexpr int CH = cw_chunk(LC, R);
+    constexpr cw_key SMASK = BITS * LC >= 64 ? ~0ull : ((1ull << (BITS * LC)) - 1ull);
+    double *Gs = reinterpret_cast<double *>(cw_smem);       // [(CH + LC - 1)][R][LC][5]: G's own layout, rows 0..R-1
     cw_key sigma = live ? P.keys[(size_t)s * CW_K + q] : 0ull;
     const int t0 = s * g.seglen;
     const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
-    const unsigned shift = (unsigned)(tid & 63 & ~3);       // this quad's bits in the wave's ballot
+    const unsigned shift = (unsigned)(tid & 63 & ~(LPE - 1));     // this lane group's bits in the wave's ballot
+    const int nw_e = R == 4 ? g.NW : g.NW5;
     int word_i = 0;
     unsigned word = 0;
     // The slice of G a chunk needs: sources c0+1-LC .. c0+nc-1.  Rows 0..3 of a source are one contiguous run of 4*L*5
     // doubles in G ([i][row][lag][col]) and go to LDS as they are (16-byte copies).  The loads of chunk k+1 are issued
     // before chunk k is walked and stay in registers under the walk: their latency is off the critical path.
-    constexpr int RUN = 4 * LC * LT_ROW, RUN2 = RUN / 2;          // doubles / double2 per source
-    constexpr int NV = ((CH + LC - 1) * RUN2 + CW_THREADS - 1) / CW_THREADS;
+    constexpr int ROWS = cw_rows(R);
+    constexpr int RUN = ROWS * LC * LT_ROW, RUN2 = RUN / 2;       // doubles / double2 per source
+    static_assert(RUN % 2 == 0, "16-byte copies");
+    constexpr int NV = ((CH + LC - 1) * RUN2 + NTHR - 1) / NTHR;
     lds_v2d pre[NV];
     auto fetch = [&](int c0) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
         const int i_lo = c0 + 1 - LC, total = (nc + LC - 1) * RUN2;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            const int e = tid + k * CW_THREADS;
+            const int e = tid + k * NTHR;
             pre[k] = lds_v2d{0.0, 0.0};
             if (e < total) {
                 const int ii = e / RUN2, r2 = e - ii * RUN2;
@@ -174,13 +195,13 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         lds_v2d *dst = reinterpret_cast<lds_v2d *>(Gs);
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            const int e = tid + k * CW_THREADS;
+            const int e = tid + k * NTHR;
             if (e < total) dst[e] = pre[k];
         }
         if (i_lo <= 0) {                                          // position 0 carries '_' whatever the digit says (row 5)
             __syncthreads();
             const int ii0 = -i_lo;                                // its slot
-            for (int e = tid; e < RUN; e += CW_THREADS) {
+            for (int e = tid; e < RUN; e += NTHR) {
                 const int l = (e / LT_ROW) % LC, bb = e % LT_ROW;
                 Gs[(size_t)ii0 * RUN + e] = P.G[(size_t)(5 * LC + l) * LT_ROW + bb];
             }
@@ -194,24 +215,26 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         __syncthreads();
         if (c0 + CH < t1) fetch(c0 + CH);
         // One step: lag l of chunk-local target tl comes from slot tl + LC - l, row = the pick made l positions ago:
-        // Gs[((slot * 4 + row) * LC + (l - 1)) * 5 + b].  rowoff(l) = that pick's row offset in doubles.
+        // Gs[((slot * ROWS + row) * LC + (l - 1)) * 5 + b].  rowoff(l) = that pick's row offset in doubles.
         auto step = [&](int tl, auto rowoff) {
-            const double *base = Gs + (size_t)tl * RUN + b;
+            const double *base = Gs + (size_t)tl * RUN + bcol;
             double x[LC];
 #pragma unroll
-            for (int l = 1; l <= LC; l++) x[l - 1] = base[((LC - l) * 4 * LC + (l - 1)) * LT_ROW + rowoff(l)];
+            for (int l = 1; l <= LC; l++) x[l - 1] = base[((LC - l) * ROWS * LC + (l - 1)) * LT_ROW + rowoff(l)];
             double acc = x[0];
 #pragma unroll
             for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
+            if (R == 5 && b >= R) acc = -INFINITY;                   // (the idle lanes of the group)
             double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
             m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
+            if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));          // row_half_mirror: the other quad of the eight lanes
             const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
-            const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & 15u);       // first wins (gretel.py:166-174)
-            sigma = ((sigma << 2) | (cw_key)d) & SMASK;
+            const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));       // first wins (gretel.py:166-174)
+            sigma = ((sigma << BITS) | (cw_key)d) & SMASK;
             const int gt = c0 - t0 + tl;                             // position inside the segment
-            word |= d << (2 * (gt & 15));
-            if ((gt & 15) == 15 || gt == t1 - t0 - 1) {
-                if (live && b == 0) P.hist[((size_t)s * g.NW + word_i) * CW_K + q] = word;
+            word |= d << (WB * (gt % PPW));
+            if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
+                if (live && b == 0) P.hist[((size_t)s * nw_e + word_i) * CW_K + q] = word;
                 word = 0;
                 word_i++;
             }
@@ -225,7 +248,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
         if (nc >= LC) {
             unsigned dig[LC];
 #pragma unroll
-            for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = ((unsigned)(sigma >> (2 * (l - 1))) & 3u) * ROWD;
+            for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = ((unsigned)(sigma >> (BITS * (l - 1))) & DMASK) * ROWD;
             for (; tl + LC <= nc; tl += LC) {
 #pragma unroll
                 for (int u = 0; u < LC; u++) {
@@ -234,7 +257,7 @@ __global__ void __launch_bounds__(CW_THREADS) k_cwalk(cw_params P)
                 }
             }
         }
-        for (; tl < nc; tl++) step(tl, [&](int l) { return ((unsigned)(sigma >> (2 * (l - 1))) & 3u) * ROWD; });
+        for (; tl < nc; tl++) step(tl, [&](int l) { return ((unsigned)(sigma >> (BITS * (l - 1))) & DMASK) * ROWD; });
     }
     if (live && b == 0) {
         P.exits[(size_t)s * CW_K + q] = sigma;
@@ -397,13 +420,21 @@ __global__ void __launch_bounds__(256) k_cemit(cw_params P)
     int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     if (t1 > Nw) t1 = Nw;
     double mn = INFINITY;
+    const bool ranked = c.ranked != 0;
     const int cand = P.true_idx[s];
     for (int tl = tid; tl < t1 - t0; tl += 256) {
         const int t = t0 + 1 + tl;
         const double *inf = P.minfo + (size_t)t * MINFO;
-        const unsigned word = P.hist[((size_t)s * g.NW + (tl >> 4)) * CW_K + cand];
-        int b5 = nth_set5((uint32_t)__double_as_longlong(inf[10]), (int)((word >> (2 * (tl & 15))) & 3u));
-        if (b5 < 0) b5 = 0;
+        int b5;
+        if (ranked) {                                       // a rank: the symbol through the candidate bits
+            const unsigned word = P.hist[((size_t)s * g.NW + (tl >> 4)) * CW_K + cand];
+            b5 = nth_set5((uint32_t)__double_as_longlong(inf[10]), (int)((word >> (2 * (tl & 15))) & 3u));
+            if (b5 < 0) b5 = 0;
+        } else {                                            // the symbol itself (A C G T -), four bits per pick
+            const unsigned word = P.hist[((size_t)s * g.NW5 + (tl >> 3)) * CW_K + cand];
+            b5 = (int)((word >> (4 * (tl & 7))) & 7u);
+            if (b5 > 4) b5 = 0;
+        }
         P.path_out[t] = (uint8_t)vsym(b5);
         P.lmsel[t] = inf[b5];
         const double m = inf[5 + b5];
@@ -433,16 +464,18 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= g.S) return;
     const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ...
+    const bool ranked = P.st->ranked != 0;                  // digits: candidate ranks (2 bits) or symbols A C G T - (3 bits)
+    const int bits = ranked ? 2 : 3;
     cw_key sigma = 0;
-    for (int l = P.L; l >= 1; l--) {                        // oldest first: the pick of lag 1 ends in bits 0..1
+    for (int l = P.L; l >= 1; l--) {                        // oldest first: the pick of lag 1 ends in the lowest bits
         const int i = p + 1 - l;
         unsigned d = 0;
         if (i >= 1) {
             const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
             const int a6 = a6_of_sym(path[i]);
-            d = (unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u;
+            d = ranked ? ((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u) : (unsigned)(a6 < 5 ? a6 : 0);
         }
-        sigma = (sigma << 2) | (cw_key)d;
+        sigma = (sigma << bits) | (cw_key)d;
     }
     cw_key *keys = P.keys + (size_t)s * CW_K;
     int n = merge ? P.npool[s] : 0;
@@ -511,6 +544,7 @@ k_cseed_reads(cw_params P, const int32_t *__restrict__ rank, const int64_t *__re
     for (int k = tid; k < CW_K; k += 256) P.walked[(size_t)s * CW_K + k] = 0;
     if (tid == 0) P.npend[s] = 0;
     const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ..., p-L+1
+    const bool ranked = P.st->ranked != 0;
     if (s == 0) {                                           // the start state
         if (tid == 0) { keys[0] = 0ull; P.last_hit[0] = P.stamp - 1; P.npool[0] = 1; }
         return;
@@ -540,7 +574,7 @@ k_cseed_reads(cw_params P, const int32_t *__restrict__ rank, const int64_t *__re
             const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
             const int a6 = sym < 0 ? 7 : a6_of_sym(sym);
             if (sym < 0 || sym == 4 || a6 > 4 || !((cm5 >> a6) & 1u)) { ok = false; break; }      // N, '_', not a candidate
-            sigma = (sigma << 2) | (cw_key)((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u);
+            sigma = ranked ? ((sigma << 2) | (cw_key)((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u)) : ((sigma << 3) | (cw_key)(unsigned)a6);
         }
         if (!ok) continue;
         // count it (open addressing on the state; a full table drops the rest: only a seed)

@@ -119,7 +119,9 @@ struct gh_handle {
     uint8_t *cw_walked;
     int8_t *cw_nxt;
     bool cw_ready;         // the pools hold states of this tensor (seeded by a serial walk since the last fill / L change)
-    bool cw_off;           // the window is not narrow (a position with five candidates): serial walkers only
+    bool cw_off;           // a position with five candidates and more than CW_MAX_L5 lags: serial walkers only
+    bool cw_wide;          // the conditional table is over the symbols, not over candidate ranks: k_cwalk<L, 5>
+    bool cw_pool_wide;     // ... and what the pools' states are made of
     int cw_rounds;         // walk/scan rounds queued per path (adapts to how often chains stay open)
     int cw_stamp;
     int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
@@ -305,7 +307,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
-    h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_rounds = 2; h->cw_stamp = 0;
+    h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
@@ -1113,7 +1115,7 @@ static int alloc_cw(gh_handle *h)
     // sized for whichever geometry a lag count gives this N (h->L can change between spins)
     const cw_geom ga = cw_geometry(h->N, CW_MIN_L), gb = cw_geometry(h->N, CW_MAX_L);
     const size_t S = (size_t)(ga.S > gb.S ? ga.S : gb.S);
-    const size_t SNW = (size_t)ga.S * ga.NW > (size_t)gb.S * gb.NW ? (size_t)ga.S * ga.NW : (size_t)gb.S * gb.NW;
+    const size_t SNW = (size_t)ga.S * ga.NW5 > (size_t)gb.S * gb.NW5 ? (size_t)ga.S * ga.NW5 : (size_t)gb.S * gb.NW5;      // (8 picks per word is the wider one)
     hipError_t e = hipMalloc((void **)&h->cw_keys, sizeof(cw_key) * S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_exits, sizeof(cw_key) * S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_last_hit, sizeof(int32_t) * S * CW_K);
@@ -1148,15 +1150,15 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     return P;
 }
 
-template <int LC>
+template <int LC, int R>
 static void launch_cwalk_lc(const cw_params &P, hipStream_t stream, int S, int dev)
 {
     static bool set[64];
     if (!set[dev & 63]) {
-        hipFuncSetAttribute((const void *)k_cwalk<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cw_lds_bytes(LC));
+        hipFuncSetAttribute((const void *)k_cwalk<LC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cw_lds_bytes(LC, R));
         set[dev & 63] = true;
     }
-    hipLaunchKernelGGL((k_cwalk<LC>), dim3(S), dim3(CW_THREADS), cw_lds_bytes(LC), stream, P);
+    hipLaunchKernelGGL((k_cwalk<LC, R>), dim3(S), dim3(CW_K * cw_lanes(R)), cw_lds_bytes(LC, R), stream, P);
 }
 
 // the kernels of one path: `rounds` x (walk what is new, link + chain), emit
@@ -1171,7 +1173,8 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
         P.check_masks = (r == 0 && !resume) ? check_masks : 0;
         P.last_round = r == rounds - 1;
         switch (h->L) {
-#define CW_CASE(n) case n: launch_cwalk_lc<n>(P, h->stream, g.S, h->dev); break;
+            // (the table over the symbols: 3 bits per pick, CW_MAX_L5 lags in a state)
+#define CW_CASE(n) case n: if (!h->cw_wide) launch_cwalk_lc<n, 4>(P, h->stream, g.S, h->dev); else launch_cwalk_lc<(n <= CW_MAX_L5 ? n : CW_MAX_L5), 5>(P, h->stream, g.S, h->dev); break;
             CW_CASE(6) CW_CASE(7) CW_CASE(8) CW_CASE(9) CW_CASE(10) CW_CASE(11) CW_CASE(12) CW_CASE(13) CW_CASE(14) CW_CASE(15) CW_CASE(16)
             CW_CASE(17) CW_CASE(18) CW_CASE(19) CW_CASE(20) CW_CASE(21) CW_CASE(22) CW_CASE(23) CW_CASE(24)
 #undef CW_CASE
@@ -1328,6 +1331,21 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
         e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);      // lt_stale, cw_unres
         if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
     }
+    // which layout did k_lt choose for this tensor?  (ranks when every position has at most four candidates, else symbols:
+    // the walker's instantiation, the bits per pick and what a pool entry means follow from it)
+    auto look_at_layout = [&](int ranked) {
+        h->cw_wide = !ranked;
+        if (h->cw_wide && h->L > CW_MAX_L5) h->cw_off = true;
+        if (h->cw_pool_wide != h->cw_wide) { h->cw_ready = false; h->cw_pool_wide = h->cw_wide; }
+    };
+    if (rc == GH_OK) rc = ensure_lt(h);
+    if (rc == GH_OK) {
+        dev_state look;
+        e = hipMemcpyAsync(&look, h->dstate, sizeof look, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+        else look_at_layout(look.ranked);
+    }
     int done = 0;
     int CHUNK = 8, clean = 0;        // paths queued between two looks at the device state: grows while every chain closes
     while (rc == GH_OK && done < max_paths) {
@@ -1399,11 +1417,11 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             // full.  Behind a chain that merely stayed open the table is current: every kernel queued behind it
             // idled, and the reweights that ran kept their rows.
             h->lt_inc_path = nullptr;
-            h->dirty_lt = hs.lt_stale || hs.cw_unres == 2;
+            h->dirty_lt = hs.lt_stale != 0;
             // an open chain costs a look, the resumed rounds and the idle launches of everything queued behind it -- far
             // more than an idle round (three empty launches) on every path: queue one round more from now on
             if (hs.cw_unres == 1 && h->cw_rounds < 8) h->cw_rounds++;
-            if (hs.cw_unres == 2) h->cw_off = true;         // five candidates somewhere: the serial walkers take the window
+            if (hs.cw_unres == 2) look_at_layout(hs.ranked);        // a rebuild changed the table's layout: the other instantiation, new pools
             else if (hs.cw_unres == 1 && done < max_paths) {
                 // the queued rounds did not close this path's chain.  Its pools keep what has been walked (the tensor
                 // has not changed): more rounds first; if the chain is still open, the serial walker takes the path

@@ -71,17 +71,23 @@ def test_pools_persist_across_spins_and_reset_on_fill():
     assert np.array_equal(h.export_band(), o2.export_band())
 
 
-def test_window_with_five_candidates_goes_back_to_the_serial_walker():
-    t = make_support_table(1200, 30000, k=8, seed=5)
+@pytest.mark.parametrize("L", [6, 7, 11, 16, 19, 21, 22])
+def test_window_with_five_candidates(L):
+    # a position that shows A, C, G, T and '-': the conditional table is over the symbols, not over candidate ranks; the
+    # pools then hold 3-bit picks (k_cwalk<L, 5>: 21 lags fit a state; beyond that the serial walker takes the window)
+    t = make_support_table(1500, 36000, k=None, seed=5 + L, k_max=24)
     bases = t.bases.copy()
     bases[np.random.default_rng(1).random(len(bases)) < 0.1] = ord('-')
     t.bases = bases
-    h, o = _pair(t, L=7)
+    h, o = _pair(t, L=L)
     assert (h.candidate_masks()[1:] == 0x2F).any()
-    res, ref = h.spin(10), o.spin(10)
+    res, ref = h.spin(14), o.spin(14)
     _same(res, ref)
-    assert h.walk_clock()[3] != 4
-    _same(h.spin(5), o.spin(5))                            # and stays there
+    assert h.walk_clock()[3] == (4 if L <= 21 else 0)
+    assert np.array_equal(h.export_band(), o.export_band())
+    _same(h.spin(5), o.spin(5))
+    hs, _ = _pair(t, L=L, walk="spec")
+    _same(hs.spin(14), res)
 
 
 def test_hole_and_stale_table_inside_a_queue():
