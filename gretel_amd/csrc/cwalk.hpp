@@ -1,26 +1,30 @@
-// cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated
-// (ranked tables: 2 bits per pick, up to 24 lags; tables over the symbols -- a five-candidate position somewhere --: 3 bits, up to 21)
-// (L = 6..24: 4^L states; segwalk.hpp enumerates up to 5^5, and 4^6 when the table is ranked), included by gretel_hip.hip behind segwalk.hpp.
+// cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated (included by
+// gretel_hip.hip behind segwalk.hpp, which enumerates up to 5^5 states, and 4^6 when the table is ranked).
+// Ranked tables (every position has at most four candidates): 2 bits per pick, L = 6..24.  Tables over the symbols
+// A C G T - (a five-candidate position somewhere): 3 bits per pick, L = 6..21.
 //
-// Same decomposition -- cut the window into <= 256 segments, know for every segment what it does to the state that
-// enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states (<= 64 per
-// segment, kept from path to path), and the chain is then VERIFIED, never assumed:
+// Same decomposition -- cut the window into <= 512 segments (<= 256 beyond 13 lags), know for every segment what it does
+// to the state that enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states
+// (<= 64 per segment, kept from path to path), and the chain is then VERIFIED, never assumed:
 //
-//   k_cwalk   one workgroup per segment, four lanes (one per candidate rank b) per pool entry that has not been walked
-//             under the current tensor: the same lag-ascending binary64 sums and first-wins arg-max as every other
-//             walker, from the conditional table staged in LDS; records the exit state and the picks.
+//   k_cwalk   one workgroup per segment, four lanes (one per candidate rank; eight per entry over the symbols) per pool
+//             entry that has not been walked under the current tensor: the same lag-ascending binary64 sums and
+//             first-wins arg-max as every other walker, from the conditional table staged in LDS; records the exit
+//             state and the picks.
 //   k_clink   (behind k_cwalk, the pools stand still) where every entry's exit state sits in the next segment's pool.
-//   k_cscan   one wavefront: chains from the start state along the links.  The chain either reaches the end -- every
+//   k_cscan   one workgroup: chains from the start state along the links.  The chain either reaches the end -- every
 //             hop an exact pool hit onto a walked entry -- or stops at a state that still has to be walked (an exit
 //             that is not in the next pool is inserted there).
-//   (repeat k_cwalk / k_cscan for the pending entries: each round walks only what is new)
+//   (repeat k_cwalk / k_clink / k_cscan for the pending entries: each round walks only what is new)
 //   k_cemit   one workgroup per segment: the picks of the entry that is on the verified chain -> path symbols, selected
 //             log-marginals, minimum marginal (as k_emit).
 //
 // Nothing approximate survives: a path is emitted only when every segment's entry state equals the previous segment's
 // exit state, both produced by exact walks.  When the rounds queued for a path do not close the chain, the kernels
-// behind flag the path unresolved and idle; the host re-queues it with more rounds or hands it to the serial walker,
-// whose states then seed the pools.  The pools start from the serial walk of the spin's first path.
+// behind flag the path unresolved and idle; the host queues more rounds for it (every round carries the verified chain
+// at least one segment further) or, up to 16 lags, hands it to the serial walker, whose states then join the pools.
+// The pools start from the states the reads show at the segment boundaries (k_cseed_reads) and from the largest
+// marginals (k_cguess): only where walks START -- never what is emitted -- depends on that.
 #pragma once
 
 #define CW_K 64                 /* pool entries per segment */
