@@ -1,7 +1,8 @@
 // cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated (included by
 // gretel_hip.hip behind segwalk.hpp, which enumerates up to 5^5 states, and 4^6 when the table is ranked).
 // Ranked tables (every position has at most four candidates): 2 bits per pick, L = 6..24.  Tables over the symbols
-// A C G T - (a five-candidate position somewhere): 3 bits per pick, L = 6..21.
+// A C G T - (a five-candidate position somewhere): 3 bits per pick, L = 6..21.  Beyond (up to 128 lags): k_cwalkg, states as
+// bytes next to their hash, the table read from global memory.
 //
 // Same decomposition -- cut the window into <= 512 segments (<= 256 beyond 13 lags), know for every segment what it does
 // to the state that enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states
@@ -98,7 +99,27 @@ struct cw_params {
     double *segmin;           // [S]
     uint8_t *path_out;
     double *lmsel;
+    // lag counts beyond what fits a 64-bit state (k_cwalkg): a key is then the HASH of the state, and the state itself -- one
+    // byte per pick, lag 1 first -- sits next to it; equal hashes are confirmed on the bytes wherever two states are compared
+    uint8_t *keys_d, *exits_d, *pend_d;       // [S][CW_K][LD], null in the packed mode
+    int LD;                   // bytes per state (L rounded up to 4)
+    int _pad2;
+    cw_key key0;              // key of the start state (0 in the packed mode)
 };
+
+__device__ __forceinline__ cw_key cw_hash_digits(const uint8_t *d, int L)
+{
+    unsigned long long h = 0xcbf29ce484222325ull;
+    for (int l = 0; l < L; l++) { h ^= d[l]; h *= 0x100000001b3ull; }
+    h ^= h >> 32; h *= 0x9e3779b97f4a7c15ull; h ^= h >> 29;
+    return h;
+}
+__device__ __forceinline__ bool cw_same_digits(const uint8_t *a, const uint8_t *b, int L)
+{
+    for (int l = 0; l < L; l++)
+        if (a[l] != b[l]) return false;
+    return true;
+}
 
 // -------------------------------------------------------------------------------------------------------------
 // k_cwalk: quad q of workgroup s walks pool entry q of segment s (if it has not been walked under this tensor), then
@@ -284,6 +305,158 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
 }
 
 // -------------------------------------------------------------------------------------------------------------
+// k_cwalkg: k_cwalk for lag counts whose table slice no longer fits the LDS and whose state no longer fits 64 bits
+// (L > 24 over ranks, L > 21 over symbols; L <= CW_MAX_LG).  The same pools, links and chain; what differs:
+//   * the L terms of a step are read from G in global memory (L independent loads per lane, CWG_CHUNK at a time, added
+//     in lag order as everywhere) -- a step is a round trip to L2, ~2 us, where the one-wavefront k_walk_global spends
+//     that on EVERY position of the window one after the other;
+//   * a state is L bytes (one per pick, lag 1 first) next to its 64-bit hash; the last L picks of an entry live in a
+//     ring in LDS.
+// -------------------------------------------------------------------------------------------------------------
+#define CW_MAX_LG 128
+#define CWG_CHUNK 32
+template <int R>
+__global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
+{
+    constexpr int LPE = cw_lanes(R);
+    constexpr int PPW = R == 4 ? 16 : 8, WB = R == 4 ? 2 : 4;
+    __shared__ uint8_t ring[CW_K][CW_MAX_LG];               // ring[q][(t - l) & 127] = pick of position t - l
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    if (P.round > 0 && c.cw_open_at < 0) return;
+    if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
+        return;
+    }
+    if ((c.ranked != 0) != (R == 4)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
+    const cw_geom g = cw_geometry(P.N, P.L);
+    const int s = blockIdx.x, tid = threadIdx.x, L = P.L, LD = P.LD;
+    if (s >= g.S) return;
+    // (1) pending states join the pool (as k_cwalk; equal hashes are confirmed on the bytes)
+    __shared__ int s_n;
+    if (tid < 64) {
+        int n0 = P.npool[s];
+        const int np = P.npend[s] < CW_K ? P.npend[s] : CW_K;
+        cw_key *keys = P.keys + (size_t)s * CW_K;
+        int32_t *lh = P.last_hit + (size_t)s * CW_K;
+        for (int k = 0; k < np; k++) {
+            const cw_key x = P.pend[(size_t)s * CW_K + k];
+            const uint8_t *xd = P.pend_d + ((size_t)s * CW_K + k) * LD;
+            const bool mine_dup = tid < n0 && keys[tid] == x && cw_same_digits(P.keys_d + ((size_t)s * CW_K + tid) * LD, xd, L);
+            if (__builtin_amdgcn_ballot_w64(mine_dup) != 0) continue;
+            int slot = n0;
+            if (n0 >= CW_K) {
+                int mine = (tid == 0 && s == 0) ? 0x7fffffff : lh[tid], who = tid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int om = __shfl_xor(mine, o), ow = __shfl_xor(who, o);
+                    if (om < mine || (om == mine && ow < who)) { mine = om; who = ow; }
+                }
+                if (mine >= P.stamp) continue;
+                slot = who;
+            } else n0++;
+            if (tid == 0) { keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = 0; }
+            for (int l = tid; l < L; l += 64) P.keys_d[((size_t)s * CW_K + slot) * LD + l] = xd[l];
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        if (tid == 0) { P.npool[s] = n0; P.npend[s] = 0; s_n = n0; }
+    }
+    __syncthreads();
+    const int n = s_n;
+    const int q = tid / LPE, b = tid & (LPE - 1);
+    const int bcol = b < R ? b : R - 1;
+    const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
+    if (!__syncthreads_or(live ? 1 : 0)) return;
+    const int t0 = s * g.seglen;
+    const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    const unsigned shift = (unsigned)(tid & 63 & ~(LPE - 1));
+    const int nw_e = R == 4 ? g.NW : g.NW5;
+    // the entry's last L picks into its ring: the pick of lag l (position t0 + 1 - l) at slot (t0 + 1 - l) & 127
+    if (live)
+        for (int l = 1 + b; l <= L; l += LPE) ring[q][(t0 + 1 - l) & (CW_MAX_LG - 1)] = P.keys_d[((size_t)s * CW_K + q) * LD + (l - 1)];
+    __syncthreads();
+    int word_i = 0;
+    unsigned word = 0;
+    const size_t src_stride = (size_t)6 * L * LT_ROW;       // doubles per source in G
+    for (int t = t0 + 1; t <= t1; t++) {
+        // lag l: source i = t - l, row = the pick made there (row 5 at position 0; positions < 0 add +0.0)
+        double acc = 0.0;
+        for (int l0 = 1; l0 <= L; l0 += CWG_CHUNK) {
+            double x[CWG_CHUNK];
+#pragma unroll
+            for (int u = 0; u < CWG_CHUNK; u++) {
+                const int l = l0 + u, i = t - l;
+                x[u] = 0.0;
+                if (l <= L && i >= 0 && live) {
+                    const int row = i == 0 ? 5 : (int)ring[q][i & (CW_MAX_LG - 1)];
+                    x[u] = P.G[(size_t)i * src_stride + ((size_t)row * L + (l - 1)) * LT_ROW + bcol];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CWG_CHUNK; u++)
+                if (l0 + u <= L) acc = (l0 + u == 1) ? x[u] : acc + x[u];
+        }
+        if (R == 5 && b >= R) acc = -INFINITY;
+        double m = vmax_f64(acc, dpp_f64<0xB1>(acc));
+        m = vmax_f64(m, dpp_f64<0x4E>(m));
+        if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));
+        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+        const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));
+        if (live && b == 0) ring[q][t & (CW_MAX_LG - 1)] = (uint8_t)d;      // (read again at the earliest one step later, by this lane group only)
+        const int gt = t - t0 - 1;
+        word |= d << (WB * (gt % PPW));
+        if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
+            if (live && b == 0) P.hist[((size_t)s * nw_e + word_i) * CW_K + q] = word;
+            word = 0;
+            word_i++;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the exit state: the last L picks, lag 1 first (out of the ring); its hash; closure as in k_cwalk
+    __syncthreads();
+    auto dg = [&](int l) -> uint8_t {                       // pick of lag l behind the segment
+        const int i = t1 + 1 - l;
+        return i >= 1 ? ring[q][i & (CW_MAX_LG - 1)] : (uint8_t)0;
+    };
+    if (live) {
+        uint8_t *xd = P.exits_d + ((size_t)s * CW_K + q) * LD;
+        for (int l = 1 + b; l <= L; l += LPE) xd[l - 1] = dg(l);
+    }
+    if (live && b == 0) {
+        unsigned long long hh = 0xcbf29ce484222325ull;      // (cw_hash_digits over the ring)
+        for (int l = 1; l <= L; l++) { hh ^= dg(l); hh *= 0x100000001b3ull; }
+        hh ^= hh >> 32; hh *= 0x9e3779b97f4a7c15ull; hh ^= hh >> 29;
+        const cw_key sigma = hh;
+        P.exits[(size_t)s * CW_K + q] = sigma;
+        P.walked[(size_t)s * CW_K + q] = 1;
+        if (s + 1 < g.S) {
+            const cw_key *kn = P.keys + (size_t)(s + 1) * CW_K;
+            bool there = false;
+            const int nn = P.npool[s + 1];
+            for (int k = 0; k < nn && k < CW_K && !there; k++) {
+                if (kn[k] != sigma) continue;
+                const uint8_t *kd = P.keys_d + ((size_t)(s + 1) * CW_K + k) * LD;
+                bool same = true;
+                for (int l = 1; l <= L && same; l++) same = kd[l - 1] == dg(l);
+                there = same;
+            }
+            if (!there) {
+                const int slot = atomicAdd(&P.npend[s + 1], 1);
+                if (slot < CW_K) {
+                    P.pend[(size_t)(s + 1) * CW_K + slot] = sigma;
+                    for (int l = 1; l <= L; l++) P.pend_d[((size_t)(s + 1) * CW_K + slot) * LD + (l - 1)] = dg(l);
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
 // k_clink: behind k_cwalk the pools stand still.  Lane q of workgroup s finds where the exit state of entry (s, q) sits
 // in pool s+1:  hop >= 0: that entry, walked under this tensor;  -2: there, still to be walked;  -1: not there.
 // -------------------------------------------------------------------------------------------------------------
@@ -306,7 +479,9 @@ __global__ void __launch_bounds__(CW_K) k_clink(cw_params P)
         const cw_key kk = ((cw_key)(unsigned)__builtin_amdgcn_readlane((int)(kn >> 32), k) << 32) |
                           (cw_key)(unsigned)__builtin_amdgcn_readlane((int)(kn & 0xffffffffull), k);
         const bool ww = __builtin_amdgcn_readlane(kw ? 1 : 0, k) != 0;
-        if (h == -1 && kk == x) h = ww ? k : -2;
+        if (h == -1 && kk == x &&
+            (!P.keys_d || cw_same_digits(P.exits_d + e * (size_t)P.LD, P.keys_d + ((size_t)(s + 1) * CW_K + k) * (size_t)P.LD, P.L)))
+            h = ww ? k : -2;
     }
     P.nxt[e] = (int8_t)(mine ? h : -1);
 }
@@ -351,7 +526,7 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
     }
     __syncthreads();
     if (tid == 0) {                                         // (2)
-        const bool start_ok = P.npool[0] > 0 && P.walked[0] && P.keys[0] == 0ull;
+        const bool start_ok = P.npool[0] > 0 && P.walked[0] && P.keys[0] == P.key0;
         int x = start_ok ? 0 : -1;
         for (int gr = 0; gr <= NG; gr++) {
             gin[gr] = x;
@@ -390,6 +565,9 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
                 if (P.pend[(size_t)(stuck + 1) * CW_K + k] == x) queued = true;
             if (!queued) {
                 P.pend[(size_t)(stuck + 1) * CW_K] = x;
+                if (P.pend_d)
+                    for (int l = 0; l < P.L; l++)
+                        P.pend_d[((size_t)(stuck + 1) * CW_K) * P.LD + l] = P.exits_d[((size_t)stuck * CW_K + tru[stuck]) * P.LD + l];
                 if (P.npend[stuck + 1] < 1) P.npend[stuck + 1] = 1;
             }
         }
@@ -470,22 +648,32 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
     const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ...
     const bool ranked = P.st->ranked != 0;                  // digits: candidate ranks (2 bits) or symbols A C G T - (3 bits)
     const int bits = ranked ? 2 : 3;
+    auto digit = [&](int i) -> unsigned {
+        if (i < 1) return 0u;
+        const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
+        const int a6 = a6_of_sym(path[i]);
+        return ranked ? ((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u) : (unsigned)(a6 < 5 ? a6 : 0);
+    };
     cw_key sigma = 0;
-    for (int l = P.L; l >= 1; l--) {                        // oldest first: the pick of lag 1 ends in the lowest bits
-        const int i = p + 1 - l;
-        unsigned d = 0;
-        if (i >= 1) {
-            const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
-            const int a6 = a6_of_sym(path[i]);
-            d = ranked ? ((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u) : (unsigned)(a6 < 5 ? a6 : 0);
-        }
-        sigma = (sigma << bits) | (cw_key)d;
+    if (!P.keys_d) {
+        for (int l = P.L; l >= 1; l--) sigma = (sigma << bits) | (cw_key)digit(p + 1 - l);      // oldest first: the pick of lag 1 ends in the lowest bits
+    } else {
+        // (the hash of the bytes, lag 1 first -- as cw_hash_digits takes them)
+        unsigned long long hh = 0xcbf29ce484222325ull;
+        for (int l = 1; l <= P.L; l++) { hh ^= digit(p + 1 - l); hh *= 0x100000001b3ull; }
+        hh ^= hh >> 32; hh *= 0x9e3779b97f4a7c15ull; hh ^= hh >> 29;
+        sigma = hh;
     }
     cw_key *keys = P.keys + (size_t)s * CW_K;
     int n = merge ? P.npool[s] : 0;
     bool there = false;
-    for (int k = 0; k < n; k++)
-        if (keys[k] == sigma) { there = true; P.last_hit[(size_t)s * CW_K + k] = P.stamp; }
+    for (int k = 0; k < n; k++) {
+        if (keys[k] != sigma) continue;
+        bool same = true;
+        if (P.keys_d)
+            for (int l = 1; l <= P.L && same; l++) same = P.keys_d[((size_t)s * CW_K + k) * P.LD + (l - 1)] == digit(p + 1 - l);
+        if (same) { there = true; P.last_hit[(size_t)s * CW_K + k] = P.stamp; }
+    }
     if (!there) {
         int slot = n;
         if (n >= CW_K) {
@@ -497,6 +685,8 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
             }
         } else n++;
         keys[slot] = sigma;
+        if (P.keys_d)
+            for (int l = 1; l <= P.L; l++) P.keys_d[((size_t)s * CW_K + slot) * P.LD + (l - 1)] = (uint8_t)digit(p + 1 - l);
         P.last_hit[(size_t)s * CW_K + slot] = P.stamp;
     }
     P.npool[s] = n;

@@ -122,6 +122,8 @@ struct gh_handle {
     bool cw_off;           // a position with five candidates and more than CW_MAX_L5 lags: serial walkers only
     bool cw_wide;          // the conditional table is over the symbols, not over candidate ranks: k_cwalk<L, 5>
     bool cw_pool_wide;     // ... and what the pools' states are made of
+    uint8_t *cw_keys_d, *cw_exits_d, *cw_pend_d;      // k_cwalkg: the states as bytes, [S][CW_K][cw_LD]
+    int cw_LD;
     int cw_rounds;         // walk/scan rounds queued per path (adapts to how often chains stay open)
     int cw_stamp;
     int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
@@ -268,6 +270,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
     if (h->stage) hipHostFree(h->stage);
+    hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
     hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_hist); hipFree(h->cw_last_hit); hipFree(h->cw_npool); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true); hipFree(h->cw_pend); hipFree(h->cw_npend);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
@@ -308,6 +311,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
     h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0;
+    h->cw_keys_d = nullptr; h->cw_exits_d = nullptr; h->cw_pend_d = nullptr; h->cw_LD = 0;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
@@ -882,7 +886,9 @@ static bool walk_depth2_ok(int wm, int L)
 }
 
 // candidate-pool segments (cwalk.hpp) for the lag counts above: spins only, narrow windows only (checked on the device)
-static bool cw_ok(int wm, int L) { return wm == WM_SEG && L >= CW_MIN_L && L <= CW_MAX_L; }
+static bool cw_ok(int wm, int L) { return wm == WM_SEG && L >= CW_MIN_L && L <= CW_MAX_LG; }
+// beyond what a 64-bit state holds (2 bits per pick over ranks, 3 over symbols): states as bytes next to their hash, k_cwalkg
+static bool cw_digit_mode(const gh_handle *h) { return h->cw_wide ? h->L > CW_MAX_L5 : h->L > CW_MAX_L; }
 
 // single windows: may k_lt build the ranked layout?  (the segment-parallel walk reads either layout)
 static bool walk_ranked_ok(int wm, int L) { return seg_ok(wm, L) || cw_ok(wm, L) || walk_depth2_ok(wm, L); }
@@ -1147,6 +1153,13 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     P.G = h->lt; P.minfo = h->minfo; P.st = h->dstate;
     P.keys = h->cw_keys; P.exits = h->cw_exits; P.last_hit = h->cw_last_hit; P.npool = h->cw_npool; P.walked = h->cw_walked; P.nxt = h->cw_nxt; P.pend = h->cw_pend; P.npend = h->cw_npend;
     P.hist = h->cw_hist; P.true_idx = h->cw_true; P.segmin = h->seg_min; P.path_out = d_path; P.lmsel = d_lmsel;
+    if (cw_digit_mode(h)) {
+        P.keys_d = h->cw_keys_d; P.exits_d = h->cw_exits_d; P.pend_d = h->cw_pend_d; P.LD = h->cw_LD;
+        unsigned long long hh = 0xcbf29ce484222325ull;      // cw_hash_digits of L zero bytes: the start state
+        for (int l = 0; l < h->L; l++) { hh ^= 0u; hh *= 0x100000001b3ull; }
+        hh ^= hh >> 32; hh *= 0x9e3779b97f4a7c15ull; hh ^= hh >> 29;
+        P.key0 = hh;
+    }
     return P;
 }
 
@@ -1172,13 +1185,17 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
         P.round = resume ? r + 1 : r;                       // (a resumed path continues behind the rounds already run)
         P.check_masks = (r == 0 && !resume) ? check_masks : 0;
         P.last_round = r == rounds - 1;
+        if (cw_digit_mode(h)) {
+            if (!h->cw_wide) hipLaunchKernelGGL((k_cwalkg<4>), dim3(g.S), dim3(CW_K * cw_lanes(4)), 0, h->stream, P);
+            else hipLaunchKernelGGL((k_cwalkg<5>), dim3(g.S), dim3(CW_K * cw_lanes(5)), 0, h->stream, P);
+        } else
         switch (h->L) {
             // (the table over the symbols: 3 bits per pick, CW_MAX_L5 lags in a state)
 #define CW_CASE(n) case n: if (!h->cw_wide) launch_cwalk_lc<n, 4>(P, h->stream, g.S, h->dev); else launch_cwalk_lc<(n <= CW_MAX_L5 ? n : CW_MAX_L5), 5>(P, h->stream, g.S, h->dev); break;
             CW_CASE(6) CW_CASE(7) CW_CASE(8) CW_CASE(9) CW_CASE(10) CW_CASE(11) CW_CASE(12) CW_CASE(13) CW_CASE(14) CW_CASE(15) CW_CASE(16)
             CW_CASE(17) CW_CASE(18) CW_CASE(19) CW_CASE(20) CW_CASE(21) CW_CASE(22) CW_CASE(23) CW_CASE(24)
 #undef CW_CASE
-            default: return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_L);
+            default: return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_LG);
         }
         hipLaunchKernelGGL(k_clink, dim3(g.S), dim3(CW_K), 0, h->stream, P);
         hipLaunchKernelGGL(k_cscan, dim3(1), dim3(1024), 0, h->stream, P);
@@ -1335,8 +1352,26 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
     // the walker's instantiation, the bits per pick and what a pool entry means follow from it)
     auto look_at_layout = [&](int ranked) {
         h->cw_wide = !ranked;
-        if (h->cw_wide && h->L > CW_MAX_L5) h->cw_off = true;
         if (h->cw_pool_wide != h->cw_wide) { h->cw_ready = false; h->cw_pool_wide = h->cw_wide; }
+        if (cw_digit_mode(h)) {
+            const int LD = (h->L + 3) & ~3;
+            if (h->cw_LD != LD) {
+                hipStreamSynchronize(h->stream);
+                hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
+                h->cw_keys_d = h->cw_exits_d = h->cw_pend_d = nullptr;
+                const cw_geom gg = cw_geometry(h->N, h->L);
+                const size_t bytes = (size_t)gg.S * CW_K * LD;
+                if (hipMalloc((void **)&h->cw_keys_d, bytes) != hipSuccess || hipMalloc((void **)&h->cw_exits_d, bytes) != hipSuccess ||
+                    hipMalloc((void **)&h->cw_pend_d, bytes) != hipSuccess) {
+                    rc = fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed");
+                    h->cw_LD = 0;
+                    return;
+                }
+                hipMemsetAsync(h->cw_keys_d, 0, bytes, h->stream); hipMemsetAsync(h->cw_exits_d, 0, bytes, h->stream); hipMemsetAsync(h->cw_pend_d, 0, bytes, h->stream);
+                h->cw_LD = LD;
+                h->cw_ready = false;
+            }
+        }
     };
     if (rc == GH_OK) rc = ensure_lt(h);
     if (rc == GH_OK) {
@@ -1371,7 +1406,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             // ... and, when the table the window was filled from is still there (and sorted), from the states its reads show at
             // the segment boundaries (k_cseed_reads); the guess then only joins them
             const gh_reads *rd = h->last_reads;
-            const bool from_reads = rd && reads_alive(rd) && rd->sorted && rd->n_reads > 0 && rd->max_k >= h->L &&
+            const bool from_reads = rd && !cw_digit_mode(h) && reads_alive(rd) && rd->sorted && rd->n_reads > 0 && rd->max_k >= h->L &&
                                     !(getenv("GH_CW_SEED_READS") && atoi(getenv("GH_CW_SEED_READS")) == 0);
             if (from_reads)
                 hipLaunchKernelGGL(k_cseed_reads, dim3(cg.S), dim3(256), 0, h->stream, P, (const int32_t *)rd->rank, (const int64_t *)rd->off,

@@ -32,7 +32,7 @@ while time.time() < t_end:
     storage = str(rng.choice(["f32", "f32", "f64"]))
     mode = str(rng.choice(["A", "A", "B", "C", "D"]))
     mt = bool(rng.random() < 0.25)
-    L = None if rng.random() < 0.4 else int(rng.integers(1, 27))
+    L = None if rng.random() < 0.4 else (int(rng.integers(1, 27)) if rng.random() < 0.85 else int(rng.integers(25, 48)))
     paths = int(rng.integers(1, 9))
     desc = dict(n=n, reads=reads, k=k, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths)
     if k is not None and rng.random() < 0.12:

@@ -34,7 +34,7 @@ def _same(res, ref):
     assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("L", [-6, 6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 24])
+@pytest.mark.parametrize("L", [-6, 6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 24, 25, 31, 40])
 def test_every_lag_count(L, monkeypatch):
     # long-read-style reads (k ~ Poisson(10)); L = 9 and up also exercises the table rows beyond the eighth lag in k_rw.
     # L = 6 in a window without a five-candidate position enumerates its 4^6 states (variant 3); -6: the pools all the same
@@ -44,7 +44,8 @@ def test_every_lag_count(L, monkeypatch):
         want = 4
     else:
         want = 3 if L == 6 else 4
-    t = make_support_table(2500, 30000, k=None, seed=200 + L)
+    # (beyond 24 lags: k_cwalkg -- the table from global memory, states as bytes next to their hash)
+    t = make_support_table(2500, 30000, k=None, seed=200 + L, k_max=max(21, L + 4), k_lambda=10.0 if L <= 24 else float(L))
     h, o = _pair(t, L=L)
     res, ref = h.spin(24), o.spin(24)
     assert h.walk_clock()[3] == want
@@ -71,11 +72,11 @@ def test_pools_persist_across_spins_and_reset_on_fill():
     assert np.array_equal(h.export_band(), o2.export_band())
 
 
-@pytest.mark.parametrize("L", [6, 7, 11, 16, 19, 21, 22])
+@pytest.mark.parametrize("L", [6, 7, 11, 16, 19, 21, 22, 30])
 def test_window_with_five_candidates(L):
     # a position that shows A, C, G, T and '-': the conditional table is over the symbols, not over candidate ranks; the
-    # pools then hold 3-bit picks (k_cwalk<L, 5>: 21 lags fit a state; beyond that the serial walker takes the window)
-    t = make_support_table(1500, 36000, k=None, seed=5 + L, k_max=24)
+    # pools then hold 3-bit picks (k_cwalk<L, 5>: 21 lags fit a state; beyond that k_cwalkg<5>)
+    t = make_support_table(1500, 36000, k=None, seed=5 + L, k_max=max(24, L + 4), k_lambda=10.0 if L <= 21 else float(L))
     bases = t.bases.copy()
     bases[np.random.default_rng(1).random(len(bases)) < 0.1] = ord('-')
     t.bases = bases
@@ -83,7 +84,7 @@ def test_window_with_five_candidates(L):
     assert (h.candidate_masks()[1:] == 0x2F).any()
     res, ref = h.spin(14), o.spin(14)
     _same(res, ref)
-    assert h.walk_clock()[3] == (4 if L <= 21 else 0)
+    assert h.walk_clock()[3] == 4
     assert np.array_equal(h.export_band(), o.export_band())
     _same(h.spin(5), o.spin(5))
     hs, _ = _pair(t, L=L, walk="spec")
