@@ -390,12 +390,14 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
             double x[CWG_CHUNK];
 #pragma unroll
             for (int u = 0; u < CWG_CHUNK; u++) {
+                // (no branch around a load: a term that does not exist reads a valid address and is replaced by +0.0)
                 const int l = l0 + u, i = t - l;
-                x[u] = 0.0;
-                if (l <= L && i >= 0 && live) {
-                    const int row = i == 0 ? 5 : (int)ring[q][i & (CW_MAX_LG - 1)];
-                    x[u] = P.G[(size_t)i * src_stride + ((size_t)row * L + (l - 1)) * LT_ROW + bcol];
-                }
+                const bool have = l <= L && i >= 0;
+                const int lc = l <= L ? l : L, ic = i >= 0 ? i : 0;
+                const int rr = live ? (int)ring[q][ic & (CW_MAX_LG - 1)] : 0;      // (an idle lane group reads row 0: its ring holds nothing)
+                const int row = i <= 0 ? 5 : rr;
+                const double v = P.G[(size_t)ic * src_stride + ((size_t)row * L + (lc - 1)) * LT_ROW + bcol];
+                x[u] = have ? v : 0.0;
             }
 #pragma unroll
             for (int u = 0; u < CWG_CHUNK; u++)
