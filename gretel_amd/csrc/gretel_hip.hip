@@ -122,6 +122,7 @@ struct gh_handle {
     bool cw_off;           // a position with five candidates and more than CW_MAX_L5 lags: serial walkers only
     bool cw_wide;          // the conditional table is over the symbols, not over candidate ranks: k_cwalk<L, 5>
     bool cw_pool_wide;     // ... and what the pools' states are made of
+    bool cw_no_rw;         // inside gh_generate_path: no reweight follows the path (k_cemit leaves the window's flags standing)
     uint8_t *cw_keys_d, *cw_exits_d, *cw_pend_d;      // k_cwalkg: the states as bytes, [S][CW_K][cw_LD]
     int cw_LD;
     int cw_rounds;         // walk/scan rounds queued per path (adapts to how often chains stay open)
@@ -311,7 +312,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
     h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0;
-    h->cw_keys_d = nullptr; h->cw_exits_d = nullptr; h->cw_pend_d = nullptr; h->cw_LD = 0;
+    h->cw_keys_d = nullptr; h->cw_exits_d = nullptr; h->cw_pend_d = nullptr; h->cw_LD = 0; h->cw_no_rw = false;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
@@ -1149,7 +1150,7 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
 {
     cw_params P;
     memset(&P, 0, sizeof P);
-    P.N = h->N; P.L = h->L; P.rearm = 1; P.stamp = h->cw_stamp;
+    P.N = h->N; P.L = h->L; P.rearm = h->cw_no_rw ? 0 : 1; P.stamp = h->cw_stamp;
     P.G = h->lt; P.minfo = h->minfo; P.st = h->dstate;
     P.keys = h->cw_keys; P.exits = h->cw_exits; P.last_hit = h->cw_last_hit; P.npool = h->cw_npool; P.walked = h->cw_walked; P.nxt = h->cw_nxt; P.pend = h->cw_pend; P.npend = h->cw_npend;
     P.hist = h->cw_hist; P.true_idx = h->cw_true; P.segmin = h->seg_min; P.path_out = d_path; P.lmsel = d_lmsel;
@@ -1206,7 +1207,7 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
 }
 
 // one path through the serial walker, its boundary states into the pools (merge: keep what is there)
-static int cw_serial_path(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double *d_lmsel, double min_remove, int slot, int merge)
+static int cw_serial_path(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double *d_lmsel, double min_remove, int slot, int merge, bool reweight = true)
 {
     // the serial depth-2 walker reads tables that k_lt keeps; behind pool paths (no k_lt between them) they are stale
     h->lt_inc_path = nullptr;
@@ -1219,10 +1220,46 @@ static int cw_serial_path(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, dou
     const cw_geom g = cw_geometry(h->N, h->L);
     hipLaunchKernelGGL(k_cseed, dim3((g.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)d_path, merge);
     if ((rc = post_launch(h, "k_cseed"))) return rc;
-    rc = launch_reweight_marg(h, d_path, 0.0, 1, d_rec, slot, false, false, 0);
+    if (reweight) rc = launch_reweight_marg(h, d_path, 0.0, 1, d_rec, slot, false, false, 0);
     h->cw_stat[1]++;
     return rc;
 }
+
+// device buffers for the paths, records and selected log-marginals of a spin of max_paths paths
+static int ensure_spin_buffers(gh_handle *h, int max_paths)
+{
+    const size_t n1 = (size_t)h->N + 1;
+    if (max_paths > h->spin_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(h->spin_paths); hipFree(h->spin_recs);
+        h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
+        hipFree(h->spin_lmsel); h->spin_lmsel = nullptr;
+        hipError_t ea = hipMalloc((void **)&h->spin_paths, n1 * max_paths);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_recs, sizeof(gh_path_rec) * max_paths);
+        // the selected symbols' log-marginals of every path, for the likelihood sums behind the loop (k_hp)
+        if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_lmsel, sizeof(double) * n1 * max_paths);
+        if (ea != hipSuccess) {
+            hipFree(h->spin_paths); h->spin_paths = nullptr;
+            hipFree(h->spin_recs); h->spin_recs = nullptr;
+            return fail(GH_ERR_NOMEM, "hipMalloc failed");
+        }
+        h->spin_cap = max_paths;
+    }
+    return GH_OK;
+}
+
+struct spin_io {
+    int max_paths;
+    double min_remove;
+    size_t n1;              // bytes per path
+    int nb;                 // stride of the per-path partial sums
+    uint8_t *d_paths;
+    gh_path_rec *d_recs;
+    uint8_t *paths_out;
+    gh_path_rec *recs;
+    bool no_reweight;       // gh_generate_path: the path is only recovered (its record closed by k_seg_fin), the tensor stays
+};
+static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, int *first_out, bool *gave_up);
 
 extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out, double *hp_current,
                                 double *hp_original, double *min_marginal, int *hole_at)
@@ -1244,13 +1281,43 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
         hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N, (const win_desc *)nullptr);
     }
     if ((rc = reset_spin_state(h))) return rc;
+    if (cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h)) {
+        // lag counts of the candidate pools: the path comes out of them (one path, no reweight: the tensor stays as it is,
+        // the pools keep what they learnt for the next call); only a window they cannot take goes on to the serial walker
+        if ((rc = ensure_spin_buffers(h, 1))) return rc;
+        gh_path_rec rec1;
+        spin_io io;
+        io.max_paths = 1; io.min_remove = 0.0; io.n1 = (size_t)h->N + 1; io.nb = 0;
+        io.d_paths = h->spin_paths; io.d_recs = h->spin_recs; io.paths_out = path_out; io.recs = &rec1; io.no_reweight = true;
+        dev_state hs1;
+        memset(&hs1, 0, sizeof hs1);
+        int first1 = 0;
+        bool gave_up = false;
+        h->cw_no_rw = true;
+        rc = spin_candidate_pools(h, io, hs1, &first1, &gave_up);
+        h->cw_no_rw = false;
+        if (rc) return rc;
+        if (!gave_up) {
+            *hole_at = hs1.stop ? hs1.hole_at : 0;
+            if (hs1.stop) {
+                // (the prefix that was walked: the reference returns what it has)
+                HIPCHK(hipMemcpy(path_out, h->spin_paths, (size_t)h->N + 1, hipMemcpyDeviceToHost));
+            } else {
+                if (hp_current) *hp_current = rec1.hp_current;
+                if (hp_original) *hp_original = rec1.hp_original;
+                if (min_marginal) *min_marginal = rec1.min_marginal;
+            }
+            return GH_OK;
+        }
+        if ((rc = reset_spin_state(h))) return rc;
+    }
     if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0, 0))) return rc;
     if (seg_ok(h->wmode, h->L)) {
         // close the record (hole / minimum marginal), then the two likelihood sums
         seg_params P;
         memset(&P, 0, sizeof P);
         P.N = h->N; P.L = h->L; P.st = h->dstate; P.segmin = h->seg_min;
-        hipLaunchKernelGGL(k_seg_fin, dim3(1), dim3(256), 0, h->stream, P, h->d_rec, 0.0);
+        hipLaunchKernelGGL(k_seg_fin, dim3(1), dim3(256), 0, h->stream, P, h->d_rec, 0.0, 0);
         hipLaunchKernelGGL(k_hp, dim3(1, 2), dim3(64), 0, h->stream, (const double *)h->lmsel1, (size_t)0, (const uint8_t *)h->d_path,
                            (size_t)0, (const double *)h->minfo, h->N, (const dev_state *)h->dstate, h->d_rec);
         if ((rc = post_launch(h, "k_seg_fin/k_hp"))) return rc;
@@ -1319,16 +1386,6 @@ static int results_to_host(gh_handle *h, uint8_t *paths_out, const uint8_t *d_pa
 // rounds for that one path, and if its chain is still open hands it to the serial walker (whose states join the pools)
 // before queueing on.  Returns with *gave_up set when the window turned out to have a position with five candidates:
 // paths *first .. go the serial walkers' way (the caller's loop).
-struct spin_io {
-    int max_paths;
-    double min_remove;
-    size_t n1;              // bytes per path
-    int nb;                 // stride of the per-path partial sums
-    uint8_t *d_paths;
-    gh_path_rec *d_recs;
-    uint8_t *paths_out;
-    gh_path_rec *recs;
-};
 
 static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, int *first_out, bool *gave_up)
 {
@@ -1343,6 +1400,15 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
     bool cw_gave_up = false;
     rc = alloc_cw(h);
     const cw_geom cg = cw_geometry(h->N, h->L);
+    // what follows the kernels of a path: the fused reweight (which also closes the path's record), or only the closing
+    auto finish_path = [&](uint8_t *pth, gh_path_rec *rec, int slot, bool chained) -> int {
+        if (!io.no_reweight) return launch_reweight_marg(h, pth, min_remove, 1, rec, slot, true, chained, cg.S);
+        seg_params SP;
+        memset(&SP, 0, sizeof SP);
+        SP.N = h->N; SP.L = h->L; SP.st = h->dstate; SP.segmin = h->seg_min;
+        hipLaunchKernelGGL(k_seg_fin, dim3(1), dim3(256), 0, h->stream, SP, rec, min_remove, cg.S);
+        return post_launch(h, "k_seg_fin");
+    };
     const int zero2[2] = {0, 0};
     if (rc == GH_OK) {
         e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);      // lt_stale, cw_unres
@@ -1414,7 +1480,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, from_reads ? 1 : 0);
             if ((rc = post_launch(h, "k_cguess/k_cseed"))) break;
             if ((rc = launch_cw_path(h, pth, h->spin_lmsel + n1 * done, CW_BOOT_ROUNDS, 0))) break;
-            if ((rc = launch_reweight_marg(h, pth, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+            if ((rc = finish_path(pth, d_recs + done, done, false))) break;
             h->cw_stat[2] += CW_BOOT_ROUNDS;
             h->cw_ready = true;
         } else {
@@ -1423,7 +1489,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             for (int s = done; s < upto && rc == GH_OK; s++) {
                 h->cw_stamp++;
                 if ((rc = launch_cw_path(h, d_paths + n1 * s, h->spin_lmsel + n1 * s, h->cw_rounds, s > done ? 1 : 0))) break;
-                rc = launch_reweight_marg(h, d_paths + n1 * s, min_remove, 1, d_recs + s, s, true, s > done, cg.S);
+                rc = finish_path(d_paths + n1 * s, d_recs + s, s, s > done);
                 h->cw_stat[2] += h->cw_rounds;
             }
             if (rc) break;
@@ -1472,7 +1538,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
                     const int tries = h->L > 16 ? (cg.S + 16) / more + 1 : 1;
                     for (int a = 0; a < tries && !closed; a++) {
                         if ((rc = launch_cw_path(h, d_paths + n1 * done, h->spin_lmsel + n1 * done, more, 0, true))) break;
-                        if ((rc = launch_reweight_marg(h, d_paths + n1 * done, min_remove, 1, d_recs + done, done, true, false, cg.S))) break;
+                        if ((rc = finish_path(d_paths + n1 * done, d_recs + done, done, false))) break;
                         h->cw_stat[2] += more;
                         e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
                         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -1488,7 +1554,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
                 }
                 if (!closed) {
                     h->cw_stamp++;
-                    if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 1))) break;
+                    if ((rc = cw_serial_path(h, d_paths + n1 * done, d_recs + done, h->spin_lmsel + n1 * done, min_remove, done, 1, !io.no_reweight))) break;
                     e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
                     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
                     if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
@@ -1499,12 +1565,15 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
         }
     }
     // the serial walkers' tables were not kept between pool paths: rebuild before anybody walks serially again
-    h->lt_inc_path = nullptr;
-    h->dirty_lt = true;
+    // (a lone path without a reweight leaves the tensor, and the table, as they were)
+    if (!io.no_reweight) {
+        h->lt_inc_path = nullptr;
+        h->dirty_lt = true;
+    }
     if (rc == GH_OK && done > 0 && !cw_gave_up) {
         hipLaunchKernelGGL(k_hp, dim3(done, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
                            (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
-        hipLaunchKernelGGL(k_reweight_finish_all, dim3(done), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
+        if (!io.no_reweight) hipLaunchKernelGGL(k_reweight_finish_all, dim3(done), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
         rc = post_launch(h, "k_hp/k_reweight_finish_all");
         if (rc == GH_OK) {
             e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
@@ -1529,22 +1598,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     int rc;
     if (!h->have_orig && (rc = gh_snapshot_original(h))) return rc;
     const size_t n1 = (size_t)h->N + 1;
-    if (max_paths > h->spin_cap) {
-        HIPCHK(hipStreamSynchronize(h->stream));
-        hipFree(h->spin_paths); hipFree(h->spin_recs);
-        h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
-        hipFree(h->spin_lmsel); h->spin_lmsel = nullptr;
-        hipError_t ea = hipMalloc((void **)&h->spin_paths, n1 * max_paths);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_recs, sizeof(gh_path_rec) * max_paths);
-        // the selected symbols' log-marginals of every path, for the likelihood sums behind the loop (k_hp)
-        if (ea == hipSuccess) ea = hipMalloc((void **)&h->spin_lmsel, sizeof(double) * n1 * max_paths);
-        if (ea != hipSuccess) {
-            hipFree(h->spin_paths); h->spin_paths = nullptr;
-            hipFree(h->spin_recs); h->spin_recs = nullptr;
-            return fail(GH_ERR_NOMEM, "hipMalloc failed");
-        }
-        h->spin_cap = max_paths;
-    }
+    if ((rc = ensure_spin_buffers(h, max_paths))) return rc;
     uint8_t *d_paths = h->spin_paths;
     gh_path_rec *d_recs = h->spin_recs;
     hipError_t e = hipSuccess;
@@ -1586,7 +1640,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     if (cw) {
         spin_io io;
         io.max_paths = max_paths; io.min_remove = min_remove; io.n1 = n1; io.nb = nb;
-        io.d_paths = d_paths; io.d_recs = d_recs; io.paths_out = paths_out; io.recs = recs;
+        io.d_paths = d_paths; io.d_recs = d_recs; io.paths_out = paths_out; io.recs = recs; io.no_reweight = false;
         rc = spin_candidate_pools(h, io, hs, &first, &cw_gave_up);
     }
     while ((!cw || cw_gave_up) && rc == GH_OK) {

@@ -638,13 +638,18 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
 }
 
 // lone gh_generate_path: no k_marg<T,true> follows, so the record is closed here
-__global__ void __launch_bounds__(256) k_seg_fin(seg_params P, gh_path_rec *rec, double min_remove)
+__global__ void __launch_bounds__(256) k_seg_fin(seg_params P, gh_path_rec *rec, double min_remove, int nseg_arg)
 {
     __shared__ double s_red[256];
     dev_state *st = P.st;
-    if (st->stop || st->lt_stale) return;
-    const int nseg = seg_count(st, P.N, P.L);
-    s_red[threadIdx.x] = (int)threadIdx.x < nseg ? P.segmin[threadIdx.x] : INFINITY;
+    if (st->stop || st->lt_stale || st->cw_unres) return;
+    const int nseg = nseg_arg > 0 ? nseg_arg : seg_count(st, P.N, P.L);      // (behind the candidate pools: their segment count)
+    double mine = INFINITY;
+    for (int q = threadIdx.x; q < nseg; q += 256) {
+        const double v = P.segmin[q];
+        if (v < mine) mine = v;
+    }
+    s_red[threadIdx.x] = mine;
     __syncthreads();
     for (int q = 128; q > 0; q >>= 1) {
         if ((int)threadIdx.x < q && s_red[threadIdx.x + q] < s_red[threadIdx.x]) s_red[threadIdx.x] = s_red[threadIdx.x + q];

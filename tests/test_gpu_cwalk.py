@@ -154,3 +154,29 @@ def test_pools_started_from_the_reads_or_from_the_guess_give_the_same_paths(monk
     h3 = Hansel(t.n_snps, band=t.band)
     h3.fill_from_support(t.rank[perm], off, t.bases[idx])
     _same(h3.spin(12), ref)
+
+
+@pytest.mark.parametrize("L,dels", [(8, False), (18, False), (30, False), (9, True)])
+def test_lone_paths_come_out_of_the_pools_too(L, dels):
+    # gh_generate_path (gretel.py:102-189 as the reference's own loop calls it, followed by reweight_hansel_from_path):
+    # the path comes out of the candidate pools, which keep what they learnt from call to call
+    t = make_support_table(1500, 24000, k=None, seed=300 + L, k_max=max(21, L + 4), k_lambda=10.0 if L <= 24 else float(L))
+    if dels:
+        bases = t.bases.copy()
+        bases[np.random.default_rng(4).random(len(bases)) < 0.1] = ord('-')
+        t.bases = bases
+    h, o = _pair(t, L=L)
+    variants = []
+    for it in range(5):
+        pg, po = h.generate_path(), o.generate_path()
+        if po[0] is None:
+            assert pg[0] is None and pg[1] == po[1]
+            break
+        assert np.array_equal(pg[0], po[0])
+        assert pg[1:] == po[1]
+        variants.append(h.walk_clock()[3])              # (a chain the queued rounds leave open goes to the serial walker)
+        ratio = max(pg[3], 0.01)
+        rg, ro = h.reweight_from_path(pg[0], ratio), o.reweight_path(po[0], ratio)
+        assert abs(rg - ro) <= 1e-9 * max(1.0, abs(ro))
+    assert 4 in variants, variants
+    assert np.array_equal(h.export_band(), o.export_band())
