@@ -1281,7 +1281,7 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
         hipLaunchKernelGGL(k_snapshot, dim3(nb8), dim3(256), 0, h->stream, h->minfo, h->minfo, h->N, (const win_desc *)nullptr);
     }
     if ((rc = reset_spin_state(h))) return rc;
-    if (cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h)) {
+    if (cw_ok(h->wmode, h->L) && !h->cw_off) {
         // lag counts of the candidate pools: the path comes out of them (one path, no reweight: the tensor stays as it is,
         // the pools keep what they learnt for the next call); only a window they cannot take goes on to the serial walker
         if ((rc = ensure_spin_buffers(h, 1))) return rc;
@@ -1485,10 +1485,14 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             h->cw_ready = true;
         } else {
             const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
+            // (conditional C / the marginal term: the reweight cannot keep the table current, k_lt rebuilds it in front of
+            // every path -- queued like everything else; otherwise once per look, and k_cwalk checks the masks)
+            const bool inc = lt_incremental_ok(h);
             if ((rc = ensure_lt(h))) break;
             for (int s = done; s < upto && rc == GH_OK; s++) {
                 h->cw_stamp++;
-                if ((rc = launch_cw_path(h, d_paths + n1 * s, h->spin_lmsel + n1 * s, h->cw_rounds, s > done ? 1 : 0))) break;
+                if (!inc && s > done && (rc = ensure_lt(h))) break;
+                if ((rc = launch_cw_path(h, d_paths + n1 * s, h->spin_lmsel + n1 * s, h->cw_rounds, (inc && s > done) ? 1 : 0))) break;
                 rc = finish_path(d_paths + n1 * s, d_recs + s, s, s > done);
                 h->cw_stat[2] += h->cw_rounds;
             }
@@ -1635,7 +1639,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     int first = 0;
     h->spin_requeues = 0;
     // lag counts 6 .. 24: segments walked from candidate pools (spin_candidate_pools above)
-    const bool cw = rc == GH_OK && !seg && cw_ok(h->wmode, h->L) && !h->cw_off && lt_incremental_ok(h);
+    const bool cw = rc == GH_OK && !seg && cw_ok(h->wmode, h->L) && !h->cw_off;
     bool cw_gave_up = false;
     if (cw) {
         spin_io io;
@@ -1771,7 +1775,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     // (read on every call: the tests switch between the two ways; -1 = always the batched kernels)
     const int batch_cut = getenv("GH_BATCH_STREAMS_MAX") ? atoi(getenv("GH_BATCH_STREAMS_MAX")) : 47;
     if (batch_cut >= 0 &&
-        ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || (cw_ok(b->hs[0]->wmode, b->L) && lt_incremental_ok(b->hs[0])))) {
+        ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || cw_ok(b->hs[0]->wmode, b->L))) {
         // The segment-parallel extensions fill the chip poorly with ONE window (four small dependent kernels per path, most
         // of their time launch and first-touch latency) but every window has its own stream: a few host threads each
         // run gh_spin over their share of the windows, and the windows' kernel chains interleave on the GPU.

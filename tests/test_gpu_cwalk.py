@@ -109,11 +109,13 @@ def test_hole_and_stale_table_inside_a_queue():
 
 @pytest.mark.parametrize("kw", [dict(cond_mode="B"), dict(cond_mode="D"), dict(storage="f64"), dict(cond_mode="C"), dict(marginal_term=True)])
 def test_switches(kw):
-    # conditional C / the marginal term rebuild the table before every path: those spins stay with the serial walker
+    # (conditional C / the marginal term: k_lt rebuilds the table in front of every path, the pools walk it all the same)
     t = make_support_table(1500, 20000, k=None, seed=77)
     h, o = _pair(t, L=7, **kw)
     _same(h.spin(12), o.spin(12))
+    assert h.walk_clock()[3] == 4
     assert np.array_equal(h.export_band(), o.export_band())
+    _same(h.spin(4), o.spin(4))
 
 
 @pytest.mark.parametrize("L", [8, 18])
