@@ -382,21 +382,34 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
     __syncthreads();
     int word_i = 0;
     unsigned word = 0;
-    const size_t src_stride = (size_t)6 * L * LT_ROW;       // doubles per source in G
+    // Element of G for lag l at target t under row r:  ((t - l) * 6 + r) * L * 5 + (l - 1) * 5 + col
+    //   = t * S6 + col - 5  +  l * (5 - S6)  +  r * 5L        with S6 = 30 L -- two integer multiply-adds per term
+    // (32-bit element offsets: (N + 16) * 30 L < 2^31 for every window the band tensor itself still fits)
+    const int S6 = 6 * L * LT_ROW, KL = LT_ROW - S6, R5 = L * LT_ROW;
+    const uint8_t *myring = ring[q];
     for (int t = t0 + 1; t <= t1; t++) {
         // lag l: source i = t - l, row = the pick made there (row 5 at position 0; positions < 0 add +0.0)
+        const int base = t * S6 + bcol - LT_ROW;
         double acc = 0.0;
         for (int l0 = 1; l0 <= L; l0 += CWG_CHUNK) {
             double x[CWG_CHUNK];
+            int rows[CWG_CHUNK];
+            // (no branch around a load: a term that does not exist reads the lag-1 address and is replaced by +0.0; the picks
+            // come out of the ring first, all reads in flight together, then the table loads)
 #pragma unroll
             for (int u = 0; u < CWG_CHUNK; u++) {
-                // (no branch around a load: a term that does not exist reads a valid address and is replaced by +0.0)
-                const int l = l0 + u, i = t - l;
-                const bool have = l <= L && i >= 0;
-                const int lc = l <= L ? l : L, ic = i >= 0 ? i : 0;
-                const int rr = live ? (int)ring[q][ic & (CW_MAX_LG - 1)] : 0;      // (an idle lane group reads row 0: its ring holds nothing)
-                const int row = i <= 0 ? 5 : rr;
-                const double v = P.G[(size_t)ic * src_stride + ((size_t)row * L + (lc - 1)) * LT_ROW + bcol];
+                const int l = l0 + u;
+                const int le = (l <= L && t - l >= 0) ? l : 1;
+                rows[u] = (int)myring[(t - le) & (CW_MAX_LG - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < CWG_CHUNK; u++) {
+                const int l = l0 + u;
+                const bool have = l <= L && t - l >= 0;
+                const int le = have ? l : 1;
+                int row = live ? rows[u] : 0;                       // (an idle lane group reads row 0: its ring holds nothing)
+                if (t - le <= 0) row = 5;
+                const double v = P.G[(unsigned)(base + le * KL + row * R5)];
                 x[u] = have ? v : 0.0;
             }
 #pragma unroll
