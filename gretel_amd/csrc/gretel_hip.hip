@@ -131,6 +131,7 @@ struct gh_handle {
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
     uint8_t *stage;        // pinned host staging for the results of a spin
     size_t stage_cap;
+    double *ew_buf;        // gh_edge_weights_at: seven weights and the candidate mask
     bool seg6;             // inside a gh_spin at L = 6 whose table is ranked: every state of every segment (4^6), not pools
     const gh_reads *last_reads;   // the table of the last gh_fill (not owned: see reads_alive)
     int cw_round_cap;      // GH_CW_ROUND_CAP=k at creation (tests): never more than k rounds per launch, so that chains stay open and the serial fallback runs
@@ -271,6 +272,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
     if (h->stage) hipHostFree(h->stage);
+    hipFree(h->ew_buf);
     hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
     hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_hist); hipFree(h->cw_last_hit); hipFree(h->cw_npool); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true); hipFree(h->cw_pend); hipFree(h->cw_npend);
     for (int k = 0; k < GH_K_COUNT; k++)
@@ -319,6 +321,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->stage = nullptr; h->stage_cap = 0;
     h->last_reads = nullptr;
     h->seg6 = false;
+    h->ew_buf = nullptr;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
     h->have_orig = false;
@@ -778,12 +781,12 @@ extern "C" int gh_edge_weights_at(gh_t *h, int p, const uint8_t *path, double w[
         if (path[p - l] >= NSYM) return fail(GH_ERR_SYMBOL, "path[%d] = %d is not a symbol index", p - l, path[p - l]);
         hist[l - 1] = path[p - l];
     }
-    uint8_t *d_hist = nullptr;
-    double *d_w = nullptr;
-    HIPCHK(hipMalloc((void **)&d_hist, lmax));
-    hipError_t e = hipMalloc((void **)&d_w, 8 * sizeof(double));
-    if (e != hipSuccess) { hipFree(d_hist); return fail(GH_ERR_NOMEM, "hipMalloc failed"); }
-    hipMemcpyAsync(d_hist, hist.data(), lmax, hipMemcpyHostToDevice, h->stream);
+    // (the handle's own scratch: the lone-path buffer holds the history, eight doubles the answer -- no allocation per call)
+    uint8_t *d_hist = h->d_path;
+    if (!h->ew_buf && hipMalloc((void **)&h->ew_buf, 8 * sizeof(double)) != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc failed");
+    double *d_w = h->ew_buf;
+    hipError_t e = hipMemcpyAsync(d_hist, hist.data(), lmax, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return fail(GH_ERR_HIP, "gh_edge_weights_at failed: %s", hipGetErrorString(e));
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_edge_weights<double>, dim3(1), dim3(64), 0, h->stream, (const double *)h->band, h->W,
                            h->cfg.cond_mode, p, h->L, h->cfg.marginal_term, h->cnt, h->marg, h->nvalid, h->cmask,
@@ -795,7 +798,6 @@ extern "C" int gh_edge_weights_at(gh_t *h, int p, const uint8_t *path, double w[
     double hw[8];
     e = hipMemcpyAsync(hw, d_w, sizeof hw, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d_hist); hipFree(d_w);
     if (e != hipSuccess) return fail(GH_ERR_HIP, "gh_edge_weights_at failed: %s", hipGetErrorString(e));
     memcpy(w, hw, 7 * sizeof(double));
     memcpy(cand_mask, &hw[7], sizeof(int));
@@ -1896,6 +1898,10 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                                    inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
             hipLaunchKernelGGL(k_reweight_finish, dim3(ng), dim3(256), 0, st, (const double *)nullptr, (int)marg_gx,
                                (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, gwd, s);
+        }
+        {
+            const hipError_t le = hipGetLastError();            // (a launch that failed is named with its path, not found at the end)
+            if (le != hipSuccess) return fail(GH_ERR_HIP, "gh_batch_spin: a launch of path %d failed: %s", s, hipGetErrorString(le));
         }
     }
     for (int g = 0; g < NG; g++) HIPCHK(hipStreamSynchronize(b->gstream[g]));

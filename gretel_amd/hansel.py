@@ -33,7 +33,9 @@ _SYM_LUT = np.frombuffer("".join(SYMBOLS).encode(), dtype=np.uint8)
 
 class HanselSymbol(str):
     """Prints as its character (gretel/cmd.py:128,164,211), equal to itself
-    (gretel/cmd.py:201), hashable (dict key of get_counts_at)."""
+    (gretel/cmd.py:201), hashable (dict key of get_counts_at).  hanselx's own symbol class is not in the
+    reference tree; everything the reference does with a symbol works on this one.  Being a str subclass it also
+    compares equal to the plain character -- a convenience of this mirror, not a claim about hanselx."""
     __slots__ = ("i",)
 
     def __new__(cls, char, i):
