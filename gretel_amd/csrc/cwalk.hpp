@@ -587,6 +587,7 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
             }
         }
         st->cw_open_at = open ? stuck + 1 : -1;
+        if (!open && P.round + 1 > c.cw_need) st->cw_need = P.round + 1;    // (one chain at a time: no atomic needed; c = the words as this launch found them)
 #ifdef CW_DIAG
         if (!open) st->dbg8[P.round < 4 ? P.round : 4] += 1;      // histogram: the round a chain closed in
 #endif

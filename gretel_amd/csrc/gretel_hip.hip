@@ -1514,7 +1514,14 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             // (a look costs ~25 us of idle GPU; an open chain costs the ~37 us of idle launches of every path queued
             // behind it: at one open chain in 50..100 paths the optimum is 8..16 paths per look)
             if (CHUNK < 16) CHUNK *= 2;
-            if (++clean >= 3 && h->cw_rounds > 1) { h->cw_rounds--; clean = 0; }     // idle rounds cost three launches each
+            // idle rounds cost three launches each: one fewer when, three looks in a row, no path needed as many as are queued
+            if (hs.cw_need > 0 && hs.cw_need < h->cw_rounds) { if (++clean >= 3) { h->cw_rounds--; clean = 0; } }
+            else clean = 0;
+            if (hs.cw_need > 0) {
+                const int zero = 0;
+                e = hipMemcpyAsync(&h->dstate->cw_need, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
+                if (e != hipSuccess) { rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e)); break; }
+            }
         } else { CHUNK = 8; clean = 0; }
         if (hs.lt_stale || hs.cw_unres) {
             e = hipMemcpyAsync(&h->dstate->lt_stale, zero2, sizeof zero2, hipMemcpyHostToDevice, h->stream);

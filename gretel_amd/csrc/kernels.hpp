@@ -43,7 +43,7 @@ struct dev_state {
     int cw_unres;    // candidate-pool walk (cwalk.hpp): 1 = the queued rounds did not close the chain, 2 = table not ranked
     double ratio;    // clamped min marginal of the path just walked
     int cw_open_at;  // k_cscan: -1 = chain closed, else the segment whose entry state is still to be walked
-    int _r1;
+    int cw_need;     // k_cscan: most rounds a path needed to close its chain since the host last cleared this (sizes the rounds queued per path)
     unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
     unsigned long long dbg8[5];  // -DGH_STAMPS / -DSEG_STAMPS builds: cycles per segment of the code
@@ -52,7 +52,7 @@ struct dev_state {
 struct dev_ctl {
     int stop, hole_at, n_done, scratch, first_hole, nodel, cm_same, narrow, ranked, cur_hole, lt_stale, cw_unres;
     double ratio;
-    int cw_open_at, _r1;
+    int cw_open_at, cw_need;
 };
 static_assert(sizeof(dev_ctl) == 64 && offsetof(dev_state, fill) == 64, "control words = the first line of dev_state");
 
