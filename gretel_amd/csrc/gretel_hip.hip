@@ -986,6 +986,15 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
     hipLaunchKernelGGL((k_seg<LC>), dim3(S), dim3(SEG_THREADS), lds_seg, stream, P);
     // algorithmic bytes of k_seg: the conditional lookups of the extension (L history cells per step)
     prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
+    // short memories / small windows: every segment map fits the LDS of the emitting workgroup, which composes them itself
+    const size_t lds_small = five ? max2(emit_small_lds_bytes(N, LC, 4), emit_small_lds_bytes(N, LC, 5)) : emit_small_lds_bytes(N, LC, 4);
+    static const bool no_small = getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0;
+    if (lds_small <= 64 * 1024 && !no_small) {
+        static size_t set_small[64];
+        if (lds_small > set_small[dv]) { hipFuncSetAttribute((const void *)k_emit_small<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small); set_small[dv] = lds_small; }
+        hipLaunchKernelGGL((k_emit_small<LC>), dim3(S), dim3(SEG_THREADS), lds_small, stream, P);
+        return;
+    }
     hipLaunchKernelGGL((k_scan<LC>), dim3(G1), dim3(SEG_THREADS), lds_scan, stream, P);
     hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, stream, P);
 }

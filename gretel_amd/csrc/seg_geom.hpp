@@ -85,3 +85,10 @@ __host__ __device__ inline size_t emit_lds_bytes(int N, int L, int R)
     return (size_t)g.G1 * g.NS * 2;             // the group maps in front (<= G1 - 1) and the segment's prefix map
 }
 
+
+// k_emit_small: the group maps in front (<= G1 x NS) and every segment map (S x NS), 2 bytes each
+__host__ __device__ inline size_t emit_small_lds_bytes(int N, int L, int R)
+{
+    const seg_geom g = seg_geometry(N, L, R);
+    return ((size_t)g.G1 + (size_t)g.S) * g.NS * 2 + 16;
+}

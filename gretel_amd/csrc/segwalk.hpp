@@ -266,7 +266,9 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
 // -------------------------------------------------------------------------------------------------------------
 // k_emit
 // -------------------------------------------------------------------------------------------------------------
-template <int R, int LC>
+// SMALL: the segment maps of the whole window fit the LDS (S * NS * 2 bytes <= 64 KB: short memories, small windows):
+// this kernel composes them itself -- group maps by all threads, then the chain -- and no k_scan runs in front of it.
+template <int R, int LC, bool SMALL = false>
 __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *smem, int first_hole)
 {
     constexpr int BITS = seg_radix<R>::BITS, DPW = seg_radix<R>::DPW;
@@ -289,10 +291,18 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
     const int grp = s / g.G2, q = s - grp * g.G2;
     uint16_t *GM = reinterpret_cast<uint16_t *>(smem);             // [grp][NS] group maps in front of this group
     uint16_t *PM = GM + (size_t)grp * NS;                          // [NS] prefix map of this segment (q >= 1)
-    for (int e = tid; e < grp * NS; e += SEG_THREADS) GM[e] = P.gmaps[e];
-    if (q > 0) {
-        const uint16_t *src = P.pmaps + (size_t)s * NS;
-        for (int e = tid; e < NS; e += SEG_THREADS) PM[e] = src[e];
+    uint16_t *MS = GM + (((size_t)g.G1 * NS + 1) & ~(size_t)1);   // SMALL: [s][NS] the segment maps in front of this one (4-byte aligned)
+    if constexpr (SMALL) {
+        // the maps of segments 0 .. s-1 (what lies behind this segment does not matter to it)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(P.maps);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(MS);
+        for (int e = tid; e < s * NS / 2 + 1; e += SEG_THREADS) dst[e] = src[e];
+    } else {
+        for (int e = tid; e < grp * NS; e += SEG_THREADS) GM[e] = P.gmaps[e];
+        if (q > 0) {
+            const uint16_t *src = P.pmaps + (size_t)s * NS;
+            for (int e = tid; e < NS; e += SEG_THREADS) PM[e] = src[e];
+        }
     }
     // the rows of minfo do not depend on the path: in flight under the chain (one position per thread and trip)
     const int npos = t1 - t0;
@@ -303,8 +313,23 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
         for (int k = 0; k < 8; k++) row[k] = src[k];
     }
     __syncthreads();
-    // the true entry state: the start state 0 through the maps of the groups in front, then the prefix map
-    if (tid == 0) {
+    if constexpr (SMALL) {
+        // the maps of the whole groups in front of this one, every state of every such group on its own thread
+        for (int e = tid; e < grp * NS; e += SEG_THREADS) {
+            const int gj = e / NS;
+            int x = e - gj * NS;
+            for (int j = 0; j < g.G2; j++) x = MS[(size_t)(gj * g.G2 + j) * NS + x];
+            GM[e] = (uint16_t)x;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int x = 0;
+            for (int j = 0; j < grp; j++) x = GM[(size_t)j * NS + x];
+            for (int j = 0; j < q; j++) x = MS[(size_t)(grp * g.G2 + j) * NS + x];
+            s_sigma = x;
+        }
+    } else if (tid == 0) {
+        // the true entry state: the start state 0 through the maps of the groups in front, then the prefix map
         int x = 0;
         for (int j = 0; j < grp; j++) x = GM[(size_t)j * NS + x];
         if (q > 0) x = PM[x];
@@ -363,6 +388,23 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit(seg_params P)
     if (blockIdx.x == 0 && threadIdx.x == 0) st->dbg[3] = 3;      // gh_debug_walk_clock: variant 3 = segment-parallel
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC>(P, seg_smem, c.cur_hole);
     else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC>(P, seg_smem, c.cur_hole);
+}
+
+// k_scan and k_emit in one launch where the window's maps fit the LDS (emit_body<.., true>)
+template <int LC>
+__global__ void __launch_bounds__(SEG_THREADS) k_emit_small(seg_params P)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->dbg[3] = 3;
+        // (k_scan's other job: the flags for the reweight that follows -- every k_seg workgroup has read them: it ran in the launch before)
+        if (P.rearm && c.cur_hole > P.N) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
+    }
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC, true>(P, seg_smem, c.cur_hole);
+    else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC, true>(P, seg_smem, c.cur_hole);
 }
 
 // what the serial walkers' bookkeeper does at the end of a walk: hole -> stop, else the record and the ratio the
