@@ -49,20 +49,21 @@ def process_vcf(vcf_path, contig_name, start_pos, end_pos):
     opener = gzip.open if _is_gzip(vcf_path) else open
     i = 0
     with opener(vcf_path, "rb") as fp:
-        for line in fp:
-            if not line or line[:1] == b"#":
-                continue
-            f = line.split(b"\t", 2)
-            if len(f) < 2 or f[0].decode() != contig_name:
-                continue
-            pos = int(f[1])
-            if pos < start_pos or pos > end_pos:              # util.py:397-400
-                continue
-            n_snps += 1
-            region[pos] = 1
-            snp_reverse[i] = pos
-            snp_forward[pos] = i
-            i += 1
+        data = fp.read()                                      # (whole file at once: line iteration over gzip is the slow part)
+    key = contig_name.encode() + b"\t"
+    klen = len(key)
+    for line in data.split(b"\n"):
+        if not line.startswith(key):                          # header lines, other contigs
+            continue
+        tab = line.find(b"\t", klen)
+        pos = int(line[klen:tab] if tab >= 0 else line[klen:])
+        if pos < start_pos or pos > end_pos:                  # util.py:397-400
+            continue
+        n_snps += 1
+        region[pos] = 1
+        snp_reverse[i] = pos
+        snp_forward[pos] = i
+        i += 1
     return {"N": n_snps, "snp_fwd": snp_forward, "snp_rev": snp_reverse, "region": region}
 
 
