@@ -109,3 +109,25 @@ def test_reweight_multiplicities():
             assert c[(p, q)] == 1
     for p in range(0, n):
         assert c[(p, p)] == 1
+
+
+def test_vcf_other_contigs_repeated_positions_and_plain_text(tmp_path):
+    """process_vcf (gretel/util.py:354-414) takes the records of ONE contig inside the window, counts a position listed
+    twice twice (n_snps, the reverse map) while the forward map and the region keep one entry, and reads plain text as
+    well as gzip."""
+    lines = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    recs = [("chr1", 5), ("chr10", 6), ("chr1", 9), ("chr1", 9), ("chr2", 9), ("chr1", 30), ("chr1", 12)]
+    lines += ["%s\t%d\t.\tA\tC\t.\t.\t." % r for r in recs]
+    plain = tmp_path / "v.vcf"
+    plain.write_text("\n".join(lines) + "\n")
+    import gzip
+    gz = tmp_path / "v.vcf.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(("\n".join(lines) + "\n").encode())
+    for path in (str(plain), str(gz)):
+        v = util.process_vcf(path, "chr1", 5, 20)
+        assert v["N"] == 4                                   # 5, 9, 9, 12 (30 lies outside, chr10 / chr2 are other contigs)
+        assert v["snp_rev"] == {0: 5, 1: 9, 2: 9, 3: 12}
+        assert v["snp_fwd"] == {5: 0, 9: 2, 12: 3}
+        assert [int(p) for p in np.nonzero(v["region"])[0]] == [5, 9, 12]
+        assert len(v["region"]) == 21
