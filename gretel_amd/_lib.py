@@ -15,7 +15,7 @@ SO_PATH = os.environ.get("GH_LIB") or os.path.join(_HERE, "libgretel_hip.so")   
 GH_OK = 0
 GH_ERR_ARG, GH_ERR_HIP, GH_ERR_BAND, GH_ERR_SYMBOL, GH_ERR_NOMEM, GH_ERR_STATE = -1, -2, -3, -4, -5, -6
 GH_STORAGE = {"f32": 0, "f64": 1}
-GH_COND = {"A": 0, "B": 1, "C": 2, "D": 3}
+GH_COND = {"A": 0, "B": 1, "C": 2, "D": 3, "E": 4}
 GH_K = {"fill": 0, "marg": 1, "lt": 2, "walk": 3, "reweight": 4, "seg": 5}
 
 
@@ -35,7 +35,8 @@ class SymbolError(GretelHipError, KeyError):
 
 class gh_config(C.Structure):
     _fields_ = [("n_snps", C.c_int32), ("band", C.c_int32), ("storage", C.c_int32),
-                ("cond_mode", C.c_int32), ("marginal_term", C.c_int32), ("device", C.c_int32)]
+                ("cond_mode", C.c_int32), ("marginal_term", C.c_int32), ("device", C.c_int32),
+                ("offer_zero", C.c_int32), ("cand_order", C.c_uint8 * 8)]
 
 
 class gh_fill_stats(C.Structure):

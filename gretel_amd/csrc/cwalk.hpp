@@ -68,13 +68,14 @@ __host__ __device__ constexpr int cw_lds_budget(int L, int R)
     return R == 4 ? (L <= 13 ? 76 * 1024 : (L <= 17 ? 96 * 1024 : (L <= 19 ? 120 * 1024 : 150 * 1024)))
                   : (L <= 12 ? 76 * 1024 : (L <= 13 ? 96 * 1024 : (L <= 15 ? 120 * 1024 : 150 * 1024)));
 }
+// (+ 5 doubles per source slot: the log-marginals of its lag-1 target, for windows walked with the marginal term)
 __host__ __device__ constexpr int cw_chunk(int L, int R)
 {
     int c = 64;
-    while (c > 2 && (c + L - 1) * cw_rows(R) * L * 5 * 8 > cw_lds_budget(L, R)) c -= 1;
+    while (c > 2 && (c + L - 1) * (cw_rows(R) * L * 5 + 5) * 8 > cw_lds_budget(L, R)) c -= 1;
     return c;
 }
-__host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)(cw_chunk(L, R) + L - 1) * cw_rows(R) * L * 5 * 8; }
+__host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)(cw_chunk(L, R) + L - 1) * (cw_rows(R) * L * 5 + 5) * 8; }
 
 struct cw_params {
     int N, L;
@@ -86,6 +87,9 @@ struct cw_params {
     int _pad;
     const double *G;          // ranked or over the symbols (st->ranked): k_cwalk<LC, 4> / k_cwalk<LC, 5>
     const double *minfo;
+    const double *rinfo;      // [N+2][8]: log10 marginal / marginal by candidate rank
+    int mt;                   // gh_config.marginal_term: log10 marginal(b, t) in front of x1 (see k_lt)
+    symmap sm;
     dev_state *st;
     cw_key *keys, *exits;     // [S][CW_K]
     int32_t *last_hit;        // [S][CW_K]
@@ -106,6 +110,12 @@ struct cw_params {
     int _pad2;
     cw_key key0;              // key of the start state (0 in the packed mode)
 };
+
+// k_cwalk's LDS: the slice of G, then the log-marginal rows (one per source slot)
+__device__ __forceinline__ double *Gs_lm(unsigned char *smem, int CH, int LC, int rows)
+{
+    return reinterpret_cast<double *>(smem) + (size_t)(CH + LC - 1) * rows * LC * LT_ROW;
+}
 
 __device__ __forceinline__ cw_key cw_hash_digits(const uint8_t *d, int L)
 {
@@ -200,9 +210,25 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     static_assert(RUN % 2 == 0, "16-byte copies");
     constexpr int NV = ((CH + LC - 1) * RUN2 + NTHR - 1) / NTHR;
     lds_v2d pre[NV];
+    // marginal term: the log-marginals of target i + 1 for every source slot (column b: rank or symbol, like G's columns),
+    // fetched with the slice, added in front of the lag-1 entries once the slice stands in LDS
+    constexpr int NLM = ((CH + LC - 1) * LT_ROW + NTHR - 1) / NTHR;
+    double *Lms = Gs_lm(cw_smem, CH, LC, ROWS);
+    double prelm[NLM];
     auto fetch = [&](int c0) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
         const int i_lo = c0 + 1 - LC, total = (nc + LC - 1) * RUN2;
+        if (P.mt) {
+#pragma unroll
+            for (int k = 0; k < NLM; k++) {
+                const int e = tid + k * NTHR;
+                const int ii = e / LT_ROW, bb = e - ii * LT_ROW;
+                const int tgt = i_lo + ii + 1;
+                prelm[k] = 0.0;
+                if (ii < nc + LC - 1 && tgt >= 1 && tgt <= P.N && bb < R)
+                    prelm[k] = R == 4 ? P.rinfo[(size_t)tgt * RINFO + bb] : P.minfo[(size_t)tgt * MINFO + bb];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             const int e = tid + k * NTHR;
@@ -231,6 +257,20 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
                 Gs[(size_t)ii0 * RUN + e] = P.G[(size_t)(5 * LC + l) * LT_ROW + bb];
             }
         }
+        if (P.mt) {
+#pragma unroll
+            for (int k = 0; k < NLM; k++) {
+                const int e = tid + k * NTHR;
+                if (e < (nc + LC - 1) * LT_ROW) Lms[e] = prelm[k];
+            }
+            __syncthreads();
+            // lag 1 of slot ii, row r, column bb:  (0.0 + lm) + x1 -- the reference's first addition
+            for (int e = tid; e < (nc + LC - 1) * ROWS * LT_ROW; e += NTHR) {
+                const int bb = e % LT_ROW, r = (e / LT_ROW) % ROWS, ii = e / (LT_ROW * ROWS);
+                double *g = Gs + (size_t)ii * RUN + (size_t)r * LC * LT_ROW + bb;
+                *g = Lms[ii * LT_ROW + bb] + *g;
+            }
+        }
     };
     fetch(t0);
     for (int c0 = t0; c0 < t1; c0 += CH) {
@@ -253,7 +293,8 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
             double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
             m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
             if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));          // row_half_mirror: the other quad of the eight lanes
-            const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+            // (R = 5: a NaN weight in first place is the reference's incumbent and stays it -- kernels.hpp, argmax8)
+            const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
             const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));       // first wins (gretel.py:166-174)
             sigma = ((sigma << BITS) | (cw_key)d) & SMASK;
             const int gt = c0 - t0 + tl;                             // position inside the segment
@@ -391,6 +432,8 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
         // lag l: source i = t - l, row = the pick made there (row 5 at position 0; positions < 0 add +0.0)
         const int base = t * S6 + bcol - LT_ROW;
         double acc = 0.0;
+        double lm_t = 0.0;                                          // marginal term: in front of x1
+        if (P.mt) lm_t = R == 4 ? P.rinfo[(size_t)t * RINFO + bcol] : P.minfo[(size_t)t * MINFO + bcol];
         for (int l0 = 1; l0 <= L; l0 += CWG_CHUNK) {
             double x[CWG_CHUNK];
             int rows[CWG_CHUNK];
@@ -414,13 +457,13 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
             }
 #pragma unroll
             for (int u = 0; u < CWG_CHUNK; u++)
-                if (l0 + u <= L) acc = (l0 + u == 1) ? x[u] : acc + x[u];
+                if (l0 + u <= L) acc = (l0 + u == 1) ? (P.mt ? lm_t + x[u] : x[u]) : acc + x[u];
         }
         if (R == 5 && b >= R) acc = -INFINITY;
         double m = vmax_f64(acc, dpp_f64<0xB1>(acc));
         m = vmax_f64(m, dpp_f64<0x4E>(m));
         if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));
-        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+        const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
         const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));
         if (live && b == 0) ring[q][t & (CW_MAX_LG - 1)] = (uint8_t)d;      // (read again at the earliest one step later, by this lane group only)
         const int gt = t - t0 - 1;
@@ -633,7 +676,7 @@ __global__ void __launch_bounds__(256) k_cemit(cw_params P)
             b5 = (int)((word >> (4 * (tl & 7))) & 7u);
             if (b5 > 4) b5 = 0;
         }
-        P.path_out[t] = (uint8_t)vsym(b5);
+        P.path_out[t] = (uint8_t)vsym(P.sm, b5);
         P.lmsel[t] = inf[b5];
         const double m = inf[5 + b5];
         if (m < mn) mn = m;
@@ -667,7 +710,7 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
     auto digit = [&](int i) -> unsigned {
         if (i < 1) return 0u;
         const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
-        const int a6 = a6_of_sym(path[i]);
+        const int a6 = a6_of_sym(P.sm, path[i]);
         return ranked ? ((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u) : (unsigned)(a6 < 5 ? a6 : 0);
     };
     cw_key sigma = 0;
@@ -727,7 +770,7 @@ __global__ void __launch_bounds__(256) k_cguess(cw_params P, uint8_t *path)
 #pragma unroll
     for (int b5 = 1; b5 < 5; b5++)
         if (inf[5 + b5] > bm) { bm = inf[5 + b5]; best = b5; }
-    path[p] = (uint8_t)vsym(best);
+    path[p] = (uint8_t)vsym(P.sm, best);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -782,7 +825,7 @@ k_cseed_reads(cw_params P, const int32_t *__restrict__ rank, const int64_t *__re
             const int i = p + 1 - l;
             const int sym = c_sym_of_char[bases[o0 + (i - rk - 1)]];
             const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
-            const int a6 = sym < 0 ? 7 : a6_of_sym(sym);
+            const int a6 = sym < 0 ? 7 : a6_of_sym(P.sm, sym);
             if (sym < 0 || sym == 4 || a6 > 4 || !((cm5 >> a6) & 1u)) { ok = false; break; }      // N, '_', not a candidate
             sigma = ranked ? ((sigma << 2) | (cw_key)((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u)) : ((sigma << 3) | (cw_key)(unsigned)a6);
         }

@@ -88,7 +88,10 @@ struct gh_handle {
     double *cnt, *marg, *minfo;
     int32_t *nvalid;
     uint32_t *cmask;
+    double *rinfo;                // [(N+2)][8] log10 marginal / marginal by candidate rank (k_marg, k_rw)
+    symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
     double *lt;
+    bool lt_baked;                // lt holds the marginal term in its lag-1 entries (built for a serial walker; only with cfg.marginal_term)
     double *ht, *yt;              // depth-2 walker tables derived from lt (k_lt), when walk_depth2_ok(L)
     unsigned long long fill_seen[6];   // host mirror of dstate->fill as last read (the counters only move under this handle's calls)
     uint8_t *spin_paths;          // gh_spin's device results, kept between calls: [spin_cap][N+1]
@@ -267,7 +270,7 @@ static void free_handle(gh_handle *h)
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
-    hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
+    hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->rinfo); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
@@ -288,7 +291,21 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     if (cfg->band < 1) return fail(GH_ERR_ARG, "band must be >= 1 (got %d)", cfg->band);
     if (cfg->storage != GH_STORAGE_F32 && cfg->storage != GH_STORAGE_F64)
         return fail(GH_ERR_ARG, "bad storage %d", cfg->storage);
-    if (cfg->cond_mode < 0 || cfg->cond_mode > 3) return fail(GH_ERR_ARG, "bad cond_mode %d", cfg->cond_mode);
+    if (cfg->cond_mode < 0 || cfg->cond_mode > GH_COND_E) return fail(GH_ERR_ARG, "bad cond_mode %d", cfg->cond_mode);
+    uint8_t order[5] = {0, 1, 2, 3, 5};
+    {
+        bool all_zero = true;
+        for (int q = 0; q < 8; q++) all_zero = all_zero && cfg->cand_order[q] == 0;
+        if (!all_zero) {
+            unsigned seen = 0;
+            for (int q = 0; q < 5; q++) {
+                if (cfg->cand_order[q] > 5 || cfg->cand_order[q] == 4) return fail(GH_ERR_ARG, "cand_order[%d] = %d is not a valid symbol index", q, cfg->cand_order[q]);
+                seen |= 1u << cfg->cand_order[q];
+                order[q] = cfg->cand_order[q];
+            }
+            if (seen != 0x2Fu) return fail(GH_ERR_ARG, "cand_order is not a permutation of the valid symbols {0,1,2,3,5}");
+        }
+    }
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev < 1) return fail(GH_ERR_HIP, "no HIP device visible");
@@ -303,6 +320,11 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     if (!h) return fail(GH_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
     h->cfg.device = dev;
+    h->cfg.offer_zero = cfg->offer_zero ? 1 : 0;
+    memset(h->cfg.cand_order, 0, sizeof h->cfg.cand_order);
+    memcpy(h->cfg.cand_order, order, 5);
+    h->sm = make_symmap(order);
+    h->rinfo = nullptr; h->lt_baked = false;
     h->dev = dev;
     h->N = cfg->n_snps;
     h->W = cfg->band;
@@ -352,6 +374,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     ALLOC(h->minfo, np * MINFO * sizeof(double));
     ALLOC(h->nvalid, np * sizeof(int32_t));
     ALLOC(h->cmask, np * sizeof(uint32_t));
+    ALLOC(h->rinfo, np * RINFO * sizeof(double));
     ALLOC(h->dstate, sizeof(dev_state));
     ALLOC(h->d_path, np);
     ALLOC(h->d_rw_path, np);
@@ -360,6 +383,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     hipMemsetAsync(h->band, 0, h->n_cells * CELL * esize(h), h->stream);
     hipMemsetAsync(h->dstate, 0, sizeof(dev_state), h->stream);
     hipMemsetAsync(h->minfo, 0, np * MINFO * sizeof(double), h->stream);
+    hipMemsetAsync(h->rinfo, 0, np * RINFO * sizeof(double), h->stream);
+    hipMemsetAsync(h->cmask, 0, np * sizeof(uint32_t), h->stream);
     HIPCHK(hipStreamSynchronize(h->stream));
     *out = h;
     return GH_OK;
@@ -693,11 +718,13 @@ static int ensure_marg(gh_handle *h)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
+                           h->sm, h->cfg.offer_zero, h->rinfo);
     else
         hipLaunchKernelGGL((k_marg<float, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
-                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                           (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
+                           h->sm, h->cfg.offer_zero, h->rinfo);
     // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
     prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
     { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
@@ -707,18 +734,28 @@ static int ensure_marg(gh_handle *h)
 
 static int alloc_lt(gh_handle *h);
 // may the fused reweight keep the conditional table current (k_marg<T,true> rewrites the rows a path changes)?
-static bool lt_incremental_ok(const gh_handle *h) { return h->cfg.cond_mode != GH_COND_C && !h->cfg.marginal_term && !h->lt_full; }
+// k_marg<T,true> (behind the serial walkers, gh_reweight_path): rows only -- conditionals whose denominator is a row sum or a
+// marginal count, and no marginal term baked into the table
+static bool lt_incremental_ok(const gh_handle *h)
+{
+    return h->cfg.cond_mode != GH_COND_C && h->cfg.cond_mode != GH_COND_E && !h->cfg.marginal_term && !h->lt_full;
+}
+// k_rw (behind the segment-parallel walks, which add the marginal term themselves): every conditional -- rows, or columns for C and E
+static bool rw_incremental_ok(const gh_handle *h) { return !h->lt_full && !h->lt_baked; }
 static bool walk_depth2_ok(int wm, int L);
 static bool walk_ranked_ok(int wm, int L);
 static bool seg_ok(int wm, int L);
 
-static int ensure_lt(gh_handle *h)
+// baked: the table is for a serial walker, which reads whole rows: with the marginal term its lag-1 entries hold lm + x1
+// (k_lt); the segment-parallel walks want the bare conditionals and add lm themselves
+static int ensure_lt(gh_handle *h, bool baked = false)
 {
     int rc = ensure_marg(h);
     if (rc) return rc;
-    if (!h->dirty_lt && h->lt && h->lt_L == h->L) return GH_OK;
+    const bool want_baked = baked && h->cfg.marginal_term;
+    if (!h->dirty_lt && h->lt && h->lt_L == h->L && h->lt_baked == want_baked) return GH_OK;
     if ((rc = alloc_lt(h))) return rc;
-    const bool inc_ok = h->lt_inc_path && lt_incremental_ok(h);
+    const bool inc_ok = h->lt_inc_path && lt_incremental_ok(h) && h->lt_baked == want_baked;
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
     const size_t total = inc ? (size_t)h->N * 4 : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
@@ -727,12 +764,12 @@ static int ensure_lt(gh_handle *h)
     prof_begin(h, GH_K_LT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
-                           h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt);
+                           h->N, h->W, h->L, h->cfg.cond_mode, want_baked ? 1 : 0, h->cnt, h->nvalid, h->cmask,
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt, h->sm);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
-                           h->N, h->W, h->L, h->cfg.cond_mode, h->cfg.marginal_term, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt);
+                           h->N, h->W, h->L, h->cfg.cond_mode, want_baked ? 1 : 0, h->cnt, h->nvalid, h->cmask,
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt, h->sm);
     const int wl = h->W < h->L ? h->W : h->L;
     // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
     prof_end(h, GH_K_LT, inc ? 8.0
@@ -740,6 +777,7 @@ static int ensure_lt(gh_handle *h)
     { int rc_ = post_launch(h, "k_lt"); if (rc_) return rc_; }
     h->dirty_lt = false;
     h->lt_inc_path = nullptr;
+    h->lt_baked = want_baked;
     return GH_OK;
 }
 
@@ -829,6 +867,7 @@ extern "C" int gh_export_cmask(gh_t *h, uint32_t *out)
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(out, h->cmask, (size_t)(h->N + 1) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int p = 0; p <= h->N; p++) out[p] = CM_CAND(out[p]);      // (the device word also carries the symbols seen: kernels.hpp)
     return GH_OK;
 }
 
@@ -1005,7 +1044,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     if (rc) return rc;
     seg_params P;
     P.N = h->N; P.L = h->L; P.rearm = rearm; P.check_masks = check_masks;
-    P.G = h->lt; P.minfo = h->minfo; P.st = h->dstate;
+    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
     prof_begin(h, GH_K_WALK);
@@ -1031,7 +1070,7 @@ static int launch_walk(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, double
     walk_params P;
     P.N = h->N; P.L = h->L; P.chunk = 0; P.rearm = rearm;
     P.G = h->lt; P.Ht = h->ht; P.Yt = h->yt; P.minfo = h->minfo;
-    P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove;
+    P.path_out = d_path; P.rec = d_rec; P.st = h->dstate; P.min_remove = min_remove; P.sm = h->sm;
     prof_begin(h, GH_K_WALK);
     launch_walk_any(h->wmode, h->N, h->L, P, h->stream, 1, nullptr, 0);
     // algorithmic bytes, SURVEY 8(d): per step the marginal cell + L history cells (49 elements each) + the original
@@ -1081,29 +1120,32 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     // this path changes; k_lt then only has to confirm that no candidate mask moved
     // (chained: a spin without k_lt between its paths -- the table is current up to the rows the previous reweight rewrote, and
     // the k_seg that ran before this reweight has checked the candidate masks)
-    const bool lt_ok = (!h->dirty_lt || chained) && h->lt && h->lt_L == h->L && lt_incremental_ok(h);
+    const bool lt_ok = (!h->dirty_lt || chained) && h->lt && h->lt_L == h->L && (seg ? rw_incremental_ok(h) : lt_incremental_ok(h));
     double *lt_rows = lt_ok ? h->lt : nullptr;
     prof_begin(h, GH_K_REWEIGHT);
     if (seg) {
         // behind a segment-parallel walk (L <= SEG_MAX_L <= 8: one table row per lane): segwalk.hpp's k_rw
-#define GH_RW_LAUNCH(T, LP)                                                                                                       \
-    hipLaunchKernelGGL((k_rw<T, LP>), dim3(nb), dim3(block), 0, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid,  \
+#define GH_RW_LAUNCH(T, LP, COL)                                                                                                  \
+    hipLaunchKernelGGL((k_rw<T, LP, COL>), dim3(nb), dim3(block), 0, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
                        h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                    \
-                       (const double *)h->seg_min, d_rec, nseg_arg)
+                       (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->rinfo)
+#define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true); else GH_RW_LAUNCH(T, LP, false); } while (0)
         const bool wide = rw_lanes(h) == 32;
-        if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH(double, 32); else GH_RW_LAUNCH(double, 8); }
-        else { if (wide) GH_RW_LAUNCH(float, 32); else GH_RW_LAUNCH(float, 8); }
+        const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;      // the table entries a reweighted cell feeds: a column
+        if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
+        else { if (wide) GH_RW_LAUNCH2(float, 32); else GH_RW_LAUNCH2(float, 8); }
+#undef GH_RW_LAUNCH2
 #undef GH_RW_LAUNCH
     } else if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
-                           (const double *)nullptr, (gh_path_rec *)nullptr);
+                           (const double *)nullptr, (gh_path_rec *)nullptr, h->sm, h->cfg.offer_zero, h->rinfo);
     else
         hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
-                           (const double *)nullptr, (gh_path_rec *)nullptr);
+                           (const double *)nullptr, (gh_path_rec *)nullptr, h->sm, h->cfg.offer_zero, h->rinfo);
     if (slot < 0)
         hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, partial, nb, h->dstate, use_state, d_rec,
                            (const win_desc *)nullptr, 0);
@@ -1162,7 +1204,7 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     cw_params P;
     memset(&P, 0, sizeof P);
     P.N = h->N; P.L = h->L; P.rearm = h->cw_no_rw ? 0 : 1; P.stamp = h->cw_stamp;
-    P.G = h->lt; P.minfo = h->minfo; P.st = h->dstate;
+    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
     P.keys = h->cw_keys; P.exits = h->cw_exits; P.last_hit = h->cw_last_hit; P.npool = h->cw_npool; P.walked = h->cw_walked; P.nxt = h->cw_nxt; P.pend = h->cw_pend; P.npend = h->cw_npend;
     P.hist = h->cw_hist; P.true_idx = h->cw_true; P.segmin = h->seg_min; P.path_out = d_path; P.lmsel = d_lmsel;
     if (cw_digit_mode(h)) {
@@ -1223,7 +1265,7 @@ static int cw_serial_path(gh_handle *h, uint8_t *d_path, gh_path_rec *d_rec, dou
     // the serial depth-2 walker reads tables that k_lt keeps; behind pool paths (no k_lt between them) they are stale
     h->lt_inc_path = nullptr;
     h->dirty_lt = true;
-    int rc = ensure_lt(h);
+    int rc = ensure_lt(h, true);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(d_lmsel, 0, sizeof(double), h->stream));      // k_hp: the walker sums this path itself
     if ((rc = launch_walk(h, d_path, d_rec, min_remove, 1, nullptr, 0))) return rc;
@@ -1277,7 +1319,8 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
 {
     if (!h || !path_out || !hole_at) return fail(GH_ERR_ARG, "null argument");
     if (set_dev(h)) return GH_ERR_HIP;
-    int rc = ensure_lt(h);
+    const bool pools = cw_ok(h->wmode, h->L) && !h->cw_off;
+    int rc = ensure_lt(h, !seg_ok(h->wmode, h->L) && !pools);      // (a serial walker wants the marginal term in the table)
     if (rc) return rc;
     const int nb8 = ((h->N + 1) * 8 + 255) / 256;
     if (original && original != h) {
@@ -1321,6 +1364,7 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
             return GH_OK;
         }
         if ((rc = reset_spin_state(h))) return rc;
+        if ((rc = ensure_lt(h, true))) return rc;                   // the pools gave the window up: the serial walker's table
     }
     if ((rc = launch_walk(h, h->d_path, h->d_rec, 0.0, 0))) return rc;
     if (seg_ok(h->wmode, h->L)) {
@@ -1330,7 +1374,7 @@ extern "C" int gh_generate_path(gh_t *h, const gh_t *original, uint8_t *path_out
         P.N = h->N; P.L = h->L; P.st = h->dstate; P.segmin = h->seg_min;
         hipLaunchKernelGGL(k_seg_fin, dim3(1), dim3(256), 0, h->stream, P, h->d_rec, 0.0, 0);
         hipLaunchKernelGGL(k_hp, dim3(1, 2), dim3(64), 0, h->stream, (const double *)h->lmsel1, (size_t)0, (const uint8_t *)h->d_path,
-                           (size_t)0, (const double *)h->minfo, h->N, (const dev_state *)h->dstate, h->d_rec);
+                           (size_t)0, (const double *)h->minfo, h->N, (const dev_state *)h->dstate, h->d_rec, h->sm);
         if ((rc = post_launch(h, "k_seg_fin/k_hp"))) return rc;
     }
     dev_state hs;
@@ -1499,8 +1543,8 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
             // (conditional C / the marginal term: the reweight cannot keep the table current, k_lt rebuilds it in front of
             // every path -- queued like everything else; otherwise once per look, and k_cwalk checks the masks)
-            const bool inc = lt_incremental_ok(h);
             if ((rc = ensure_lt(h))) break;
+            const bool inc = rw_incremental_ok(h);
             for (int s = done; s < upto && rc == GH_OK; s++) {
                 h->cw_stamp++;
                 if (!inc && s > done && (rc = ensure_lt(h))) break;
@@ -1595,7 +1639,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
     }
     if (rc == GH_OK && done > 0 && !cw_gave_up) {
         hipLaunchKernelGGL(k_hp, dim3(done, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
-                           (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
+                           (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs, h->sm);
         if (!io.no_reweight) hipLaunchKernelGGL(k_reweight_finish_all, dim3(done), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
         rc = post_launch(h, "k_hp/k_reweight_finish_all");
         if (rc == GH_OK) {
@@ -1647,7 +1691,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     // term): no k_lt between two paths.  Its only job there is to notice that a candidate mask moved (a count reached
     // zero; rare) and rebuild the table; instead the next k_seg sees the flag k_marg left, marks the table stale and the
     // rest of the queue does nothing.  The host then rebuilds and queues the remaining paths again.
-    const bool optimistic = seg && lt_incremental_ok(h);
+    const bool optimistic = seg && !h->lt_full;
     if (rc == GH_OK && seg) {
         const int zero = 0;
         e = hipMemcpyAsync(&h->dstate->lt_stale, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
@@ -1669,7 +1713,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     while ((!cw || cw_gave_up) && rc == GH_OK) {
         int launched = first;
         for (int s = first; s < max_paths && rc == GH_OK; s++) {
-            if (!optimistic || s == first) { if ((rc = ensure_lt(h))) break; }
+            if (!optimistic || s == first) { if ((rc = ensure_lt(h, !seg))) break; }
             if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1, h->spin_lmsel + n1 * s,
                                   !(optimistic && s > first) ? 0 : (s == h->force_stale_at && h->spin_requeues == 0 ? 2 : 1)))) break;
             if ((rc = launch_reweight_marg(h, d_paths + n1 * s, seg ? min_remove : 0.0, 1, d_recs + s, s, seg, optimistic && s > first))) break;
@@ -1678,12 +1722,12 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         // the likelihood sums of every path in one launch (strictly sequential additions, one wavefront per sum)
         if (rc == GH_OK && launched > 0 && (seg || cw_gave_up)) {
             hipLaunchKernelGGL(k_hp, dim3(launched, 2), dim3(64), 0, h->stream, (const double *)h->spin_lmsel, n1, (const uint8_t *)d_paths, n1,
-                               (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs);
+                               (const double *)h->minfo, h->N, (const dev_state *)h->dstate, d_recs, h->sm);
             rc = post_launch(h, "k_hp");
         }
         // bring the table in step with the last reweight while its path is still allocated (the next call would
         // otherwise refresh it from a freed buffer); rebuilds it in full when a candidate mask moved
-        if (rc == GH_OK && launched > 0) rc = ensure_lt(h);
+        if (rc == GH_OK && launched > 0) rc = ensure_lt(h, !seg);
         // the removed mass of every path in one launch (it is only ever read by the host)
         if (rc == GH_OK && launched > 0) {
             hipLaunchKernelGGL(k_reweight_finish_all, dim3(launched), dim3(256), 0, h->stream, h->partial, nb, h->dstate, d_recs);
@@ -1750,7 +1794,8 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
         gh_handle *h = handles[w];
         if (!h) return fail(GH_ERR_ARG, "null handle at %d", w);
         if (h->N != h0->N || h->W != h0->W || h->dev != h0->dev || h->cfg.storage != h0->cfg.storage ||
-            h->cfg.cond_mode != h0->cfg.cond_mode || h->cfg.marginal_term != h0->cfg.marginal_term)
+            h->cfg.cond_mode != h0->cfg.cond_mode || h->cfg.marginal_term != h0->cfg.marginal_term ||
+            h->cfg.offer_zero != h0->cfg.offer_zero || memcmp(h->cfg.cand_order, h0->cfg.cand_order, 5) != 0)
             return fail(GH_ERR_ARG, "window %d differs from window 0 in shape, storage, mode or device", w);
         for (int v = 0; v < w; v++)
             if (handles[v] == h) return fail(GH_ERR_ARG, "window %d is the same handle as window %d", w, v);
@@ -1833,7 +1878,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     for (int w = 0; w < n; w++) {
         gh_handle *h = b->hs[w];
         wd[w].band = h->band; wd[w].cnt = h->cnt; wd[w].marg = h->marg; wd[w].minfo = h->minfo;
-        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
+        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].rinfo = h->rinfo; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
         wd[w].partial = b->d_partial + (size_t)w * b->nb;
         wd[w].paths = b->d_paths + n1 * max_paths * w;
         wd[w].recs = b->d_recs + (size_t)max_paths * w;
@@ -1853,7 +1898,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     if (lt_nb > 4096) lt_nb = 4096;
     walk_params P;
     P.N = N; P.L = L; P.chunk = 0; P.rearm = 1; P.G = nullptr; P.Ht = nullptr; P.Yt = nullptr; P.minfo = nullptr; P.path_out = nullptr; P.rec = nullptr; P.st = nullptr;
-    P.min_remove = min_remove;
+    P.min_remove = min_remove; P.sm = h0->sm;
     size_t lt_nb_inc = 64;                  // batched launches keep no walker tables: the steady-state k_lt only checks flags
     if (lt_nb_inc > 4096) lt_nb_inc = 4096;
     const bool inc_mode = lt_incremental_ok(h0);
@@ -1883,35 +1928,39 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                 if (f64)
                     hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, N, W,
                                        (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                       (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                                       (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
+                                       h0->sm, h0->cfg.offer_zero, (double *)nullptr);
                 else
                     hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, ng), dim3(256), 0, st, (float *)nullptr, N, W,
                                        (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
-                                       (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr);
+                                       (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
+                                       h0->sm, h0->cfg.offer_zero, (double *)nullptr);
                 hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, (const double *)nullptr, N, gwd);
             }
             if (f64)
                 hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), ng), dim3(256), 0, st, (const double *)nullptr, N, W, L,
                                    h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                    (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
+                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm);
             else
                 hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), ng), dim3(256), 0, st, (const float *)nullptr, N, W, L,
                                    h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                    (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr);
+                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm);
             launch_walk_any(bwm, N, L, P, st, ng, gwd, s);
             if (s == 0 && g + 1 < NG) hipEventRecord(b->gevent[g], st);
             if (f64)
                 hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                    (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
-                                   inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
+                                   inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr,
+                                   h0->sm, h0->cfg.offer_zero, (double *)nullptr);   // non-null = take G from wd
             else
                 hipLaunchKernelGGL((k_marg<float, true>), dim3(marg_gx, ng), dim3(256), 0, st, (float *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
                                    (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
-                                   inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr);   // non-null = take G from wd
+                                   inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr,
+                                   h0->sm, h0->cfg.offer_zero, (double *)nullptr);   // non-null = take G from wd
             hipLaunchKernelGGL(k_reweight_finish, dim3(ng), dim3(256), 0, st, (const double *)nullptr, (int)marg_gx,
                                (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, gwd, s);
         }

@@ -13,7 +13,15 @@
 //   minfo[p][16] f64              [0..4] log10 marginal of b5, [5..9] marginal of b5,
 //                                 [10] candidate bitmask over b5 (as u64 bits),
 //                                 [11..15] log10 ORIGINAL marginal of b5 (written by the snapshot)
+//   rinfo[p][8] f64               [0..3] log10 marginal, [4..7] marginal of the r-th candidate of p (candidates in compact order;
+//                                 a rank that does not exist: 0.0 / +inf) -- what the ranked tables' readers add / track per pick
 //   G[i][a6][l-1][b5] f64         source-major conditional table, see k_lt
+//
+// The compact order IS the order the candidates are offered in (gh_config.cand_order, default A C G T -): "first wins" over
+// compact indices -- columns of G, candidate ranks -- is the tie-break of gretel/gretel.py:166-174 for that order.  Kernels
+// get the two maps as a `symmap` argument.
+// cmask[p] holds two masks over the SYMBOLS: bits 0..6 the valid symbols seen at p (c_s > 0: V(p) counts them), bits 8..14 the
+// candidates get_edge_weights_at offers there (the same, or every valid symbol with gh_config.offer_zero).
 #pragma once
 #include "seg_geom.hpp"
 
@@ -25,6 +33,25 @@
 #define LT_ROW 5
 #define LT_BLK 30        /* 6 from-symbols x 5 to-symbols */
 #define MINFO 16
+#define RINFO 8
+#define CM_SEEN(w) ((w) & 0x7Fu)
+#define CM_CAND(w) (((w) >> 8) & 0x7Fu)
+
+struct symmap {
+    uint32_t fwd;   // nibble b5 (0..4): the symbol with that compact index
+    uint32_t inv;   // nibble s (symbol 0..6): its compact from-index a6 (valid symbols 0..4, '_' 5, N 7 = none)
+};
+__host__ __device__ inline symmap make_symmap(const uint8_t order[5])
+{
+    symmap m;
+    m.fwd = 0;
+    m.inv = (7u << (4 * SYM_N)) | (5u << (4 * SYM_US));
+    for (int b5 = 0; b5 < 5; b5++) {
+        m.fwd |= (uint32_t)order[b5] << (4 * b5);
+        m.inv |= (uint32_t)b5 << (4 * order[b5]);
+    }
+    return m;
+}
 
 // The first 64 bytes are the control words every kernel of a path reads: one line, one (scalar) load -- each separate
 // dependent load of a word the previous kernel wrote costs a kernel about a microsecond before it can start.
@@ -66,6 +93,7 @@ struct win_desc {
     double *cnt, *marg, *minfo;
     int32_t *nvalid;
     uint32_t *cmask;
+    double *rinfo;
     double *G;
     double *Ht, *Yt;       // depth-2 walker tables (k_lt)
     dev_state *st;
@@ -89,11 +117,17 @@ __constant__ int8_t c_sym_of_char[256];
 // segwalk.hpp (segment-parallel path extension); k_marg<T,true> closes the path record behind it
 __device__ __forceinline__ void seg_finish(dev_state *st, gh_path_rec *rec, int N, double minm, double min_remove);
 
-__device__ __forceinline__ int vsym(int b5) { return b5 < 4 ? b5 : 5; }            // b5 -> symbol
-__device__ __forceinline__ int fsym(int a6) { return a6 < 4 ? a6 : a6 + 1; }       // a6 -> symbol (4->5, 5->6)
-__device__ __forceinline__ int a6_of_sym(int s) { return s < 4 ? s : s - 1; }      // symbol -> a6 (5->4, 6->5); N invalid
-// candidate masks: cmask has one bit per SYMBOL (A0 C1 G2 T3 -5), cm5 one bit per compact index b5 (A0 C1 G2 T3 -4)
-__device__ __forceinline__ uint32_t cm5_of_cmask(uint32_t cm) { return (cm & 15u) | (((cm >> 5) & 1u) << 4); }
+__device__ __forceinline__ int vsym(symmap m, int b5) { return (int)((m.fwd >> (4 * b5)) & 7u); }                 // b5 -> symbol
+__device__ __forceinline__ int fsym(symmap m, int a6) { return a6 < 5 ? vsym(m, a6) : SYM_US; }                        // a6 -> symbol
+__device__ __forceinline__ int a6_of_sym(symmap m, int s) { return (int)((m.inv >> (4 * s)) & 7u); }                  // symbol -> a6 (N: 7)
+// candidate masks: one bit per SYMBOL in cmask, cm5 one bit per compact index b5
+__device__ __forceinline__ uint32_t cm5_of_cmask(symmap m, uint32_t cm)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int b5 = 0; b5 < 5; b5++) r |= ((cm >> vsym(m, b5)) & 1u) << b5;
+    return r;
+}
 // index of the r-th set bit of a 5-bit mask (r = 0 is the lowest), -1 if there are fewer
 __device__ __forceinline__ int nth_set5(uint32_t m, int r)
 {
@@ -152,13 +186,12 @@ __device__ __forceinline__ double log_conditional(const T *__restrict__ band, in
     if (l <= W) {
         obs = (double)band[bidx(W, i, l, a, b)];
         if (cond_mode == GH_COND_A || cond_mode == GH_COND_D) sum = rowsum(band, W, i, l, a);
-        else if (cond_mode == GH_COND_C) sum = colsum(band, W, i, l, b);
+        else if (cond_mode == GH_COND_C || cond_mode == GH_COND_E) sum = colsum(band, W, i, l, b);
     }
     double den;
-    if (cond_mode == GH_COND_A) den = (double)nvalid[j] + sum;
+    if (cond_mode == GH_COND_A || cond_mode == GH_COND_E) den = (double)nvalid[j] + sum;
     else if (cond_mode == GH_COND_B) den = (double)nvalid[i] + cnt[(size_t)i * 8 + a];
-    else if (cond_mode == GH_COND_D) den = (double)nvalid[i] + sum;
-    else den = (double)nvalid[i] + sum;
+    else den = (double)nvalid[i] + sum;          // C, D
     return gh_log10((1.0 + obs) / den);
 }
 
@@ -346,7 +379,7 @@ __global__ void __launch_bounds__(256)
 k_marg(T *band, int N, int W, double *cnt, double *marg,
        int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st, const win_desc *wd,
        const uint8_t *rw_path, double ratio_arg, int use_state_ratio, double *partial, int spin,
-       double *G, int L, int cond_mode, const double *segmin, gh_path_rec *seg_rec)
+       double *G, int L, int cond_mode, const double *segmin, gh_path_rec *seg_rec, symmap sm, int offer_zero, double *rinfo)
 {
     __shared__ double s_red[256];
     bool live = true;
@@ -372,7 +405,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
     }
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
-        band = (T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st;
+        band = (T *)d.band; cnt = d.cnt; marg = d.marg; nvalid = d.nvalid; cmask = d.cmask; minfo = d.minfo; st = d.st; rinfo = d.rinfo;
         if (RW) { rw_path = d.paths + (size_t)spin * (N + 1); partial = d.partial; if (G) G = d.G; }
         live = !st->stop;
     }
@@ -434,29 +467,47 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         c[x] = __shfl(mine, x, 8);
         if (c[x] > 0) {
             tot += c[x];
-            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; cm5 |= 1u << a6_of_sym(x); }
+            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; }
         }
+    }
+    // the candidates get_edge_weights_at offers at p: the valid symbols seen there, or every valid symbol (offer_zero)
+    const uint32_t cand = offer_zero ? VALID_MASK : cm;
+    const uint32_t cmw = cm | (cand << 8);
+    cm5 = cm5_of_cmask(sm, cand);
+    double my_m = 0.0, my_lm = 0.0;
+    if (s < NSYM) {
+        my_m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
+        if ((VALID_MASK >> s) & 1) my_lm = gh_log10(my_m);
     }
     if (act) {
         if (s < NSYM) {
-            const double m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
             cnt[(size_t)p * 8 + s] = c[s];
-            marg[(size_t)p * 8 + s] = m;
+            marg[(size_t)p * 8 + s] = my_m;
             if ((VALID_MASK >> s) & 1) {
-                const int b5 = a6_of_sym(s);
-                minfo[(size_t)p * MINFO + b5] = gh_log10(m);
-                minfo[(size_t)p * MINFO + 5 + b5] = m;
+                const int b5 = a6_of_sym(sm, s);
+                minfo[(size_t)p * MINFO + b5] = my_lm;
+                minfo[(size_t)p * MINFO + 5 + b5] = my_m;
+                // the same by candidate rank (rinfo): this symbol's rank among the candidates of p
+                if (((cand >> s) & 1u) && __popc(cm5 & ((1u << b5) - 1u)) < 4) {
+                    const int r = __popc(cm5 & ((1u << b5) - 1u));
+                    rinfo[(size_t)p * RINFO + r] = my_lm;
+                    rinfo[(size_t)p * RINFO + 4 + r] = my_m;
+                }
             }
         } else {
             cnt[(size_t)p * 8 + 7] = tot;
             marg[(size_t)p * 8 + 7] = 0.0;
             nvalid[p] = nv;
             // (the window's flags are collected per workgroup and leave with one atomic each at the end: see k_rw)
-            if (cmask[p] != cm) flag_bits |= 1u;                  // the conditional table must then be rebuilt in full
-            cmask[p] = cm;
+            if (cmask[p] != cmw) flag_bits |= 1u;                 // the conditional table must then be rebuilt in full
+            cmask[p] = cmw;
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
-            if (p >= 1 && cm == 0) hole_p = p;
-            if (p >= 1 && (cm & (1u << 5))) flag_bits |= 2u;
+            for (int r = __popc(cm5); r < 4; r++) {               // ranks that do not exist
+                rinfo[(size_t)p * RINFO + r] = 0.0;
+                rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
+            }
+            if (p >= 1 && cand == 0) hole_p = p;
+            if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
             if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
         }
     }
@@ -465,8 +516,9 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         // lags 1..L (the lane that rewrote element (p, p+l) also owns lag l, so it reads its own store back).
         // nvalid / cmask of the targets are read while other groups rewrite them: k_lt trusts these rows only
         // when no candidate mask moved (st->cm_same), and then old and new values are the same.
+        // (conditionals A, B, D without a baked marginal term only: the host passes G = nullptr otherwise)
         const int a = rw_path[p];
-        const int a6 = a6_of_sym(a);
+        const int a6 = a6_of_sym(sm, a);
         const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
         // ranked tables (k_lt): the row of symbol a is the row of its rank among the candidates of p, the columns of
         // lag l are the candidates of p+l in ascending order; a path symbol that is no candidate has no row
@@ -493,13 +545,17 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
 #pragma unroll
                 for (int x = 0; x < NSYM; x++) rowv[x] = 0.0;
             }
-            const uint32_t cmj = cmask[snp];
+            const uint32_t cmj = CM_CAND(cmask[snp]);
             const double den = (cond_mode == GH_COND_A) ? (double)nvalid[snp] + sum : (cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
             double xq[LT_ROW], v[LT_ROW];
             bool odd = false;
 #pragma unroll
             for (int b5 = 0; b5 < LT_ROW; b5++) {
-                xq[b5] = (1.0 + rowv[vsym(b5)]) / den;
+                double rv = rowv[0];
+                const int sb = vsym(sm, b5);
+#pragma unroll
+                for (int x = 1; x < NSYM; x++) rv = (sb == x) ? rowv[x] : rv;
+                xq[b5] = (1.0 + rv) / den;
                 odd |= !gh_log10_is_normal(xq[b5]);
             }
 #pragma unroll
@@ -510,9 +566,9 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             }
             if (!ranked) {
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmj >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
+                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmj >> vsym(sm, b5)) & 1) ? v[b5] : -INFINITY;
             } else {
-                const uint32_t cj5 = cm5_of_cmask(cmj);
+                const uint32_t cj5 = cm5_of_cmask(sm, cmj);
 #pragma unroll
                 for (int rb = 0; rb < LT_ROW; rb++) {
                     const int b5 = nth_set5(cj5, rb);
@@ -580,9 +636,15 @@ __global__ void k_snapshot(double *dst_minfo, const double *src_minfo, int N, co
 //   G[i][a6][l-1][b5]  (i = source position 0..N-1, target snp = i+l)
 //     = -inf                                   if b5 is not a candidate at snp (bakes the
 //                                              candidate mask of gretel.py:166-174 into the sum)
-//     = log10( (1 + H[a,b,i,snp]) / den )      otherwise   (+ log10 marginal(b,snp) pre-added
-//                                              to the lag-1 entry when marginal_term is on:
-//                                              (0.0 + lm) + x1 == lm + x1 bit for bit)
+//     = log10( (1 + H[a,b,i,snp]) / den )      otherwise.  The marginal term of the edge weight
+//                                              (gh_config.marginal_term: w = log10 marginal + x1 + x2 ...;
+//                                              (0.0 + lm) + x1 == lm + x1 bit for bit) is NOT in the table:
+//                                              the segment-parallel readers add lm in front of x1 themselves
+//                                              (k_seg, k_cwalk, k_cwalkg: from rinfo / minfo), so that a
+//                                              reweight, which moves every marginal of every position, leaves
+//                                              all but the path's own rows (columns) of G as they are.  Only
+//                                              for the serial walkers (bake_lm: they read whole rows) the
+//                                              lag-1 entry is stored as lm + x1, and rebuilt before every path.
 //     = 0.0                                    for snp > N, i >= N (padding) and rows a path can
 //                                              never select ('_' anywhere but position 0)
 // One row G[i][a6] (L x 5 doubles) is everything position i contributes to the next L steps once
@@ -611,16 +673,16 @@ __host__ __device__ constexpr size_t walk_lds_bytes(int L, bool deep)
 }
 
 template <typename T>
-__device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond_mode, int marginal_term,
+__device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond_mode, int bake_lm,
                                            const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
-                                           const double *minfo, int i, int a6, int l, int b5)
+                                           const double *minfo, int i, int a6, int l, int b5, symmap sm)
 {
     const int snp = i + l;
     if (!(i < N && snp <= N && (a6 < 5 || i == 0))) return 0.0;
-    const int b = vsym(b5);
-    if (!((cmask[snp] >> b) & 1)) return -INFINITY;
-    double v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(a6), b, i, snp);
-    if (marginal_term && l == 1) v = minfo[(size_t)snp * MINFO + b5] + v;
+    const int b = vsym(sm, b5);
+    if (!((CM_CAND(cmask[snp]) >> b) & 1)) return -INFINITY;
+    double v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(sm, a6), b, i, snp);
+    if (bake_lm && l == 1) v = minfo[(size_t)snp * MINFO + b5] + v;
     return v;
 }
 
@@ -636,17 +698,17 @@ __host__ __device__ constexpr int deep_nyp(int L) { return L > 2 ? ((L - 2 + 1) 
 
 // what k_lt stores at G[i][row6][lag - 1][col5] in the ranked layout
 template <typename T>
-__device__ __forceinline__ double lt_entry_ranked(const T *band, int N, int W, int cond_mode, int marginal_term,
+__device__ __forceinline__ double lt_entry_ranked(const T *band, int N, int W, int cond_mode, int bake_lm,
                                                   const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
-                                                  const double *minfo, int i, int row6, int lag, int col5)
+                                                  const double *minfo, int i, int row6, int lag, int col5, symmap sm)
 {
     const int snp = i + lag;
     if (!(i < N && snp <= N && row6 != 4)) return 0.0;
     int a6 = row6;
-    if (a6 < 4) a6 = nth_set5(cm5_of_cmask(cmask[i]), a6);
+    if (a6 < 4) a6 = nth_set5(cm5_of_cmask(sm, CM_CAND(cmask[i])), a6);
     if (a6 < 0) return 0.0;
-    const int b5 = nth_set5(cm5_of_cmask(cmask[snp]), col5);
-    return b5 >= 0 ? lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, lag, b5) : -INFINITY;
+    const int b5 = nth_set5(cm5_of_cmask(sm, CM_CAND(cmask[snp])), col5);
+    return b5 >= 0 ? lt_entry(band, N, W, cond_mode, bake_lm, cnt, nvalid, cmask, minfo, i, a6, lag, b5, sm) : -INFINITY;
 }
 
 // inc_path == nullptr: rebuild every entry.  Otherwise (conditional A or B, no marginal term, and the
@@ -656,10 +718,10 @@ __device__ __forceinline__ double lt_entry_ranked(const T *band, int N, int W, i
 // a candidate mask change (V(p) or the -inf masks moved) or the path was cut short by a hole: then it rebuilds everything.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
+k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term /* = bake_lm, see above */,
      const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
      const double *minfo, double *G, dev_state *st, const uint8_t *inc_path, const win_desc *wd, int spin,
-     int allow_ranked, double *Ht, double *Yt)
+     int allow_ranked, double *Ht, double *Yt, symmap sm)
 {
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
@@ -680,8 +742,8 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
         for (size_t idx = gtid; idx < total; idx += gsize) {
             const int p = (int)(idx >> 2), b = (int)(idx & 3);
             if (p == 0) continue;                               // position 0 is done below
-            const int a6 = a6_of_sym(inc_path[p]);
-            const uint32_t c5 = cm5_of_cmask(cmask[p]);
+            const int a6 = a6_of_sym(sm, inc_path[p]);
+            const uint32_t c5 = cm5_of_cmask(sm, CM_CAND(cmask[p]));
             if (inc_path[p] == 4 || a6 > 4 || !((c5 >> a6) & 1u)) continue;
             const int r = __popc(c5 & ((1u << a6) - 1u));
             const double g1 = Gat(p, r, 1, b), g2 = Gat(p, r, 2, b);
@@ -723,8 +785,8 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
         r /= L;
         const int a6 = (int)(r % 6);
         const int i = (int)(r / 6);
-        G[t] = ranked ? lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5)
-                      : lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5);
+        G[t] = ranked ? lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5, sm)
+                      : lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5, sm);
     }
     if (!(ranked && Ht)) return;
     // the derived tables in full, from the band (other threads are still writing G)
@@ -735,9 +797,9 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
         double v = 0.0;
         if (tt >= 1 && tt - 1 < nsrc_all) {
             const int s1 = tt - 1, s2 = tt - 2;
-            v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s1, s1 == 0 ? 5 : a1, 1, b);
+            v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s1, s1 == 0 ? 5 : a1, 1, b, sm);
             if (tt >= 2 && L >= 2)
-                v = v + lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s2, s2 == 0 ? 5 : a2, 2, b);
+                v = v + lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s2, s2 == 0 ? 5 : a2, 2, b, sm);
         }
         Ht[q] = v;
     }
@@ -747,7 +809,7 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term,
             const int i = (int)(q / ypos), r = (int)(q % ypos), wb = r / nyp, li = r % nyp;
             double v = 0.0;
             if (i < nsrc_all && li + 2 < L)
-                v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, i == 0 ? 5 : (wb >> 2), li + 3, wb & 3);
+                v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, i == 0 ? 5 : (wb >> 2), li + 3, wb & 3, sm);
             Yt[q] = v;
         }
     }
@@ -775,6 +837,7 @@ struct walk_params {
     gh_path_rec *rec;         // device
     dev_state *st;
     double min_remove;
+    symmap sm;
 };
 
 __device__ __forceinline__ void copy_to_lds(double *dst, const double *src, size_t n_dbl, int tid, int nthr)
@@ -810,7 +873,9 @@ __device__ __forceinline__ int argmax8(double acc)
     m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
     m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
     m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
-    const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+    // (a NaN weight -- log10 of a zero marginal plus an infinite conditional, zero-count candidates only -- in FIRST place is
+    // the reference's incumbent and nothing compares greater than it; anywhere else it never wins: v_max ignores it)
+    const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m || ((threadIdx.x & 7) == 0 && acc != acc));
     return (int)__builtin_ctzll(win);
 }
 
@@ -831,7 +896,7 @@ __device__ __forceinline__ void book_chunk(const walk_params &P, const unsigned 
         lm = inf[w];
         mg = inf[5 + w];
         lm0 = inf[11 + w];
-        P.path_out[t] = (uint8_t)vsym(w);
+        P.path_out[t] = (uint8_t)vsym(P.sm, w);
     }
     for (int j = 0; j < ns; j++) {
         const double m = readlane_f64(mg, j);           // gretel.py:182
@@ -976,6 +1041,7 @@ __device__ __forceinline__ unsigned long long group_argmax(double acc)
     m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
     m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
     if (!NODEL) m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
+    if (!NODEL) return __builtin_amdgcn_ballot_w64(acc == m || ((threadIdx.x & 7) == 0 && acc != acc));      // (NaN in first place: see argmax8)
     return __builtin_amdgcn_ballot_w64(acc == m);
 }
 
@@ -1026,7 +1092,7 @@ __device__ __forceinline__ void book_consume(const walk_params &P, const unsigne
             mg = (w == q) ? row[5 + q] : mg;
             lm0 = (w == q) ? row[11 + q] : lm0;
         }
-        P.path_out[j] = (uint8_t)vsym(w);
+        P.path_out[j] = (uint8_t)vsym(P.sm, w);
     }
     if (mg < lane_min) lane_min = mg;                   // gretel.py:182, per lane; reduced over lanes at the end (min is exact)
     int s = 0;
@@ -1614,7 +1680,7 @@ __global__ void __launch_bounds__(64) k_walk_global(walk_params P, int hist_len,
         hp_orig += inf[11 + b5];
         if (lane == 0) {
             lpath[snp & hmask] = (uint8_t)w;
-            P.path_out[snp] = (uint8_t)vsym(b5);
+            P.path_out[snp] = (uint8_t)vsym(P.sm, b5);
         }
         __syncthreads();
     }
@@ -1730,7 +1796,7 @@ __global__ void k_edge_weights(const T *__restrict__ band, int W, int cond_mode,
                                double *w, int *mask)
 {
     const int lane = threadIdx.x;
-    const uint32_t cm = cmask[p];
+    const uint32_t cm = CM_CAND(cmask[p]);
     if (lane == 0) *mask = (int)cm;
     if (lane >= NSYM) return;
     double acc = 0.0;

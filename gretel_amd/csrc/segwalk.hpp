@@ -34,6 +34,9 @@ struct seg_params {
     int check_masks;          // spins without a k_lt between paths: a candidate mask that moved under the last reweight makes the table stale
     const double *G;          // [(N+LT_PAD)][6][L][5], ranked or not (st->ranked)
     const double *minfo;      // [N+2][16]
+    const double *rinfo;      // [N+2][8]: log10 marginal / marginal by candidate rank
+    int mt;                   // gh_config.marginal_term: the edge weight starts with log10 marginal(b, t) (added in front of x1)
+    symmap sm;
     dev_state *st;
     uint32_t *hist;           // [S][NW][NS] picks of every entry state, DPW per word, the first lowest
     uint16_t *maps;           // [S][NS] segment maps
@@ -63,6 +66,10 @@ __device__ __forceinline__ unsigned seg_argmax(const double (&v)[R])
     if constexpr (R == 5) {
         const double m = vmax_f64(m01, m23);
         idx = v[4] > m ? 4u : idx;
+        // (a NaN -- zero-count candidates with the marginal term: log10(0) + an infinite conditional -- offered FIRST is the
+        // incumbent of the scan and nothing compares greater than it; anywhere else it never wins, as here: kernels.hpp, argmax8.
+        // The ranked layout never sees one: its columns are candidates that were observed.)
+        idx = v[0] != v[0] ? 0u : idx;
     }
     return idx;
 }
@@ -94,13 +101,30 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
         // (1a) the slice of G this chunk needs: sources c0+1-LC .. c0+nc-1 (slot ii = i - (c0+1-LC)), every lag, the
         // rows of the R digits and the R candidate columns.  Position 0 carries '_' whatever the digit says (row 5);
         // positions < 0 do not exist: their terms are +0.0, which leaves every partial sum as it is.
+        // One thread per (slot, lag, digit): the R columns are one run of G (wide loads; G rows are 40 bytes apart, so
+        // the loads are 8-byte aligned only -- fine for global memory) and one aligned run of Gs.  With the marginal
+        // term the lag-1 entries get log10 marginal(b, i + 1) added in front: (0.0 + lm) + x1, the reference's first
+        // addition -- by candidate rank (rinfo) or by symbol (minfo), like the columns.
         const int nsrc = nc + LC - 1;
-        for (int e = tid; e < nsrc * LC * (int)RR; e += SEG_THREADS) {
-            const int b = e % R, d = (e / R) % R, l = (e / RR) % LC, ii = e / (RR * LC);
+        for (int e = tid; e < nsrc * LC * R; e += SEG_THREADS) {
+            const int d = e % R, l = (e / R) % LC, ii = e / (R * LC);
             const int i = c0 + 1 - LC + ii;
-            double v = 0.0;
-            if (i >= 0) v = P.G[(((size_t)i * 6 + (i == 0 ? 5 : d)) * LC + l) * LT_ROW + b];
-            Gs[e] = v;
+            double v[R];
+#pragma unroll
+            for (int b = 0; b < R; b++) v[b] = 0.0;
+            if (i >= 0) {
+                const double *src = P.G + (((size_t)i * 6 + (i == 0 ? 5 : d)) * LC + l) * LT_ROW;
+#pragma unroll
+                for (int b = 0; b < R; b++) v[b] = src[b];
+                if (P.mt && l == 0) {
+                    const double *lm = R == 4 ? P.rinfo + (size_t)(i + 1) * RINFO : P.minfo + (size_t)(i + 1) * MINFO;
+#pragma unroll
+                    for (int b = 0; b < R; b++) v[b] = lm[b] + v[b];
+                }
+            }
+            double *dst = Gs + (size_t)e * R;
+#pragma unroll
+            for (int b = 0; b < R; b++) dst[b] = v[b];
         }
         __syncthreads();
         SEG_STAMP(1);
@@ -360,7 +384,7 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
             lm = (b5 == k) ? r16[k] : lm;
             m = (b5 == k) ? r16[5 + k] : m;
         }
-        P.path_out[t] = (uint8_t)vsym(b5);
+        P.path_out[t] = (uint8_t)vsym(P.sm, b5);
         P.lmsel[t] = lm;
         if (m < mn) mn = m;
     }
@@ -442,11 +466,23 @@ __device__ __forceinline__ int seg_count(const dev_state *st, int N, int L)
 // read back after a store.
 // -------------------------------------------------------------------------------------------------------------
 // LP lanes per position: 8, or 32 for bands / lag counts above 8 (every distance and every lag in one round)
-template <typename T, int LP>
+// COL: conditionals C and E, whose denominator is a COLUMN sum of the cell: reweighting element (path[p], path[p+d]) of
+// cell (p, p+d) then moves the entries G[p][x][d-1][col of path[p+d]] of EVERY from-row x -- one column of the table
+// block instead of one row (the same number of entries); the lane reads the cell's column instead of its row.
+template <typename V>
+__device__ __forceinline__ V pick7(const V (&r)[NSYM], int x)
+{
+    V v = r[0];
+#pragma unroll
+    for (int q = 1; q < NSYM; q++) v = (x == q) ? r[q] : v;
+    return v;
+}
+
+template <typename T, int LP, bool COL>
 __global__ void __launch_bounds__(256)
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
-     gh_path_rec *rec, int nseg_arg)
+     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo)
 {
     __shared__ double s_red[256];
     const int tid = threadIdx.x;
@@ -468,7 +504,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const bool act = p <= N;
     const int pp = act ? p : 0;
     // ---- round 1 ---------------------------------------------------------------------------------------------
-    const int d0 = s + 1;                                   // this lane's distance (reweight) and lag (table row)
+    const int d0 = s + 1;                                   // this lane's distance (reweight) and lag (table row / column)
     const int j0 = pp + d0;
     int mult0 = 0;                                          // multiplicities of the reference's pair enumeration
     if (act && d0 <= W) {
@@ -478,13 +514,14 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     }
     const int a = path[pp];
     const int b0 = mult0 ? ((j0 == N + 1) ? path[0] : path[j0]) : 0;
-    const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N;       // this lane owns the table row of lag d0
+    // this lane owns the table entries of lag d0: a row (every lag up to L), or a column (only where the cell changed)
+    const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N && (!COL || (mult0 > 0 && d0 <= W));
     T crow[NSYM];
 #pragma unroll
     for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? band[bidx(W, pp, 1, s, x)] : (T)0;      // cell (p, p+1), row s
     int nv_t = 0;
     uint32_t cm_t = 0;
-    if (lag_row) { nv_t = nvalid[j0]; cm_t = cmask[j0]; }
+    if (lag_row) { nv_t = nvalid[j0]; cm_t = CM_CAND(cmask[j0]); }
     const uint32_t cm_old = (act && s == 7) ? cmask[pp] : 0u;
     static_assert(LP == 8 || LP == 32, "lane groups of 8 or 32");
     // ---- the path's minimum marginal, while round 1 is in flight ----------------------------------------------
@@ -499,45 +536,32 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     RW_STAMP(1);
     const double ratio = minm < min_remove ? min_remove : minm;
     if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, minm, min_remove);
-    // ---- round 2: the row of cell (p, p+d0) under the path's symbol at p ---------------------------------------
+    // ---- round 2: the row of cell (p, p+d0) under the path's symbol at p -- or its column under the symbol at p+d0 ---
     const bool need_row = act && d0 <= W && (mult0 > 0 || lag_row);
-    T *rowp = band + bidx(W, pp, d0 <= W ? d0 : 1, a, 0);
+    T *rowp = COL ? band + bidx(W, pp, d0 <= W ? d0 : 1, 0, b0) : band + bidx(W, pp, d0 <= W ? d0 : 1, a, 0);
+    constexpr int one = 1;
+    const int estride = COL ? W * NSYM : one;               // elements between two entries of the run this lane reads
+    const int esel = COL ? a : b0;                          // the entry of the run that is reweighted
     T rrow[NSYM];
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rowp[x] : (T)0;
+    for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rowp[(size_t)x * estride] : (T)0;
     RW_STAMP(2);
     // ---- reweight ---------------------------------------------------------------------------------------------
     double removed = 0.0;
     int na = -1, nb = -1;
     T nval = (T)0;
     if (mult0) {
-        T cur = (T)0;
-#pragma unroll
-        for (int x = 0; x < NSYM; x++) cur = (x == b0) ? rrow[x] : cur;
+        T cur = pick7(rrow, esel);
         for (int q = 0; q < mult0; q++) {
             const double old = (double)cur;
             const double nw = old - ratio * old;
             cur = (T)nw;
             removed += old - nw;
         }
-        rowp[b0] = cur;
+        rowp[(size_t)esel * estride] = cur;
 #pragma unroll
-        for (int x = 0; x < NSYM; x++) rrow[x] = (x == b0) ? cur : rrow[x];
+        for (int x = 0; x < NSYM; x++) rrow[x] = (x == esel) ? cur : rrow[x];
         if (d0 == 1) { na = a; nb = b0; nval = cur; }
-    }
-    for (int d = d0 + LP; act && d <= W; d += LP) {         // bands wider than the lane group: the remaining distances, one by one
-        const int j = p + d;
-        int mult = 0;
-        if (j <= N - 1) mult = 1;
-        else if (j == N + 1) mult = (p == N) ? 1 : 0;
-        if (mult) {
-            const int b = (j == N + 1) ? path[0] : path[j];
-            T *e = band + bidx(W, p, d, a, b);
-            const double old = (double)*e;
-            const double nw = old - ratio * old;
-            *e = (T)nw;
-            removed += old - nw;
-        }
     }
     na = __shfl(na, 0, LP); nb = __shfl(nb, 0, LP);
     nval = (T)__shfl((double)nval, 0, LP);
@@ -561,41 +585,114 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         cs[x] = __shfl(mine, x, LP);
         if (cs[x] > 0) {
             tot += cs[x];
-            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; cm5 |= 1u << a6_of_sym(x); }
+            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; }
         }
     }
+    const uint32_t cand = offer_zero ? VALID_MASK : cm;     // (k_marg)
+    const uint32_t cmw = cm | (cand << 8);
+    cm5 = cm5_of_cmask(sm, cand);
     if (act) {
         if (s < NSYM) {
             const double m = (cs[s] > 0 && tot != 0.0) ? cs[s] / tot : 0.0;
             cnt[(size_t)p * 8 + s] = cs[s];
             marg[(size_t)p * 8 + s] = m;
             if ((VALID_MASK >> s) & 1) {
-                const int b5 = a6_of_sym(s);
-                minfo[(size_t)p * MINFO + b5] = gh_log10(m);
+                const int b5 = a6_of_sym(sm, s);
+                const double lm = gh_log10(m);
+                minfo[(size_t)p * MINFO + b5] = lm;
                 minfo[(size_t)p * MINFO + 5 + b5] = m;
+                const int r = __popc(cm5 & ((1u << b5) - 1u));
+                if (((cand >> s) & 1u) && r < 4) {
+                    rinfo[(size_t)p * RINFO + r] = lm;
+                    rinfo[(size_t)p * RINFO + 4 + r] = m;
+                }
             }
         } else if (s == 7) {
             cnt[(size_t)p * 8 + 7] = tot;
             marg[(size_t)p * 8 + 7] = 0.0;
             nvalid[p] = nv;
-            cmask[p] = cm;
+            cmask[p] = cmw;
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
+            for (int r = __popc(cm5); r < 4; r++) {
+                rinfo[(size_t)p * RINFO + r] = 0.0;
+                rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
+            }
             // the window's flags: collected per workgroup in LDS, one global atomic per flag and workgroup (thousands of
             // positions and-ing the same word one by one cost 12 ns each: 0.2 ms per path in a window full of '-')
-            if (cm_old != cm) flag_bits |= 1u;                     // the conditional table must then be rebuilt in full
-            if (p >= 1 && (cm & (1u << 5))) flag_bits |= 2u;
+            if (cm_old != cmw) flag_bits |= 1u;                    // the conditional table must then be rebuilt in full
+            if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
             if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
-            if (p >= 1 && cm == 0) hole_p = p;
+            if (p >= 1 && cand == 0) hole_p = p;
         }
     }
     RW_STAMP(3);
-    // ---- the table rows of lags d0, d0 + 8, ... (k_marg: same divisions, same log10) --------------------------------
-    if (G && act && p < N && a != 4) {
-        const int a6 = a6_of_sym(a);
-        const double nv_i = (double)nv, ca = __shfl(mine, a, LP);
-        const bool ranked = c.ranked != 0;
+    const bool ranked = c.ranked != 0;
+    const double nv_i = (double)nv;
+    // ---- bands wider than the lane group: the remaining distances, one by one (and, COL, their table columns) -------
+    // COL: entries G[p][x][l-1][col(b)] for every from-row x that exists, from the column `colT` of cell (p, p+l)
+    auto table_col = [&](int l, const T (&colT)[NSYM], int nvt, uint32_t cmt, int b) {
+        T cacc = (T)0;
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) cacc = cacc + colT[x];
+        const double den = (cond_mode == GH_COND_C ? nv_i : (double)nvt) + (double)cacc;
+        const int b5c = a6_of_sym(sm, b);
+        const uint32_t cj5 = cm5_of_cmask(sm, cmt);
+        if (b5c >= 5 || !((cj5 >> b5c) & 1u)) return;        // no column for this symbol (N, '_', or no candidate: a rebuild follows)
+        const int col = ranked ? __popc(cj5 & ((1u << b5c) - 1u)) : b5c;
+        double xq[6], v[6];
+        bool odd = false;
+#pragma unroll
+        for (int x6 = 0; x6 < 6; x6++) {
+            xq[x6] = (1.0 + (double)pick7(colT, fsym(sm, x6))) / den;
+            odd |= !gh_log10_is_normal(xq[x6]);
+        }
+#pragma unroll
+        for (int x6 = 0; x6 < 6; x6++) v[x6] = gh_log10_normal(xq[x6], 0);
+        if (odd) {
+#pragma unroll
+            for (int x6 = 0; x6 < 6; x6++) v[x6] = gh_log10(xq[x6]);
+        }
+#pragma unroll
+        for (int x6 = 0; x6 < 6; x6++) {
+            int row6 = x6;
+            if (x6 == 5) { if (p != 0) continue; }           // the '_' row exists at position 0 only
+            else if (ranked) {
+                if (!((cm5 >> x6) & 1u)) continue;           // not a candidate of p: no row
+                row6 = __popc(cm5 & ((1u << x6) - 1u));
+                if (row6 > 3) continue;
+            }
+            G[(((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW + col] = v[x6];
+        }
+    };
+    for (int d = d0 + LP; act && d <= W; d += LP) {
+        const int j = p + d;
+        int mult = 0;
+        if (j <= N - 1) mult = 1;
+        else if (j == N + 1) mult = (p == N) ? 1 : 0;
+        if (mult) {
+            const int b = (j == N + 1) ? path[0] : path[j];
+            T *e = band + bidx(W, p, d, a, b);
+            const double old = (double)*e;
+            const double nw = old - ratio * old;
+            *e = (T)nw;
+            removed += old - nw;
+            if (COL && G && p < N && d <= L && j <= N) {
+                T colT[NSYM];
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) colT[x] = (x == a) ? (T)nw : band[bidx(W, p, d, x, b)];
+                table_col(d, colT, nvalid[j], CM_CAND(cmask[j]), b);
+            }
+        }
+    }
+    // ---- the table entries of lag d0: the row of path[p] (same divisions, same log10 as k_lt), or the column ---------
+    if (COL) {
+        if (lag_row) table_col(d0, rrow, nv_t, cm_t, b0);
+    } else if (G && act && p < N && a != 4) {
+        const int a6 = a6_of_sym(sm, a);
+        const double ca = __shfl(mine, a, LP);
         int row6 = a6;
         if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
+        const bool ident = sm.fwd == 0x53210u;              // the default order: compile-time register indices
         auto table_row = [&](int l, const T (&rowT)[NSYM], int nvt, uint32_t cmt) {
             double *out = G + (((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW;
             if (!(p + l <= N && (a6 < 5 || p == 0))) {
@@ -611,11 +708,15 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             const double den = (cond_mode == GH_COND_A) ? (double)nvt + sum : (cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
             double xq[LT_ROW], v[LT_ROW];
             bool odd = false;
+            if (ident) {
 #pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) {
-                xq[b5] = (1.0 + rowv[vsym(b5)]) / den;
-                odd |= !gh_log10_is_normal(xq[b5]);
+                for (int b5 = 0; b5 < LT_ROW; b5++) xq[b5] = (1.0 + rowv[b5 < 4 ? b5 : 5]) / den;
+            } else {
+#pragma unroll
+                for (int b5 = 0; b5 < LT_ROW; b5++) xq[b5] = (1.0 + pick7(rowv, vsym(sm, b5))) / den;
             }
+#pragma unroll
+            for (int b5 = 0; b5 < LT_ROW; b5++) odd |= !gh_log10_is_normal(xq[b5]);
 #pragma unroll
             for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
             if (odd) {
@@ -624,9 +725,9 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             }
             if (!ranked) {
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmt >> vsym(b5)) & 1) ? v[b5] : -INFINITY;
+                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmt >> vsym(sm, b5)) & 1) ? v[b5] : -INFINITY;
             } else {
-                const uint32_t cj5 = cm5_of_cmask(cmt);
+                const uint32_t cj5 = cm5_of_cmask(sm, cmt);
 #pragma unroll
                 for (int rb = 0; rb < LT_ROW; rb++) {
                     const int b5 = nth_set5(cj5, rb);
@@ -651,7 +752,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
                     for (int x = 0; x < NSYM; x++) rowT[x] = rc[x];
                 }
                 nvt = nvalid[p + l];
-                cmt = cmask[p + l];
+                cmt = CM_CAND(cmask[p + l]);
             }
             table_row(l, rowT, nvt, cmt);
         }
@@ -712,13 +813,13 @@ __global__ void __launch_bounds__(256) k_seg_fin(seg_params P, gh_path_rec *rec,
 // -------------------------------------------------------------------------------------------------------------
 #define HP_CHUNK 512
 template <int WHICH>
-__device__ __forceinline__ double hp_sum(const double *lm, const uint8_t *path, const double *minfo, int N, double (*buf)[HP_CHUNK])
+__device__ __forceinline__ double hp_sum(const double *lm, const uint8_t *path, const double *minfo, int N, double (*buf)[HP_CHUNK], symmap sm)
 {
     const int lane = threadIdx.x;
     // (no branches around the loads: a slot beyond the window reads position N and is replaced by +0.0)
     auto value = [&](int t) -> double {
         const int tt = t <= N ? t : N;
-        const double v = WHICH == 0 ? lm[tt] : minfo[(size_t)tt * MINFO + 11 + a6_of_sym(path[tt])];
+        const double v = WHICH == 0 ? lm[tt] : minfo[(size_t)tt * MINFO + 11 + a6_of_sym(sm, path[tt])];
         return t <= N ? v : 0.0;
     };
     constexpr int PER = HP_CHUNK / 64;
@@ -744,7 +845,7 @@ __device__ __forceinline__ double hp_sum(const double *lm, const uint8_t *path, 
 
 __global__ void __launch_bounds__(64)
 k_hp(const double *lmsel, size_t lmsel_stride, const uint8_t *paths, size_t path_stride, const double *minfo, int N,
-     const dev_state *st, gh_path_rec *recs)
+     const dev_state *st, gh_path_rec *recs, symmap sm)
 {
     __shared__ double buf[2][HP_CHUNK];
     const int s = blockIdx.x, which = blockIdx.y;
@@ -752,7 +853,7 @@ k_hp(const double *lmsel, size_t lmsel_stride, const uint8_t *paths, size_t path
     const double *lm = lmsel + (size_t)s * lmsel_stride;
     if (lm[0] != 1.0) return;                                      // walked by a serial walker, which summed for itself
     const uint8_t *path = paths + (size_t)s * path_stride;
-    const double acc = which == 0 ? hp_sum<0>(lm, path, minfo, N, buf) : hp_sum<1>(lm, path, minfo, N, buf);
+    const double acc = which == 0 ? hp_sum<0>(lm, path, minfo, N, buf, sm) : hp_sum<1>(lm, path, minfo, N, buf, sm);
     if (threadIdx.x == 0) {
         if (which == 0) recs[s].hp_current = acc;
         else recs[s].hp_original = acc;

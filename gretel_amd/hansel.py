@@ -49,10 +49,16 @@ def _p(a):
 
 
 class Hansel:
-    def __init__(self, n_snps, band=None, storage="f32", cond_mode="A", marginal_term=False, device=-1):
+    def __init__(self, n_snps, band=None, storage="f32", cond_mode="A", marginal_term=False, device=-1,
+                 cand_order="ACGT-", offer_zero=False):
+        """storage / cond_mode / marginal_term / cand_order / offer_zero: the switches of the Hansel arithmetic that the
+        reference leaves to hanselx (include/gretel_hip.h: gh_config; same names as oracle.hansel_ref.HanselSpec)."""
         self._lib = _lib.load()
         self.n = int(n_snps)
-        self._cfg = dict(storage=storage, cond_mode=cond_mode, marginal_term=bool(marginal_term), device=device)
+        if sorted(cand_order) != sorted("ACGT-"):
+            raise ValueError("cand_order must be a permutation of 'ACGT-' (got %r)" % (cand_order,))
+        self._cfg = dict(storage=storage, cond_mode=cond_mode, marginal_term=bool(marginal_term), device=device,
+                         cand_order=str(cand_order), offer_zero=bool(offer_zero))
         self.symbols = [HanselSymbol(c, i) for i, c in enumerate(SYMBOLS)]
         self.unsymbols = list(UNSYMBOLS)
         self.symbols_d = {str(s): s for s in self.symbols}
@@ -75,9 +81,10 @@ class Hansel:
         return Hansel(n_snps, band=band, **kw)
 
     def _create(self, band):
+        order = (C.c_uint8 * 8)(*[SYMBOLS.index(c) for c in self._cfg["cand_order"]], 0, 0, 0)
         cfg = _lib.gh_config(self.n, max(1, band), _lib.GH_STORAGE[self._cfg["storage"]],
                              _lib.GH_COND[self._cfg["cond_mode"]], int(self._cfg["marginal_term"]),
-                             self._cfg["device"])
+                             self._cfg["device"], int(self._cfg["offer_zero"]), order)
         h = C.c_void_p()
         check(self._lib.gh_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -237,7 +244,9 @@ class Hansel:
         w = np.zeros(7)
         mask = C.c_int()
         check(self._lib.gh_edge_weights_at(self._h, int(at_pos), _p(path), _p(w), C.byref(mask)))
-        return {s: float(w[s.i]) for s in self.symbols if (mask.value >> s.i) & 1}
+        # (keys in the order the candidates are offered in: the tie-break of gretel/gretel.py:166-174)
+        offered = [self.symbols_d[c] for c in self._cfg["cand_order"]]
+        return {s: float(w[s.i]) for s in offered if (mask.value >> s.i) & 1}
 
     def candidate_masks(self):
         """uint32[N+1]: bit s set <=> valid symbol s is a candidate at that position."""

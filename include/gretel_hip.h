@@ -52,6 +52,9 @@ typedef enum {
 #define GH_COND_B 1   /* (1+H[a,b,i,j]) / (V(i) + c_a(i))                            */
 #define GH_COND_C 2   /* (1+H[a,b,i,j]) / (V(i) + sum_x H[x,b,i,j])                  */
 #define GH_COND_D 3   /* (1+H[a,b,i,j]) / (V(i) + sum_x H[a,x,i,j])   the reading of gretel.py:10's TODO with V at pos_from */
+#define GH_COND_E 4   /* (1+H[a,b,i,j]) / (V(j) + sum_x H[x,b,i,j])   C with the "unique variants" term at pos_to       */
+/* (C and E read a cell as P(a at i | b at j): the earlier variant given the candidate -- the naive-Bayes form of the
+ * published method, reference README.md:79-94; A and D read it as P(b at j | a at i); B conditions on c_a(i).) */
 
 typedef struct {
     int32_t n_snps;         /* N: number of SNPs of the window (VCF_h["N"], gretel/util.py:409) */
@@ -60,6 +63,10 @@ typedef struct {
     int32_t cond_mode;      /* GH_COND_*  */
     int32_t marginal_term;  /* 1: edge weight also adds log10(marginal) (App. A-7) */
     int32_t device;         /* HIP device ordinal, -1 = current */
+    int32_t offer_zero;     /* 1: get_edge_weights_at offers every valid symbol, also those with a zero count at the position (App. A-4/5) */
+    uint8_t cand_order[8];  /* [0..4]: the order the candidates are offered in = dict insertion order of get_edge_weights_at =
+                             * the tie-break of gretel/gretel.py:166-174 (first key wins); a permutation of the valid symbol
+                             * indices {0,1,2,3,5}.  All zero = the default A C G T - (symbol index order). */
 } gh_config;
 
 typedef struct {

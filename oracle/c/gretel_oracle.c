@@ -46,6 +46,8 @@ typedef struct orc {
     int n, band, storage, cond_mode, marginal_term, use_libm;
     int L;
     int full_enum;              /* reweight walks all N(N+3)/2+1 cells like the reference */
+    int order[5];               /* the order get_edge_weights_at offers the candidates in (symbol indices; spec.cand_order) */
+    int offer_zero;             /* spec.offer_zero: every valid symbol is a candidate, a zero count included */
     int64_t n_slices, n_crumbs, covered;
     void *h;                    /* live matrix    [(n+2)*band*49] */
     void *h0;                   /* hansel.copy()  (gretel/cmd.py:79) */
@@ -140,6 +142,7 @@ orc_t *orc_create(int n, int band, int storage, int cond_mode, int marginal_term
     if (band < 1) band = 1;
     o->n = n; o->band = band; o->storage = storage; o->cond_mode = cond_mode;
     o->marginal_term = marginal_term; o->use_libm = use_libm; o->L = 1;
+    for (int q = 0; q < 5; q++) o->order[q] = VALID[q];
     size_t bytes = cells(o) * (storage ? 8 : 4);
     o->h = calloc(1, bytes);
     if (!o->h) { free(o); return NULL; }
@@ -155,6 +158,19 @@ void orc_destroy(orc_t *o)
 void orc_set_L(orc_t *o, int L) { o->L = L; }
 int orc_get_L(const orc_t *o) { return o->L; }
 void orc_set_full_enum(orc_t *o, int v) { o->full_enum = v; }
+/* spec.cand_order (a permutation of the five valid symbol indices 0 1 2 3 5) and spec.offer_zero */
+int orc_set_candidates(orc_t *o, const int32_t order[5], int offer_zero)
+{
+    int seen = 0;
+    for (int q = 0; q < 5; q++) {
+        if (order[q] < 0 || order[q] > 5 || order[q] == SYM_N) return -1;
+        seen |= 1 << order[q];
+    }
+    if (seen != 0x2F) return -1;
+    for (int q = 0; q < 5; q++) o->order[q] = order[q];
+    o->offer_zero = offer_zero;
+    return 0;
+}
 int64_t orc_reweight_calls(const orc_t *o) { return o->reweight_calls; }
 void orc_get_stats(const orc_t *o, int64_t out[3])
 {
@@ -282,11 +298,12 @@ double orc_conditional(const orc_t *o, int a, int b, int i, int j)
     if (o->cond_mode == 0) den = (double)n_valid_at(o, j) + row_sum(o, o->h, a, i, j);
     else if (o->cond_mode == 1) den = (double)n_valid_at(o, i) + row_sum(o, o->h, a, i, i + 1);
     else if (o->cond_mode == 2) den = (double)n_valid_at(o, i) + col_sum(o, o->h, b, i, j);
+    else if (o->cond_mode == 4) den = (double)n_valid_at(o, j) + col_sum(o, o->h, b, i, j);   /* E: V(pos_to) + column sum */
     else den = (double)n_valid_at(o, i) + row_sum(o, o->h, a, i, j);          /* D: V(pos_from) + row sum */
     return (1.0 + obs) / den;
 }
 
-/* w[s] for s in 0..6; returns bitmask of candidates (valid symbols with c_s(p) > 0) */
+/* w[s] for s in 0..6; returns bitmask of candidates (valid symbols with c_s(p) > 0; every valid symbol with offer_zero) */
 int orc_edge_weights(const orc_t *o, int p, const uint8_t *path, double w[NSYM])
 {
     double c[8];
@@ -296,10 +313,10 @@ int orc_edge_weights(const orc_t *o, int p, const uint8_t *path, double w[NSYM])
     for (int q = 0; q < 5; q++) {
         int b = VALID[q];
         w[b] = 0.0;
-        if (!(c[b] > 0)) continue;
+        if (!o->offer_zero && !(c[b] > 0)) continue;
         mask |= 1 << b;
         double acc = 0.0;
-        if (o->marginal_term) acc += lg(o, c[b] / c[7]);
+        if (o->marginal_term) acc += lg(o, (c[b] > 0 && c[7] != 0.0) ? c[b] / c[7] : 0.0);
         for (int l = 1; l <= lmax; l++)
             acc += lg(o, orc_conditional(o, path[p - l], b, p - l, p));
         w[b] = acc;
@@ -320,8 +337,8 @@ int orc_generate_path(orc_t *o, uint8_t *path, double *hp_cur, double *hp_orig, 
         int mask = orc_edge_weights(o, snp, path, w);
         int next_m = -1;
         double next_v = 0.0;
-        for (int q = 0; q < 5; q++) {                 /* gretel.py:166-174 */
-            int b = VALID[q];
+        for (int q = 0; q < 5; q++) {                 /* gretel.py:166-174, keys in the order the dict was filled */
+            int b = o->order[q];
             if (!(mask & (1 << b))) continue;
             if (next_m < 0) { next_v = w[b]; next_m = b; }
             else if (w[b] > next_v) { next_v = w[b]; next_m = b; }

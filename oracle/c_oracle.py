@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 SYMS = "ACGTN-_"
-COND_MODES = {"A": 0, "B": 1, "C": 2, "D": 3}
+COND_MODES = {"A": 0, "B": 1, "C": 2, "D": 3, "E": 4}
 
 
 def build():
@@ -36,6 +36,7 @@ def lib():
         L.orc_set_L.argtypes = [vp, i32]
         L.orc_get_L.argtypes = [vp]
         L.orc_set_full_enum.argtypes = [vp, i32]
+        L.orc_set_candidates.argtypes = [vp, vp, i32]
         L.orc_reweight_calls.restype = i64
         L.orc_reweight_calls.argtypes = [vp]
         L.orc_get_stats.argtypes = [vp, C.POINTER(i64)]
@@ -70,12 +71,16 @@ def _p(a):
 
 
 class COracle:
-    def __init__(self, n, band, storage="f32", cond_mode="A", marginal_term=False, use_libm=False):
+    def __init__(self, n, band, storage="f32", cond_mode="A", marginal_term=False, use_libm=False,
+                 cand_order="ACGT-", offer_zero=False):
         self.n, self.band = n, max(1, band)
         self._h = lib().orc_create(n, self.band, 0 if storage == "f32" else 1,
                                    COND_MODES[cond_mode], int(marginal_term), int(use_libm))
         if not self._h:
             raise MemoryError
+        order = np.array([SYMS.index(c) for c in cand_order], dtype=np.int32)
+        if len(order) != 5 or lib().orc_set_candidates(self._h, _p(order), int(bool(offer_zero))):
+            raise ValueError("cand_order must be a permutation of 'ACGT-' (got %r)" % (cand_order,))
 
     def __del__(self):
         if getattr(self, "_h", None):

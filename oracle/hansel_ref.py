@@ -41,12 +41,21 @@ same thing):
         mode "A": (1 + H[a,b,i,j]) / (V(j) + sum_x H[a,x,i,j])     [frozen default]
         mode "B": (1 + H[a,b,i,j]) / (V(i) + c_a(i))
         mode "C": (1 + H[a,b,i,j]) / (V(i) + sum_x H[x,b,i,j])
+        mode "D": (1 + H[a,b,i,j]) / (V(i) + sum_x H[a,x,i,j])
+        mode "E": (1 + H[a,b,i,j]) / (V(j) + sum_x H[x,b,i,j])
+      (C and E read the cell as P(a at i | b at j) -- the earlier variant given the candidate,
+      the naive-Bayes form of the published method, README.md:79-94 -- with the "unique
+      variants" term of gretel/gretel.py:10's TODO at i-l (C) or at i (E); A and D read it
+      as P(b at j | a at i); B conditions on the marginal count of a.)
     row/col sums in the storage dtype, x ascending; the quotient in float64
     with IEEE semantics (x/0 -> inf).
   * edge weight of candidate b at p given path:
         w = 0.0 (+ log10(marginal(b,p)) if spec.marginal_term)
         for l = 1..min(L,p):  w += log10(conditional(path[p-l]@p-l -> b@p))
-    candidates = valid symbols with c_b(p) > 0, in symbol index order.
+    candidates = valid symbols with c_b(p) > 0 (spec.offer_zero: every valid symbol, a
+    zero count included), offered in spec.cand_order (default: symbol index order
+    A C G T -).  The order is the insertion order of the returned dict and therefore the
+    tie-break of gretel/gretel.py:166-174 (first key wins, later keys on strict >).
   * reweight_observation: old=H[..]; new = f64(old) - ratio*f64(old);
     H[..] = storage(new);  return f64(old) - new.
 """
@@ -64,8 +73,16 @@ UNSYMBOLS = ['N', '_']                             # gretel/util.py:83
 @dataclass(frozen=True)
 class HanselSpec:
     storage: str = "f32"          # "f32" | "f64"      
-    cond_mode: str = "A"          # "A" | "B" | "C" | "D"    (D = V(pos_from) + row sum)
+    cond_mode: str = "A"          # "A" | "B" | "C" | "D" | "E"   (D = V(pos_from) + row sum; E = V(pos_to) + column sum)
     marginal_term: bool = False   # add log10(marginal) to edge weights (App. A-7)
+    cand_order: str = "ACGT-"     # order in which get_edge_weights_at offers the candidates (dict insertion order = tie-break)
+    offer_zero: bool = False      # offer every valid symbol, also those never observed at the position (App. A-4/5 [M])
+
+    def __post_init__(self):
+        if sorted(self.cand_order) != sorted("ACGT-"):
+            raise ValueError("cand_order must be a permutation of 'ACGT-' (got %r)" % (self.cand_order,))
+        if self.cond_mode not in ("A", "B", "C", "D", "E"):
+            raise ValueError("cond_mode %r" % (self.cond_mode,))
 
     @property
     def np_dtype(self):
@@ -268,6 +285,8 @@ class Hansel:
             den = float(self._n_valid_at(pos_from)) + float(self._col_sum(b, pos_from, pos_to))
         elif mode == "D":
             den = float(self._n_valid_at(pos_from)) + float(self._row_sum(a, pos_from, pos_to))
+        elif mode == "E":
+            den = float(self._n_valid_at(pos_to)) + float(self._col_sum(b, pos_from, pos_to))
         else:
             raise ValueError(mode)
         num = 1.0 + obs
@@ -279,8 +298,9 @@ class Hansel:
         """gretel/gretel.py:155"""
         counts = self._counts(at_pos)
         out = {}
-        for v in self._valid:
-            if not counts[v] > 0:
+        for c in self.spec.cand_order:
+            v = self.symbols_d[c].i
+            if not self.spec.offer_zero and not counts[v] > 0:
                 continue
             sym = self.symbols[v]
             w = 0.0

@@ -8,17 +8,20 @@ from oracle import gretel_ref as G
 from oracle.c_oracle import COracle, paths_to_str
 from oracle.hansel_ref import Hansel, HanselSpec, SYMBOLS, UNSYMBOLS
 
-CASES = [("A", False, "f32", None), ("A", False, "f32", 3), ("B", False, "f32", None), ("C", True, "f32", None), ("D", False, "f32", None),
-         ("A", True, "f64", None), ("B", True, "f64", 4)]
+CASES = [("A", False, "f32", None, {}), ("A", False, "f32", 3, {}), ("B", False, "f32", None, {}), ("C", True, "f32", None, {}),
+         ("D", False, "f32", None, {}), ("A", True, "f64", None, {}), ("B", True, "f64", 4, {}),
+         ("E", False, "f32", None, {}), ("E", True, "f64", None, {}),
+         ("A", False, "f32", None, dict(cand_order="-TGCA")), ("C", True, "f32", None, dict(cand_order="GA-TC")),
+         ("A", False, "f32", None, dict(offer_zero=True)), ("E", True, "f32", None, dict(offer_zero=True, cand_order="TGCA-"))]
 
 
-@pytest.mark.parametrize("mode,mt,storage,band", CASES)
-def test_c_equals_python(mode, mt, storage, band):
+@pytest.mark.parametrize("mode,mt,storage,band,extra", CASES)
+def test_c_equals_python(mode, mt, storage, band, extra):
     t = make_support_table(50, 1200, k=4, seed=5)
-    spec = HanselSpec(storage=storage, cond_mode=mode, marginal_term=mt)
+    spec = HanselSpec(storage=storage, cond_mode=mode, marginal_term=mt, **extra)
     h = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, t.n_snps, spec, band=band)
     st = G.fill_from_support(h, t.reads(), t.n_snps)
-    c = COracle(t.n_snps, t.band, storage, mode, mt, use_libm=True)
+    c = COracle(t.n_snps, t.band, storage, mode, mt, use_libm=True, **extra)
     assert c.fill(t) == st
     assert c.L == h.L
     # lookups before any reweight
@@ -28,6 +31,13 @@ def test_c_equals_python(mode, mt, storage, band):
         assert cc[7] == m["total"]
         for s in h.symbols:
             assert cc[s.i] == m.get(s, 0.0)
+    # edge weights: values, candidate set AND the order they are offered in
+    path = [h.symbols_d['_']] + [h.symbols_d[c] for c in "ACGTACG"]
+    for p in (1, 3, 7):
+        ew = h.get_edge_weights_at(p, path)
+        mask, w = c.edge_weights(p, [s.i for s in path])
+        assert [str(k) for k in ew] == [ch for ch in spec.cand_order if (mask >> "ACGTN-_".index(ch)) & 1]
+        assert all(w[k.i] == v for k, v in ew.items())
     recs, _ = G.recover_paths(h, t.n_snps, 8)
     r = c.spin(8)
     assert r["n"] == len(recs) == 8
