@@ -92,15 +92,31 @@ class HanselSpec:
 DEFAULT_SPEC = HanselSpec()
 
 
-class HanselSymbol(str):
-    """A symbol object: prints as its character (gretel/cmd.py:128,164,211),
-    compares equal to the same symbol (gretel/cmd.py:201), hashable."""
-    __slots__ = ("i",)
+class HanselSymbol:
+    """A symbol object: str() gives its character (gretel/cmd.py:128,164,211), it equals the same symbol object
+    (gretel/cmd.py:201) and is hashable (a key of get_counts_at / get_edge_weights_at).  It is NOT a str and does not
+    compare or hash equal to one: the reference has to coerce the keys of get_counts_at with str() before it can look
+    "A" up (gretel/cmd.py:128; SURVEY.md App. A-3 [R]), so hanselx's symbols are not strings either."""
+    __slots__ = ("c", "i")
 
-    def __new__(cls, char, i):
-        o = str.__new__(cls, char)
-        o.i = i
-        return o
+    def __init__(self, char, i):
+        self.c = char
+        self.i = i
+
+    def __str__(self):
+        return self.c
+
+    def __repr__(self):
+        return self.c
+
+    def __eq__(self, other):
+        return isinstance(other, HanselSymbol) and other.i == self.i
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def __hash__(self):
+        return hash(("HanselSymbol", self.i))
 
 
 def _log10(x):
