@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="throughput mode: this many independent windows per GPU in one batched launch")
     ap.add_argument("--cpu-snps", type=int, default=3000, help="SNP prefix used for the Python CPU baseline sample")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (BAM + VCF files -> haplotypes)")
+    ap.add_argument("--no-spec-matrix", action="store_true", help="skip the leg that times the step under every Hansel-arithmetic switch")
+    ap.add_argument("--cond", default="A", choices=list("ABCDE"), help="conditional of the Hansel arithmetic (gh_config.cond_mode); default = the frozen spec")
+    ap.add_argument("--marginal-term", action="store_true", help="edge weights start with log10 marginal (gh_config.marginal_term)")
+    ap.add_argument("--storage", default="f32", choices=["f32", "f64"], help="storage dtype of the tensor (gh_config.storage)")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline as BASELINE.md section 3 plans it: the Python oracle on the "
                     "whole contig (C2: every path; C3: 3 paths; minutes), instead of the bounded sample of the default run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -301,7 +305,8 @@ def main():
         return bench_batch(args, cfg_name, paths, desc, rank, world, local, comm_dev)
 
     table = make_config(cfg_name, seed=rank)               # one independent window per GPU
-    h = Hansel(table.n_snps, band=table.band, device=local)
+    spec_kw = dict(cond_mode=args.cond, marginal_term=args.marginal_term, storage=args.storage)
+    h = Hansel(table.n_snps, band=table.band, device=local, **spec_kw)
     reads = DeviceReads(h, table.rank, table.off, table.bases)   # inputs resident in HBM before timing
 
     def step():
@@ -408,7 +413,8 @@ def main():
                        "n_snps": n, "n_reads": table.n_reads, "L": L, "band": table.band, "paths": paths,
                        "parallelism": "%d independent window(s), one per rank; %s broadcast/gather of control records, no data-path collective"
                                       % (world, "RCCL" if args.backend == "nccl" else "gloo"),
-                       "backend": args.backend, "share_gpu": bool(args.share_gpu)},
+                       "backend": args.backend, "share_gpu": bool(args.share_gpu),
+                       "hansel_spec": dict(spec_kw, cand_order="ACGT-", offer_zero=False)},
             "edge_evals_per_s": hap_s * (cond_evals + rw_cells),
             "edge_evals_per_path": {"conditionals": cond_evals, "reweight_cells": rw_cells},
             "fill": {"n_slices": stats[0], "n_crumbs": stats[1],
@@ -511,6 +517,34 @@ def main():
                 del hw, rw
             except Exception as exc:
                 out["wide_window"] = {"error": repr(exc)}
+        if world == 1 and not args.no_spec_matrix:
+            # the switches of the Hansel arithmetic the reference leaves to hanselx: the same step
+            # (clear + fill + `paths` spins) under every conditional x marginal term x storage.  Every spec runs the same
+            # kernels with the same incremental table maintenance; the figure to watch is max/min.
+            try:
+                import itertools
+                rows = []
+                for st_, cm_, mt_ in itertools.product(("f32", "f64"), "ABCDE", (False, True)):
+                    hx = Hansel(n, band=table.band, device=local, storage=st_, cond_mode=cm_, marginal_term=mt_)
+
+                    def xstep():
+                        hx.clear()
+                        hx.fill_from_support(None, None, None, reads_handle=reads)
+                        return hx.spin(paths)
+                    xstep(); xstep()
+                    torch.cuda.synchronize(); hx.sync()
+                    tx = time.perf_counter()
+                    nx = sum(xstep()["n"] for _ in range(5))
+                    hx.sync()
+                    tx = time.perf_counter() - tx
+                    rows.append({"cond_mode": cm_, "marginal_term": mt_, "storage": st_, "value": nx / tx,
+                                 "walker_variant": hx.walk_clock()[3], "table_requeues": hx.walk_clock()[0]})
+                    del hx
+                vals = [r["value"] for r in rows]
+                out["spec_matrix"] = {"unit": "haplotypes/s", "workload": "the benchmark step (clear + fill + %d spins), 2 warm-up + 5 timed steps per spec" % paths,
+                                      "max_over_min": max(vals) / min(vals), "min": min(vals), "max": max(vals), "rows": rows}
+            except Exception as exc:
+                out["spec_matrix"] = {"error": repr(exc)}
         if world == 1 and not args.no_e2e:
             try:
                 out["end_to_end"] = end_to_end_leg(table, paths, local)

@@ -1126,9 +1126,19 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     if (seg) {
         // behind a segment-parallel walk (L <= SEG_MAX_L <= 8: one table row per lane): segwalk.hpp's k_rw
 #define GH_RW_LAUNCH(T, LP, COL)                                                                                                  \
-    hipLaunchKernelGGL((k_rw<T, LP, COL>), dim3(nb), dim3(block), 0, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
-                       h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                    \
-                       (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->rinfo)
+    do {                                                                                                                          \
+        /* COL: the band block of the workgroup's positions staged in LDS when it fits (k_rw) */                                   \
+        const size_t blk_b = (size_t)(256 / LP) * NSYM * h->W * NSYM * sizeof(T);                                                 \
+        const int stage = (COL && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0;    \
+        static size_t set_lds[64];                                                                                                \
+        if (stage && blk_b > set_lds[h->dev & 63]) {                                                                              \
+            hipFuncSetAttribute((const void *)k_rw<T, LP, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_b);          \
+            set_lds[h->dev & 63] = blk_b;                                                                                         \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((k_rw<T, LP, COL>), dim3(nb), dim3(block), stage ? blk_b : 0, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
+                           h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                \
+                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->rinfo, stage);               \
+    } while (0)
 #define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true); else GH_RW_LAUNCH(T, LP, false); } while (0)
         const bool wide = rw_lanes(h) == 32;
         const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;      // the table entries a reweighted cell feeds: a column

@@ -482,11 +482,27 @@ template <typename T, int LP, bool COL>
 __global__ void __launch_bounds__(256)
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
-     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo)
+     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage)
 {
     __shared__ double s_red[256];
+    extern __shared__ __align__(16) unsigned char rw_smem[];
     const int tid = threadIdx.x;
     RW_STAMP(0);
+    // COL, stage != 0: the band block of this workgroup's positions goes to LDS as it lies in memory (one contiguous run,
+    // 16-byte loads, issued before anything else): the columns are then LDS reads.  Strided 4-byte column loads straight
+    // from memory measured 6-12 us for k_rw<float, 8, true> at C3 (every line of the band, cold, one sector per lane).
+    T *blk = reinterpret_cast<T *>(rw_smem);
+    constexpr int PPB = 256 / LP;                           // positions per workgroup
+    const size_t pos_elems = (size_t)NSYM * W * NSYM;
+    if (COL && stage) {
+        const int p0 = blockIdx.x * PPB;
+        const int np = p0 + PPB <= N + 2 ? PPB : (N + 2 > p0 ? N + 2 - p0 : 0);
+        typedef T vecT __attribute__((ext_vector_type(16 / sizeof(T))));
+        const size_t nv = (size_t)np * pos_elems * sizeof(T) / 16;
+        const vecT *src = reinterpret_cast<const vecT *>(band + (size_t)p0 * pos_elems);
+        vecT *dst = reinterpret_cast<vecT *>(blk);
+        for (size_t q = tid; q < nv; q += 256) dst[q] = src[q];
+    }
     const dev_ctl c = load_ctl(st);
     const int nseg = nseg_arg > 0 ? nseg_arg : seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
     double my_segmin = INFINITY;                            // (<= 512 segments: two per thread at most)
@@ -517,8 +533,10 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     // this lane owns the table entries of lag d0: a row (every lag up to L), or a column (only where the cell changed)
     const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N && (!COL || (mult0 > 0 && d0 <= W));
     T crow[NSYM];
+    if (!(COL && stage)) {
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? band[bidx(W, pp, 1, s, x)] : (T)0;      // cell (p, p+1), row s
+        for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? band[bidx(W, pp, 1, s, x)] : (T)0;      // cell (p, p+1), row s
+    }
     int nv_t = 0;
     uint32_t cm_t = 0;
     if (lag_row) { nv_t = nvalid[j0]; cm_t = CM_CAND(cmask[j0]); }
@@ -542,9 +560,24 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     constexpr int one = 1;
     const int estride = COL ? W * NSYM : one;               // elements between two entries of the run this lane reads
     const int esel = COL ? a : b0;                          // the entry of the run that is reweighted
+    // (no branch around the loads: a lane without a run reads the start of its position's block and drops it -- behind a branch the
+    // compiler waits for each of the seven strided loads before it issues the next: 7 round trips, 15 us for k_rw<float, 8, COL>)
+    const T *runp = need_row ? rowp : band + bidx(W, pp, 1, 0, 0);      // (its own position's block)
     T rrow[NSYM];
+    if (COL && stage) {
+        // (the reduction above has passed barriers behind the staging stores)
+        const T *lp = blk + (size_t)(tid / LP) * pos_elems;                // this position's block in LDS
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rowp[(size_t)x * estride] : (T)0;
+        for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? lp[((size_t)s * W) * NSYM + x] : (T)0;
+        const T *lc = lp + ((size_t)(d0 <= W ? d0 : 1) - 1) * NSYM + b0;
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) rrow[x] = lc[(size_t)x * estride];
+    } else {
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) rrow[x] = runp[(size_t)x * estride];
+    }
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rrow[x] : (T)0;
     RW_STAMP(2);
     // ---- reweight ---------------------------------------------------------------------------------------------
     double removed = 0.0;
@@ -679,7 +712,9 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             if (COL && G && p < N && d <= L && j <= N) {
                 T colT[NSYM];
 #pragma unroll
-                for (int x = 0; x < NSYM; x++) colT[x] = (x == a) ? (T)nw : band[bidx(W, p, d, x, b)];
+                for (int x = 0; x < NSYM; x++) colT[x] = band[bidx(W, p, d, x, b)];      // (all seven in flight; the element just rewritten is replaced)
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) colT[x] = (x == a) ? (T)nw : colT[x];
                 table_col(d, colT, nvalid[j], CM_CAND(cmask[j]), b);
             }
         }

@@ -146,3 +146,45 @@ def test_c5_deep_reweight_1000_paths():
     band1 = h.export_band()
     assert np.all(band1 <= band0) and np.all(band1 >= 0)
     assert abs((band0 - band1).sum() - res["magnitude"].sum()) <= 1e-5 * res["magnitude"].sum()
+
+
+# ---- the switches of the Hansel arithmetic at full size and depth (tests/test_gpu_specs.py covers them on small windows) ----
+SPECS = [dict(cond_mode="C", marginal_term=True), dict(cond_mode="A", marginal_term=True), dict(cond_mode="D"),
+         dict(storage="f64"), dict(cond_mode="E", marginal_term=True), dict(cond_mode="C", storage="f64"), dict(cond_mode="B", marginal_term=True)]
+
+
+def _spec_run(t, kw, paths):
+    from spec_util import make_pair, same
+    h, o = make_pair(t, **kw)
+    res, ref = h.spin(paths), o.spin(paths)
+    assert res["n"] == ref["n"] == paths
+    same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    return h
+
+
+@pytest.mark.parametrize("kw", SPECS, ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
+def test_c2_100_paths_under_every_switch(kw):
+    # config C2: 1k SNPs / 50k reads / L = 3, the reference's default depth of 100 paths
+    h = _spec_run(make_config("C2", seed=0), kw, 100)
+    assert h.L == 3 and h.walk_clock()[3] == 3
+
+
+@pytest.mark.parametrize("kw", SPECS[:5], ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
+def test_c3_20_paths_under_every_switch(c3, kw):
+    h = _spec_run(c3, kw, 20)
+    assert h.L == 5 and h.walk_clock()[3] == 3
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7])
+def test_c4_windows_of_the_other_ranks(seed):
+    # config C4 = eight independent C3 windows, seed = rank (bench.py): seed 0 is checked above at 100 paths; these are
+    # the windows ranks 1..7 own, recovered here on ONE GPU -- fill + 20 paths each, bit for bit
+    t = make_config("C3", seed=seed)
+    h = Hansel(t.n_snps, band=t.band)
+    o = COracle(t.n_snps, t.band)
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    res, ref = h.spin(20), o.spin(20)
+    from spec_util import same
+    same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
