@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROF_STRIDE = 25       # HIP-event brackets on every 25th launch of each kernel (an event pair costs the stream ~10 us)
+PROF_STRIDE = 50       # HIP-event brackets on every 50th launch of each kernel (an event pair costs the stream ~10 us)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 

@@ -111,6 +111,10 @@ struct gh_handle {
     uint32_t *seg_hist;    // picks of every (segment, entry state)
     uint16_t *seg_maps, *seg_pmaps, *seg_gmaps;
     double *seg_min;       // [CW_MAX_SEG]
+    double *seg_smin, *seg_gmin;   // minimum marginal per (segment, entry state) / per (group, entry state)
+    uint8_t *cm5snap;      // [N+2] candidate bits as the last k_seg saw them
+    size_t fuse_lds;       // LDS of k_rw's fused prologue for this spin's state space
+    bool fuse;             // inside a gh_spin over the enumerated states: no k_emit, k_rw chains the maps itself (segwalk.hpp)
     double *lmsel1;        // [N+1] selected log-marginals of a lone gh_generate_path
     double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
     int seg_L;
@@ -274,6 +278,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
+    hipFree(h->seg_smin); hipFree(h->seg_gmin); hipFree(h->cm5snap);
     if (h->stage) hipHostFree(h->stage);
     hipFree(h->ew_buf);
     hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
@@ -333,6 +338,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
+    h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr; h->fuse = false;
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
     h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0;
@@ -987,7 +993,9 @@ static int alloc_seg(gh_handle *h)
     if (h->seg_hist && h->seg_L == h->L) return GH_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1);
+    hipFree(h->seg_smin); hipFree(h->seg_gmin); hipFree(h->cm5snap);
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
+    h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr;
     // the layout is decided on the device (st->ranked): size for both (L = 6: ranked tables only, see gh_spin)
     const seg_geom g4 = seg_geometry(h->N, h->L, 4), g5 = seg_radix_ok(5, h->L) ? seg_geometry(h->N, h->L, 5) : g4;
     const size_t hist_b = max2((size_t)g4.S * g4.NW * g4.NS, (size_t)g5.S * g5.NW * g5.NS) * 4;
@@ -995,8 +1003,11 @@ static int alloc_seg(gh_handle *h)
     const size_t gmaps_b = max2((size_t)g4.G1 * g4.NS, (size_t)g5.G1 * g5.NS) * 2;
     hipError_t e = hipMalloc((void **)&h->seg_hist, hist_b);
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_maps, maps_b);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_pmaps, maps_b);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmaps, gmaps_b);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_pmaps, maps_b + 16);        // (+ slack: 16-byte copies in k_rw)
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmaps, gmaps_b + 16);      // (+ slack: k_rw copies the group maps four bytes at a time)
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_smin, maps_b * 4);          // doubles where the maps hold 2-byte states
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmin, gmaps_b * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cm5snap, (size_t)h->N + 2);
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_min, CW_MAX_SEG * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&h->lmsel1, ((size_t)h->N + 2) * sizeof(double));
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the segment-parallel walk failed: %s", hipGetErrorString(e));
@@ -1011,18 +1022,28 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
     const int N = h->N, dev = h->dev;
     constexpr bool five = seg_radix_ok(5, LC);
     const seg_geom g4 = seg_geometry(N, LC, 4), g5 = five ? seg_geometry(N, LC, 5) : g4;
-    const size_t lds_seg = five ? max2(seg_lds_bytes(4, LC), seg_lds_bytes(5, LC)) : seg_lds_bytes(4, LC);
+    const size_t lds_seg = five ? max2(seg_lds_total(4, LC), seg_lds_total(5, LC)) : seg_lds_total(4, LC);
     const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
     const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
     // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
-    static size_t set_seg[64], set_scan[64], set_emit[64];
+    static size_t set_seg[64], set_scan[64], set_emit[64], set_segt[64], set_scant[64];
     const int dv = dev & 63;
-    if (lds_seg > set_seg[dv]) { hipFuncSetAttribute((const void *)k_seg<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg); set_seg[dv] = lds_seg; }
-    if (lds_scan > set_scan[dv]) { hipFuncSetAttribute((const void *)k_scan<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan); set_scan[dv] = lds_scan; }
-    if (lds_emit > set_emit[dv]) { hipFuncSetAttribute((const void *)k_emit<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit); set_emit[dv] = lds_emit; }
     const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
+    if (h->fuse) {
+        // spins without k_emit: k_seg / k_scan also carry the minimum marginals (TRACK), k_rw chains the group maps itself
+        if (lds_seg > set_segt[dv]) { hipFuncSetAttribute((const void *)k_seg<LC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg); set_segt[dv] = lds_seg; }
+        if (lds_scan > set_scant[dv]) { hipFuncSetAttribute((const void *)k_scan<LC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan); set_scant[dv] = lds_scan; }
+        prof_begin(h, GH_K_SEG);
+        hipLaunchKernelGGL((k_seg<LC, true>), dim3(S), dim3(SEG_THREADS), lds_seg, stream, P);
+        prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
+        hipLaunchKernelGGL((k_scan<LC, true>), dim3(G1), dim3(SEG_THREADS), lds_scan, stream, P);
+        return;
+    }
+    if (lds_seg > set_seg[dv]) { hipFuncSetAttribute((const void *)k_seg<LC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg); set_seg[dv] = lds_seg; }
+    if (lds_scan > set_scan[dv]) { hipFuncSetAttribute((const void *)k_scan<LC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan); set_scan[dv] = lds_scan; }
+    if (lds_emit > set_emit[dv]) { hipFuncSetAttribute((const void *)k_emit<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit); set_emit[dv] = lds_emit; }
     prof_begin(h, GH_K_SEG);
-    hipLaunchKernelGGL((k_seg<LC>), dim3(S), dim3(SEG_THREADS), lds_seg, stream, P);
+    hipLaunchKernelGGL((k_seg<LC, false>), dim3(S), dim3(SEG_THREADS), lds_seg, stream, P);
     // algorithmic bytes of k_seg: the conditional lookups of the extension (L history cells per step)
     prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
     // short memories / small windows: every segment map fits the LDS of the emitting workgroup, which composes them itself
@@ -1034,7 +1055,7 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
         hipLaunchKernelGGL((k_emit_small<LC>), dim3(S), dim3(SEG_THREADS), lds_small, stream, P);
         return;
     }
-    hipLaunchKernelGGL((k_scan<LC>), dim3(G1), dim3(SEG_THREADS), lds_scan, stream, P);
+    hipLaunchKernelGGL((k_scan<LC, false>), dim3(G1), dim3(SEG_THREADS), lds_scan, stream, P);
     hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, stream, P);
 }
 
@@ -1046,6 +1067,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     P.N = h->N; P.L = h->L; P.rearm = rearm; P.check_masks = check_masks;
     P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
+    P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
     P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
     prof_begin(h, GH_K_WALK);
     switch (h->L) {
@@ -1105,7 +1127,7 @@ static int rw_blocks(const gh_handle *h, bool seg) { return (int)(((size_t)(h->N
 // seg: the walk just before was segment-parallel: the kernel reduces the minimum marginal itself, clamps it to `ratio`
 // (= min_remove) and closes the record
 static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double ratio, int use_state, gh_path_rec *d_rec, int slot = -1,
-                                bool seg = false, bool chained = false, int nseg_arg = 0)
+                                bool seg = false, bool chained = false, int nseg_arg = 0, double *d_lmsel = nullptr)
 {
     const int block = 256;
     const int nb = rw_blocks(h, seg);
@@ -1130,18 +1152,28 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         /* COL: the band block of the workgroup's positions staged in LDS when it fits (k_rw) */                                   \
         const size_t blk_b = (size_t)(256 / LP) * NSYM * h->W * NSYM * sizeof(T);                                                 \
         const int stage = (COL && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0;    \
+        const size_t lds_b = fuse_lds + (stage ? blk_b : 0);                                                                      \
         static size_t set_lds[64];                                                                                                \
-        if (stage && blk_b > set_lds[h->dev & 63]) {                                                                              \
-            hipFuncSetAttribute((const void *)k_rw<T, LP, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blk_b);          \
-            set_lds[h->dev & 63] = blk_b;                                                                                         \
+        if (lds_b > set_lds[h->dev & 63]) {                                                                                       \
+            hipFuncSetAttribute((const void *)k_rw<T, LP, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);          \
+            set_lds[h->dev & 63] = lds_b;                                                                                         \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_rw<T, LP, COL>), dim3(nb), dim3(block), stage ? blk_b : 0, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
+        hipLaunchKernelGGL((k_rw<T, LP, COL>), dim3(nb), dim3(block), lds_b, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
                            h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                \
-                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->rinfo, stage);               \
+                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->rinfo, stage, fz, (int)fuse_lds); \
     } while (0)
 #define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true); else GH_RW_LAUNCH(T, LP, false); } while (0)
         const bool wide = rw_lanes(h) == 32;
         const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;      // the table entries a reweighted cell feeds: a column
+        // behind k_seg + k_scan without a k_emit (h->fuse): the kernel finds its picks itself and writes the path to d_path / d_lmsel
+        fuse_params fz;
+        memset(&fz, 0, sizeof fz);
+        size_t fuse_lds = 0;
+        if (h->fuse && nseg_arg == 0) {
+            fz.hist = h->seg_hist; fz.pmaps = h->seg_pmaps; fz.gmaps = h->seg_gmaps; fz.gmin = h->seg_gmin; fz.cm5snap = h->cm5snap;
+            fz.path_out = const_cast<uint8_t *>(d_path); fz.lmsel = d_lmsel;
+            fuse_lds = h->fuse_lds;
+        }
         if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
         else { if (wide) GH_RW_LAUNCH2(float, 32); else GH_RW_LAUNCH2(float, 8); }
 #undef GH_RW_LAUNCH2
@@ -1694,6 +1726,34 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             else if (look.ranked) { seg = true; h->seg6 = true; }
         }
     }
+    // Spins over the enumerated states run without k_emit where the group maps fit k_rw's LDS beside everything else
+    // (1024 states: 32 KB; the five-symbol radix from 5^5 states on, and 4^6, keep k_emit) and the band is not wider than
+    // the halo k_rw resolves: which radix applies is the table's layout, decided on the device -- one look per spin.
+    h->fuse = false;
+    // MEASURED (C3, MI355X): three launches are bit-identical but NOT faster than four -- k_emit and its
+    // boundary (6.8 us) go, the prologue k_rw needs instead (group maps to LDS, the chain, one more round trip) costs 6.5 us,
+    // and carrying the minima through k_seg / k_scan another 2.9 us: 40.8 against 38.7 us per path.  So it is opt-in:
+    // GH_FUSE=1 (large windows) or 2 (every window the maps fit; the tests).
+    if (rc == GH_OK && seg && h->W <= RW_FUSE_HALO && getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1) {
+        rc = ensure_lt(h);
+        dev_state look;
+        if (rc == GH_OK) {
+            e = hipMemcpyAsync(&look, h->dstate, sizeof look, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+            else {
+                const int R = look.ranked ? 4 : 5;
+                const int ppb = 256 / rw_lanes(h);
+                // (windows whose segment maps all fit one workgroup's LDS keep k_emit_small: three launches as well, and a lighter k_rw)
+                const bool small = emit_small_lds_bytes(h->N, h->L, R) <= 64 * 1024 && !(getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0);
+                const bool force = getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) == 2;      // (tests: fused whatever the size)
+                if ((!small || force) && seg_radix_ok(R, h->L) && rw_fuse_lds_bytes(h->N, h->L, R, ppb, h->W) <= 64 * 1024 && (rc = alloc_seg(h)) == GH_OK) {
+                    h->fuse = true;
+                    h->fuse_lds = rw_fuse_lds_bytes(h->N, h->L, R, ppb, h->W);
+                }
+            }
+        }
+    }
     const int nb = rw_blocks(h, seg || cw_ok(h->wmode, h->L));       // (the widest reweight kernel this spin may launch)
     h->spin_partial_stride = nb;
     if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);       // L only changes through gh_set_L / gh_fill, never inside a spin
@@ -1726,7 +1786,8 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             if (!optimistic || s == first) { if ((rc = ensure_lt(h, !seg))) break; }
             if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1, h->spin_lmsel + n1 * s,
                                   !(optimistic && s > first) ? 0 : (s == h->force_stale_at && h->spin_requeues == 0 ? 2 : 1)))) break;
-            if ((rc = launch_reweight_marg(h, d_paths + n1 * s, seg ? min_remove : 0.0, 1, d_recs + s, s, seg, optimistic && s > first))) break;
+            if ((rc = launch_reweight_marg(h, d_paths + n1 * s, seg ? min_remove : 0.0, 1, d_recs + s, s, seg, optimistic && s > first, 0,
+                                           h->spin_lmsel + n1 * s))) break;
             launched = s + 1;
         }
         // the likelihood sums of every path in one launch (strictly sequential additions, one wavefront per sum)
@@ -1761,6 +1822,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     }
     h->spin_partial_stride = 0;
     h->seg6 = false;
+    h->fuse = false;
     if (rc) return rc;
     *n_out = hs.n_done;
     *hole_at = hs.stop ? hs.hole_at : 0;

@@ -36,7 +36,7 @@ __host__ __device__ constexpr int seg_chunk(int R, int L)
 {
     const int NI = seg_ipow(R, L - 1), sz = R == 4 ? 1 : 2;
     int c = 64;
-    while (c > 8 && ((c + L - 1) * L * R * R * 8 + c * NI * sz) > 96 * 1024) c -= 8;
+    while (c > 8 && ((c + L - 1) * L * R * R * 8 + c * NI * sz + c * R * 8) > 96 * 1024) c -= 8;
     return c / seg_dpw(R) * seg_dpw(R);        // whole words of hist per chunk
 }
 
@@ -70,10 +70,12 @@ __host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
     return g;
 }
 
+// the slice of G and the Next tables (rounded up to 8 bytes: the marginal table of the chunk follows)
 __host__ __device__ constexpr size_t seg_lds_bytes(int R, int L)
 {
-    return (size_t)(seg_chunk(R, L) + L - 1) * L * R * R * 8 + (size_t)seg_chunk(R, L) * seg_ipow(R, L - 1) * (R == 4 ? 1 : 2);
+    return ((size_t)(seg_chunk(R, L) + L - 1) * L * R * R * 8 + (size_t)seg_chunk(R, L) * seg_ipow(R, L - 1) * (R == 4 ? 1 : 2) + 7) & ~(size_t)7;
 }
+__host__ __device__ constexpr size_t seg_lds_total(int R, int L) { return seg_lds_bytes(R, L) + (size_t)seg_chunk(R, L) * R * 8; }
 __host__ __device__ inline size_t scan_lds_bytes(int N, int L, int R)
 {
     const seg_geom g = seg_geometry(N, L, R);

@@ -19,6 +19,10 @@
 //            (<= 15 lookups) and its prefix map = its TRUE entry state, reads that state's picks from hist, and does
 //            the bookkeeping of gretel.py:182-187 for its positions (path symbols, the selected symbols'
 //            log-marginals, the minimum marginal).
+//   Spins (gh_spin) run WITHOUT k_emit: k_seg also carries, per entry state, the minimum marginal of the picks made on the
+//   way, k_scan composes (map, min) pairs -- min is associative along the chain --, and the reweight kernel k_rw chains the
+//   <= 16 group maps itself: its true entry states, the picks of its own positions (and of the W behind them), and the
+//   path's minimum marginal = the ratio every reweighted cell needs.  Three launches per path instead of four.
 //   k_hp     the two log-likelihood sums of gretel.py:185-186, strictly left to right in binary64 (one wavefront per
 //            sum); they feed nothing on the device, so gh_spin runs them for all paths at once behind the loop.
 //
@@ -43,6 +47,9 @@ struct seg_params {
     uint16_t *pmaps;          // [S][NS] prefix maps: entry state of the group -> entry state of the segment
     uint16_t *gmaps;          // [G1][NS] group maps
     double *segmin;           // [S] minimum marginal of the symbols selected in each segment
+    double *smin;             // [S][NS] minimum marginal of the picks of every (segment, entry state)   (k_seg)
+    double *gmin;             // [G1][NS] the same over a whole group, by the group's entry state       (k_scan)
+    uint8_t *cm5snap;         // [N+2] candidate bits of every position as k_seg saw them (rank -> symbol for whoever emits)
     uint8_t *path_out;        // [N+1]
     double *lmsel;            // [N+1] log10 marginal of the selected symbol per position (for k_hp)
 };
@@ -74,7 +81,16 @@ __device__ __forceinline__ unsigned seg_argmax(const double (&v)[R])
     return idx;
 }
 
-template <int R, int LC>
+// min without the canonicalising v_max(x,x) pair the compiler adds around fmin (no NaNs here: marginals, +inf)
+__device__ __forceinline__ double vmin_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// TRACK: spins without k_emit -- per entry state also the minimum marginal of its picks (smin)
+template <int R, int LC, bool TRACK>
 __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *smem)
 {
     typedef typename seg_radix<R>::next_t next_t;
@@ -90,6 +106,10 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
     const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     double *Gs = reinterpret_cast<double *>(smem);                 // [(CH + LC - 1)][LC][R][R]
     next_t *Nx = reinterpret_cast<next_t *>(Gs + (size_t)(CH + LC - 1) * LC * RR);   // [CH][NI]
+    double *Ms = reinterpret_cast<double *>(smem + seg_lds_bytes(R, LC));            // [CH][R] marginal of column b at every target
+    double mn[SPT];                                                // minimum marginal of the picks, per entry state
+#pragma unroll
+    for (int q = 0; q < SPT; q++) mn[q] = INFINITY;
 
     unsigned sigma[SPT];                                           // (threads beyond NS walk state 0 and store nothing)
 #pragma unroll
@@ -125,6 +145,14 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
             double *dst = Gs + (size_t)e * R;
 #pragma unroll
             for (int b = 0; b < R; b++) dst[b] = v[b];
+        }
+        // the marginals of the columns at targets c0+1 .. c0+nc (by rank or by symbol, like the columns)
+        if (TRACK) {
+            for (int e = tid; e < nc * R; e += SEG_THREADS) {
+                const int tl = e / R, b = e - tl * R;
+                const int t = c0 + 1 + tl;
+                Ms[e] = R == 4 ? P.rinfo[(size_t)t * RINFO + 4 + b] : P.minfo[(size_t)t * MINFO + 5 + b];
+            }
         }
         __syncthreads();
         SEG_STAMP(1);
@@ -203,6 +231,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
                             const unsigned d = ((unsigned)rows[u * NI + idx] >> (BITS * hi)) & MASK;
                             word[q] |= d << (BITS * u);
                             sigma[q] = idx * R + d;
+                            if (TRACK) mn[q] = vmin_f64(mn[q], Ms[(tw + u) * R + d]);
                         }
                     }
                 }
@@ -222,12 +251,15 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
 #pragma unroll
     for (int q = 0; q < SPT; q++) {
         const unsigned s0 = tid + q * SEG_THREADS;
-        if (s0 < NS) P.maps[(size_t)s * NS + s0] = (uint16_t)sigma[q];
+        if (s0 < NS) {
+            P.maps[(size_t)s * NS + s0] = (uint16_t)sigma[q];
+            if (TRACK) P.smin[(size_t)s * NS + s0] = mn[q];
+        }
     }
     SEG_STAMP(4);
 }
 
-template <int LC>
+template <int LC, bool TRACK>
 __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
@@ -242,14 +274,14 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
     }
     // the flags k_marg left for this path; k_scan re-arms them for the next k_marg, k_emit reads the copy
     if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC>(P, seg_smem);
-    else if constexpr (seg_radix_ok(5, LC)) seg_body<5, LC>(P, seg_smem);      // (beyond: the host only launches this for ranked tables)
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC, TRACK>(P, seg_smem);
+    else if constexpr (seg_radix_ok(5, LC)) seg_body<5, LC, TRACK>(P, seg_smem);      // (beyond: the host only launches this for ranked tables)
 }
 
 // -------------------------------------------------------------------------------------------------------------
 // k_scan: group map = composition of the group's segment maps
 // -------------------------------------------------------------------------------------------------------------
-template <int R, int LC>
+template <int R, int LC, bool TRACK>
 __device__ __forceinline__ void scan_body(const seg_params &P, unsigned char *smem)
 {
     constexpr int NS = seg_ipow(R, LC);
@@ -261,18 +293,41 @@ __device__ __forceinline__ void scan_body(const seg_params &P, unsigned char *sm
     uint16_t *M = reinterpret_cast<uint16_t *>(smem);              // [n][NS]
     const uint16_t *src = P.maps + (size_t)s_lo * NS;
     for (int e = tid; e < n * NS; e += SEG_THREADS) M[e] = src[e];
+    // the candidate bits of this group's positions as this path's kernels see them: the reweight behind rewrites them
+    // while its neighbours still map ranks to symbols (k_rw without k_emit reads this copy)
+    if (TRACK) {
+        const int t_lo = s_lo * g.seglen + 1;
+        int t_hi = (s_lo + n) * g.seglen;
+        if (t_hi > P.N) t_hi = P.N;
+        for (int t = t_lo + tid; t <= t_hi; t += SEG_THREADS)
+            P.cm5snap[t] = (uint8_t)__double_as_longlong(P.minfo[(size_t)t * MINFO + 10]);
+    }
     __syncthreads();
     for (int s0 = tid; s0 < NS; s0 += SEG_THREADS) {
         int x = s0;
-        for (int j = 0; j < n; j++) {
-            if (j > 0) P.pmaps[(size_t)(s_lo + j) * NS + s0] = (uint16_t)x;      // what enters segment s_lo + j
-            x = M[(size_t)j * NS + x];
+        // (map, min) pairs compose along the chain: the group's minimum for entry state s0 is the minimum over its segments of
+        // what each holds for the state that enters IT.  The gathers go out as the states become known, the minimum is taken last.
+        double mv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            mv[j] = INFINITY;
+            if (j < n) {
+                if (j > 0) P.pmaps[(size_t)(s_lo + j) * NS + s0] = (uint16_t)x;      // what enters segment s_lo + j
+                if (TRACK) mv[j] = P.smin[(size_t)(s_lo + j) * NS + x];
+                x = M[(size_t)j * NS + x];
+            }
         }
         P.gmaps[(size_t)grp * NS + s0] = (uint16_t)x;
+        if (TRACK) {
+            double m = mv[0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) m = vmin_f64(m, mv[j]);
+            P.gmin[(size_t)grp * NS + s0] = m;
+        }
     }
 }
 
-template <int LC>
+template <int LC, bool TRACK>
 __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
 {
     extern __shared__ __align__(16) unsigned char seg_smem[];
@@ -283,8 +338,8 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
     if (P.rearm && c.cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
         st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f;
     }
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) scan_body<4, LC>(P, seg_smem);
-    else if constexpr (seg_radix_ok(5, LC)) scan_body<5, LC>(P, seg_smem);
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) scan_body<4, LC, TRACK>(P, seg_smem);
+    else if constexpr (seg_radix_ok(5, LC)) scan_body<5, LC, TRACK>(P, seg_smem);
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -478,21 +533,50 @@ __device__ __forceinline__ V pick7(const V (&r)[NSYM], int x)
     return v;
 }
 
+// k_rw without a k_emit in front of it (fz.hist != nullptr; spins over the enumerated states): what it reads instead of
+// `path` and `segmin`.  Everything here was written by the k_seg / k_scan of this path and is not touched by this kernel.
+struct fuse_params {
+    const uint32_t *hist;     // [S][NW][NS]
+    const uint16_t *pmaps;    // [S][NS]
+    const uint16_t *gmaps;    // [G1][NS]
+    const double *gmin;       // [G1][NS]
+    const uint8_t *cm5snap;   // [N+2]
+    uint8_t *path_out;        // [N+1]  this path's symbols (every workgroup writes its own positions)
+    double *lmsel;            // [N+1]  log10 marginal of every selected symbol, as it was when the path was walked (k_hp)
+};
+#define RW_FUSE_HALO 64       /* fused: band widths up to this (the picks of the W positions behind a workgroup's own) */
+#define RW_FUSE_SEGS 24       /* ... and at most this many segments under one workgroup's positions + halo */
+// segments under the positions of one workgroup (ppb of them) and the W behind: their prefix maps are staged too
+__host__ __device__ inline int rw_fuse_nts(int N, int L, int R, int ppb, int W)
+{
+    const seg_geom g = seg_geometry(N, L, R);
+    int n = (ppb + W + g.seglen - 1) / g.seglen + 1;
+    return n < g.S ? n : g.S;
+}
+__host__ __device__ inline size_t rw_fuse_lds_bytes(int N, int L, int R, int ppb, int W)
+{
+    const seg_geom g = seg_geometry(N, L, R);
+    // the group maps; the prefix maps of the segments underneath; entry states of the groups and segments; picks
+    return (((size_t)g.G1 * g.NS * 2 + 15) & ~(size_t)15) + (size_t)rw_fuse_nts(N, L, R, ppb, W) * g.NS * 2 + 512;
+}
+
 template <typename T, int LP, bool COL>
 __global__ void __launch_bounds__(256)
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
-     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage)
+     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage, fuse_params fz, int fuse_lds)
 {
     __shared__ double s_red[256];
-    extern __shared__ __align__(16) unsigned char rw_smem[];
+    extern __shared__ __align__(16) unsigned char rw_smem_all[];
     const int tid = threadIdx.x;
+    constexpr int PPB = 256 / LP;                           // positions per workgroup
+    const bool fused = fz.hist != nullptr;
+    unsigned char *rw_smem = rw_smem_all + fuse_lds;        // (the fused prologue's LDS lies in front of the staged band block)
     RW_STAMP(0);
     // COL, stage != 0: the band block of this workgroup's positions goes to LDS as it lies in memory (one contiguous run,
     // 16-byte loads, issued before anything else): the columns are then LDS reads.  Strided 4-byte column loads straight
     // from memory measured 6-12 us for k_rw<float, 8, true> at C3 (every line of the band, cold, one sector per lane).
     T *blk = reinterpret_cast<T *>(rw_smem);
-    constexpr int PPB = 256 / LP;                           // positions per workgroup
     const size_t pos_elems = (size_t)NSYM * W * NSYM;
     if (COL && stage) {
         const int p0 = blockIdx.x * PPB;
@@ -504,11 +588,36 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         for (size_t q = tid; q < nv; q += 256) dst[q] = src[q];
     }
     const dev_ctl c = load_ctl(st);
-    const int nseg = nseg_arg > 0 ? nseg_arg : seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
+    const int Rr = c.ranked != 0 ? 4 : 5;
+    const seg_geom sg = seg_geometry(N, L, Rr);
+    const int nseg = nseg_arg > 0 ? nseg_arg : sg.S;
     double my_segmin = INFINITY;                            // (<= 512 segments: two per thread at most)
-    for (int q = tid; q < nseg; q += 256) {
-        const double v = segmin[q];
-        if (v < my_segmin) my_segmin = v;
+    uint16_t *GM = reinterpret_cast<uint16_t *>(rw_smem_all);           // fused: [G1][NS] group maps
+    const int nts = rw_fuse_nts(N, L, Rr, PPB, W);
+    uint16_t *PMs = reinterpret_cast<uint16_t *>(rw_smem_all + (((size_t)sg.G1 * sg.NS * 2 + 15) & ~(size_t)15));      // [nts][NS] prefix maps
+    int *xs = reinterpret_cast<int *>(PMs + (size_t)nts * sg.NS);      // [32] entry state of every group
+    int *ent = xs + 32;                                     // [RW_FUSE_SEGS] entry state of the segments under this workgroup
+    uint8_t *sym = reinterpret_cast<uint8_t *>(ent + RW_FUSE_SEGS);     // [PPB + halo] symbol picked at p0 + u ...
+    uint8_t *pk5 = sym + 128;                               // ... and its compact index
+    if (!fused) {
+        for (int q = tid; q < nseg; q += 256) {
+            const double v = segmin[q];
+            if (v < my_segmin) my_segmin = v;
+        }
+    } else {
+        // the group maps -> LDS (they do not depend on anything this kernel computes): 16-byte copies, the allocation has slack
+        const uint4 *src = reinterpret_cast<const uint4 *>(fz.gmaps);
+        uint4 *dst = reinterpret_cast<uint4 *>(GM);
+        const int n128 = (sg.G1 * sg.NS * 2 + 15) / 16;
+        for (int q = tid; q < n128; q += 256) dst[q] = src[q];
+        // ... and the prefix maps of the segments under this workgroup's positions and halo (2 KB each at 1024 states)
+        const int p0 = blockIdx.x * PPB;
+        const int s_first = p0 >= 1 ? (p0 - 1) / sg.seglen : 0;
+        const int ns = s_first + nts <= sg.S ? nts : sg.S - s_first;
+        const uint4 *ps = reinterpret_cast<const uint4 *>(fz.pmaps + (size_t)s_first * sg.NS);      // (NS * 2 bytes: a multiple of 16 or
+        uint4 *pd = reinterpret_cast<uint4 *>(PMs);                                                   //  the allocation's slack covers the tail)
+        const int np128 = ns > 0 ? (ns * sg.NS * 2 + 15) / 16 : 0;
+        for (int q = tid; q < np128; q += 256) pd[q] = ps[q];
     }
     if (c.stop || c.lt_stale || c.cw_unres) return;
     if (c.cur_hole <= N) {                                  // the walk ended in a hole: nothing to reweight (gretel.py:176-180)
@@ -519,6 +628,16 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const int p = t / LP, s = t % LP;
     const bool act = p <= N;
     const int pp = act ? p : 0;
+    const int p0w = blockIdx.x * PPB;                       // first position of this workgroup
+    // fused: what the positions of this workgroup and the W behind them need before the path's symbols are known -- the
+    // candidate bits k_seg saw (rank -> symbol), this position's log-marginals as the walk saw them (lmsel)
+    int cm5_u = 0;
+    double lm_old = 0.0;
+    if (fused) {
+        const int tu = p0w + tid;                           // thread u < PPB + halo: position p0 + u
+        if (tid < PPB + RW_FUSE_HALO && tu >= 1 && tu <= N) cm5_u = fz.cm5snap[tu];
+        if (act && s < 5) lm_old = minfo[(size_t)pp * MINFO + s];
+    }
     // ---- round 1 ---------------------------------------------------------------------------------------------
     const int d0 = s + 1;                                   // this lane's distance (reweight) and lag (table row / column)
     const int j0 = pp + d0;
@@ -528,8 +647,11 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         else if (j0 == N) mult0 = (d0 == 1) ? 1 : 0;
         else if (j0 == N + 1) mult0 = (pp == N) ? 1 : 0;
     }
-    const int a = path[pp];
-    const int b0 = mult0 ? ((j0 == N + 1) ? path[0] : path[j0]) : 0;
+    int a = 0, b0 = 0;
+    if (!fused) {
+        a = path[pp];
+        b0 = mult0 ? ((j0 == N + 1) ? path[0] : path[j0]) : 0;
+    }
     // this lane owns the table entries of lag d0: a row (every lag up to L), or a column (only where the cell changed)
     const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N && (!COL || (mult0 > 0 && d0 <= W));
     T crow[NSYM];
@@ -543,6 +665,52 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const uint32_t cm_old = (act && s == 7) ? cmask[pp] : 0u;
     static_assert(LP == 8 || LP == 32, "lane groups of 8 or 32");
     // ---- the path's minimum marginal, while round 1 is in flight ----------------------------------------------
+    if (fused) {
+        // (1) the start state through the group maps: the state that enters every group; and, through the prefix maps, every
+        // segment under this workgroup's positions and halo (a group's first segment is entered as the group is)
+        const int s_first = p0w >= 1 ? (p0w - 1) / sg.seglen : 0;
+        __syncthreads();
+        if (tid == 0) {
+            int x = 0;
+            for (int j = 0; j < sg.G1; j++) { xs[j] = x; x = GM[(size_t)j * sg.NS + x]; }
+            for (int k = 0; k < nts && s_first + k < sg.S; k++) {
+                const int sq = s_first + k, grp = sq / sg.G2;
+                ent[k] = sq > grp * sg.G2 ? (int)PMs[(size_t)k * sg.NS + xs[grp]] : xs[grp];
+            }
+        }
+        __syncthreads();
+        // (2) ONE round trip: the groups' minima for those states (their minimum is the path's), and the picks of positions
+        // p0 .. p0 + PPB - 1 + halo out of hist, for their segment's true entry state
+        if (tid < sg.G1) my_segmin = fz.gmin[(size_t)tid * sg.NS + xs[tid]];
+        if (tid < PPB + RW_FUSE_HALO) {
+            const int tu = p0w + tid;
+            int sy = SYM_US, k5 = 0;
+            if (tu >= 1 && tu <= N && tid < PPB + W) {
+                const int sq = (tu - 1) / sg.seglen, tl = (tu - 1) - sq * sg.seglen;
+                const int bits = Rr == 4 ? 2 : 3, dpw = Rr == 4 ? 16 : 10;
+                const unsigned word = fz.hist[((size_t)sq * sg.NW + tl / dpw) * sg.NS + ent[sq - s_first]];
+                k5 = (int)((word >> (bits * (tl % dpw))) & ((1u << bits) - 1u));
+                if (Rr == 4) { k5 = nth_set5((uint32_t)cm5_u, k5); if (k5 < 0) k5 = 0; }
+                sy = vsym(sm, k5);
+            }
+            sym[tid] = (uint8_t)sy;
+            pk5[tid] = (uint8_t)k5;
+        }
+        __syncthreads();
+        const int pl = tid / LP;                            // this lane's position inside the workgroup
+        a = sym[pl];
+        b0 = mult0 ? ((j0 == N + 1) ? SYM_US : sym[j0 - p0w]) : 0;
+        if (blockIdx.x == 0 && tid == 0) st->dbg[3] = 3;    // gh_debug_walk_clock: variant 3 = segment-parallel (k_emit's mark)
+        // this workgroup's share of the path record: symbols and selected log-marginals of its own positions
+        if (act && s == 0) {
+            fz.path_out[p] = p == 0 ? (uint8_t)SYM_US : (uint8_t)a;
+        }
+        {
+            const int k5 = pk5[pl];
+            const double lmv = __shfl(lm_old, k5, LP);
+            if (act && s == 0) fz.lmsel[p] = p == 0 ? 1.0 : lmv;       // ([0] = 1.0: k_hp still has this path's sums to take)
+        }
+    }
     s_red[tid] = my_segmin;
     __syncthreads();
     for (int q = 128; q > 0; q >>= 1) {
@@ -584,7 +752,9 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     int na = -1, nb = -1;
     T nval = (T)0;
     if (mult0) {
-        T cur = pick7(rrow, esel);
+        T cur = rrow[0];
+#pragma unroll
+        for (int x = 1; x < NSYM; x++) cur = (x == esel) ? rrow[x] : cur;
         for (int q = 0; q < mult0; q++) {
             const double old = (double)cur;
             const double nw = old - ratio * old;
@@ -663,7 +833,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const double nv_i = (double)nv;
     // ---- bands wider than the lane group: the remaining distances, one by one (and, COL, their table columns) -------
     // COL: entries G[p][x][l-1][col(b)] for every from-row x that exists, from the column `colT` of cell (p, p+l)
-    auto table_col = [&](int l, const T (&colT)[NSYM], int nvt, uint32_t cmt, int b) {
+    auto table_col = [&](int l, const T (&colT)[NSYM], int nvt, uint32_t cmt, int b) __attribute__((always_inline)) {
         T cacc = (T)0;
 #pragma unroll
         for (int x = 0; x < NSYM; x++) cacc = cacc + colT[x];
@@ -672,21 +842,25 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         const uint32_t cj5 = cm5_of_cmask(sm, cmt);
         if (b5c >= 5 || !((cj5 >> b5c) & 1u)) return;        // no column for this symbol (N, '_', or no candidate: a rebuild follows)
         const int col = ranked ? __popc(cj5 & ((1u << b5c) - 1u)) : b5c;
+        // the six from-symbols a path can hold, in SYMBOL order (compile-time register indices); the order the candidates are
+        // offered in only moves the row an entry is stored in
+        constexpr int FS[6] = {0, 1, 2, 3, 5, 6};
         double xq[6], v[6];
         bool odd = false;
 #pragma unroll
-        for (int x6 = 0; x6 < 6; x6++) {
-            xq[x6] = (1.0 + (double)pick7(colT, fsym(sm, x6))) / den;
-            odd |= !gh_log10_is_normal(xq[x6]);
+        for (int q = 0; q < 6; q++) {
+            xq[q] = (1.0 + (double)colT[FS[q]]) / den;
+            odd |= !gh_log10_is_normal(xq[q]);
         }
 #pragma unroll
-        for (int x6 = 0; x6 < 6; x6++) v[x6] = gh_log10_normal(xq[x6], 0);
+        for (int q = 0; q < 6; q++) v[q] = gh_log10_normal(xq[q], 0);
         if (odd) {
 #pragma unroll
-            for (int x6 = 0; x6 < 6; x6++) v[x6] = gh_log10(xq[x6]);
+            for (int q = 0; q < 6; q++) v[q] = gh_log10(xq[q]);
         }
 #pragma unroll
-        for (int x6 = 0; x6 < 6; x6++) {
+        for (int q = 0; q < 6; q++) {
+            const int x6 = a6_of_sym(sm, FS[q]);
             int row6 = x6;
             if (x6 == 5) { if (p != 0) continue; }           // the '_' row exists at position 0 only
             else if (ranked) {
@@ -694,7 +868,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
                 row6 = __popc(cm5 & ((1u << x6) - 1u));
                 if (row6 > 3) continue;
             }
-            G[(((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW + col] = v[x6];
+            G[(((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW + col] = v[q];
         }
     };
     for (int d = d0 + LP; act && d <= W; d += LP) {
@@ -703,7 +877,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         if (j <= N - 1) mult = 1;
         else if (j == N + 1) mult = (p == N) ? 1 : 0;
         if (mult) {
-            const int b = (j == N + 1) ? path[0] : path[j];
+            const int b = (j == N + 1) ? (fused ? SYM_US : (int)path[0]) : (fused ? (int)sym[j - p0w] : (int)path[j]);
             T *e = band + bidx(W, p, d, a, b);
             const double old = (double)*e;
             const double nw = old - ratio * old;
@@ -727,8 +901,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         const double ca = __shfl(mine, a, LP);
         int row6 = a6;
         if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
-        const bool ident = sm.fwd == 0x53210u;              // the default order: compile-time register indices
-        auto table_row = [&](int l, const T (&rowT)[NSYM], int nvt, uint32_t cmt) {
+        auto table_row = [&](int l, const T (&rowT)[NSYM], int nvt, uint32_t cmt) __attribute__((always_inline)) {
             double *out = G + (((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW;
             if (!(p + l <= N && (a6 < 5 || p == 0))) {
 #pragma unroll
@@ -741,36 +914,33 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             for (int x = 0; x < NSYM; x++) { rowv[x] = (double)rowT[x]; racc = racc + rowT[x]; }      // zeros beyond the band
             const double sum = (double)racc;
             const double den = (cond_mode == GH_COND_A) ? (double)nvt + sum : (cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
+            // the five candidates in SYMBOL order (compile-time register indices); the order they are offered in only moves
+            // the column an entry is stored in
+            constexpr int VS[LT_ROW] = {0, 1, 2, 3, 5};
             double xq[LT_ROW], v[LT_ROW];
             bool odd = false;
-            if (ident) {
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) xq[b5] = (1.0 + rowv[b5 < 4 ? b5 : 5]) / den;
-            } else {
+            for (int q = 0; q < LT_ROW; q++) xq[q] = (1.0 + rowv[VS[q]]) / den;
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) xq[b5] = (1.0 + pick7(rowv, vsym(sm, b5))) / den;
-            }
+            for (int q = 0; q < LT_ROW; q++) odd |= !gh_log10_is_normal(xq[q]);
 #pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) odd |= !gh_log10_is_normal(xq[b5]);
-#pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
+            for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_normal(xq[q], 0);
             if (odd) {
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
+                for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10(xq[q]);
             }
             if (!ranked) {
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = ((cmt >> vsym(sm, b5)) & 1) ? v[b5] : -INFINITY;
+                for (int q = 0; q < LT_ROW; q++) out[a6_of_sym(sm, VS[q])] = ((cmt >> VS[q]) & 1) ? v[q] : -INFINITY;
             } else {
+                // column = the candidate's rank at the target; ranks that do not exist hold -inf
                 const uint32_t cj5 = cm5_of_cmask(sm, cmt);
 #pragma unroll
-                for (int rb = 0; rb < LT_ROW; rb++) {
-                    const int b5 = nth_set5(cj5, rb);
-                    double r = -INFINITY;
-#pragma unroll
-                    for (int q = 0; q < LT_ROW; q++) r = (b5 == q) ? v[q] : r;
-                    out[rb] = r;
+                for (int q = 0; q < LT_ROW; q++) {
+                    const int b5 = a6_of_sym(sm, VS[q]);
+                    if ((cj5 >> b5) & 1u) out[__popc(cj5 & ((1u << b5) - 1u))] = v[q];
                 }
+                for (int rb = __popc(cj5); rb < LT_ROW; rb++) out[rb] = -INFINITY;
             }
         };
         if (d0 <= L && row6 >= 0) table_row(d0, rrow, nv_t, cm_t);

@@ -129,3 +129,48 @@ def test_every_switch(kw):
     _same(h.spin(5), o.spin(5))
     assert h.walk_clock()[3] == 3
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("kw", [dict(), dict(cond_mode="C", marginal_term=True), dict(storage="f64", cond_mode="B")])
+def test_three_launches_per_path(L, wide, kw, monkeypatch):
+    # Spins of large windows run without k_emit: k_seg / k_scan carry the minimum marginal of every entry state's picks, and
+    # k_rw chains the group maps itself (its entry states, its picks, the path's minimum marginal).  GH_FUSE=2 forces that
+    # path on windows small enough for k_emit_small; GH_FUSE=0 switches it off.  Same paths, likelihoods, ratios, tensors.
+    from spec_util import make_pair, same, with_dels
+    t = make_support_table(2600, 60000, k=6, seed=300 + L)
+    if wide:
+        if L == 5:
+            pytest.skip("5^5 states: the group maps do not fit k_rw's LDS; k_emit stays")
+        t = with_dels(t, 0.1, L)
+    monkeypatch.setenv("GH_FUSE", "2")
+    h, o = make_pair(t, L=L, **kw)
+    h.profile_enable(1)
+    h.profile_reset()
+    res, ref = h.spin(9), o.spin(9)
+    same(res, ref)
+    assert h.walk_clock()[3] == 3
+    assert np.array_equal(h.export_band(), o.export_band())
+    monkeypatch.setenv("GH_FUSE", "0")
+    h2, _ = make_pair(t, L=L, **kw)
+    same(h2.spin(9), ref)
+    assert np.array_equal(h2.export_band(), o.export_band())
+
+
+def test_three_launches_with_a_hole_and_a_stale_table(monkeypatch):
+    from spec_util import make_pair, same
+    monkeypatch.setenv("GH_FUSE", "2")
+    t = make_support_table(300, 2000, k=3, n_haps=1, err=0.0, seed=1)
+    h, o = make_pair(t)
+    res, ref = h.spin(6), o.spin(6)
+    same(res, ref)
+    assert res["n"] == 1 and res["hole_at"] >= 1
+    t = make_support_table(1500, 40000, k=5, seed=3)
+    monkeypatch.setenv("GH_SEG_FORCE_STALE", "4")
+    h, o = make_pair(t)
+    monkeypatch.delenv("GH_SEG_FORCE_STALE")
+    res, ref = h.spin(12), o.spin(12)
+    assert h.walk_clock()[:4] == (1, 0, 0, 3)
+    same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
