@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="control-plane backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host sockets "
                          "(lets several ranks share one GPU: --share-gpu)")
+    ap.add_argument("--dump-gathered", default="", help="rank 0 writes what it gathered in the last timed step (every rank's paths and "
+                    "records) to this .npz -- the tests compare it with the oracle, rank by rank")
     ap.add_argument("--share-gpu", action="store_true", help="ranks take GPU (rank mod visible GPUs) instead of one each (gloo only)")
     return ap.parse_args()
 
@@ -71,6 +73,78 @@ def self_launch(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rcs = [p.wait() for p in procs]
     sys.exit(max(abs(rc) for rc in rcs))
+
+
+def kernel_source_sha():
+    """Identity of the build a profile was taken with: a hash over the kernel sources (the GPU box has no .git)."""
+    import glob
+    import hashlib
+    hh = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "gretel_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        hh.update(os.path.basename(f).encode())
+        hh.update(open(f, "rb").read())
+    return hh.hexdigest()[:16]
+
+
+def seg_geometry(n, L, R):
+    """gretel_amd/csrc/seg_geom.hpp: states, entries per position, positions per segment, segments."""
+    ns = R ** L
+    g2 = max(1, min(16, (65536 if ns > 3125 else 32768) // ns))
+    smax = (25 if 2048 < ns <= 3125 else 16) * g2
+    seglen = max((n + smax - 1) // smax, 8)
+    return dict(NS=ns, NI=ns // R, seglen=seglen, S=(n + seglen - 1) // seglen)
+
+
+def issue_model_seg(n, L, ranked, clock_ghz, measured_ms):
+    """k_seg is bound by vector-ALU issue (binary64 adds / compares / selects for every state of every position, then one
+    table lookup per state and position), not by HBM.  Floor = the instructions of its two inner loops as compiled
+    (profiles/seg_isa_count.py -> profiles/r3_seg_isa.json) x trips per SIMD x issue cost / clock, for the ONE workgroup a CU
+    runs (all segments run at once: <= 256 workgroups on 256 CUs, 16 waves = 4 per SIMD)."""
+    isa = json.load(open(os.path.join(ROOT, "profiles", "r3_seg_isa.json")))
+    ent = isa["L"].get(str(L), {}).get("R4" if ranked else "R5")
+    if not ent or "next_table_loop" not in ent or "state_walk_loop" not in ent or not ranked:
+        return None
+    R = 4
+    g = seg_geometry(n, L, R)
+    nj = g["NI"] // (R if L >= 4 else 1)                     # tasks (thread-iterations of the Next loop) per position
+    next_trips_per_simd = g["seglen"] * nj / 64.0 / 4.0        # wave-iterations per SIMD
+    dpw = 16
+    spt = max(1, (g["NS"] + 1023) // 1024)                   # states per thread of the walk loop (its body holds all of them)
+    walk_trips_per_simd = 4.0 * g["seglen"] / dpw              # 16 waves = 4 per SIMD, one trip per word of 16 picks
+    cyc = next_trips_per_simd * ent["next_table_loop"]["issue_cycles_per_iteration"] + \
+        walk_trips_per_simd * ent["state_walk_loop"]["issue_cycles_per_iteration"]
+    floor_us = cyc / (clock_ghz * 1e3)
+    return {"kernel": "k_seg<%d>" % L, "binding_resource": "vector-ALU issue (binary64)",
+            "states": g["NS"], "segments": g["S"], "positions_per_segment": g["seglen"],
+            "next_table_loop": {k: ent["next_table_loop"][k] for k in ("instructions", "by_class", "issue_cycles_per_iteration")},
+            "state_walk_loop": {k: ent["state_walk_loop"][k] for k in ("instructions", "by_class", "issue_cycles_per_iteration")},
+            "instructions_per_position_and_state": nj * ent["next_table_loop"]["instructions"] / g["NS"] + ent["state_walk_loop"]["instructions"] / dpw / spt,
+            "issue_cycles_per_simd": cyc, "clock_ghz": clock_ghz, "floor_us": floor_us,
+            "measured_us": measured_ms * 1e3, "frac": floor_us / (measured_ms * 1e3) if measured_ms > 0 else None,
+            "isa_profile": {"file": "profiles/r3_seg_isa.json", "git_head": isa.get("git_head"), "cost_cycles": isa["cost_cycles_per_wave_instruction"]},
+            "note": "floor = compute phases only (Next tables + state walk); the kernel also stages its table slice (~1.5 us) and pays "
+                    "launch + teardown (~3.4 us), see DESIGN.md section 4.1"}
+
+
+def issue_model_pools(n, L, clock_ghz, measured_ms):
+    """k_cwalk: one wavefront walks 16 pool entries through its segment, a chain of dependent steps: instructions per step
+    (profiles/r3_seg_isa.json, 'cwalk') x steps per segment x cycles per instruction of a wave that shares its SIMD with at
+    most one other (5 alone, 2.5 with a partner: cwalk.hpp)."""
+    isa = json.load(open(os.path.join(ROOT, "profiles", "r3_seg_isa.json")))
+    ent = isa.get("cwalk", {}).get("L", {}).get(str(L))
+    if not ent:
+        return None
+    smax = 512 if L <= 13 else 256
+    seglen = max((n + smax - 1) // smax, 32)
+    cpi = 5.0
+    floor_us = seglen * ent["instructions_per_step"] * cpi / (clock_ghz * 1e3)
+    return {"kernel": "k_cwalk<%d, 4>" % L, "binding_resource": "instruction issue of one wavefront per 16 pool entries",
+            "instructions_per_step": ent["instructions_per_step"], "steps_per_segment": seglen, "cycles_per_instruction": cpi,
+            "clock_ghz": clock_ghz, "floor_us": floor_us, "measured_us": measured_ms * 1e3,
+            "frac": floor_us / (measured_ms * 1e3) if measured_ms > 0 else None,
+            "isa_profile": {"file": "profiles/r3_seg_isa.json", "git_head": isa.get("git_head")},
+            "note": "measured = the first k_cwalk launch of a path (every pool entry is walked; later rounds walk only what is new)"}
 
 
 def edge_evals_per_path(cmask, n, L):
@@ -350,6 +424,9 @@ def main():
     else:
         dt_max, n_paths_total = dt, float(n_paths_local)
 
+    if rank == 0 and args.dump_gathered:
+        np.savez(args.dump_gathered, world=world, **{"%s_%d" % (k, r): np.asarray(g[k]) for r, g in enumerate(gathered)
+                                                      for k in ("n", "hole_at", "paths", "hp_current", "hp_original", "ratio", "magnitude")})
     if rank == 0:
         n, L = table.n_snps, h.L
         cyc, ticks, nsteps, variant = h.walk_clock()
@@ -372,29 +449,53 @@ def main():
             dom_bytes_def = "SURVEY 8(d) path extension: N*((1+L)*196+28) per path"
         dom_ms = dom["ms"] / max(1, dom["launches"])
         achieved = dom["bytes_per_launch"] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected per the
-        # MI355X guide: separate --pmc runs, FETCH_SIZE x2 on gfx950); null when no profile matches
-        traffic = None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected per the MI355X guide: separate
+        # --pmc runs, FETCH_SIZE x2 on gfx950).  A profile is only quoted for the build it was taken with (kernel_source_sha);
+        # otherwise null, with the reason.
+        traffic, traffic_note = None, "no PMC profile for this config"
+        src_sha = kernel_source_sha()
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json" if segwalk else "r1_pmc_traffic.json")))["kernels"]
-            if cfg_name == "C3":
-                traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pm.items() if k.startswith("k_seg" if segwalk else "k_walk"))
-        except Exception:
-            traffic = None
-        # serial walker only: one wavefront issues an instruction every 5 cycles (scratch/ubench6/7.hip), so the
-        # floor is 5 x the instructions per step of the inner loop as compiled (profiles/walker_isa_count.py, no GPU needed)
+            pmf = "r3_pmc_traffic_c5.json" if cfg_name == "C5" else "r3_pmc_traffic.json"
+            pmj = json.load(open(os.path.join(ROOT, "profiles", pmf)))
+            if cfg_name in ("C3", "C5") and spec_kw == dict(cond_mode="A", marginal_term=False, storage="f32"):
+                if pmj.get("kernel_source_sha") != src_sha:
+                    traffic_note = "profiles/%s was taken with kernel sources %s (git %s), this build is %s: not quoted" % (
+                        pmf, pmj.get("kernel_source_sha"), pmj.get("git_head"), src_sha)
+                else:
+                    want = "k_seg" if segwalk else ("k_cwalk" if variant == 4 else "k_walk")
+                    traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pmj["kernels"].items() if k.startswith(want))
+                    traffic_note = "profiles/%s (git %s, kernel sources %s)" % (pmf, pmj.get("git_head"), src_sha)
+        except Exception as exc:
+            traffic, traffic_note = None, "no usable PMC profile: %r" % (exc,)
+        from gretel_amd._lib import device_clock_khz
+        clock_ghz = device_clock_khz(local) / 1e6
+        # what actually binds the dominant kernel: instruction issue, priced from the ISA (profiles/r3_seg_isa.json)
         issue_model = None
         try:
-            isa = json.load(open(os.path.join(ROOT, "profiles", "r1_walker_isa.json")))
-            ent = isa["L"].get(str(L))
-            if ent and variant == 2 and nsteps:
-                floor = ent["issue_floor_cycles_per_step"]
-                issue_model = {"instructions_per_step": ent["instructions_per_step"],
-                               "cycles_per_instruction_lone_wave": isa["cycles_per_instruction_lone_wave"],
-                               "floor_cycles_per_step": floor, "measured_cycles_per_step": cyc / nsteps,
-                               "frac": floor / (cyc / nsteps)}
-        except Exception:
-            issue_model = None
+            if segwalk and seg["launches"]:
+                ranked = not bool((h.candidate_masks()[1:] == 0x2F).any())
+                issue_model = issue_model_seg(n, L, ranked, clock_ghz, max(dom_ms - ev_nop_ms, 1e-6))
+            elif variant == 4 and seg["launches"]:
+                issue_model = issue_model_pools(n, L, clock_ghz, max(seg["ms"] / seg["launches"] - ev_nop_ms, 1e-6))
+            elif variant == 2 and nsteps:
+                isa = json.load(open(os.path.join(ROOT, "profiles", "r1_walker_isa.json")))
+                ent = isa["L"].get(str(L))
+                if ent:
+                    floor = ent["issue_floor_cycles_per_step"]
+                    issue_model = {"instructions_per_step": ent["instructions_per_step"],
+                                   "cycles_per_instruction_lone_wave": isa["cycles_per_instruction_lone_wave"],
+                                   "floor_cycles_per_step": floor, "measured_cycles_per_step": cyc / nsteps,
+                                   "frac": floor / (cyc / nsteps)}
+        except Exception as exc:
+            issue_model = {"error": repr(exc)}
+        # the whole step against HBM -- (B_fill + P (B_ext + B_rw)) / wall / peak
+        n_adds = stats[1] + 2 * 0          # crumbs; the sentinel cases add a second observation to a handful of reads
+        b_fill = 8.0 * stats[1] + float(table.n_reads) * 8.0 + float(len(table.bases))
+        b_ext = n * (1 + L) * 196.0 + n * 28.0
+        b_rw = 8.0 * n * min(table.band, n)
+        step_bytes = b_fill + paths * (b_ext + b_rw)
+        step_s = dt_max / desc["steps"]
+        kernels_per_path = 4 if segwalk else (None if variant == 4 else 2)
         out = {
             "metric": "haplotypes/sec + SNP-edge-evals/sec on 10k-SNP synthetic contig",
             "value": hap_s,
@@ -423,7 +524,18 @@ def main():
             "kernels_launches": {k: v["launches"] for k, v in prof.items()},
             "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         "binding_resource": (issue_model or {}).get("binding_resource", "instruction issue / launch latency (see note)"),
+                         "step_frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                         "step_bytes": {"definition": "SURVEY 8(d): B_fill + P (B_ext + B_rw); B_fill = 8 x adds + sum(8 + k), "
+                                                      "B_ext = N (1 + L) 196 + 28 N, B_rw = 8 N W",
+                                        "fill": b_fill, "extension_per_path": b_ext, "reweight_per_path": b_rw, "step": step_bytes},
+                         "launch_floor_us": {"empty_kernel_between_two_events": (ev_nop_ms - ev_empty_ms) * 1e3,
+                                             "dependent_launches_per_path": kernels_per_path,
+                                             "per_path": (kernels_per_path * (ev_nop_ms - ev_empty_ms) * 1e3) if kernels_per_path else None,
+                                             "note": "what the dependent launches of one path cost before any of them does work (HIP events "
+                                                     "around an empty kernel, minus the bracket itself); rocprofv3 reads 2.8 us for the same empty kernel"},
+                         "kernel_source_sha": src_sha,
                          "algorithmic_bytes_per_launch": dom["bytes_per_launch"],
                          "algorithmic_bytes_definition": dom_bytes_def,
                          "avg_launch_ms_hip_events": dom_ms,

@@ -69,6 +69,7 @@ def load():
     L.gh_last_error.argtypes = []
     sigs = {
         "gh_device_count": [P(i32)],
+        "gh_device_clock_khz": [i32, P(i32)],
         "gh_create": [P(gh_config), P(vp)],
         "gh_destroy": [vp],
         "gh_copy": [vp, P(vp)],
@@ -125,6 +126,12 @@ def check(rc):
     if rc == GH_ERR_SYMBOL:
         raise SymbolError(rc, msg)
     raise GretelHipError(rc, msg)
+
+
+def device_clock_khz(device=-1):
+    k = C.c_int(0)
+    check(load().gh_device_clock_khz(int(device), C.byref(k)))
+    return k.value
 
 
 def device_count():

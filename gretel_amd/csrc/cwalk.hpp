@@ -24,8 +24,9 @@
 // exit state, both produced by exact walks.  When the rounds queued for a path do not close the chain, the kernels
 // behind flag the path unresolved and idle; the host queues more rounds for it (every round carries the verified chain
 // at least one segment further) or, up to 16 lags, hands it to the serial walker, whose states then join the pools.
-// The pools start from the states the reads show at the segment boundaries (k_cseed_reads) and from the largest
-// marginals (k_cguess): only where walks START -- never what is emitted -- depends on that.
+// The pools start from the largest marginals (k_cguess): only where walks START -- never what is emitted -- depends on
+// that.  (Round 2 also carried a kernel that started them from the states the reads show; measured, it closed no chain
+// earlier -- after the first handful of paths a deep spin follows chimeras of what the reweights left -- and it is gone.)
 #pragma once
 
 #define CW_K 64                 /* pool entries per segment */
@@ -771,100 +772,4 @@ __global__ void __launch_bounds__(256) k_cguess(cw_params P, uint8_t *path)
     for (int b5 = 1; b5 < 5; b5++)
         if (inf[5 + b5] > bm) { bm = inf[5 + b5]; best = b5; }
     path[p] = (uint8_t)vsym(P.sm, best);
-}
-
-// -------------------------------------------------------------------------------------------------------------
-// k_cseed_reads: pools that hold nothing yet are started from the READS (a support table sorted by rank).  A read that
-// spans the L positions in front of a segment boundary shows a state some haplotype really has there; the states seen
-// most often (at most CW_K - 1 per pool) become the pool.  A path that follows real haplotypes then finds its entry
-// states waiting in the first round, instead of having them discovered by closure one round later.  Like k_cguess this
-// only chooses where walks START: nothing is emitted that the verified chain does not confirm.
-// One workgroup per segment; the reads that can span the boundary p = s * seglen start at ranks p - max_k .. p - L.
-// -------------------------------------------------------------------------------------------------------------
-#define CW_SEED_SLOTS 512
-__global__ void __launch_bounds__(256)
-k_cseed_reads(cw_params P, const int32_t *__restrict__ rank, const int64_t *__restrict__ off, const uint8_t *__restrict__ bases,
-              long long n_reads, int max_k)
-{
-    __shared__ unsigned long long tkey[CW_SEED_SLOTS];
-    __shared__ unsigned tcnt[CW_SEED_SLOTS];
-    __shared__ unsigned s_best[4];
-    __shared__ int s_who[4];
-    const cw_geom g = cw_geometry(P.N, P.L);
-    const int s = blockIdx.x, tid = threadIdx.x;
-    if (s >= g.S) return;
-    cw_key *keys = P.keys + (size_t)s * CW_K;
-    for (int k = tid; k < CW_K; k += 256) P.walked[(size_t)s * CW_K + k] = 0;
-    if (tid == 0) P.npend[s] = 0;
-    const int p = s * g.seglen;                             // the state entering target p + 1: picks of p, p-1, ..., p-L+1
-    const bool ranked = P.st->ranked != 0;
-    if (s == 0) {                                           // the start state
-        if (tid == 0) { keys[0] = 0ull; P.last_hit[0] = P.stamp - 1; P.npool[0] = 1; }
-        return;
-    }
-    for (int k = tid; k < CW_SEED_SLOTS; k += 256) { tkey[k] = ~0ull; tcnt[k] = 0; }
-    __syncthreads();
-    // first read with rank >= p - max_k, first read with rank > p - L (ranks ascend)
-    auto lower = [&](int v) {
-        long long lo = 0, hi = n_reads;
-        while (lo < hi) {
-            const long long mid = (lo + hi) >> 1;
-            if (rank[mid] < v) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const long long r_lo = lower(p - max_k), r_hi = lower(p - P.L + 1);
-    for (long long r = r_lo + tid; r < r_hi; r += 256) {
-        const int rk = rank[r];
-        const long long o0 = off[r];
-        const int k = (int)(off[r + 1] - o0);
-        if (rk + k < p || rk + 1 > p - P.L + 1) continue;   // does not span p-L+1 .. p  (base i of the read sits at position rk + 1 + i)
-        cw_key sigma = 0;
-        bool ok = true;
-        for (int l = P.L; l >= 1; l--) {                    // oldest first: the pick of lag 1 ends in bits 0..1
-            const int i = p + 1 - l;
-            const int sym = c_sym_of_char[bases[o0 + (i - rk - 1)]];
-            const uint32_t cm5 = (uint32_t)__double_as_longlong(P.minfo[(size_t)i * MINFO + 10]);
-            const int a6 = sym < 0 ? 7 : a6_of_sym(P.sm, sym);
-            if (sym < 0 || sym == 4 || a6 > 4 || !((cm5 >> a6) & 1u)) { ok = false; break; }      // N, '_', not a candidate
-            sigma = ranked ? ((sigma << 2) | (cw_key)((unsigned)__popc(cm5 & ((1u << a6) - 1u)) & 3u)) : ((sigma << 3) | (cw_key)(unsigned)a6);
-        }
-        if (!ok) continue;
-        // count it (open addressing on the state; a full table drops the rest: only a seed)
-        unsigned hsh = (unsigned)((sigma * 0x9e3779b97f4a7c15ull) >> 40) & (CW_SEED_SLOTS - 1);
-        for (int probe = 0; probe < CW_SEED_SLOTS; probe++) {
-            const unsigned long long seen = atomicCAS(&tkey[hsh], ~0ull, sigma);
-            if (seen == ~0ull || seen == sigma) { atomicAdd(&tcnt[hsh], 1u); break; }
-            hsh = (hsh + 1) & (CW_SEED_SLOTS - 1);
-        }
-    }
-    __syncthreads();
-    // the CW_K - 1 most frequent states, most frequent first (ties: lowest slot)
-    int n = 0;
-    for (; n < CW_K - 1; n++) {
-        unsigned best = 0;
-        int who = -1;
-        for (int k = tid; k < CW_SEED_SLOTS; k += 256)
-            if (tcnt[k] > best) { best = tcnt[k]; who = k; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned ob = __shfl_xor(best, o);
-            const int ow = __shfl_xor(who, o);
-            if (ob > best || (ob == best && ob > 0 && ow >= 0 && (who < 0 || ow < who))) { best = ob; who = ow; }
-        }
-        if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_who[tid >> 6] = who; }
-        __syncthreads();
-        best = s_best[0]; who = s_who[0];
-        for (int w = 1; w < 4; w++)
-            if (s_best[w] > best || (s_best[w] == best && best > 0 && s_who[w] < who)) { best = s_best[w]; who = s_who[w]; }
-        __syncthreads();
-        if (best == 0) break;
-        if (tid == 0) {
-            keys[n] = tkey[who];
-            P.last_hit[(size_t)s * CW_K + n] = P.stamp - 1;
-            tcnt[who] = 0;
-        }
-        __syncthreads();
-    }
-    if (tid == 0) P.npool[s] = n;
 }

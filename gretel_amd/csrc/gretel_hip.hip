@@ -140,7 +140,6 @@ struct gh_handle {
     size_t stage_cap;
     double *ew_buf;        // gh_edge_weights_at: seven weights and the candidate mask
     bool seg6;             // inside a gh_spin at L = 6 whose table is ranked: every state of every segment (4^6), not pools
-    const gh_reads *last_reads;   // the table of the last gh_fill (not owned: see reads_alive)
     int cw_round_cap;      // GH_CW_ROUND_CAP=k at creation (tests): never more than k rounds per launch, so that chains stay open and the serial fallback runs
     int spin_partial_stride;   // doubles between two paths' partial sums of the removed mass in a spin (0 outside spins)
     int spin_requeues;     // how often the last gh_spin rebuilt the table and queued the remaining paths again
@@ -174,16 +173,6 @@ struct gh_reads {
     int span_pos;     // sorted tables: widest run of positions one workgroup of k_fill_sorted (FILL_RPB reads) covers
 };
 #define FILL_RPB 2048     /* reads per workgroup of k_fill_sorted */
-
-// The read tables that are alive: a handle remembers the table it was last filled from (the candidate pools of
-// cwalk.hpp are started from its reads) but does not own it -- the pointer is only used while it is still in this set.
-static std::mutex g_reads_mu;
-static std::vector<const gh_reads *> g_reads_live;
-static bool reads_alive(const gh_reads *r)
-{
-    std::lock_guard<std::mutex> g(g_reads_mu);
-    return std::find(g_reads_live.begin(), g_reads_live.end(), r) != g_reads_live.end();
-}
 
 static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STORAGE_F64 ? 8 : 4; }
 
@@ -268,6 +257,14 @@ extern "C" int gh_device_count(int *n)
     return GH_OK;
 }
 
+extern "C" int gh_device_clock_khz(int device, int *khz)
+{
+    if (!khz) return fail(GH_ERR_ARG, "null argument");
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    HIPCHK(hipDeviceGetAttribute(khz, hipDeviceAttributeClockRate, device));
+    return GH_OK;
+}
+
 static void free_handle(gh_handle *h)
 {
     if (!h) return;
@@ -347,7 +344,6 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
     h->stage = nullptr; h->stage_cap = 0;
-    h->last_reads = nullptr;
     h->seg6 = false;
     h->ew_buf = nullptr;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
@@ -517,10 +513,6 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
         delete r;
         return fail(GH_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
-    {
-        std::lock_guard<std::mutex> g(g_reads_mu);
-        g_reads_live.push_back(r);
-    }
     *out = r;
     return GH_OK;
 }
@@ -528,10 +520,6 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
 extern "C" int gh_reads_free(gh_reads_t *r)
 {
     if (!r) return GH_OK;
-    {
-        std::lock_guard<std::mutex> g(g_reads_mu);
-        g_reads_live.erase(std::remove(g_reads_live.begin(), g_reads_live.end(), (const gh_reads *)r), g_reads_live.end());
-    }
     hipSetDevice(r->dev);
     hipFree(r->rank); hipFree(r->off); hipFree(r->bases);
     delete r;
@@ -1026,7 +1014,7 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
     const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
     const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
     // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
-    static size_t set_seg[64], set_scan[64], set_emit[64], set_segt[64], set_scant[64];
+    static std::atomic<size_t> set_seg[64], set_scan[64], set_emit[64], set_segt[64], set_scant[64];      // (gh_batch_spin runs gh_spin on several host threads)
     const int dv = dev & 63;
     const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
     if (h->fuse) {
@@ -1050,7 +1038,7 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
     const size_t lds_small = five ? max2(emit_small_lds_bytes(N, LC, 4), emit_small_lds_bytes(N, LC, 5)) : emit_small_lds_bytes(N, LC, 4);
     static const bool no_small = getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0;
     if (lds_small <= 64 * 1024 && !no_small) {
-        static size_t set_small[64];
+        static std::atomic<size_t> set_small[64];
         if (lds_small > set_small[dv]) { hipFuncSetAttribute((const void *)k_emit_small<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small); set_small[dv] = lds_small; }
         hipLaunchKernelGGL((k_emit_small<LC>), dim3(S), dim3(SEG_THREADS), lds_small, stream, P);
         return;
@@ -1069,6 +1057,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
     P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
+    if (h->L < 1 || h->L > SEG_MAX_L_NARROW) return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L_NARROW);
     prof_begin(h, GH_K_WALK);
     switch (h->L) {
         case 1: launch_seg_lc<1>(h, P); break;
@@ -1077,7 +1066,6 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
         case 4: launch_seg_lc<4>(h, P); break;
         case 5: launch_seg_lc<5>(h, P); break;
         case 6: launch_seg_lc<6>(h, P); break;      // (ranked tables only: gh_spin decides)
-        default: return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L_NARROW);
     }
     prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
     return post_launch(h, "k_seg/k_scan/k_emit");
@@ -1153,7 +1141,7 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         const size_t blk_b = (size_t)(256 / LP) * NSYM * h->W * NSYM * sizeof(T);                                                 \
         const int stage = (COL && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0;    \
         const size_t lds_b = fuse_lds + (stage ? blk_b : 0);                                                                      \
-        static size_t set_lds[64];                                                                                                \
+        static std::atomic<size_t> set_lds[64];                                                                                   \
         if (lds_b > set_lds[h->dev & 63]) {                                                                                       \
             hipFuncSetAttribute((const void *)k_rw<T, LP, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);          \
             set_lds[h->dev & 63] = lds_b;                                                                                         \
@@ -1235,9 +1223,16 @@ static int alloc_cw(gh_handle *h)
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_last_hit, 0, sizeof(int32_t) * S * CW_K, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_keys, 0, sizeof(cw_key) * S * CW_K, h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->cw_exits, 0, sizeof(cw_key) * S * CW_K, h->stream);
-    if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed: %s", hipGetErrorString(e));
-    if (!h->seg_min && hipMalloc((void **)&h->seg_min, CW_MAX_SEG * sizeof(double)) != hipSuccess)      // (alloc_seg sizes for L <= 5 only)
-        return fail(GH_ERR_NOMEM, "hipMalloc failed");
+    if (e == hipSuccess && !h->seg_min) e = hipMalloc((void **)&h->seg_min, CW_MAX_SEG * sizeof(double));      // (alloc_seg sizes for L <= 5 only)
+    if (e != hipSuccess) {
+        // all or nothing: a later call must not find cw_keys set next to pool buffers that never came to be
+        hipStreamSynchronize(h->stream);
+        hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_last_hit); hipFree(h->cw_hist); hipFree(h->cw_npool); hipFree(h->cw_pend);
+        hipFree(h->cw_npend); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true);
+        h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_last_hit = nullptr; h->cw_hist = nullptr; h->cw_npool = nullptr; h->cw_pend = nullptr;
+        h->cw_npend = nullptr; h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr;
+        return fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed: %s", hipGetErrorString(e));
+    }
     return GH_OK;
 }
 
@@ -1262,7 +1257,7 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
 template <int LC, int R>
 static void launch_cwalk_lc(const cw_params &P, hipStream_t stream, int S, int dev)
 {
-    static bool set[64];
+    static std::atomic<bool> set[64];
     if (!set[dev & 63]) {
         hipFuncSetAttribute((const void *)k_cwalk<LC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cw_lds_bytes(LC, R));
         set[dev & 63] = true;
@@ -1276,11 +1271,13 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
     const cw_geom g = cw_geometry(h->N, h->L);
     cw_params P = cw_make_params(h, d_path, d_lmsel);
     if (h->cw_round_cap > 0 && rounds > h->cw_round_cap) rounds = h->cw_round_cap;
+    if (!cw_digit_mode(h) && (h->L < CW_MIN_L || h->L > CW_MAX_L)) return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_LG);
     prof_begin(h, GH_K_WALK);
     for (int r = 0; r < rounds; r++) {
         P.round = resume ? r + 1 : r;                       // (a resumed path continues behind the rounds already run)
         P.check_masks = (r == 0 && !resume) ? check_masks : 0;
         P.last_round = r == rounds - 1;
+        if (r == 0) prof_begin(h, GH_K_SEG);                // (bench.py: the pool walker alone, first round of a path)
         if (cw_digit_mode(h)) {
             if (!h->cw_wide) hipLaunchKernelGGL((k_cwalkg<4>), dim3(g.S), dim3(CW_K * cw_lanes(4)), 0, h->stream, P);
             else hipLaunchKernelGGL((k_cwalkg<5>), dim3(g.S), dim3(CW_K * cw_lanes(5)), 0, h->stream, P);
@@ -1293,6 +1290,7 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
 #undef CW_CASE
             default: return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_LG);
         }
+        if (r == 0) prof_end(h, GH_K_SEG, (double)h->N * (double)h->L * CELL * esize(h));
         hipLaunchKernelGGL(k_clink, dim3(g.S), dim3(CW_K), 0, h->stream, P);
         hipLaunchKernelGGL(k_cscan, dim3(1), dim3(1024), 0, h->stream, P);
     }
@@ -1567,15 +1565,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             uint8_t *pth = d_paths + n1 * done;
             cw_params P = cw_make_params(h, pth, h->spin_lmsel + n1 * done);
             hipLaunchKernelGGL(k_cguess, dim3((unsigned)((h->N + 256) / 256)), dim3(256), 0, h->stream, P, pth);
-            // ... and, when the table the window was filled from is still there (and sorted), from the states its reads show at
-            // the segment boundaries (k_cseed_reads); the guess then only joins them
-            const gh_reads *rd = h->last_reads;
-            const bool from_reads = rd && !cw_digit_mode(h) && reads_alive(rd) && rd->sorted && rd->n_reads > 0 && rd->max_k >= h->L &&
-                                    !(getenv("GH_CW_SEED_READS") && atoi(getenv("GH_CW_SEED_READS")) == 0);
-            if (from_reads)
-                hipLaunchKernelGGL(k_cseed_reads, dim3(cg.S), dim3(256), 0, h->stream, P, (const int32_t *)rd->rank, (const int64_t *)rd->off,
-                                   (const uint8_t *)rd->bases, (long long)rd->n_reads, rd->max_k);
-            hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, from_reads ? 1 : 0);
+            hipLaunchKernelGGL(k_cseed, dim3((cg.S + 255) / 256), dim3(256), 0, h->stream, P, (const uint8_t *)pth, 0);
             if ((rc = post_launch(h, "k_cguess/k_cseed"))) break;
             if ((rc = launch_cw_path(h, pth, h->spin_lmsel + n1 * done, CW_BOOT_ROUNDS, 0))) break;
             if ((rc = finish_path(pth, d_recs + done, done, false))) break;
@@ -2147,7 +2137,7 @@ extern "C" int gh_coverage_sites(int device, const int32_t *ref_start, const int
             if (nb > 256 * 16) nb = 256 * 16;
             hipLaunchKernelGGL(k_cov, dim3((unsigned)nb), dim3(256), 0, 0, d_ref, d_off, d_codes, n_runs, start0, len, d_counts);
         }
-        hipLaunchKernelGGL(k_sites, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, d_counts, len, (unsigned)(depth < 0 ? 0 : depth), d_site);
+        hipLaunchKernelGGL(k_sites, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, 0, d_counts, len, depth, d_site);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(site_out, d_site, (size_t)len, hipMemcpyDeviceToHost);
@@ -2200,7 +2190,7 @@ extern "C" int gh_profile_overhead(gh_t *h, int reps, double out[2])
     std::vector<float> a, b;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return fail(GH_ERR_HIP, "hipEventCreate failed"); }
     for (int pass = 0; pass < 2; pass++)
         for (int r = 0; r < reps; r++) {
             // a kernel in front, as in the timed region (the stream is never idle there)
@@ -2209,7 +2199,10 @@ extern "C" int gh_profile_overhead(gh_t *h, int reps, double out[2])
             if (pass == 1) hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, h->stream);
             hipEventRecord(e1, h->stream);
             hipLaunchKernelGGL(k_nop, dim3(256), dim3(256), 0, h->stream);
-            HIPCHK(hipStreamSynchronize(h->stream));
+            if (hipStreamSynchronize(h->stream) != hipSuccess) {
+                hipEventDestroy(e0); hipEventDestroy(e1);
+                return fail(GH_ERR_HIP, "gh_profile_overhead: hipStreamSynchronize failed");
+            }
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) (pass ? b : a).push_back(ms);
         }

@@ -1838,12 +1838,13 @@ k_cov(const int32_t *__restrict__ ref_start, const int64_t *__restrict__ off, co
     }
 }
 
-__global__ void k_sites(const unsigned *__restrict__ counts, int32_t len, unsigned depth, uint8_t *__restrict__ site)
+// (depth compares as the reference's `counts > depth` does, signed: a negative depth marks every position a site, snpper.py:38-40)
+__global__ void k_sites(const unsigned *__restrict__ counts, int32_t len, int32_t depth, uint8_t *__restrict__ site)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= len) return;
     int n = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) n += counts[(size_t)c * len + p] > depth ? 1 : 0;
+    for (int c = 0; c < 4; c++) n += (long long)counts[(size_t)c * len + p] > (long long)depth ? 1 : 0;
     site[p] = n > 1 ? 1 : 0;
 }

@@ -82,7 +82,6 @@ class Hansel:
         self._L = 1
         # observations staged on the host until the band width is known (init_matrix gives no hint)
         self._staged = []
-        self._reads_keep = None
         if band is not None:
             self._create(int(band))
 
@@ -291,15 +290,11 @@ class Hansel:
             self._ensure(max(1, reads_handle.max_k - 1))
         st = _lib.gh_fill_stats()
         check(self._lib.gh_fill(self._h, reads_handle._r, int(bool(use_end_sentinels)), C.byref(st)))
-        # the table stays on the device until the next fill or clear: the candidate pools of lag counts >= 6 are started
-        # from the states its reads show (the library only uses it while it is alive)
-        self._reads_keep = reads_handle
         self._L = int(st.L)
         return int(st.n_slices), int(st.n_crumbs), int(st.covered_snps)
 
     def clear(self):
         self._staged = []
-        self._reads_keep = None
         if self._h is not None:
             check(self._lib.gh_clear(self._h))
         self._L = 1

@@ -87,6 +87,8 @@ typedef struct {
 
 const char *gh_last_error(void);
 int gh_device_count(int *n);
+/* peak shader clock of a device in kHz (bench.py prices its instruction-issue floors with it) */
+int gh_device_clock_khz(int device, int *khz);
 
 /* Hansel.init_matrix(['A','C','G','T','N','-','_'], ['N','_'], N) -- gretel/util.py:83.
  * Allocates the zeroed banded tensor [(N+2)][band][7][7] in HBM. */

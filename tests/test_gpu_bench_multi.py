@@ -13,11 +13,11 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra):
+def _run(extra, paths="20"):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C2", "--steps", "2", "--warmup", "1",
-                          "--paths", "20", "--no-cpu-baseline", "--no-throughput-leg"] + extra,
+                          "--paths", paths, "--no-cpu-baseline", "--no-throughput-leg", "--no-spec-matrix", "--no-e2e"] + extra,
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -43,3 +43,39 @@ def test_nccl_backend_refuses_to_share_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--config", "C2"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and "--backend gloo" in out.stderr
+
+
+def _check_gathered(path, world, paths):
+    """What rank 0 gathered, against the oracle: rank r owns the window of seed r (bench.py: seed = rank)."""
+    import numpy as np
+    from gretel_amd.synth import make_config
+    from oracle.c_oracle import COracle
+    z = np.load(path)
+    assert int(z["world"]) == world
+    for r in range(world):
+        t = make_config("C2", seed=r)
+        o = COracle(t.n_snps, t.band)
+        o.fill(t)
+        ref = o.spin(paths)
+        assert int(z["n_%d" % r]) == ref["n"] == paths and int(z["hole_at_%d" % r]) == 0
+        assert np.array_equal(z["paths_%d" % r], ref["paths"]), "rank %d's paths differ from the oracle's for seed %d" % (r, r)
+        assert z["hp_current_%d" % r].tolist() == ref["hp_current"].tolist()
+        assert z["hp_original_%d" % r].tolist() == ref["hp_original"].tolist()
+        assert z["ratio_%d" % r].tolist() == ref["ratio"].tolist()
+        assert np.allclose(z["magnitude_%d" % r], ref["magnitude"], rtol=1e-10, atol=0)
+
+
+def test_what_rank_0_gathers_is_every_ranks_own_window(tmp_path):
+    dump = str(tmp_path / "g.npz")
+    two = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--dump-gathered", dump])
+    assert two["n_gpus"] == 2
+    _check_gathered(dump, 2, 20)
+
+
+def test_eight_ranks_on_one_gpu(tmp_path):
+    # the world = 8 code path (ownership w mod 8, eight gathers) of BASELINE config C4, at C2 size, on the one GPU of a test box
+    dump = str(tmp_path / "g8.npz")
+    eight = _run(["--gpus", "8", "--backend", "gloo", "--share-gpu", "--dump-gathered", dump], paths="10")
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "weak"
+    assert abs(eight["value"] * eight["ms_per_step"] * 1e-3 * 2 - 8 * 2 * 10) < 1e-6 * 160
+    _check_gathered(dump, 8, 10)
