@@ -9,7 +9,8 @@
 // (<= 64 per segment, kept from path to path), and the chain is then VERIFIED, never assumed:
 //
 //   k_cwalk   one workgroup per segment, four lanes (one per candidate rank; eight per entry over the symbols) per pool
-//             entry that has not been walked under the current tensor: the same lag-ascending binary64 sums and
+//             entry that has not been walked under the current tensor (and, "run-on", up to CW_RUNON segments further for
+//             an entry whose exit state the next pool does not hold: its walk there arrives with the request to join): the same lag-ascending binary64 sums and
 //             first-wins arg-max as every other walker, from the conditional table staged in LDS; records the exit
 //             state and the picks.
 //   k_clink   (behind k_cwalk, the pools stand still) where every entry's exit state sits in the next segment's pool.
@@ -36,6 +37,7 @@ typedef unsigned long long cw_key;
 #define CW_MAX_SEG 512
 #define CW_MIN_LEN 32
 #define CW_BOOT_ROUNDS 8        /* rounds queued for the first path of a tensor (pools started from k_cguess) */
+#define CW_RUNON 8              /* segments a walker may run on into, behind its own, with an exit state the next pool does not hold */
 
 // Segments: a wavefront alone on its SIMD issues an instruction every ~5 cycles, so where the table slice of a chunk
 // leaves room for two workgroups per CU (L <= 13: 76 KB each) the window is cut into twice as many, half as long
@@ -97,6 +99,19 @@ struct cw_params {
     int32_t *npool;           // [S]
     cw_key *pend;             // [S][CW_K]: states waiting to join the pool (exits of the previous segment's walks)
     int32_t *npend;           // [S]
+    // run-on (k_cwalk): a walker whose exit state the next pool does not hold walks on into the next segment itself and leaves
+    // the RESULT with the request -- the owner then merges a walked entry, and a new track is discovered in one launch
+    // instead of one segment per round
+    cw_key *pend_exit;        // [S][CW_K] exit state of a pending entry that arrives walked
+    int32_t *pend_ready;      // [S][CW_K] the path (P.stamp) under whose tensor pend_exit / phist were walked; 0 = a bare request.
+                              // (a request may outlive its path -- the chain closed before its pool merged again: its walk is then stale)
+    uint32_t *phist;          // [S][NW][CW_K] its picks
+    // The request lists are double-buffered by launch: a k_cwalk APPENDS to the set above and CONSUMES (merges, then empties)
+    // the set below, which the previous launch appended to and nobody touches now -- a slot is never handed out again while
+    // a run-on walk that reserved it may still be writing its result.  (k_cwalkg: both sets are the same, as before.)
+    cw_key *pend_c, *pend_exit_c;
+    int32_t *npend_c, *pend_ready_c;
+    uint32_t *phist_c;
     uint8_t *walked;          // [S][CW_K]: walked under the current tensor
     int8_t *nxt;              // [S][CW_K]: index of the entry's exit state in the next segment's pool, -1 = not there
     uint32_t *hist;           // [S][NW][CW_K]
@@ -164,11 +179,11 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     __shared__ int s_n;
     if (tid < 64) {
         int n0 = P.npool[s];
-        const int np = P.npend[s] < CW_K ? P.npend[s] : CW_K;
+        const int np = P.npend_c[s] < CW_K ? P.npend_c[s] : CW_K;
         cw_key *keys = P.keys + (size_t)s * CW_K;
         int32_t *lh = P.last_hit + (size_t)s * CW_K;
         for (int k = 0; k < np; k++) {
-            const cw_key x = P.pend[(size_t)s * CW_K + k];
+            const cw_key x = P.pend_c[(size_t)s * CW_K + k];
             const bool dup = __builtin_amdgcn_ballot_w64(tid < n0 && keys[tid] == x) != 0;
             if (dup) continue;
             int slot = n0;
@@ -182,10 +197,19 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
                 if (mine >= P.stamp) continue;              // every entry was on a chain of this path (cannot happen: one per path)
                 slot = who;
             } else n0++;
-            if (tid == 0) { keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = 0; }
+            // (a request that arrives with its walk -- run-on -- joins as a walked entry: exit state and picks are copied)
+            const bool ready = P.pend_ready_c && P.pend_ready_c[(size_t)s * CW_K + k] == P.stamp && P.stamp != 0;
+            if (tid == 0) {
+                keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = ready ? 1 : 0;
+                if (ready) P.exits[(size_t)s * CW_K + slot] = P.pend_exit_c[(size_t)s * CW_K + k];
+            }
+            if (ready) {
+                const int nw_m = R == 4 ? g.NW : g.NW5;
+                for (int w = tid; w < nw_m; w += 64) P.hist[((size_t)s * nw_m + w) * CW_K + slot] = P.phist_c[((size_t)s * nw_m + w) * CW_K + k];
+            }
             __builtin_amdgcn_s_waitcnt(0);                  // the next candidate's duplicate search reads keys[]
         }
-        if (tid == 0) { P.npool[s] = n0; P.npend[s] = 0; s_n = n0; }
+        if (tid == 0) { P.npool[s] = n0; P.npend_c[s] = 0; s_n = n0; }
     }
     __syncthreads();
     const int n = s_n;
@@ -197,12 +221,16 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     constexpr cw_key SMASK = BITS * LC >= 64 ? ~0ull : ((1ull << (BITS * LC)) - 1ull);
     double *Gs = reinterpret_cast<double *>(cw_smem);       // [(CH + LC - 1)][R][LC][5]: G's own layout, rows 0..R-1
     cw_key sigma = live ? P.keys[(size_t)s * CW_K + q] : 0ull;
-    const int t0 = s * g.seglen;
-    const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    int seg = s;                                            // the segment being walked: s, then (run-on) s + 1, ...
+    int t0 = s * g.seglen;
+    int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     const unsigned shift = (unsigned)(tid & 63 & ~(LPE - 1));     // this lane group's bits in the wave's ballot
     const int nw_e = R == 4 ? g.NW : g.NW5;
     int word_i = 0;
     unsigned word = 0;
+    bool active = live;                                     // this lane group still walks
+    int pslot = 0;                                          // run-on: the pending slot of pool `seg` this walk belongs to
+    uint32_t *hdst = P.hist + (size_t)s * nw_e * CW_K + q;  // where its words of picks go (stride CW_K): the entry's own, or a pending slot's
     // The slice of G a chunk needs: sources c0+1-LC .. c0+nc-1.  Rows 0..3 of a source are one contiguous run of 4*L*5
     // doubles in G ([i][row][lag][col]) and go to LDS as they are (16-byte copies).  The loads of chunk k+1 are issued
     // before chunk k is walked and stay in registers under the walk: their latency is off the critical path.
@@ -273,6 +301,7 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
             }
         }
     };
+    for (int hop = 0; ; hop++) {
     fetch(t0);
     for (int c0 = t0; c0 < t1; c0 += CH) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
@@ -301,7 +330,7 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
             const int gt = c0 - t0 + tl;                             // position inside the segment
             word |= d << (WB * (gt % PPW));
             if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
-                if (live && b == 0) P.hist[((size_t)s * nw_e + word_i) * CW_K + q] = word;
+                if (active && b == 0) hdst[(size_t)word_i * CW_K] = word;
                 word = 0;
                 word_i++;
             }
@@ -326,23 +355,50 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
         }
         for (; tl < nc; tl++) step(tl, [&](int l) { return ((unsigned)(sigma >> (BITS * (l - 1))) & DMASK) * ROWD; });
     }
-    if (live && b == 0) {
-        P.exits[(size_t)s * CW_K + q] = sigma;
-        P.walked[(size_t)s * CW_K + q] = 1;
+    // the segment is walked.  hop 0: the entry's own walk; later hops: a walk on behalf of a pending request of pool `seg`
+    int go_on = 0;
+    if (active && b == 0) {
+        if (hop == 0) {
+            P.exits[(size_t)s * CW_K + q] = sigma;
+            P.walked[(size_t)s * CW_K + q] = 1;
+        } else {
+            const size_t pe = (size_t)seg * CW_K + (size_t)pslot;
+            P.pend_exit[pe] = sigma;
+            P.pend_ready[pe] = P.stamp;
+        }
         // (3) closure: an exit state the next pool does not hold asks to join it.  (The next workgroup may be merging
         // its own pending list right now: a missed match only costs a duplicate request, dropped at the merge; the hops
-        // themselves are resolved by k_clink, after this kernel.)
-        if (s + 1 < g.S) {
-            const cw_key *kn = P.keys + (size_t)(s + 1) * CW_K;
+        // themselves are resolved by k_clink, after this kernel.)  Run-on: this lane group then walks the next segment
+        // itself, from that state, and the request carries the walk -- the chain of a NEW track is found in one launch, not
+        // one segment per round.
+        if (seg + 1 < g.S) {
+            const cw_key *kn = P.keys + (size_t)(seg + 1) * CW_K;
             bool there = false;
-            const int nn = P.npool[s + 1];                // (entries behind the count are leftovers of earlier tensors)
+            const int nn = P.npool[seg + 1];              // (entries behind the count are leftovers of earlier tensors)
             for (int k = 0; k < nn && k < CW_K; k++)
                 if (kn[k] == sigma) { there = true; break; }
             if (!there) {
-                const int slot = atomicAdd(&P.npend[s + 1], 1);
-                if (slot < CW_K) P.pend[(size_t)(s + 1) * CW_K + slot] = sigma;
+                const int slot = atomicAdd(&P.npend[seg + 1], 1);
+                if (slot < CW_K) {
+                    P.pend[(size_t)(seg + 1) * CW_K + slot] = sigma;
+                    if (P.pend_ready) {
+                        P.pend_ready[(size_t)(seg + 1) * CW_K + slot] = 0;
+                        if (hop < CW_RUNON) go_on = 1 + slot;
+                    }
+                }
             }
         }
+    }
+    go_on = __shfl(go_on, (int)(tid & 63 & ~(LPE - 1)));      // lane b == 0 of the group decides
+    active = go_on != 0;
+    if (!__syncthreads_or(active ? 1 : 0)) break;           // nobody walks on: done
+    seg++;
+    t0 = seg * g.seglen;
+    t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    word_i = 0;
+    word = 0;
+    pslot = active ? go_on - 1 : 0;
+    hdst = P.phist + (size_t)seg * nw_e * CW_K + pslot;
     }
 }
 
@@ -624,6 +680,7 @@ __global__ void __launch_bounds__(1024) k_cscan(cw_params P)
                 if (P.pend[(size_t)(stuck + 1) * CW_K + k] == x) queued = true;
             if (!queued) {
                 P.pend[(size_t)(stuck + 1) * CW_K] = x;
+                if (P.pend_ready) P.pend_ready[(size_t)(stuck + 1) * CW_K] = 0;      // (a bare request: to be walked)
                 if (P.pend_d)
                     for (int l = 0; l < P.L; l++)
                         P.pend_d[((size_t)(stuck + 1) * CW_K) * P.LD + l] = P.exits_d[((size_t)stuck * CW_K + tru[stuck]) * P.LD + l];
@@ -751,6 +808,7 @@ __global__ void __launch_bounds__(256) k_cseed(cw_params P, const uint8_t *path,
     }
     P.npool[s] = n;
     P.npend[s] = 0;
+    P.npend_c[s] = 0;
     for (int k = 0; k < CW_K; k++) P.walked[(size_t)s * CW_K + k] = 0;
 }
 

@@ -119,7 +119,9 @@ struct gh_handle {
     double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
     int seg_L;
     // candidate-pool segment walk (cwalk.hpp)
-    cw_key *cw_keys, *cw_exits, *cw_pend;
+    cw_key *cw_keys, *cw_exits, *cw_pend, *cw_pend_exit;
+    int32_t *cw_pend_ready;
+    uint32_t *cw_phist;
     uint32_t *cw_hist;
     int32_t *cw_npend;
     int32_t *cw_last_hit, *cw_npool, *cw_true;
@@ -134,6 +136,8 @@ struct gh_handle {
     int cw_LD;
     int cw_rounds;         // walk/scan rounds queued per path (adapts to how often chains stay open)
     int cw_stamp;
+    int cw_pp;             // k_cwalk launches so far: which of the two request-list sets this launch appends to (cwalk.hpp)
+    size_t cw_S;           // segments the pool buffers are sized for (the second set of request lists lies cw_S entries behind the first)
     int64_t cw_stat[4];    // paths through the pools, paths handed to the serial walker, rounds queued, re-queues
     int force_stale_at;    // GH_SEG_FORCE_STALE=k at creation (tests): path k of every gh_spin finds the table stale once
     uint8_t *stage;        // pinned host staging for the results of a spin
@@ -279,6 +283,7 @@ static void free_handle(gh_handle *h)
     if (h->stage) hipHostFree(h->stage);
     hipFree(h->ew_buf);
     hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
+    hipFree(h->cw_pend_exit); hipFree(h->cw_pend_ready); hipFree(h->cw_phist);
     hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_hist); hipFree(h->cw_last_hit); hipFree(h->cw_npool); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true); hipFree(h->cw_pend); hipFree(h->cw_npend);
     for (int k = 0; k < GH_K_COUNT; k++)
         for (hipEvent_t e : h->ps[k].ev) hipEventDestroy(e);
@@ -338,7 +343,8 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr; h->fuse = false;
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
-    h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0;
+    h->cw_pend_exit = nullptr; h->cw_pend_ready = nullptr; h->cw_phist = nullptr;
+    h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0; h->cw_pp = 0; h->cw_S = 0;
     h->cw_keys_d = nullptr; h->cw_exits_d = nullptr; h->cw_pend_d = nullptr; h->cw_LD = 0; h->cw_no_rw = false;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
@@ -1211,9 +1217,15 @@ static int alloc_cw(gh_handle *h)
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_last_hit, sizeof(int32_t) * S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_hist, sizeof(uint32_t) * SNW * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npool, sizeof(int32_t) * S);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(cw_key) * S * CW_K);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npend, sizeof(int32_t) * S);
-    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npend, 0, sizeof(int32_t) * S, h->stream);
+    // (the request lists twice: a launch appends to one set and consumes the other, cwalk.hpp)
+    h->cw_S = S;
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend, sizeof(cw_key) * 2 * S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend_exit, sizeof(cw_key) * 2 * S * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_pend_ready, sizeof(int32_t) * 2 * S * CW_K);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_pend_ready, 0, sizeof(int32_t) * 2 * S * CW_K, h->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_phist, sizeof(uint32_t) * 2 * SNW * CW_K);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->cw_npend, sizeof(int32_t) * 2 * S);
+    if (e == hipSuccess) e = hipMemsetAsync(h->cw_npend, 0, sizeof(int32_t) * 2 * S, h->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_walked, S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_nxt, S * CW_K);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cw_true, sizeof(int32_t) * S);
@@ -1227,6 +1239,8 @@ static int alloc_cw(gh_handle *h)
     if (e != hipSuccess) {
         // all or nothing: a later call must not find cw_keys set next to pool buffers that never came to be
         hipStreamSynchronize(h->stream);
+        hipFree(h->cw_pend_exit); hipFree(h->cw_pend_ready); hipFree(h->cw_phist);
+        h->cw_pend_exit = nullptr; h->cw_pend_ready = nullptr; h->cw_phist = nullptr;
         hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_last_hit); hipFree(h->cw_hist); hipFree(h->cw_npool); hipFree(h->cw_pend);
         hipFree(h->cw_npend); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true);
         h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_last_hit = nullptr; h->cw_hist = nullptr; h->cw_npool = nullptr; h->cw_pend = nullptr;
@@ -1244,6 +1258,21 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
     P.keys = h->cw_keys; P.exits = h->cw_exits; P.last_hit = h->cw_last_hit; P.npool = h->cw_npool; P.walked = h->cw_walked; P.nxt = h->cw_nxt; P.pend = h->cw_pend; P.npend = h->cw_npend;
     P.hist = h->cw_hist; P.true_idx = h->cw_true; P.segmin = h->seg_min; P.path_out = d_path; P.lmsel = d_lmsel;
+    const bool no_runon = getenv("GH_CW_RUNON") && atoi(getenv("GH_CW_RUNON")) == 0;      // (read per launch: the tests switch it)
+    P.pend_c = P.pend; P.npend_c = P.npend;
+    if (!cw_digit_mode(h)) {
+        // the set this launch appends to / the set it consumes (what the launch before appended to)
+        const cw_geom gg = cw_geometry(h->N, h->L);
+        const size_t nw = (size_t)(h->cw_wide ? gg.NW5 : gg.NW);
+        const size_t a = (size_t)(h->cw_pp & 1), c = a ^ 1;
+        P.pend = h->cw_pend + a * h->cw_S * CW_K;            P.pend_c = h->cw_pend + c * h->cw_S * CW_K;
+        P.npend = h->cw_npend + a * h->cw_S;                 P.npend_c = h->cw_npend + c * h->cw_S;
+        if (!no_runon) {
+            P.pend_exit = h->cw_pend_exit + a * h->cw_S * CW_K;   P.pend_exit_c = h->cw_pend_exit + c * h->cw_S * CW_K;
+            P.pend_ready = h->cw_pend_ready + a * h->cw_S * CW_K; P.pend_ready_c = h->cw_pend_ready + c * h->cw_S * CW_K;
+            P.phist = h->cw_phist + a * gg.S * nw * CW_K;         P.phist_c = h->cw_phist + c * gg.S * nw * CW_K;
+        }
+    }
     if (cw_digit_mode(h)) {
         P.keys_d = h->cw_keys_d; P.exits_d = h->cw_exits_d; P.pend_d = h->cw_pend_d; P.LD = h->cw_LD;
         unsigned long long hh = 0xcbf29ce484222325ull;      // cw_hash_digits of L zero bytes: the start state
@@ -1277,6 +1306,13 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
         P.round = resume ? r + 1 : r;                       // (a resumed path continues behind the rounds already run)
         P.check_masks = (r == 0 && !resume) ? check_masks : 0;
         P.last_round = r == rounds - 1;
+        {
+            // every k_cwalk launch appends to the request lists the launch before consumed, and the other way round
+            h->cw_pp++;
+            const cw_params Q = cw_make_params(h, d_path, d_lmsel);
+            P.pend = Q.pend; P.npend = Q.npend; P.pend_exit = Q.pend_exit; P.pend_ready = Q.pend_ready; P.phist = Q.phist;
+            P.pend_c = Q.pend_c; P.npend_c = Q.npend_c; P.pend_exit_c = Q.pend_exit_c; P.pend_ready_c = Q.pend_ready_c; P.phist_c = Q.phist_c;
+        }
         if (r == 0) prof_begin(h, GH_K_SEG);                // (bench.py: the pool walker alone, first round of a path)
         if (cw_digit_mode(h)) {
             if (!h->cw_wide) hipLaunchKernelGGL((k_cwalkg<4>), dim3(g.S), dim3(CW_K * cw_lanes(4)), 0, h->stream, P);

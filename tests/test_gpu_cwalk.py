@@ -122,7 +122,9 @@ def test_switches(kw):
 def test_chains_left_open_go_to_the_serial_walker_and_change_nothing(L, monkeypatch):
     # GH_CW_ROUND_CAP=1 (read when the handle is created): one round per launch, so most chains stay open, the host
     # re-queues, and the serial walker takes the paths -- its states join the pools (k_cseed).  Same results.
+    # (run-on off: with it a walker follows a new track through the next segments itself and even one round closes most chains)
     t = make_support_table(3000, 36000, k=None, seed=77)
+    monkeypatch.setenv("GH_CW_RUNON", "0")
     monkeypatch.setenv("GH_CW_ROUND_CAP", "1")
     h, o = _pair(t, L=L)
     monkeypatch.delenv("GH_CW_ROUND_CAP")
@@ -174,3 +176,27 @@ def test_lone_paths_come_out_of_the_pools_too(L, dels):
         assert abs(rg - ro) <= 1e-9 * max(1.0, abs(ro))
     assert 4 in variants, variants
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [7, 9, 12, 19])
+@pytest.mark.parametrize("dels", [False, True])
+def test_run_on_changes_nothing(L, dels, monkeypatch):
+    # a walker whose exit state the next pool does not hold walks on into the next segments itself (up to CW_RUNON of them)
+    # and leaves the walk with its request to join: same paths with it and without it, with one round per launch and with many
+    t = make_support_table(4000, 48000, k=None, seed=400 + L, k_max=max(21, L + 4))
+    if dels:
+        bases = t.bases.copy()
+        bases[np.random.default_rng(7).random(len(bases)) < 0.08] = ord('-')
+        t.bases = bases
+    h, o = _pair(t, L=L)
+    ref = o.spin(30)
+    _same(h.spin(30), ref)
+    assert h.walk_clock()[3] == 4
+    assert np.array_equal(h.export_band(), o.export_band())
+    monkeypatch.setenv("GH_CW_RUNON", "0")
+    h0, _ = _pair(t, L=L)
+    _same(h0.spin(30), ref)
+    monkeypatch.delenv("GH_CW_RUNON")
+    monkeypatch.setenv("GH_CW_ROUND_CAP", "1")
+    h1, _ = _pair(t, L=L)
+    _same(h1.spin(30), ref)
