@@ -123,7 +123,7 @@ struct cw_params {
     // byte per pick, lag 1 first -- sits next to it; equal hashes are confirmed on the bytes wherever two states are compared
     uint8_t *keys_d, *exits_d, *pend_d;       // [S][CW_K][LD], null in the packed mode
     int LD;                   // bytes per state (L rounded up to 4)
-    int _pad2;
+    int runon;                // k_cwalk: segments a walker may run on into behind its own (<= CW_RUNON)
     cw_key key0;              // key of the start state (0 in the packed mode)
 };
 
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
                     P.pend[(size_t)(seg + 1) * CW_K + slot] = sigma;
                     if (P.pend_ready) {
                         P.pend_ready[(size_t)(seg + 1) * CW_K + slot] = 0;
-                        if (hop < CW_RUNON) go_on = 1 + slot;
+                        if (hop < P.runon) go_on = 1 + slot;
                     }
                 }
             }

@@ -89,6 +89,8 @@ struct gh_handle {
     int32_t *nvalid;
     uint32_t *cmask;
     double *rinfo;                // [(N+2)][8] log10 marginal / marginal by candidate rank (k_marg, k_rw)
+    bool need_rinfo;              // ... kept only where somebody reads it: with the marginal term (k_seg, k_cwalk add it in front of x1) and
+                                  // for the three-launch spins (GH_FUSE at creation); nullptr goes to the kernels otherwise (C5: k_rw is bound by its stores)
     symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
     double *lt;
     bool lt_baked;                // lt holds the marginal term in its lag-1 entries (built for a serial walker; only with cfg.marginal_term)
@@ -332,6 +334,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memcpy(h->cfg.cand_order, order, 5);
     h->sm = make_symmap(order);
     h->rinfo = nullptr; h->lt_baked = false;
+    h->need_rinfo = cfg->marginal_term != 0 || (getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1);
     h->dev = dev;
     h->N = cfg->n_snps;
     h->W = cfg->band;
@@ -719,12 +722,12 @@ static int ensure_marg(gh_handle *h)
         hipLaunchKernelGGL((k_marg<double, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (double *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
-                           h->sm, h->cfg.offer_zero, h->rinfo);
+                           h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr);
     else
         hipLaunchKernelGGL((k_marg<float, false>), dim3((threads + block - 1) / block), dim3(block), 0, h->stream,
                            (float *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
-                           h->sm, h->cfg.offer_zero, h->rinfo);
+                           h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr);
     // algorithmic bytes: read the (p,p+1) cell, write cnt/marg (2x64), minfo (88), nvalid+cmask (8)
     prof_end(h, GH_K_MARG, (double)(h->N + 1) * (CELL * esize(h) + 2 * 64 + 88 + 8));
     { int rc_ = post_launch(h, "k_marg"); if (rc_) return rc_; }
@@ -1141,7 +1144,7 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     prof_begin(h, GH_K_REWEIGHT);
     if (seg) {
         // behind a segment-parallel walk (L <= SEG_MAX_L <= 8: one table row per lane): segwalk.hpp's k_rw
-#define GH_RW_LAUNCH(T, LP, COL)                                                                                                  \
+#define GH_RW_LAUNCH(T, LP, COL, FZ)                                                                                              \
     do {                                                                                                                          \
         /* COL: the band block of the workgroup's positions staged in LDS when it fits (k_rw) */                                   \
         const size_t blk_b = (size_t)(256 / LP) * NSYM * h->W * NSYM * sizeof(T);                                                 \
@@ -1149,14 +1152,15 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         const size_t lds_b = fuse_lds + (stage ? blk_b : 0);                                                                      \
         static std::atomic<size_t> set_lds[64];                                                                                   \
         if (lds_b > set_lds[h->dev & 63]) {                                                                                       \
-            hipFuncSetAttribute((const void *)k_rw<T, LP, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);          \
+            hipFuncSetAttribute((const void *)k_rw<T, LP, COL, FZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);      \
             set_lds[h->dev & 63] = lds_b;                                                                                         \
         }                                                                                                                         \
-        hipLaunchKernelGGL((k_rw<T, LP, COL>), dim3(nb), dim3(block), lds_b, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
+        hipLaunchKernelGGL((k_rw<T, LP, COL, FZ>), dim3(nb), dim3(block), lds_b, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
                            h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                \
-                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->rinfo, stage, fz, (int)fuse_lds); \
+                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr, stage, fz, (int)fuse_lds); \
     } while (0)
-#define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true); else GH_RW_LAUNCH(T, LP, false); } while (0)
+#define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true, false); else GH_RW_LAUNCH(T, LP, false, false); } while (0)
+#define GH_RW_LAUNCHF(T) do { if (col) GH_RW_LAUNCH(T, 8, true, true); else GH_RW_LAUNCH(T, 8, false, true); } while (0)
         const bool wide = rw_lanes(h) == 32;
         const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;      // the table entries a reweighted cell feeds: a column
         // behind k_seg + k_scan without a k_emit (h->fuse): the kernel finds its picks itself and writes the path to d_path / d_lmsel
@@ -1168,20 +1172,23 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
             fz.path_out = const_cast<uint8_t *>(d_path); fz.lmsel = d_lmsel;
             fuse_lds = h->fuse_lds;
         }
-        if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
+        if (fz.hist) {                                      // (three-launch spins: lane groups of 8 only, gh_spin decides)
+            if (h->cfg.storage == GH_STORAGE_F64) GH_RW_LAUNCHF(double); else GH_RW_LAUNCHF(float);
+        } else if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
         else { if (wide) GH_RW_LAUNCH2(float, 32); else GH_RW_LAUNCH2(float, 8); }
+#undef GH_RW_LAUNCHF
 #undef GH_RW_LAUNCH2
 #undef GH_RW_LAUNCH
     } else if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL((k_marg<double, true>), dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
-                           (const double *)nullptr, (gh_path_rec *)nullptr, h->sm, h->cfg.offer_zero, h->rinfo);
+                           (const double *)nullptr, (gh_path_rec *)nullptr, h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr);
     else
         hipLaunchKernelGGL((k_marg<float, true>), dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W,
                            h->cnt, h->marg, h->nvalid, h->cmask, h->minfo, h->dstate, (const win_desc *)nullptr,
                            d_path, ratio, use_state, partial, 0, lt_rows, h->L, h->cfg.cond_mode,
-                           (const double *)nullptr, (gh_path_rec *)nullptr, h->sm, h->cfg.offer_zero, h->rinfo);
+                           (const double *)nullptr, (gh_path_rec *)nullptr, h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr);
     if (slot < 0)
         hipLaunchKernelGGL(k_reweight_finish, dim3(1), dim3(256), 0, h->stream, partial, nb, h->dstate, use_state, d_rec,
                            (const win_desc *)nullptr, 0);
@@ -1258,7 +1265,15 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
     P.keys = h->cw_keys; P.exits = h->cw_exits; P.last_hit = h->cw_last_hit; P.npool = h->cw_npool; P.walked = h->cw_walked; P.nxt = h->cw_nxt; P.pend = h->cw_pend; P.npend = h->cw_npend;
     P.hist = h->cw_hist; P.true_idx = h->cw_true; P.segmin = h->seg_min; P.path_out = d_path; P.lmsel = d_lmsel;
-    const bool no_runon = getenv("GH_CW_RUNON") && atoi(getenv("GH_CW_RUNON")) == 0;      // (read per launch: the tests switch it)
+    // run-on (cwalk.hpp): how far a walker follows a new track beyond its own segment -- some two hundred positions: the launch
+    // lasts as long as its longest walker (GH_CW_RUNON=k pins the number of segments, 0 = off; read per launch: the tests switch it)
+    const cw_geom ggr = cw_geometry(h->N, h->L);
+    int runon = ggr.seglen <= 64 ? 256 / ggr.seglen : 0;      // (C5, 98 positions per segment: 168 us per path without, 175 with two segments of run-on)
+    if (runon > CW_RUNON) runon = CW_RUNON;
+    if (getenv("GH_CW_RUNON")) runon = atoi(getenv("GH_CW_RUNON"));
+    if (runon > CW_RUNON) runon = CW_RUNON;
+    const bool no_runon = runon <= 0;
+    P.runon = runon;
     P.pend_c = P.pend; P.npend_c = P.npend;
     if (!cw_digit_mode(h)) {
         // the set this launch appends to / the set it consumes (what the launch before appended to)
@@ -1760,7 +1775,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     // boundary (6.8 us) go, the prologue k_rw needs instead (group maps to LDS, the chain, one more round trip) costs 6.5 us,
     // and carrying the minima through k_seg / k_scan another 2.9 us: 40.8 against 38.7 us per path.  So it is opt-in:
     // GH_FUSE=1 (large windows) or 2 (every window the maps fit; the tests).
-    if (rc == GH_OK && seg && h->W <= RW_FUSE_HALO && getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1) {
+    if (rc == GH_OK && seg && h->need_rinfo && h->W <= RW_FUSE_HALO && rw_lanes(h) == 8 && getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1) {
         rc = ensure_lt(h);
         dev_state look;
         if (rc == GH_OK) {
@@ -1976,7 +1991,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     for (int w = 0; w < n; w++) {
         gh_handle *h = b->hs[w];
         wd[w].band = h->band; wd[w].cnt = h->cnt; wd[w].marg = h->marg; wd[w].minfo = h->minfo;
-        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].rinfo = h->rinfo; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
+        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].rinfo = h->need_rinfo ? h->rinfo : nullptr; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
         wd[w].partial = b->d_partial + (size_t)w * b->nb;
         wd[w].paths = b->d_paths + n1 * max_paths * w;
         wd[w].recs = b->d_recs + (size_t)max_paths * w;

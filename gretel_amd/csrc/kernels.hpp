@@ -488,7 +488,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
                 minfo[(size_t)p * MINFO + b5] = my_lm;
                 minfo[(size_t)p * MINFO + 5 + b5] = my_m;
                 // the same by candidate rank (rinfo): this symbol's rank among the candidates of p
-                if (((cand >> s) & 1u) && __popc(cm5 & ((1u << b5) - 1u)) < 4) {
+                if (rinfo && ((cand >> s) & 1u) && __popc(cm5 & ((1u << b5) - 1u)) < 4) {
                     const int r = __popc(cm5 & ((1u << b5) - 1u));
                     rinfo[(size_t)p * RINFO + r] = my_lm;
                     rinfo[(size_t)p * RINFO + 4 + r] = my_m;
@@ -502,7 +502,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
             if (cmask[p] != cmw) flag_bits |= 1u;                 // the conditional table must then be rebuilt in full
             cmask[p] = cmw;
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
-            for (int r = __popc(cm5); r < 4; r++) {               // ranks that do not exist
+            for (int r = __popc(cm5); rinfo && r < 4; r++) {      // ranks that do not exist
                 rinfo[(size_t)p * RINFO + r] = 0.0;
                 rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
             }

@@ -560,8 +560,10 @@ __host__ __device__ inline size_t rw_fuse_lds_bytes(int N, int L, int R, int ppb
     return (((size_t)g.G1 * g.NS * 2 + 15) & ~(size_t)15) + (size_t)rw_fuse_nts(N, L, R, ppb, W) * g.NS * 2 + 512;
 }
 
-template <typename T, int LP, bool COL>
-__global__ void __launch_bounds__(256)
+// (row mode within 72 VGPRs = seven waves per SIMD: at C5 the kernel is a stream of dependent round trips and its
+// throughput follows the waves in flight -- 78 registers, six waves, cost 10 of 50 us)
+template <typename T, int LP, bool COL, bool FUSED>
+__global__ void __launch_bounds__(256, (COL || FUSED) ? 4 : 7)
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
      gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage, fuse_params fz, int fuse_lds)
@@ -570,7 +572,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     extern __shared__ __align__(16) unsigned char rw_smem_all[];
     const int tid = threadIdx.x;
     constexpr int PPB = 256 / LP;                           // positions per workgroup
-    const bool fused = fz.hist != nullptr;
+    constexpr bool fused = FUSED;                           // (a compile-time switch: the prologue's registers cost the plain kernel a wave per SIMD)
     unsigned char *rw_smem = rw_smem_all + fuse_lds;        // (the fused prologue's LDS lies in front of the staged band block)
     RW_STAMP(0);
     // COL, stage != 0: the band block of this workgroup's positions goes to LDS as it lies in memory (one contiguous run,
@@ -740,9 +742,14 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         const T *lc = lp + ((size_t)(d0 <= W ? d0 : 1) - 1) * NSYM + b0;
 #pragma unroll
         for (int x = 0; x < NSYM; x++) rrow[x] = lc[(size_t)x * estride];
-    } else {
+    } else if (COL) {
 #pragma unroll
         for (int x = 0; x < NSYM; x++) rrow[x] = runp[(size_t)x * estride];
+    } else {
+        // (a row is one contiguous run: the compiler fetches it with two wide loads, and a lane without one issues nothing --
+        // with bands of 20 a third of the lanes have no row, and this kernel is bound by the memory instructions it issues)
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rowp[x] : (T)0;
     }
 #pragma unroll
     for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? rrow[x] : (T)0;
@@ -805,7 +812,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
                 minfo[(size_t)p * MINFO + b5] = lm;
                 minfo[(size_t)p * MINFO + 5 + b5] = m;
                 const int r = __popc(cm5 & ((1u << b5) - 1u));
-                if (((cand >> s) & 1u) && r < 4) {
+                if (rinfo && ((cand >> s) & 1u) && r < 4) {
                     rinfo[(size_t)p * RINFO + r] = lm;
                     rinfo[(size_t)p * RINFO + 4 + r] = m;
                 }
@@ -816,7 +823,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             nvalid[p] = nv;
             cmask[p] = cmw;
             minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
-            for (int r = __popc(cm5); r < 4; r++) {
+            for (int r = __popc(cm5); rinfo && r < 4; r++) {
                 rinfo[(size_t)p * RINFO + r] = 0.0;
                 rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
             }
@@ -929,7 +936,27 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
 #pragma unroll
                 for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10(xq[q]);
             }
-            if (!ranked) {
+            if (sm.fwd == 0x53210u) {
+                // the default order: compact index q IS the q-th valid symbol -- the row is put together in registers and leaves
+                // as one contiguous 40-byte run (C5: the kernel is bound by its stores)
+                double r[LT_ROW];
+                if (!ranked) {
+#pragma unroll
+                    for (int q = 0; q < LT_ROW; q++) r[q] = ((cmt >> VS[q]) & 1) ? v[q] : -INFINITY;
+                } else {
+                    const uint32_t cj5 = (cmt & 15u) | (((cmt >> 5) & 1u) << 4);
+#pragma unroll
+                    for (int rb = 0; rb < LT_ROW; rb++) {
+                        const int b5 = nth_set5(cj5, rb);
+                        double x = -INFINITY;
+#pragma unroll
+                        for (int q = 0; q < LT_ROW; q++) x = (b5 == q) ? v[q] : x;
+                        r[rb] = x;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) out[q] = r[q];
+            } else if (!ranked) {
 #pragma unroll
                 for (int q = 0; q < LT_ROW; q++) out[a6_of_sym(sm, VS[q])] = ((cmt >> VS[q]) & 1) ? v[q] : -INFINITY;
             } else {
