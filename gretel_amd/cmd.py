@@ -34,8 +34,10 @@ def build_parser():
     p.add_argument("--quiet", default=False, action="store_true", help="do not print the per-SNP table")
     p.add_argument("-o", "--out", default=".", help="output directory [default: .]")
     p.add_argument("-@", "--threads", type=int, default=1, help="accepted for compatibility (the fill runs on the GPU)")
-    p.add_argument("--debugreads", type=str, default="", help="accepted for compatibility")
-    p.add_argument("--debugpos", type=str, default="", help="accepted for compatibility")
+    p.add_argument("--debugreads", type=str, default="", help="A newline delimited list of read names to output debug data when parsing the BAM")
+    p.add_argument("--debugpos", type=str, default="", help="A newline delimited list of 1-indexed genomic positions to output debug data when parsing the BAM")
+    p.add_argument("--max-depth", type=int, default=0, help="drop reads that start where this many are already open, as the pileup the "
+                   "reference inherits does at pysam's default of 8000 (0 = keep every read; > 0 switches to the Python BAM decoder)")
     p.add_argument("--debughpos", type=str, default=",", help="comma delimited 1-indexed SNP ranks to print branch weights for")
     p.add_argument("--dumpmatrix", type=str, default=None, help="dump the Hansel tensor (.npz) to this path")
     p.add_argument("--dumpsnps", type=str, default=None, help="dump the SNP positions to this path")
@@ -206,7 +208,15 @@ def main(argv=None):
         with open(args.dumpsnps, "w") as fh:
             for k in sorted(vcf_h["snp_fwd"].keys()):
                 fh.write("%d\t%d\t%d\n" % (vcf_h["snp_fwd"][k] + 1, k, k - args.start + 1))
+    debug_reads, debug_pos = set(), set()                                          # cmd.py:57-67
+    if args.debugreads:
+        with open(args.debugreads) as fh:
+            debug_reads = {line.strip() for line in fh}
+    if args.debugpos:
+        with open(args.debugpos) as fh:
+            debug_pos = {int(line.strip()) for line in fh if line.strip()}
     hansel = util.load_from_bam(args.bam, args.contig, args.start, args.end, vcf_h, n_threads=args.threads,
+                                debug_reads=debug_reads, debug_pos=debug_pos, max_depth=args.max_depth,
                                 stepper="all" if args.pepper else "samtools")     # cmd.py:78
     hansel.snapshot_original()                                                    # cmd.py:79 (what the copy is used for)
     if args.dumpmatrix:

@@ -138,21 +138,30 @@ def get_ref_len_from_bam(bam_path, target_contig, decoder="native"):
     raise KeyError(target_contig)
 
 
-def _support_of_read(rec, region, start_pos, end_pos):
+def _support_of_read(rec, region, start_pos, end_pos, positions=None):
     """Walk the CIGAR like htslib's pileup and return (leftmost_1pos, aligned_query_len,
-    [support chars at the SNP columns the read covers, in reference order])."""
+    [support chars at the SNP columns the read covers, in reference order]).
+    positions (a list, --debugreads / --debugpos): receives (1-based position, the whole captured sequence) per column --
+    the base plus what an insertion right behind it carries (gretel/util.py:183-186), '-' in a deletion (util.py:180-182)."""
     ref = rec.pos            # 0-based
     q = 0
     chars = []
     qalen = 0
     hi = min(end_pos, len(region) - 1)
-    for op, ln in rec.cigar:
+    cig = rec.cigar
+    for ci, (op, ln) in enumerate(cig):
         if op in (0, 7, 8):                       # M = X : one pileup column per base
             lo1 = max(ref + 1, 1)
             hi1 = min(ref + ln, hi)
             if hi1 >= lo1:
                 for pos1 in np.flatnonzero(region[lo1:hi1 + 1]) + lo1:
-                    chars.append(rec.base(q + (int(pos1) - 1 - ref)))     # util.py:186-189: b[0] is this base
+                    qi = q + (int(pos1) - 1 - ref)
+                    chars.append(rec.base(qi))     # util.py:186-189: b[0] is this base
+                    if positions is not None:
+                        seq = rec.base(qi)
+                        if int(pos1) == ref + ln and ci + 1 < len(cig) and cig[ci + 1][0] == 1:      # p_read.indel > 0
+                            seq += "".join(rec.base(qi + 1 + x) for x in range(cig[ci + 1][1]))
+                        positions.append((int(pos1), seq))
             ref += ln
             q += ln
             qalen += ln
@@ -161,6 +170,8 @@ def _support_of_read(rec, region, start_pos, end_pos):
             hi1 = min(ref + ln, hi)
             if hi1 >= lo1:
                 chars.extend("-" * int(region[lo1:hi1 + 1].sum()))
+                if positions is not None:
+                    positions.extend((int(pos1), "-") for pos1 in np.flatnonzero(region[lo1:hi1 + 1]) + lo1)
             ref += ln
         elif op == 1:                             # I
             q += ln
@@ -172,11 +183,14 @@ def _support_of_read(rec, region, start_pos, end_pos):
 
 
 def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper="samtools",
-                           decoder="native"):
+                           decoder="native", max_depth=0, debug_reads=None, debug_pos=None, debug_out=None):
     """The pileup half of load_from_bam (gretel/util.py:137-209) -> support table arrays.
     decoder="native": libgretel_io.so (C++/zlib, include/gretel_io.h); "python": the pure-Python restatement
-    below (same rules; kept as the readable specification and as a cross-check in the tests)."""
-    if decoder == "native":
+    below (same rules; kept as the readable specification and as a cross-check in the tests).
+    max_depth > 0 (python decoder only, opt-in): drop a read that starts where that many kept reads are already open --
+    what the pileup the reference inherits does at pysam's default of 8000 (gretel/util.py:137 passes none).
+    debug_reads / debug_pos: the prints of gretel/util.py:211-224 (python decoder), to debug_out (default stdout)."""
+    if decoder == "native" and not (max_depth or debug_reads or debug_pos):
         from . import bamio
         return bamio.native_support_table(bam_path, target_contig, start_pos, end_pos, vcf_handler["region"], stepper)
     refs, records = read_bam(bam_path)
@@ -188,6 +202,10 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
     csum = np.concatenate([[0], np.cumsum(region)])          # csum[x] = sum(region[0:x])
     reads = {}
     order = []
+    import heapq
+    open_ends = []                                   # max_depth: reference ends of the kept reads still open
+    dbg = {}                                         # key -> (query name, [(pos, sequence)]) for --debugreads / --debugpos
+    want_dbg = bool(debug_reads) or bool(debug_pos)
     for rec in records:
         if rec.ref_id != tid or rec.flag & _FLAG_DROP:
             continue
@@ -199,7 +217,14 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
         if rec.flag & 0x1:
             one_or_two = 1 if rec.flag & 0x40 else (2 if rec.flag & 0x80 else 0)
         key = "%s_%s_%d" % (rec.name, str(rec.flag), one_or_two)          # util.py:160
-        leftmost, qalen, chars = _support_of_read(rec, region, start_pos, end_pos)
+        if max_depth > 0:
+            while open_ends and open_ends[0] <= rec.pos:
+                heapq.heappop(open_ends)
+            if len(open_ends) >= max_depth:
+                continue
+            heapq.heappush(open_ends, rec.pos + sum(ln for op, ln in rec.cigar if op in (0, 2, 3, 7, 8)))
+        plist = [] if want_dbg else None
+        leftmost, qalen, chars = _support_of_read(rec, region, start_pos, end_pos, plist)
         if leftmost < start_pos:                                          # util.py:165-171
             if leftmost + qalen < start_pos:
                 continue
@@ -212,6 +237,19 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
             reads[key] = [rank, []]
             order.append(key)
         reads[key][1].extend(c[0] for c in chars)
+        if want_dbg:
+            dbg.setdefault(key, (rec.name, []))[1].extend(plist)
+    if want_dbg:
+        out = debug_out if debug_out is not None else sys.stdout
+        for key in sorted(k for k, (name, _) in dbg.items() if debug_reads and name in debug_reads):      # util.py:211-216
+            for pos1, seq in dbg[key][1]:
+                print(key, pos1, seq, file=out)
+            print("RANK", key, reads[key][0], file=out)
+        if debug_pos:                                                                                 # util.py:218-222
+            for key in order:
+                seen = [p1 for p1, _ in dbg[key][1]]
+                for d_pos in set(seen) & set(debug_pos):
+                    print(key, d_pos, dbg[key][1][seen.index(d_pos)][1], file=out)
     rank = np.array([reads[k][0] for k in order], dtype=np.int32)
     seqs = ["".join(reads[k][1]) for k in order]
     off = np.zeros(len(order) + 1, dtype=np.int64)
@@ -222,9 +260,14 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
 
 
 def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_end_sentinels=False,
-                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", decoder="native", **hansel_kw):
-    """gretel/util.py:33-335.  Returns a device-backed Hansel with n_slices, n_crumbs and L set."""
-    rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper, decoder)
+                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", decoder="native", max_depth=0, **hansel_kw):
+    """gretel/util.py:33-335.  Returns a device-backed Hansel with n_slices, n_crumbs and L set.
+    n_threads is the reference's number of BAM iterator processes (util.py:288-326): the native decoder runs its own
+    threads and the fill is one kernel, so the value changes nothing here -- said once on stderr when it is not 1."""
+    if n_threads not in (None, 1):
+        sys.stderr.write("[NOTE] -@/--threads %s ignored: the BAM is decoded by libgretel_io.so's own threads and the matrix is filled on the GPU\n" % n_threads)
+    rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper, decoder,
+                                              max_depth=max_depth, debug_reads=debug_reads or None, debug_pos=debug_pos or None)
     max_k = int(np.diff(off).max()) if len(rank) else 0
     hansel = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, vcf_handler["N"], band=max(1, max_k - 1), **hansel_kw)
     n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels)

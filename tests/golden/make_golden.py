@@ -27,6 +27,12 @@ CASES = [
     dict(name="synth_60_k4_B_mt", n_snps=60, n_reads=1500, k=4, seed=3, paths=8, spec=dict(cond_mode="B", marginal_term=True)),
     dict(name="synth_60_k4_C_f64", n_snps=60, n_reads=1500, k=4, seed=3, paths=8, spec=dict(cond_mode="C", storage="f64")),
     dict(name="synth_90_kvar_A", n_snps=90, n_reads=1200, k=None, seed=7, paths=6, spec=dict()),
+    # round 3: the switches added for the naive-Bayes readings of the published method and for the candidate dict
+    dict(name="synth_60_k4_C_mt", n_snps=60, n_reads=1500, k=4, seed=3, paths=8, spec=dict(cond_mode="C", marginal_term=True)),
+    dict(name="synth_60_k4_E_mt", n_snps=60, n_reads=1500, k=4, seed=3, paths=8, spec=dict(cond_mode="E", marginal_term=True)),
+    dict(name="synth_60_k4_E_f64", n_snps=60, n_reads=1500, k=4, seed=3, paths=8, spec=dict(cond_mode="E", storage="f64")),
+    dict(name="synth_90_kvar_D_order", n_snps=90, n_reads=1200, k=None, seed=7, paths=6, spec=dict(cond_mode="D", cand_order="-TGCA")),
+    dict(name="synth_60_k4_zero", n_snps=60, n_reads=1500, k=4, seed=3, paths=8, spec=dict(offer_zero=True)),
 ]
 
 
@@ -52,8 +58,13 @@ def run(case):
 
 
 if __name__ == "__main__":
-    vec = [run(c) for c in CASES]
+    # cases are only ever APPENDED: every case carries its own reads, so a vector made in an earlier round keeps pinning
+    # the oracle even when gretel_amd.synth (which only helped to draw them) changes
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_vectors.json")
+    doc = json.load(open(path)) if os.path.exists(path) else dict(note="oracle-defined, not hanselx-verified; see make_golden.py", cases=[])
+    have = {c["name"] for c in doc["cases"]}
+    new = [run(c) for c in CASES if c["name"] not in have]
+    doc["cases"] += new
     with open(path, "w") as fh:
-        json.dump(dict(note="oracle-defined, not hanselx-verified; see make_golden.py", cases=vec), fh, indent=1)
-    print("wrote", path, sum(len(c["records"]) for c in vec), "path records")
+        json.dump(doc, fh, indent=1)
+    print("wrote", path, "added", [c["name"] for c in new])

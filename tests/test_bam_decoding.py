@@ -123,3 +123,24 @@ def test_match_runs_rebuild_the_coverage_counts(tmp_path):
             ok = c < 4
             np.add.at(cov, (c[ok], p[ok]), 1)
         assert np.array_equal(cov, bamio.native_count_coverage(bam, contig, a, b))
+
+
+def test_debug_prints_and_depth_cap(capsys):
+    """--debugreads / --debugpos (gretel/util.py:211-224) and the opt-in max_depth of the pileup the reference inherits, on the
+    reference's own fixture: read keys are name_flag_1or2 (util.py:160), positions 1-based."""
+    import io
+    from gretel_amd import util
+    v = util.process_vcf(VCF, 'hoot', 1, 20)
+    out = io.StringIO()
+    rank, off, bases = util.support_table_from_bam(BAM, 'hoot', 1, 20, v, debug_reads={"read1"}, debug_pos={2}, debug_out=out)
+    ref = util.support_table_from_bam(BAM, 'hoot', 1, 20, v)
+    assert np.array_equal(rank, ref[0]) and np.array_equal(off, ref[1]) and np.array_equal(bases, ref[2])
+    lines = out.getvalue().splitlines()
+    assert "read1_0_0 1 A" in lines and "read1_0_0 2 A" in lines and "read1_0_0 10 A" in lines and "RANK read1_0_0 0" in lines
+    at2 = [l for l in lines if l.split()[1] == "2" and not l.startswith("RANK")]
+    assert len(at2) >= 4                                  # every read covering position 2 is listed for --debugpos
+    # depth cap: with one read allowed open at a time only the first of the reads starting together survives
+    r1 = util.support_table_from_bam(BAM, 'hoot', 1, 20, v, max_depth=1)
+    assert 0 < len(r1[0]) < len(ref[0])
+    r9 = util.support_table_from_bam(BAM, 'hoot', 1, 20, v, max_depth=8000)
+    assert np.array_equal(r9[2], ref[2])
