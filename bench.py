@@ -301,6 +301,7 @@ def bench_batch(args, cfg_name, paths, desc, rank, world, local, dev):
 
     for _ in range(desc["warmup"]):
         step()
+    batch.profile_enable(10)
     fence()
     t0 = time.perf_counter()
     n_paths = 0
@@ -317,7 +318,17 @@ def bench_batch(args, cfg_name, paths, desc, rank, world, local, dev):
         dt, n_paths = float(tmax[0]), float(tsum[1])
     if rank == 0:
         t = tables[0]
+        bp = batch.profile_get()
+        rw = bp["reweight"]
+        rw_ms = rw["ms"] / max(1, rw["launches"])
         print(json.dumps({
+            "roofline": {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)",
+                         "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
+                         "algorithmic_bytes_per_launch": rw["bytes_per_launch"],
+                         "achieved": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9) if rw_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rw_ms > 0 else None,
+                         "traffic": None, "kernel_source_sha": kernel_source_sha(),
+                         "note": "window groups on their own streams overlap: a bracket around one group's launch also waits for the others' kernels"},
             "metric": "haplotypes/sec, batched windows (throughput mode)", "value": n_paths / dt, "unit": "haplotypes/s",
             "n_gpus": world, "steps": desc["steps"], "warmup": desc["warmup"], "ms_per_step": dt / desc["steps"] * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 counts / f64 log-likelihoods",
@@ -592,13 +603,39 @@ def main():
                 for hh in hs:
                     hh.fill_from_support(None, None, None, reads_handle=reads)
                 hb = HanselBatch(hs)
+                hb.profile_enable(10)
                 torch.cuda.synchronize()
                 tb = time.perf_counter()
                 rb = hb.spin(paths)
                 tb = time.perf_counter() - tb
+                bp = hb.profile_get()
+                rw, wk = bp["reweight"], bp["walk"]
+                rw_ms = rw["ms"] / max(1, rw["launches"])
+                wk_ms = wk["ms"] / max(1, wk["launches"])
+                tm_traffic, tm_note = None, "no PMC profile for the batched kernels of this build"
+                try:
+                    pmb = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic_batch256.json")))
+                    if pmb.get("kernel_source_sha") == src_sha:
+                        tm_traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pmb["kernels"].items() if k.startswith("k_marg<float, true>"))
+                        tm_note = "profiles/r3_pmc_traffic_batch256.json (git %s): bytes per batched launch over all windows of a group" % pmb.get("git_head")
+                    else:
+                        tm_note = "profiles/r3_pmc_traffic_batch256.json was taken with kernel sources %s, this build is %s: not quoted" % (pmb.get("kernel_source_sha"), src_sha)
+                except Exception as exc:
+                    tm_note = "no usable PMC profile: %r" % (exc,)
                 out["throughput_mode_256"] = {"windows": reps, "value": sum(r["n"] for r in rb) / tb, "unit": "haplotypes/s",
                                               "note": "256 replicas of the benchmark contig, one batched spin of %d paths each (fill not included, "
-                                                      "results copied back to the host included)" % paths}
+                                                      "results copied back to the host included)" % paths,
+                                              "roofline": {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)",
+                                                           "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
+                                                           "algorithmic_bytes_per_launch": rw["bytes_per_launch"],
+                                                           "achieved": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9) if rw_ms > 0 else None,
+                                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                           "frac": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rw_ms > 0 else None,
+                                                           "traffic": tm_traffic, "traffic_source": tm_note,
+                                                           "hip_event_sampling": "every 10th path, first window group (%d launches)" % rw["launches"]},
+                                              "extension": {"kernel": "k_walk_spec (one serial walker per window)", "windows_per_launch": wk["windows"],
+                                                            "avg_launch_ms_hip_events": wk_ms, "algorithmic_bytes_per_launch": wk["bytes_per_launch"],
+                                                            "achieved_GBs": (wk["bytes_per_launch"] / (wk_ms * 1e-3) / 1e9) if wk_ms > 0 else None}}
                 del hb, hs
             except Exception as exc:
                 out["throughput_mode_256"] = {"error": repr(exc)}

@@ -1882,6 +1882,11 @@ struct gh_batch {
     gh_path_rec *d_recs;
     double *d_partial;
     int cap_paths, nb;
+    int prof_every;             // gh_batch_profile_enable
+    std::vector<hipEvent_t> pev[2];     // [0] extension, [1] reweight: start/stop pairs of the last spin (group 0's stream)
+    size_t pused[2];
+    int prof_windows;
+    double prof_bytes[2];
 };
 
 extern "C" int gh_batch_destroy(gh_batch_t *b)
@@ -1894,6 +1899,8 @@ extern "C" int gh_batch_destroy(gh_batch_t *b)
         if (b->gstream[g]) { hipStreamSynchronize(b->gstream[g]); hipStreamDestroy(b->gstream[g]); }
         if (b->gevent[g]) hipEventDestroy(b->gevent[g]);
     }
+    for (int k = 0; k < 2; k++)
+        for (hipEvent_t e : b->pev[k]) hipEventDestroy(e);
     if (b->stream) hipStreamDestroy(b->stream);
     delete b;
     return GH_OK;
@@ -1921,6 +1928,7 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
     for (int g = 0; g < 3; g++) { b->gstream[g] = nullptr; b->gevent[g] = nullptr; }
     b->cap_paths = 0;
+    b->prof_every = 0; b->pused[0] = b->pused[1] = 0; b->prof_windows = 0; b->prof_bytes[0] = b->prof_bytes[1] = 0.0;
     b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_marg<.., true>
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_wd, sizeof(win_desc) * n);
@@ -2027,6 +2035,15 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         if (!b->gstream[g]) HIPCHK(hipStreamCreateWithFlags(&b->gstream[g], hipStreamNonBlocking));
         if (!b->gevent[g]) HIPCHK(hipEventCreateWithFlags(&b->gevent[g], hipEventDisableTiming));
     }
+    b->pused[0] = b->pused[1] = 0;
+    auto pmark = [&](int k, hipStream_t st) {            // one event of a start/stop pair of kernel k
+        if (b->pused[k] >= b->pev[k].size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            b->pev[k].push_back(e);
+        }
+        hipEventRecord(b->pev[k][b->pused[k]++], st);
+    };
     for (int s = 0; s < max_paths; s++) {
         // any non-null pointer tells k_lt that the fused reweight of spin s-1 has already rewritten the rows it changed
         const uint8_t *inc = (s > 0 && inc_mode) ? b->d_paths : nullptr;
@@ -2060,8 +2077,12 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                                    h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                    (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
                                    inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm);
+            const bool sample = g == 0 && b->prof_every > 0 && s > 0 && (s % b->prof_every) == 0;
+            if (sample) { b->prof_windows = ng; pmark(0, st); }
             launch_walk_any(bwm, N, L, P, st, ng, gwd, s);
+            if (sample) pmark(0, st);
             if (s == 0 && g + 1 < NG) hipEventRecord(b->gevent[g], st);
+            if (sample) pmark(1, st);
             if (f64)
                 hipLaunchKernelGGL((k_marg<double, true>), dim3(marg_gx, ng), dim3(256), 0, st, (double *)nullptr, N, W,
                                    (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
@@ -2074,6 +2095,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                                    (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 1, (double *)nullptr, s,
                                    inc_mode ? (double *)b->d_paths : (double *)nullptr, L, h0->cfg.cond_mode, (const double *)nullptr, (gh_path_rec *)nullptr,
                                    h0->sm, h0->cfg.offer_zero, (double *)nullptr);   // non-null = take G from wd
+            if (sample) pmark(1, st);
             hipLaunchKernelGGL(k_reweight_finish, dim3(ng), dim3(256), 0, st, (const double *)nullptr, (int)marg_gx,
                                (dev_state *)nullptr, 1, (gh_path_rec *)nullptr, gwd, s);
         }
@@ -2084,6 +2106,14 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     }
     for (int g = 0; g < NG; g++) HIPCHK(hipStreamSynchronize(b->gstream[g]));
     HIPCHK(hipGetLastError());
+    {
+        // algorithmic bytes per window and launch (launch_walk / launch_reweight_marg use the same definitions)
+        const double es = f64 ? 8.0 : 4.0;
+        const int wl = W < L ? W : L;
+        b->prof_bytes[0] = (double)N * ((1.0 + (double)L) * CELL * es + 28.0);
+        b->prof_bytes[1] = (double)(N + 1) * ((double)W * 2.0 * es + 1.0 + CELL * es + 2 * 64 + 88 + 8) +
+                           (inc_mode ? (double)N * ((double)wl * 7 * es + (double)L * LT_ROW * 8.0) : 0.0);
+    }
     std::vector<dev_state> hs(n);
     for (int w = 0; w < n; w++)
         HIPCHK(hipMemcpyAsync(&hs[w], b->hs[w]->dstate, sizeof(dev_state), hipMemcpyDeviceToHost, b->stream));
@@ -2096,6 +2126,30 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true;
         b->hs[w]->lt_inc_path = nullptr;       // the batch reweighted many paths and maintains no walker tables: rebuild in full
     }
+    return GH_OK;
+}
+
+extern "C" int gh_batch_profile_enable(gh_batch_t *b, int every)
+{
+    if (!b) return fail(GH_ERR_ARG, "null batch");
+    b->prof_every = every > 0 ? every : 0;
+    return GH_OK;
+}
+
+extern "C" int gh_batch_profile_get(gh_batch_t *b, int kernel, double *total_ms, int64_t *launches, int32_t *windows, double *bytes_per_launch)
+{
+    if (!b || (kernel != GH_K_WALK && kernel != GH_K_REWEIGHT)) return fail(GH_ERR_ARG, "bad argument");
+    const int k = kernel == GH_K_WALK ? 0 : 1;
+    double ms = 0.0;
+    int64_t n = 0;
+    for (size_t q = 0; q + 1 < b->pused[k]; q += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, b->pev[k][q], b->pev[k][q + 1]) == hipSuccess) { ms += t; n++; }
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = n;
+    if (windows) *windows = b->prof_windows;
+    if (bytes_per_launch) *bytes_per_launch = b->prof_bytes[k] * b->prof_windows;
     return GH_OK;
 }
 

@@ -433,6 +433,18 @@ class HanselBatch:
         except Exception:
             pass
 
+    def profile_enable(self, every=10):
+        """HIP events around the batched extension and the batched reweight of every `every`-th path (first window group)."""
+        check(self._lib.gh_batch_profile_enable(self._b, int(every)))
+
+    def profile_get(self):
+        out = {}
+        for name in ("walk", "reweight"):
+            ms, n, w, by = C.c_double(), C.c_int64(), C.c_int32(), C.c_double()
+            check(self._lib.gh_batch_profile_get(self._b, _lib.GH_K[name], C.byref(ms), C.byref(n), C.byref(w), C.byref(by)))
+            out[name] = dict(ms=ms.value, launches=n.value, windows=w.value, bytes_per_launch=by.value)
+        return out
+
     def spin(self, max_paths=100, min_remove=0.01):
         n = len(self.hansels)
         n1 = self.hansels[0].n + 1

@@ -169,6 +169,13 @@ int gh_batch_create(gh_t **handles, int n, gh_batch_t **out);
 int gh_batch_destroy(gh_batch_t *b);
 int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
                   int *n_out, int *hole_at);
+/* HIP-event timing of the batched kernels (bench.py's roofline of the throughput mode): every = k > 0 brackets the batched
+ * launches of every k-th path of the FIRST window group on its stream (0 = off).  gh_batch_profile_get: kernel GH_K_WALK
+ * (the batched serial extension) or GH_K_REWEIGHT (the fused reweight k_marg<T,true>) of the last gh_batch_spin --
+ * milliseconds summed over the sampled launches, their number, the windows one such launch covers, and the algorithmic
+ * bytes per launch (per window x windows; the definitions of DESIGN.md section 3). */
+int gh_batch_profile_enable(gh_batch_t *b, int every);
+int gh_batch_profile_get(gh_batch_t *b, int kernel, double *total_ms, int64_t *launches, int32_t *windows, double *bytes_per_launch);
 
 /* tensor export/import for --dumpmatrix (gretel/cmd.py:81-82) and tests:
  * band layout [(N+2)][band][7][7] as doubles; dense layout [7][7][N+2][N+2] (gretel/cmd.py:76-77). */

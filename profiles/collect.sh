@@ -1,27 +1,38 @@
 #!/bin/bash
 # Profiles of one round, to be run on the GPU box from the repo root:
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r2'
-# Kernel trace and the two PMC passes are separate runs (never combined with other trace domains); rocprofv3 is
-# given python3 directly.  Summaries are then copied from gpurun_out/prof_<round>/ into profiles/ by hand
-# (profiles/pmc_summarize.py for the counters).
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r3'
+# Kernel trace and the PMC passes are separate runs (never combined with other trace domains); rocprofv3 is given python3
+# directly.  Back in the build container the summaries are made from gpurun_out/prof_<round>/ (where git is):
+#   cp gpurun_out/prof_r3/bench_default.json profiles/r3_bench_default.json   (... c2, c5, batch256, 2 ranks, fused)
+#   cp gpurun_out/prof_r3/kt/kt_kernel_stats.csv profiles/r3_kernel_stats_bench_c3.csv   (... kt_c5, kt_b256)
+#   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc > profiles/r3_pmc_traffic.json
+#   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc_c5 > profiles/r3_pmc_traffic_c5.json
+#   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc_b256 > profiles/r3_pmc_traffic_batch256.json
+#   python profiles/seg_isa_count.py > profiles/r3_seg_isa.json          (no GPU needed)
 set -u
-R=${1:-r2}
+R=${1:-r3}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --config C2 > $out/bench_c2.json 2> $out/bench_c2.err
 python3 bench.py --config C5 --steps 2 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err
-python3 bench.py --gpus 2 --backend gloo --share-gpu --steps 3 --no-cpu-baseline --no-throughput-leg --no-e2e > $out/bench_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
+python3 bench.py --gpus 2 --backend gloo --share-gpu --steps 3 --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
 python3 bench.py --batch 256 --steps 1 --warmup 1 > $out/bench_batch256.json 2> $out/bench_batch256.err
+GH_FUSE=1 python3 bench.py --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_three_launches.json 2> $out/bench_three_launches.err
+python3 scratch/l_sweep.py > $out/l_sweep.txt 2>&1
 if [ "${2:-}" = "cpu-full" ]; then
-  python3 bench.py --config C2 --steps 2 --cpu-full --no-throughput-leg --no-e2e > $out/bench_c2_cpu_full.json 2> $out/bench_c2_cpu_full.err
-  python3 bench.py --steps 2 --cpu-full --no-throughput-leg --no-e2e > $out/bench_c3_cpu_full.json 2> $out/bench_c3_cpu_full.err
+  python3 bench.py --config C2 --steps 2 --cpu-full --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_c2_cpu_full.json 2> $out/bench_c2_cpu_full.err
+  python3 bench.py --steps 2 --cpu-full --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_c3_cpu_full.json 2> $out/bench_c3_cpu_full.err
 fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-throughput-leg --no-e2e > $out/bench_under_rocprof.json 2> $out/kt.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c5 -o kt_c5 -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-leg --no-e2e > $out/bench_c5_under_rocprof.json 2> $out/kt_c5.err
+Q="--no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $Q > $out/bench_under_rocprof.json 2> $out/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c5 -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --steps 1 --warmup 1 $Q > $out/bench_c5_under_rocprof.json 2> $out/kt_c5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_b256 -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --batch 256 --steps 1 --warmup 1 > $out/bench_batch256_under_rocprof.json 2> $out/kt_b256.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-throughput-leg --no-e2e > $out/pmc_$c.json 2> $out/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 $Q > $out/pmc_$c.json 2> $out/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_c5_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --paths 100 --steps 1 --warmup 0 $Q > $out/pmc_c5_$c.json 2> $out/pmc_c5_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_b256_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --batch 256 --paths 20 --steps 1 --warmup 0 > $out/pmc_b256_$c.json 2> $out/pmc_b256_$c.err
 done
-find $out -name "*.csv" | head -40
+find $out -name "*.csv" | head -60

@@ -2,7 +2,11 @@
 
 FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced
 reads (MI355X_MICROARCH.md, HBM / rocprofv3 section), hence the x2.  Usage:
-    python profiles/pmc_summarize.py gpurun_out/prof_r1 > profiles/r1_pmc_traffic.json
+    python profiles/pmc_summarize.py gpurun_out/prof_r3 [pmc] > profiles/r3_pmc_traffic.json
+(second argument: the prefix of the two pass directories, pmc -> pmc_FETCH_SIZE / pmc_WRITE_SIZE; pmc_c5, pmc_b256 likewise).
+The summary records the build it belongs to: kernel_source_sha (what bench.py printed in that very run: a hash over the
+kernel sources, the GPU box has no .git) and the git HEAD of the tree the summary is made in -- bench.py quotes a
+traffic figure only for the build it was measured on.
 """
 import collections
 import csv
@@ -17,11 +21,11 @@ def short(name):
     return re.sub(r"\(.*$", "", name)
 
 
-def main(root):
+def main(root, prefix="pmc"):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     launches = collections.defaultdict(lambda: collections.defaultdict(int))
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        for path in glob.glob("%s/pmc_%s/**/*counter_collection.csv" % (root, ctr), recursive=True):
+        for path in glob.glob("%s/%s_%s/**/*counter_collection.csv" % (root, prefix, ctr), recursive=True):
             for row in csv.DictReader(open(path)):
                 if row["Counter_Name"] != ctr:
                     continue
@@ -32,6 +36,16 @@ def main(root):
                       "--warmup 0 --no-cpu-baseline --no-throughput-leg (two separate passes, profiles/collect.sh)",
            "correction": "FETCH_SIZE x2 (gfx950 reports half of wide coalesced reads), WRITE_SIZE as is, x1024 (KB -> bytes)",
            "kernels": {}}
+    import os
+    import subprocess
+    try:
+        line = [l for l in open("%s/%s_FETCH_SIZE.json" % (root, prefix)) if l.startswith("{")][-1]
+        out["kernel_source_sha"] = json.loads(line)["roofline"]["kernel_source_sha"]
+    except Exception:
+        out["kernel_source_sha"] = None
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out["git_head"] = subprocess.run(["git", "-C", here, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    out["git_dirty"] = bool(subprocess.run(["git", "-C", here, "status", "--porcelain", "--", "gretel_amd/csrc", "include"], capture_output=True, text=True).stdout.strip())
     for k in acc:
         n = max(launches[k].values())
         f = acc[k]["FETCH_SIZE"] / max(1, launches[k]["FETCH_SIZE"])
@@ -43,4 +57,4 @@ def main(root):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r1")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r3", sys.argv[2] if len(sys.argv) > 2 else "pmc")
