@@ -170,7 +170,10 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
         if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;      // (the flags stand until k_cemit re-arms them)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->cur_hole = c.first_hole;      // (the flags stand until k_cemit re-arms them)
+        if (P.round == 0) st->cw_open_at = 0;           // a new path: its chain is open until a k_cscan says otherwise (round 0's may be skipped)
+    }
     const cw_geom g = cw_geometry(P.N, P.L);
     const int s = blockIdx.x, tid = threadIdx.x;
     if (s >= g.S) return;

@@ -194,9 +194,11 @@ def test_run_on_changes_nothing(L, dels, monkeypatch):
     assert h.walk_clock()[3] == 4
     assert np.array_equal(h.export_band(), o.export_band())
     monkeypatch.setenv("GH_CW_RUNON", "0")
+    monkeypatch.setenv("GH_CW_SKIP0", "0")              # ... and with the chain followed behind every round, the first included
     h0, _ = _pair(t, L=L)
     _same(h0.spin(30), ref)
     monkeypatch.delenv("GH_CW_RUNON")
+    monkeypatch.delenv("GH_CW_SKIP0")
     monkeypatch.setenv("GH_CW_ROUND_CAP", "1")
     h1, _ = _pair(t, L=L)
     _same(h1.spin(30), ref)
