@@ -93,6 +93,7 @@ struct gh_handle {
                                   // for the three-launch spins (GH_FUSE at creation); nullptr goes to the kernels otherwise (C5: k_rw is bound by its stores)
     symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
     double *lt;
+    bool ht_stale;                // an incremental refresh left the depth-2 walker's tables (ht, yt) out: a full rebuild before they are read
     bool lt_baked;                // lt holds the marginal term in its lag-1 entries (built for a serial walker; only with cfg.marginal_term)
     double *ht, *yt;              // depth-2 walker tables derived from lt (k_lt), when walk_depth2_ok(L)
     unsigned long long fill_seen[6];   // host mirror of dstate->fill as last read (the counters only move under this handle's calls)
@@ -333,7 +334,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memset(h->cfg.cand_order, 0, sizeof h->cfg.cand_order);
     memcpy(h->cfg.cand_order, order, 5);
     h->sm = make_symmap(order);
-    h->rinfo = nullptr; h->lt_baked = false;
+    h->rinfo = nullptr; h->lt_baked = false; h->ht_stale = false;
     h->need_rinfo = cfg->marginal_term != 0 || (getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1);
     h->dev = dev;
     h->N = cfg->n_snps;
@@ -751,14 +752,17 @@ static bool seg_ok(int wm, int L);
 
 // baked: the table is for a serial walker, which reads whole rows: with the marginal term its lag-1 entries hold lm + x1
 // (k_lt); the segment-parallel walks want the bare conditionals and add lm themselves
-static int ensure_lt(gh_handle *h, bool baked = false)
+// derived = false (the candidate pools' looks): the depth-2 serial walker's tables Ht / Yt are left alone -- nobody reads them
+// until a serial walk, in front of which the table is rebuilt in full anyway (45 us per look at C5 otherwise)
+static int ensure_lt(gh_handle *h, bool baked = false, bool derived = true)
 {
     int rc = ensure_marg(h);
     if (rc) return rc;
     const bool want_baked = baked && h->cfg.marginal_term;
-    if (!h->dirty_lt && h->lt && h->lt_L == h->L && h->lt_baked == want_baked) return GH_OK;
+    const bool need_derived = derived && h->ht_stale;
+    if (!h->dirty_lt && h->lt && h->lt_L == h->L && h->lt_baked == want_baked && !need_derived) return GH_OK;
     if ((rc = alloc_lt(h))) return rc;
-    const bool inc_ok = h->lt_inc_path && lt_incremental_ok(h) && h->lt_baked == want_baked;
+    const bool inc_ok = h->lt_inc_path && lt_incremental_ok(h) && h->lt_baked == want_baked && !need_derived;
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
     const size_t total = inc ? (size_t)h->N * 4 : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
@@ -768,11 +772,13 @@ static int ensure_lt(gh_handle *h, bool baked = false)
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, want_baked ? 1 : 0, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt, h->sm);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L),
+                           derived ? h->ht : (double *)nullptr, derived ? h->yt : (double *)nullptr, h->sm);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, want_baked ? 1 : 0, h->cnt, h->nvalid, h->cmask,
-                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L), h->ht, h->yt, h->sm);
+                           h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L),
+                           derived ? h->ht : (double *)nullptr, derived ? h->yt : (double *)nullptr, h->sm);
     const int wl = h->W < h->L ? h->W : h->L;
     // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
     prof_end(h, GH_K_LT, inc ? 8.0
@@ -781,6 +787,8 @@ static int ensure_lt(gh_handle *h, bool baked = false)
     h->dirty_lt = false;
     h->lt_inc_path = nullptr;
     h->lt_baked = want_baked;
+    if (inc && !derived && h->ht) h->ht_stale = true;       // (a full build writes them from the band whatever `derived` says -- k_lt)
+    else if (!inc) h->ht_stale = !derived && h->ht != nullptr;
     return GH_OK;
 }
 
@@ -1630,7 +1638,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             const int upto = done + CHUNK < max_paths ? done + CHUNK : max_paths;
             // (conditional C / the marginal term: the reweight cannot keep the table current, k_lt rebuilds it in front of
             // every path -- queued like everything else; otherwise once per look, and k_cwalk checks the masks)
-            if ((rc = ensure_lt(h))) break;
+            if ((rc = ensure_lt(h, false, false))) break;
             const bool inc = rw_incremental_ok(h);
             for (int s = done; s < upto && rc == GH_OK; s++) {
                 h->cw_stamp++;
