@@ -13,20 +13,30 @@ import sys
 from . import bamio
 
 
-def coverage_on_gpu(bam, contig, start0, end, depth=0, device=-1, want_counts=False):
+def coverage_on_gpu(bam, contig, start0, end, depth=0, device=-1, want_counts=False, window=1 << 20):
     """(site mask uint8[end-start0], counts int32[4][end-start0] or None) from the GPU histogram (gh_coverage_sites)."""
     import ctypes as C
 
     import numpy as np
 
     from . import _lib
-    ref, off, codes = bamio.native_match_runs(bam, contig, start0, end)
     n = max(0, end - start0)
     site = np.zeros(n, dtype=np.uint8)
     counts = np.zeros((4, n), dtype=np.int32) if want_counts else None
-    _lib.check(_lib.load().gh_coverage_sites(int(device), ref.ctypes.data, off.ctypes.data, codes.ctypes.data, len(ref),
-                                            int(start0), int(n), int(depth),
-                                            counts.ctypes.data if want_counts else None, site.ctypes.data))
+    # one window of the contig at a time: the decoder hands over one byte per aligned base, and a deep BAM over a whole
+    # contig would not fit the host (the reference streams into a 4 x length array, snpper.py:29).  The runs are clipped to
+    # the window and a position's counts only need the reads that cover it, so the windows are independent.
+    for w0 in range(start0, end, window):
+        w1 = min(end, w0 + window)
+        ref, off, codes = bamio.native_match_runs(bam, contig, w0, w1)
+        wsite = np.zeros(w1 - w0, dtype=np.uint8)
+        wcounts = np.zeros((4, w1 - w0), dtype=np.int32) if want_counts else None
+        _lib.check(_lib.load().gh_coverage_sites(int(device), ref.ctypes.data, off.ctypes.data, codes.ctypes.data, len(ref),
+                                                int(w0), int(w1 - w0), int(depth),
+                                                wcounts.ctypes.data if want_counts else None, wsite.ctypes.data))
+        site[w0 - start0:w1 - start0] = wsite
+        if want_counts:
+            counts[:, w0 - start0:w1 - start0] = wcounts
     return site, counts
 
 

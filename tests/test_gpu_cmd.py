@@ -175,6 +175,11 @@ def test_snpper_gpu_histogram_matches_the_host_counter(tmp_path, capsys):
     contig, s, e = bamio.synth_to_files(t, bam, vcf)
     site, counts = snpper.coverage_on_gpu(bam, contig, 0, e, depth=0, want_counts=True)
     assert np.array_equal(counts, bamio.native_count_coverage(bam, contig, 0, e))
+    # the contig goes through in windows (bounded host memory): any window size gives the same counts and sites
+    site_w, counts_w = snpper.coverage_on_gpu(bam, contig, 0, e, depth=0, want_counts=True, window=777)
+    assert np.array_equal(counts_w, counts) and np.array_equal(site_w, site)
+    # a negative depth compares as the reference's `counts > depth` does: every base passes, every position is a site
+    assert snpper.call_sites(bam, contig, 5, 60, depth=-1) == snpper.call_sites(bam, contig, 5, 60, depth=-1, host=True) == list(range(5, 61))
     for depth in (0, 1, 3, 10):
         for (a, b) in ((1, None), (3000, 9000)):
             assert snpper.call_sites(bam, contig, a, b, depth) == snpper.call_sites(bam, contig, a, b, depth, host=True)
