@@ -117,6 +117,9 @@ struct gh_handle {
     double *seg_smin, *seg_gmin;   // minimum marginal per (segment, entry state) / per (group, entry state)
     uint8_t *cm5snap;      // [N+2] candidate bits as the last k_seg saw them
     size_t fuse_lds;       // LDS of k_rw's fused prologue for this spin's state space
+    void *seg_halo;        // k_rwseg: per segment, the band blocks of the L positions in front of it (k_emit's copy)
+    size_t seg_halo_bytes;
+    bool rws;              // inside a gh_spin whose paths run as k_rwseg + k_scan + k_emit (segwalk.hpp)
     bool fuse;             // inside a gh_spin over the enumerated states: no k_emit, k_rw chains the maps itself (segwalk.hpp)
     double *lmsel1;        // [N+1] selected log-marginals of a lone gh_generate_path
     double *spin_lmsel;    // [spin_cap][N+1] the same for every path of a spin
@@ -282,7 +285,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
     hipFree(h->seg_hist); hipFree(h->seg_maps); hipFree(h->seg_pmaps); hipFree(h->seg_gmaps); hipFree(h->seg_min); hipFree(h->lmsel1); hipFree(h->spin_lmsel);
-    hipFree(h->seg_smin); hipFree(h->seg_gmin); hipFree(h->cm5snap);
+    hipFree(h->seg_smin); hipFree(h->seg_gmin); hipFree(h->cm5snap); hipFree(h->seg_halo);
     if (h->stage) hipHostFree(h->stage);
     hipFree(h->ew_buf);
     hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
@@ -345,6 +348,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
     h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr; h->fuse = false;
+    h->seg_halo = nullptr; h->seg_halo_bytes = 0; h->rws = false;
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
     h->cw_pend_exit = nullptr; h->cw_pend_ready = nullptr; h->cw_phist = nullptr;
@@ -1073,6 +1077,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
+    P.rws = 0; P.W = h->W; P.esz = (int)esize(h); P.band = h->band; P.halo = h->rws ? h->seg_halo : nullptr; P.patch_off = 0;
     P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
     if (h->L < 1 || h->L > SEG_MAX_L_NARROW) return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L_NARROW);
     prof_begin(h, GH_K_WALK);
@@ -1086,6 +1091,81 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     }
     prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
     return post_launch(h, "k_seg/k_scan/k_emit");
+}
+
+// ---- k_rwseg: reweight of the path before + this path's k_seg in one launch, then k_scan, k_emit (segwalk.hpp) ----------
+static size_t rws_lds_bytes(int LC, bool five)
+{
+    size_t b = five ? max2(seg_lds_total(4, LC), seg_lds_total(5, LC)) : seg_lds_total(4, LC);
+    if (b < (size_t)SEG_THREADS * 8) b = (size_t)SEG_THREADS * 8;      // the reweight phase's reduction scratch
+    return (b + 15) & ~(size_t)15;
+}
+
+template <typename T, int LC, bool COL>
+static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
+{
+    constexpr bool five = seg_radix_ok(5, LC);
+    const int N = h->N;
+    const seg_geom g4 = seg_geometry(N, LC, 4), g5 = five ? seg_geometry(N, LC, 5) : g4;
+    const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
+    size_t off = rws_lds_bytes(LC, five);
+    if (COL) {
+        // column mode stages the band blocks of the workgroup's positions (halo + own) behind the reduction scratch
+        const int longest = g4.seglen > g5.seglen ? g4.seglen : g5.seglen;
+        const size_t need = (size_t)SEG_THREADS * 8 + (size_t)(longest + LC + 1) * NSYM * h->W * NSYM * sizeof(T);
+        if (need > off) off = (need + 15) & ~(size_t)15;
+    }
+    const size_t lds = off + sizeof(seg_patch);
+    const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
+    const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
+    static std::atomic<size_t> set_rws[64], set_scan[64], set_emit[64];
+    const int dv = h->dev & 63;
+    if (lds > set_rws[dv]) { hipFuncSetAttribute((const void *)k_rwseg<T, LC, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_rws[dv] = lds; }
+    if (lds_scan > set_scan[dv]) { hipFuncSetAttribute((const void *)k_scan<LC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scan); set_scan[dv] = lds_scan; }
+    if (lds_emit > set_emit[dv]) { hipFuncSetAttribute((const void *)k_emit<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit); set_emit[dv] = lds_emit; }
+    P.patch_off = (int)off;
+    P.rws = 1;
+    prof_begin(h, GH_K_SEG);
+    hipLaunchKernelGGL((k_rwseg<T, LC, COL>), dim3(S), dim3(SEG_THREADS), lds, h->stream, P, Q);
+    prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
+    hipLaunchKernelGGL((k_scan<LC, false>), dim3(G1), dim3(SEG_THREADS), lds_scan, h->stream, P);
+    hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, h->stream, P);
+}
+
+// reweights along d_prev (record d_prev_rec, removed mass into slot prev_slot) and walks the next path into d_path
+static int launch_rwseg(gh_handle *h, const uint8_t *d_prev, gh_path_rec *d_prev_rec, int prev_slot, double min_remove,
+                        uint8_t *d_path, double *d_lmsel, int check_masks)
+{
+    int rc = alloc_seg(h);
+    if (rc) return rc;
+    seg_params P;
+    P.N = h->N; P.L = h->L; P.rearm = 1; P.check_masks = check_masks;
+    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
+    P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
+    P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
+    P.rws = 1; P.W = h->W; P.esz = (int)esize(h); P.band = h->band; P.halo = h->seg_halo; P.patch_off = 0;
+    P.path_out = d_path; P.lmsel = d_lmsel;
+    rws_params Q;
+    Q.band = h->band; Q.cnt = h->cnt; Q.marg = h->marg; Q.minfo = h->minfo; Q.rinfo = h->need_rinfo ? h->rinfo : nullptr; Q.G = h->lt;
+    Q.nvalid = h->nvalid; Q.cmask = h->cmask; Q.path = d_prev; Q.min_remove = min_remove;
+    Q.partial = h->partial + (size_t)prev_slot * h->spin_partial_stride;
+    Q.rec = d_prev_rec; Q.cond_mode = h->cfg.cond_mode; Q.offer_zero = h->cfg.offer_zero;
+    prof_begin(h, GH_K_WALK);
+    const bool f64 = h->cfg.storage == GH_STORAGE_F64;
+    const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;
+    switch (h->L) {
+#define RWS_CASE(n) case n: if (f64) { if (col) launch_rwseg_lc<double, n, true>(h, P, Q); else launch_rwseg_lc<double, n, false>(h, P, Q); } \
+                            else { if (col) launch_rwseg_lc<float, n, true>(h, P, Q); else launch_rwseg_lc<float, n, false>(h, P, Q); } break;
+        RWS_CASE(1) RWS_CASE(2) RWS_CASE(3) RWS_CASE(4) RWS_CASE(5) RWS_CASE(6)
+#undef RWS_CASE
+        default: return fail(GH_ERR_STATE, "k_rwseg needs L <= %d", SEG_MAX_L_NARROW);
+    }
+    prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
+    // (what launch_reweight_marg notes behind a fused reweight: the table is current up to the rows this path's reweight wrote)
+    h->lt_inc_path = d_prev;
+    h->dirty_lt = true;
+    h->dirty_marg = false;
+    return post_launch(h, "k_rwseg/k_scan/k_emit");
 }
 
 // serial walkers: the record is closed by the walker itself.  Segment-parallel: by the k_marg<T,true> that follows
@@ -1807,9 +1887,38 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             }
         }
     }
-    const int nb = rw_blocks(h, seg || cw_ok(h->wmode, h->L));       // (the widest reweight kernel this spin may launch)
+    // k_rwseg (segwalk.hpp): the reweight of a path rides in the k_seg launch of the next one.  Row conditionals, lane groups of 8,
+    // windows whose k_scan / k_emit are separate launches, at most 128 positions per workgroup with the halo.
+    h->rws = false;
+    int rws_S = 0;
+    if (rc == GH_OK && seg && !h->fuse && !h->lt_full && rw_lanes(h) == 8 &&
+        !(getenv("GH_RWSEG") && atoi(getenv("GH_RWSEG")) == 0)) {
+        const bool five = seg_radix_ok(5, h->L);
+        const seg_geom g4 = seg_geometry(h->N, h->L, 4), g5 = five ? seg_geometry(h->N, h->L, 5) : g4;
+        const bool small = (five ? max2(emit_small_lds_bytes(h->N, h->L, 4), emit_small_lds_bytes(h->N, h->L, 5)) : emit_small_lds_bytes(h->N, h->L, 4)) <= 64 * 1024 &&
+                           !(getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0);
+        const int longest = g4.seglen > g5.seglen ? g4.seglen : g5.seglen;
+        if (!small && longest + h->L + 1 <= SEG_THREADS / 8 && (rc = alloc_seg(h)) == GH_OK) {
+            rws_S = g4.S > g5.S ? g4.S : g5.S;
+            const size_t need = (size_t)rws_S * h->L * NSYM * h->W * NSYM * esize(h);
+            if (need > h->seg_halo_bytes) {
+                HIPCHK(hipStreamSynchronize(h->stream));
+                hipFree(h->seg_halo); h->seg_halo = nullptr; h->seg_halo_bytes = 0;
+                if (hipMalloc(&h->seg_halo, need) != hipSuccess) rc = fail(GH_ERR_NOMEM, "hipMalloc failed");
+                else h->seg_halo_bytes = need;
+            }
+            h->rws = rc == GH_OK;
+        }
+    }
+    int nb = rw_blocks(h, seg || cw_ok(h->wmode, h->L));       // (the widest reweight kernel this spin may launch)
+    if (h->rws && rws_S > nb) nb = rws_S;                       // ... k_rwseg leaves one partial sum per segment
     h->spin_partial_stride = nb;
     if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);       // L only changes through gh_set_L / gh_fill, never inside a spin
+    if (rc == GH_OK && h->rws) {
+        // (every slot is summed over the whole stride: what a kernel with fewer workgroups leaves untouched must read 0)
+        e = hipMemsetAsync(h->partial, 0, sizeof(double) * (size_t)nb * max_paths, h->stream);
+        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+    }
     // Segment-parallel walks with a conditional table that the fused reweight keeps current (conditional A/B, no marginal
     // term): no k_lt between two paths.  Its only job there is to notice that a candidate mask moved (a count reached
     // zero; rare) and rebuild the table; instead the next k_seg sees the flag k_marg left, marks the table stale and the
@@ -1837,8 +1946,18 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         int launched = first;
         for (int s = first; s < max_paths && rc == GH_OK; s++) {
             if (!optimistic || s == first) { if ((rc = ensure_lt(h, !seg))) break; }
-            if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1, h->spin_lmsel + n1 * s,
-                                  !(optimistic && s > first) ? 0 : (s == h->force_stale_at && h->spin_requeues == 0 ? 2 : 1)))) break;
+            const int cmk = !(optimistic && s > first) ? 0 : (s == h->force_stale_at && h->spin_requeues == 0 ? 2 : 1);
+            if (h->rws) {
+                // path s is walked by the launch that reweights path s - 1; the last path's reweight is a plain k_rw
+                if (s == first) rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1, h->spin_lmsel + n1 * s, cmk);
+                else rc = launch_rwseg(h, d_paths + n1 * (s - 1), d_recs + (s - 1), s - 1, min_remove, d_paths + n1 * s, h->spin_lmsel + n1 * s, cmk);
+                if (rc == GH_OK && s == max_paths - 1)
+                    rc = launch_reweight_marg(h, d_paths + n1 * s, min_remove, 1, d_recs + s, s, true, s > first, 0, h->spin_lmsel + n1 * s);
+                if (rc) break;
+                launched = s + 1;
+                continue;
+            }
+            if ((rc = launch_walk(h, d_paths + n1 * s, d_recs + s, min_remove, 1, h->spin_lmsel + n1 * s, cmk))) break;
             if ((rc = launch_reweight_marg(h, d_paths + n1 * s, seg ? min_remove : 0.0, 1, d_recs + s, s, seg, optimistic && s > first, 0,
                                            h->spin_lmsel + n1 * s))) break;
             launched = s + 1;
@@ -1876,6 +1995,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     h->spin_partial_stride = 0;
     h->seg6 = false;
     h->fuse = false;
+    h->rws = false;
     if (rc) return rc;
     *n_out = hs.n_done;
     *hole_at = hs.stop ? hs.hole_at : 0;

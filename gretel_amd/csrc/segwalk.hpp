@@ -52,6 +52,13 @@ struct seg_params {
     uint8_t *cm5snap;         // [N+2] candidate bits of every position as k_seg saw them (rank -> symbol for whoever emits)
     uint8_t *path_out;        // [N+1]
     double *lmsel;            // [N+1] log10 marginal of the selected symbol per position (for k_hp)
+    // k_rwseg (the reweight of the path before, fused into this path's k_seg launch): k_emit leaves, for every segment, a copy
+    // of the band blocks of the LC positions in front of it (they belong to its neighbour, who rewrites them in that launch)
+    int rws;                  // 1: k_scan takes over k_seg's look at the flags (they are only final when k_rwseg has ended)
+    int W, esz;               // band width, bytes per element
+    const void *band;
+    void *halo;               // [S][LC][7][W][7] elements
+    int patch_off;            // k_rwseg: byte offset of the halo rows in its dynamic LDS (behind k_seg's regions for either radix)
 };
 
 // -------------------------------------------------------------------------------------------------------------
@@ -90,8 +97,20 @@ __device__ __forceinline__ double vmin_f64(double a, double b)
 }
 
 // TRACK: spins without k_emit -- per entry state also the minimum marginal of its picks (smin)
+// halo rows of k_rwseg: for the LC positions in front of the segment, the table row of the path's symbol as it stands AFTER the
+// reweight this launch applies (the neighbour who owns those positions writes it to G in this very launch: what G holds
+// there when this workgroup stages its slice is one or the other)
+struct seg_patch {
+    double row[SEG_MAX_L_NARROW][SEG_MAX_L_NARROW][LT_ROW];   // [halo position][lag - 1][column]   (column mode: [..][..][digit row])
+    int row6[SEG_MAX_L_NARROW];                                // the row it replaces (digit), -1 = none
+    // conditionals C / E: a reweighted cell moves one COLUMN of the block of (position, lag) -- the entry of every digit row
+    int col[SEG_MAX_L_NARROW][SEG_MAX_L_NARROW];               // the column, -1 = none
+    unsigned rmask[SEG_MAX_L_NARROW][SEG_MAX_L_NARROW];        // the digit rows that exist
+    int colmode;
+};
+
 template <int R, int LC, bool TRACK>
-__device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *smem)
+__device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *smem, const seg_patch *patch = nullptr)
 {
     typedef typename seg_radix<R>::next_t next_t;
     constexpr int BITS = seg_radix<R>::BITS;
@@ -147,6 +166,37 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
             for (int b = 0; b < R; b++) dst[b] = v[b];
         }
         // the marginals of the columns at targets c0+1 .. c0+nc (by rank or by symbol, like the columns)
+        if (patch && c0 == t0 && t0 > 0) {
+            // the first chunk's slots 0 .. LC-1 are the halo sources t0+1-LC .. t0: their path rows from the patch
+            __syncthreads();
+            for (int e = tid; e < LC * LC * R; e += SEG_THREADS) {
+                const int b = e % R, l = (e / R) % LC, hp = e / (R * LC);
+                if (patch->colmode) {
+                    // column mode: b runs over the digit rows
+                    const int col = patch->col[hp][l];
+                    if (col >= 0 && col < R && ((patch->rmask[hp][l] >> b) & 1u)) {
+                        double v = patch->row[hp][l][b];
+                        if (P.mt && l == 0) {
+                            const int i = t0 + 1 - LC + hp;
+                            const double *lm = R == 4 ? P.rinfo + (size_t)(i + 1) * RINFO : P.minfo + (size_t)(i + 1) * MINFO;
+                            v = lm[col] + v;
+                        }
+                        Gs[((size_t)(hp * LC + l) * R + b) * R + col] = v;
+                    }
+                    continue;
+                }
+                const int d = patch->row6[hp];
+                if (d >= 0 && d < R) {
+                    double v = patch->row[hp][l][b];
+                    if (P.mt && l == 0) {
+                        const int i = t0 + 1 - LC + hp;
+                        const double *lm = R == 4 ? P.rinfo + (size_t)(i + 1) * RINFO : P.minfo + (size_t)(i + 1) * MINFO;
+                        v = lm[b] + v;
+                    }
+                    Gs[((size_t)(hp * LC + l) * R + d) * R + b] = v;
+                }
+            }
+        }
         if (TRACK) {
             for (int e = tid; e < nc * R; e += SEG_THREADS) {
                 const int tl = e / R, b = e - tl * R;
@@ -334,8 +384,18 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
     dev_state *st = P.st;
     const dev_ctl c = load_ctl(st);
     if (c.stop || c.lt_stale) return;
+    int cur_hole = c.cur_hole;
+    if (P.rws) {
+        // behind k_rwseg the flags of the reweight only stand now: k_seg's look at them happens here
+        if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
+            return;
+        }
+        cur_hole = c.first_hole;
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
+    }
     // (a path that ends in a hole is followed by no k_marg: the flags must stand, as after the serial walkers)
-    if (P.rearm && c.cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (P.rearm && cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
         st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f;
     }
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) scan_body<4, LC, TRACK>(P, seg_smem);
@@ -363,6 +423,14 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
     int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     if (t1 > Nw) t1 = Nw;
     if (s == 0 && tid == 0) { P.path_out[0] = SYM_US; P.lmsel[0] = 1.0; }      // gretel.py:138; k_hp: sums still to be taken
+    if (P.halo && s + 1 < g.S) {
+        // for k_rwseg: the band blocks of this segment's last LC positions (the halo of the next one) as they stand now
+        const int te = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+        const size_t words = (size_t)LC * NSYM * P.W * NSYM * P.esz / 4;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(static_cast<const unsigned char *>(P.band) + (size_t)(te + 1 - LC) * NSYM * P.W * NSYM * P.esz);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(static_cast<unsigned char *>(P.halo) + (size_t)(s + 1) * LC * NSYM * P.W * NSYM * P.esz);
+        for (size_t e = tid; e < words; e += SEG_THREADS) dst[e] = src[e];
+    }
     if (t0 >= t1) {
         if (tid == 0) P.segmin[s] = INFINITY;
         return;
@@ -1010,6 +1078,342 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         if (f & 4u) atomicAnd(&st->narrow, 0);
         if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
     }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_rwseg: the reweight of path k-1 and the k_seg of path k in ONE launch -- three dependent launches per path instead of
+// four, and the table rows a path's reweight writes are used by the very workgroup that wrote them.
+//
+// Workgroup s owns the positions of segment s (t0+1 .. t1; workgroup 0 also position 0) and does for them what k_rw does
+// (8 lanes per position: reweight the cells on the path, the marginals, the table row of the path's symbol) -- then walks
+// segment s as k_seg does.  Its k_seg needs the table rows of the LC positions in front of the segment too, and those are
+// rewritten by its neighbour in this same launch: it recomputes exactly those rows itself, from a copy of the neighbour's
+// band blocks that k_emit made one launch earlier (seg_params::halo), and patches them into its LDS slice.  No workgroup
+// waits for another, nothing is read that somebody else is writing (except, as in k_rw, nvalid / cmask of the targets,
+// which only count while no candidate mask moves).
+// The flags the reweight leaves (first hole, moved masks) are only final when the launch has ended: k_scan looks at them
+// (seg_params::rws).  COL (conditionals C, E): the cell's column instead of its row, the band blocks of the workgroup's positions
+// staged in LDS, the patch carries columns.  Lane groups of 8 (W <= 8), at most 128 positions per workgroup with the halo: gh_spin checks.
+// -------------------------------------------------------------------------------------------------------------
+struct rws_params {
+    void *band;
+    double *cnt, *marg, *minfo, *rinfo, *G;
+    int32_t *nvalid;
+    uint32_t *cmask;
+    const uint8_t *path;      // the path to reweight (k - 1)
+    double min_remove;
+    double *partial;          // removed mass, one per workgroup
+    gh_path_rec *rec;
+    int cond_mode, offer_zero;
+};
+
+template <typename T, int LC, bool COL>
+__device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_params &Q, const dev_ctl &c, unsigned char *smem, seg_patch *patch)
+{
+    const int N = P.N, W = P.W, L = LC, tid = threadIdx.x, sblk = blockIdx.x;
+    const symmap sm = P.sm;
+    dev_state *st = P.st;
+    double *sred = reinterpret_cast<double *>(smem);                  // [SEG_THREADS] scratch (k_seg's regions are not in use yet)
+    if (tid < SEG_MAX_L_NARROW) patch->row6[tid] = -1;               // (the barriers of the reduction below lie between this and the halo lanes' writes)
+    if (tid < SEG_MAX_L_NARROW * SEG_MAX_L_NARROW) { (&patch->col[0][0])[tid] = -1; (&patch->rmask[0][0])[tid] = 0u; }
+    if (tid == 0) patch->colmode = COL ? 1 : 0;
+    const int R = c.ranked != 0 ? 4 : 5;
+    const seg_geom g = seg_geometry(N, L, R);
+    // ---- the path's minimum marginal over the segments (k_rw) ------------------------------------------------------
+    double v0 = INFINITY;
+    for (int q = tid; q < g.S; q += SEG_THREADS) { const double v = P.segmin[q]; if (v < v0) v0 = v; }
+    sred[tid] = v0;
+    __syncthreads();
+    for (int q = SEG_THREADS / 2; q > 0; q >>= 1) {
+        if (tid < q && sred[tid + q] < sred[tid]) sred[tid] = sred[tid + q];
+        __syncthreads();
+    }
+    const double minm = sred[0];
+    __syncthreads();
+    const double ratio = minm < Q.min_remove ? Q.min_remove : minm;
+    if (sblk == 0 && tid == 0) seg_finish(st, Q.rec, N, minm, Q.min_remove);
+    if (sblk >= g.S) { if (tid == 0) Q.partial[sblk] = 0.0; return false; }
+    // ---- this workgroup's positions: the halo (recomputed, nothing stored), then its own ---------------------------
+    const int t0 = sblk * g.seglen;
+    const int t1 = t0 + g.seglen < N ? t0 + g.seglen : N;
+    const int nh = sblk > 0 ? L : 0;                                  // halo positions t0+1-L .. t0
+    const int nown = (t1 - t0) + (sblk == 0 ? 1 : 0);                 // own: t0+1 .. t1, and position 0 for workgroup 0
+    const int slot = tid >> 3, s = tid & 7;
+    const bool in = slot < nh + nown;
+    const bool halo = in && slot < nh;
+    const int p = !in ? 0 : (halo ? t0 + 1 - L + slot : (sblk == 0 ? slot : t0 + 1 + (slot - nh)));
+    const bool act = in && p <= N;
+    const bool own = act && !halo;
+    const size_t pos_elems = (size_t)NSYM * W * NSYM;
+    T *bandT = static_cast<T *>(Q.band);
+    const T *blk = halo ? static_cast<const T *>(P.halo) + ((size_t)sblk * L + slot) * pos_elems : bandT + (size_t)p * pos_elems;
+    if (COL) {
+        // column mode: the band blocks of all this workgroup's positions -> LDS (behind the reduction scratch), as they lie in
+        // memory: the halo from k_emit's copy, the own ones from the band -- two contiguous runs, 16-byte loads (k_rw's staging)
+        T *blkL = reinterpret_cast<T *>(smem + (size_t)SEG_THREADS * 8);
+        const size_t wper = pos_elems * sizeof(T) / 4;                // 4-byte words per position (a block is 196 W bytes: 16-byte
+        const uint32_t *srcH = reinterpret_cast<const uint32_t *>(static_cast<const T *>(P.halo) + (size_t)sblk * L * pos_elems);      // copies only fit W = 4, 8)
+        const int p_first = sblk == 0 ? 0 : t0 + 1;
+        const uint32_t *srcO = reinterpret_cast<const uint32_t *>(bandT + (size_t)p_first * pos_elems);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(blkL);
+        for (size_t q = tid; q < (size_t)nh * wper; q += SEG_THREADS) dst[q] = srcH[q];
+        for (size_t q = tid; q < (size_t)nown * wper; q += SEG_THREADS) dst[(size_t)nh * wper + q] = srcO[q];
+        __syncthreads();
+        blk = blkL + (size_t)(in ? slot : 0) * pos_elems;
+    }
+    const int d0 = s + 1, j0 = p + d0;
+    int mult0 = 0;
+    if (act && d0 <= W) {
+        if (j0 <= N - 1) mult0 = (d0 == 1) ? 2 : 1;
+        else if (j0 == N) mult0 = (d0 == 1) ? 1 : 0;
+        else if (j0 == N + 1) mult0 = (p == N) ? 1 : 0;
+    }
+    const int a = act ? Q.path[p] : 0;
+    const int b0 = mult0 ? ((j0 == N + 1) ? Q.path[0] : Q.path[j0]) : 0;
+    const bool lag_row = Q.G && act && p < N && d0 <= L && j0 <= N && (!COL || (mult0 > 0 && d0 <= W));
+    T crow[NSYM];
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? blk[((size_t)s * W) * NSYM + x] : (T)0;     // cell (p, p+1), row s
+    int nv_t = 0;
+    uint32_t cm_t = 0;
+    if (lag_row) { nv_t = Q.nvalid[j0]; cm_t = CM_CAND(Q.cmask[j0]); }
+    const uint32_t cm_old = (own && s == 7) ? Q.cmask[p] : 0u;
+    const bool need_row = act && d0 <= W && (mult0 > 0 || lag_row);
+    const size_t roff = ((size_t)a * W + (size_t)((d0 <= W ? d0 : 1) - 1)) * NSYM;
+    // the run this lane works on: the ROW of the path's symbol at p, or (COL) the COLUMN of the path's symbol at p + d0
+    const size_t run0 = COL ? ((size_t)((d0 <= W ? d0 : 1) - 1)) * NSYM + b0 : roff;
+    const size_t rstride = COL ? (size_t)W * NSYM : 1;
+    const int esel = COL ? a : b0;                                  // the entry of the run that is reweighted
+    T rrow[NSYM];
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? blk[run0 + (size_t)x * rstride] : (T)0;
+    double removed = 0.0;
+    int na = -1, nb = -1;
+    T nval = (T)0;
+    if (mult0) {
+        T cur = rrow[0];
+#pragma unroll
+        for (int x = 1; x < NSYM; x++) cur = (x == esel) ? rrow[x] : cur;
+        for (int q = 0; q < mult0; q++) {
+            const double old = (double)cur;
+            const double nw = old - ratio * old;
+            cur = (T)nw;
+            if (own) removed += old - nw;
+        }
+        if (own) bandT[(size_t)p * pos_elems + roff + b0] = cur;
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) rrow[x] = (x == esel) ? cur : rrow[x];
+        if (d0 == 1) { na = a; nb = b0; nval = cur; }
+    }
+    na = __shfl(na, 0, 8); nb = __shfl(nb, 0, 8);
+    nval = (T)__shfl((double)nval, 0, 8);
+    // ---- marginals of position p (k_marg / k_rw: same order of operations) ----------------------------------------------
+    unsigned flag_bits = 0;
+    int hole_p = 0x7fffffff;
+    double cs[NSYM];
+    double tot = 0.0;
+    int nv = 0;
+    uint32_t cm = 0;
+    T acc = (T)0;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) {
+        T v = crow[x];
+        if (s == na && x == nb) v = nval;
+        acc = acc + v;
+    }
+    const double mine = (double)acc;
+#pragma unroll
+    for (int x = 0; x < NSYM; x++) {
+        cs[x] = __shfl(mine, x, 8);
+        if (cs[x] > 0) {
+            tot += cs[x];
+            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; }
+        }
+    }
+    const uint32_t cand = Q.offer_zero ? VALID_MASK : cm;
+    const uint32_t cmw = cm | (cand << 8);
+    const uint32_t cm5 = cm5_of_cmask(sm, cand);
+    if (own) {
+        if (s < NSYM) {
+            const double m = (cs[s] > 0 && tot != 0.0) ? cs[s] / tot : 0.0;
+            Q.cnt[(size_t)p * 8 + s] = cs[s];
+            Q.marg[(size_t)p * 8 + s] = m;
+            if ((VALID_MASK >> s) & 1) {
+                const int b5 = a6_of_sym(sm, s);
+                const double lm = gh_log10(m);
+                Q.minfo[(size_t)p * MINFO + b5] = lm;
+                Q.minfo[(size_t)p * MINFO + 5 + b5] = m;
+                const int r = __popc(cm5 & ((1u << b5) - 1u));
+                if (Q.rinfo && ((cand >> s) & 1u) && r < 4) {
+                    Q.rinfo[(size_t)p * RINFO + r] = lm;
+                    Q.rinfo[(size_t)p * RINFO + 4 + r] = m;
+                }
+            }
+        } else {
+            Q.cnt[(size_t)p * 8 + 7] = tot;
+            Q.marg[(size_t)p * 8 + 7] = 0.0;
+            Q.nvalid[p] = nv;
+            Q.cmask[p] = cmw;
+            Q.minfo[(size_t)p * MINFO + 10] = __longlong_as_double((long long)cm5);
+            for (int r = __popc(cm5); Q.rinfo && r < 4; r++) {
+                Q.rinfo[(size_t)p * RINFO + r] = 0.0;
+                Q.rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
+            }
+            if (cm_old != cmw) flag_bits |= 1u;
+            if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
+            if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
+            if (p >= 1 && cand == 0) hole_p = p;
+        }
+    }
+    // ---- the table row of lag d0 (k_rw's table_row): to G for an own position, into the patch for a halo position ---------
+    const double ca = __shfl(mine, a, 8);                  // c_a(p) (every lane of the group takes part: lane a may own no lag row)
+    if (COL) {
+        // the COLUMN of lag d0 that the cell (p, p + d0) feeds (k_rw's table_col): one entry per from-row that exists
+        if (lag_row) {
+            const bool ranked = c.ranked != 0;
+            T cacc = (T)0;
+#pragma unroll
+            for (int x = 0; x < NSYM; x++) cacc = cacc + rrow[x];
+            const double den = (Q.cond_mode == GH_COND_C ? (double)nv : (double)nv_t) + (double)cacc;
+            const int b5c = a6_of_sym(sm, b0);
+            const uint32_t cj5 = cm5_of_cmask(sm, cm_t);
+            if (b5c < 5 && ((cj5 >> b5c) & 1u)) {
+                const int col = ranked ? __popc(cj5 & ((1u << b5c) - 1u)) : b5c;
+                constexpr int FS[6] = {0, 1, 2, 3, 5, 6};
+                double xq[6], v[6];
+                bool odd = false;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    xq[q] = (1.0 + (double)rrow[FS[q]]) / den;
+                    odd |= !gh_log10_is_normal(xq[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; q++) v[q] = gh_log10_normal(xq[q], 0);
+                if (odd) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) v[q] = gh_log10(xq[q]);
+                }
+                unsigned rmask = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const int x6 = a6_of_sym(sm, FS[q]);
+                    int row6 = x6;
+                    if (x6 == 5) { if (p != 0) continue; }
+                    else if (ranked) {
+                        if (!((cm5 >> x6) & 1u)) continue;
+                        row6 = __popc(cm5 & ((1u << x6) - 1u));
+                        if (row6 > 3) continue;
+                    }
+                    if (own) Q.G[(((size_t)p * 6 + row6) * L + (d0 - 1)) * LT_ROW + col] = v[q];
+                    else if (row6 < LT_ROW) { patch->row[slot][d0 - 1][row6] = v[q]; rmask |= 1u << row6; }
+                }
+                if (!own) { patch->col[slot][d0 - 1] = col; patch->rmask[slot][d0 - 1] = rmask; }
+            }
+        }
+    } else if (lag_row && a != 4) {
+        const bool ranked = c.ranked != 0;
+        const int a6 = a6_of_sym(sm, a);
+        const double nv_i = (double)nv;
+        int row6 = a6;
+        if (ranked && a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
+        if (row6 >= 0) {
+            double out[LT_ROW];
+            if (!(a6 < 5 || p == 0)) {
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) out[q] = 0.0;
+            } else {
+                double rowv[NSYM];
+                T racc = (T)0;
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) { rowv[x] = (double)rrow[x]; racc = racc + rrow[x]; }
+                const double sum = (double)racc;
+                const double den = (Q.cond_mode == GH_COND_A) ? (double)nv_t + sum : (Q.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
+                constexpr int VS[LT_ROW] = {0, 1, 2, 3, 5};
+                double xq[LT_ROW], v[LT_ROW];
+                bool odd = false;
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) xq[q] = (1.0 + rowv[VS[q]]) / den;
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) odd |= !gh_log10_is_normal(xq[q]);
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_normal(xq[q], 0);
+                if (odd) {
+#pragma unroll
+                    for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10(xq[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) out[q] = -INFINITY;
+                if (!ranked) {
+#pragma unroll
+                    for (int q = 0; q < LT_ROW; q++) {
+                        const int b5 = a6_of_sym(sm, VS[q]);
+                        const double val = ((cm_t >> VS[q]) & 1) ? v[q] : -INFINITY;
+#pragma unroll
+                        for (int w = 0; w < LT_ROW; w++) out[w] = (b5 == w) ? val : out[w];
+                    }
+                } else {
+                    const uint32_t cj5 = cm5_of_cmask(sm, cm_t);
+#pragma unroll
+                    for (int q = 0; q < LT_ROW; q++) {
+                        const int b5 = a6_of_sym(sm, VS[q]);
+                        const int rb = ((cj5 >> b5) & 1u) ? __popc(cj5 & ((1u << b5) - 1u)) : -1;
+#pragma unroll
+                        for (int w = 0; w < LT_ROW; w++) out[w] = (rb == w) ? v[q] : out[w];
+                    }
+                }
+            }
+            if (own) {
+                double *dst = Q.G + (((size_t)p * 6 + row6) * L + (d0 - 1)) * LT_ROW;
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) dst[q] = out[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < LT_ROW; q++) patch->row[slot][d0 - 1][q] = out[q];
+                if (s == 0) patch->row6[slot] = row6;
+            }
+        }
+    }
+    // ---- flags, removed mass ---------------------------------------------------------------------------------------
+    __shared__ unsigned s_flags;
+    __shared__ int s_hole;
+    if (tid == 0) { s_flags = 0; s_hole = 0x7fffffff; }
+    sred[tid] = removed;
+    __syncthreads();
+    if (flag_bits) atomicOr(&s_flags, flag_bits);
+    if (hole_p != 0x7fffffff) atomicMin(&s_hole, hole_p);
+    for (int q = SEG_THREADS / 2; q > 0; q >>= 1) {
+        if (tid < q) sred[tid] += sred[tid + q];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        Q.partial[sblk] = sred[0];
+        const unsigned f = s_flags;
+        if (f & 1u) atomicAnd(&st->cm_same, 0);
+        if (f & 2u) atomicAnd(&st->nodel, 0);
+        if (f & 4u) atomicAnd(&st->narrow, 0);
+        if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
+    }
+    // what this workgroup stored (G rows, marginals) is read back by its own k_seg part
+    __threadfence_block();
+    __syncthreads();
+    return true;
+}
+
+template <typename T, int LC, bool COL>
+__global__ void __launch_bounds__(SEG_THREADS) k_rwseg(seg_params P, rws_params Q)
+{
+    extern __shared__ __align__(16) unsigned char seg_smem[];
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    if (c.cur_hole <= P.N) {                                // the path before ended in a hole: nothing to reweight, nothing more to walk
+        if (blockIdx.x == 0 && threadIdx.x == 0) seg_finish(st, Q.rec, P.N, 0.0, Q.min_remove);
+        return;
+    }
+    seg_patch *patch = reinterpret_cast<seg_patch *>(seg_smem + P.patch_off);
+    if (!rwseg_reweight<T, LC, COL>(P, Q, c, seg_smem, patch)) return;
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC, false>(P, seg_smem, patch);
+    else if constexpr (seg_radix_ok(5, LC)) seg_body<5, LC, false>(P, seg_smem, patch);
 }
 
 // lone gh_generate_path: no k_marg<T,true> follows, so the record is closed here

@@ -174,3 +174,54 @@ def test_three_launches_with_a_hole_and_a_stale_table(monkeypatch):
     assert h.walk_clock()[:4] == (1, 0, 0, 3)
     same(res, ref)
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("kw", [dict(), dict(cond_mode="B"), dict(cond_mode="D", marginal_term=True), dict(storage="f64"),
+                                dict(cond_mode="B", cand_order="-TGCA"), dict(offer_zero=True),
+                                dict(cond_mode="C", marginal_term=True), dict(cond_mode="E"), dict(cond_mode="E", marginal_term=True, storage="f64"),
+                                dict(cond_mode="C", cand_order="GA-TC")],
+                         ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())) or "default")
+def test_reweight_rides_in_the_next_paths_launch(L, wide, kw, monkeypatch):
+    # k_rwseg: the reweight of path k-1 and the k_seg of path k in one launch; every workgroup recomputes the table rows of the
+    # L positions in front of its segment from the copy k_emit made of its neighbour's band blocks.  Windows whose k_scan and
+    # k_emit are separate launches (the default there); GH_RWSEG=0 gives the four-launch flow.  Same everything.
+    from spec_util import make_pair, same, with_dels
+    t = make_support_table(2700, 60000, k=6, seed=700 + L)
+    if wide:
+        t = with_dels(t, 0.1, L)
+    h, o = make_pair(t, L=L, **kw)
+    res, ref = h.spin(11), o.spin(11)
+    same(res, ref)
+    assert h.walk_clock()[3] == 3
+    assert np.array_equal(h.export_band(), o.export_band())
+    same(h.spin(3), o.spin(3))                                 # a second spin continues from the reweighted tensor
+    monkeypatch.setenv("GH_RWSEG", "0")
+    h2, o2 = make_pair(t, L=L, **kw)
+    same(h2.spin(11), ref)
+
+
+def test_reweight_in_the_next_launch_with_a_hole_and_a_stale_table(monkeypatch):
+    from spec_util import make_pair, same
+    # one haplotype: the first reweight empties the matrix, the second path ends in a hole (gretel.py:176-180)
+    t = make_support_table(3000, 20000, k=3, n_haps=1, err=0.0, seed=1)
+    h, o = make_pair(t)
+    res, ref = h.spin(6), o.spin(6)
+    same(res, ref)
+    assert res["n"] == 1 and res["hole_at"] >= 1
+    assert h.spin(3)["n"] == 0
+    # a table found stale at path 4: the queue behind idles, the host rebuilds and queues the remaining paths again
+    t = make_support_table(2600, 60000, k=5, seed=3)
+    monkeypatch.setenv("GH_SEG_FORCE_STALE", "4")
+    h, o = make_pair(t)
+    monkeypatch.delenv("GH_SEG_FORCE_STALE")
+    res, ref = h.spin(12), o.spin(12)
+    assert h.walk_clock()[:4] == (1, 0, 0, 3)
+    same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    # a spin of ONE path, and of two
+    h, o = make_pair(t)
+    same(h.spin(1), o.spin(1))
+    same(h.spin(2), o.spin(2))
+    assert np.array_equal(h.export_band(), o.export_band())
