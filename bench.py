@@ -96,13 +96,14 @@ def seg_geometry(n, L, R):
     return dict(NS=ns, NI=ns // R, seglen=seglen, S=(n + seglen - 1) // seglen)
 
 
-def issue_model_seg(n, L, ranked, clock_ghz, measured_ms):
+def issue_model_seg(n, L, ranked, clock_ghz, measured_ms, rw_bytes=None):
     """k_seg is bound by vector-ALU issue (binary64 adds / compares / selects for every state of every position, then one
     table lookup per state and position), not by HBM.  Floor = the instructions of its two inner loops as compiled
     (profiles/seg_isa_count.py -> profiles/r3_seg_isa.json) x trips per SIMD x issue cost / clock, for the ONE workgroup a CU
     runs (all segments run at once: <= 256 workgroups on 256 CUs, 16 waves = 4 per SIMD)."""
     isa = json.load(open(os.path.join(ROOT, "profiles", "r3_seg_isa.json")))
-    ent = isa["L"].get(str(L), {}).get("R4" if ranked else "R5")
+    sec = isa.get("rwseg", {}).get("L") if rw_bytes is not None else None      # (the same two loops as compiled inside k_rwseg)
+    ent = (sec or isa["L"]).get(str(L), {}).get("R4" if ranked else "R5")
     if not ent or "next_table_loop" not in ent or "state_walk_loop" not in ent or not ranked:
         return None
     R = 4
@@ -115,6 +116,14 @@ def issue_model_seg(n, L, ranked, clock_ghz, measured_ms):
     cyc = next_trips_per_simd * ent["next_table_loop"]["issue_cycles_per_iteration"] + \
         walk_trips_per_simd * ent["state_walk_loop"]["issue_cycles_per_iteration"]
     floor_us = cyc / (clock_ghz * 1e3)
+    extra = {}
+    if rw_bytes is not None:
+        # k_rwseg: the reweight phase in front is HBM work (band cells and table rows, read and written once) behind three
+        # dependent round trips (minimum marginal, ratio, the halo's patch); its floor is its bytes at the HBM peak
+        rw_floor_us = rw_bytes / (HBM_PEAK_GBS * 1e3)
+        extra = {"kernel": "k_rwseg<%d>" % L, "extension_issue_floor_us": floor_us, "reweight_hbm_floor_us": rw_floor_us,
+                 "reweight_bytes": rw_bytes}
+        floor_us += rw_floor_us
     return {"kernel": "k_seg<%d>" % L, "binding_resource": "vector-ALU issue (binary64)",
             "states": g["NS"], "segments": g["S"], "positions_per_segment": g["seglen"],
             "next_table_loop": {k: ent["next_table_loop"][k] for k in ("instructions", "by_class", "issue_cycles_per_iteration")},
@@ -124,7 +133,7 @@ def issue_model_seg(n, L, ranked, clock_ghz, measured_ms):
             "measured_us": measured_ms * 1e3, "frac": floor_us / (measured_ms * 1e3) if measured_ms > 0 else None,
             "isa_profile": {"file": "profiles/r3_seg_isa.json", "git_head": isa.get("git_head"), "cost_cycles": isa["cost_cycles_per_wave_instruction"]},
             "note": "floor = compute phases only (Next tables + state walk); the kernel also stages its table slice (~1.5 us) and pays "
-                    "launch + teardown (~3.4 us), see DESIGN.md section 4.1"}
+                    "launch + teardown (~3.4 us), see DESIGN.md section 4.1", **extra}
 
 
 def issue_model_pools(n, L, clock_ghz, measured_ms):
@@ -449,7 +458,14 @@ def main():
         walk_ms = walk["ms"] / max(1, walk["launches"])
         seg = prof.get("seg", {"ms": 0.0, "launches": 0, "bytes_per_launch": 0.0})
         segwalk = variant == 3                     # segment-parallel extension: k_seg + k_scan + k_emit per path
-        if segwalk and seg["launches"]:
+        rwseg = prof.get("rwseg", {"ms": 0.0, "launches": 0, "bytes_per_launch": 0.0})
+        fused_rw = segwalk and rwseg["launches"] > 0   # k_rwseg: the reweight of path k-1 rides in the k_seg launch of path k
+        if fused_rw:
+            dom, dom_name = rwseg, ("k_rwseg (reweight of the path before + segment-parallel extension of this one: band cells, "
+                                    "table rows, Next tables + all entry states of every segment)")
+            dom_bytes_def = ("SURVEY 8(d): conditional lookups of the extension N*L*196 + the reweight of a path "
+                             "(N+1)*(2*W*esz + 196*esz + 217) + the table rows it rewrites N*(7*min(W,L)*esz + L*5*6*8)")
+        elif segwalk and seg["launches"]:
             dom, dom_name = seg, "k_seg (segment-parallel path extension: Next tables + all entry states of every segment)"
             dom_bytes_def = "SURVEY 8(d), conditional lookups of the extension: N*L*196 per path (the marginal cell and the original marginals, N*224, belong to k_emit)"
         elif variant == 4:
@@ -473,7 +489,7 @@ def main():
                     traffic_note = "profiles/%s was taken with kernel sources %s (git %s), this build is %s: not quoted" % (
                         pmf, pmj.get("kernel_source_sha"), pmj.get("git_head"), src_sha)
                 else:
-                    want = "k_seg" if segwalk else ("k_cwalk" if variant == 4 else "k_walk")
+                    want = "k_rwseg" if fused_rw else "k_seg" if segwalk else ("k_cwalk" if variant == 4 else "k_walk")
                     traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pmj["kernels"].items() if k.startswith(want))
                     traffic_note = "profiles/%s (git %s, kernel sources %s)" % (pmf, pmj.get("git_head"), src_sha)
         except Exception as exc:
@@ -483,9 +499,11 @@ def main():
         # what actually binds the dominant kernel: instruction issue, priced from the ISA (profiles/r3_seg_isa.json)
         issue_model = None
         try:
-            if segwalk and seg["launches"]:
+            if segwalk and (seg["launches"] or fused_rw):
                 ranked = not bool((h.candidate_masks()[1:] == 0x2F).any())
-                issue_model = issue_model_seg(n, L, ranked, clock_ghz, max(dom_ms - ev_nop_ms, 1e-6))
+                issue_model = issue_model_seg(n, L, ranked, clock_ghz, max(dom_ms - ev_nop_ms, 1e-6),
+                                              rw_bytes=(rwseg["bytes_per_launch"] - n * L * 49.0 * (8 if spec_kw["storage"] == "f64" else 4))
+                                              if fused_rw else None)
             elif variant == 4 and seg["launches"]:
                 issue_model = issue_model_pools(n, L, clock_ghz, max(seg["ms"] / seg["launches"] - ev_nop_ms, 1e-6))
             elif variant == 2 and nsteps:
@@ -506,7 +524,7 @@ def main():
         b_rw = 8.0 * n * min(table.band, n)
         step_bytes = b_fill + paths * (b_ext + b_rw)
         step_s = dt_max / desc["steps"]
-        kernels_per_path = 4 if segwalk else (None if variant == 4 else 2)
+        kernels_per_path = (3 if fused_rw else 4) if segwalk else (None if variant == 4 else 2)
         out = {
             "metric": "haplotypes/sec + SNP-edge-evals/sec on 10k-SNP synthetic contig",
             "value": hap_s,
@@ -563,8 +581,10 @@ def main():
                          "issue_model": issue_model,
                          "note": ("k_seg evaluates Next[t][state] for all R^L states of every position (binary64 adds and compares: "
                                   "vector-ALU bound, then LDS-latency bound in the state walk), so its HBM traffic stays far below the "
-                                  "bandwidth roofline by construction; a path is 4 dependent kernels (k_seg, k_scan, k_emit, k_rw) "
-                                  "of 5-12 us each, about 4 us of which is launch + first-touch latency; see DESIGN.md section 4")
+                                  "bandwidth roofline by construction; a path is %s "
+                                  "about 4 us of each is launch + first-touch latency; see DESIGN.md section 4"
+                                  % ("3 dependent kernels (k_rwseg: the reweight of the path before + k_seg; k_scan; k_emit) of 5-21 us,"
+                                     if fused_rw else "4 dependent kernels (k_seg, k_scan, k_emit, k_rw) of 5-12 us each,"))
                                  if segwalk else
                                  ("each segment of the window is walked from a pool of candidate entry states by one wavefront per 16 "
                                   "candidates (196 dependent steps per segment at C5), the chain of segments is verified exactly; "
@@ -682,15 +702,20 @@ def main():
                         return hx.spin(paths)
                     xstep(); xstep()
                     torch.cuda.synchronize(); hx.sync()
-                    tx = time.perf_counter()
-                    nx = sum(xstep()["n"] for _ in range(5))
-                    hx.sync()
-                    tx = time.perf_counter() - tx
-                    rows.append({"cond_mode": cm_, "marginal_term": mt_, "storage": st_, "value": nx / tx,
+                    # each step ends with results on the host, so the steps are timed one by one and the median is quoted
+                    # (a stall of the host in one 4 ms step would otherwise read as a slow spec)
+                    ts_, nx = [], 0
+                    for _ in range(7):
+                        tx = time.perf_counter()
+                        nx = xstep()["n"]
+                        ts_.append(time.perf_counter() - tx)
+                    ts_.sort()
+                    rows.append({"cond_mode": cm_, "marginal_term": mt_, "storage": st_, "value": nx / ts_[len(ts_) // 2],
+                                 "slowest_step_over_median": ts_[-1] / ts_[len(ts_) // 2],
                                  "walker_variant": hx.walk_clock()[3], "table_requeues": hx.walk_clock()[0]})
                     del hx
                 vals = [r["value"] for r in rows]
-                out["spec_matrix"] = {"unit": "haplotypes/s", "workload": "the benchmark step (clear + fill + %d spins), 2 warm-up + 5 timed steps per spec" % paths,
+                out["spec_matrix"] = {"unit": "haplotypes/s", "workload": "the benchmark step (clear + fill + %d spins), 2 warm-up steps, then the median of 7 steps timed one by one, per spec" % paths,
                                       "max_over_min": max(vals) / min(vals), "min": min(vals), "max": max(vals), "rows": rows}
             except Exception as exc:
                 out["spec_matrix"] = {"error": repr(exc)}

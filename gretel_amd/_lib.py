@@ -16,7 +16,7 @@ GH_OK = 0
 GH_ERR_ARG, GH_ERR_HIP, GH_ERR_BAND, GH_ERR_SYMBOL, GH_ERR_NOMEM, GH_ERR_STATE = -1, -2, -3, -4, -5, -6
 GH_STORAGE = {"f32": 0, "f64": 1}
 GH_COND = {"A": 0, "B": 1, "C": 2, "D": 3, "E": 4}
-GH_K = {"fill": 0, "marg": 1, "lt": 2, "walk": 3, "reweight": 4, "seg": 5}
+GH_K = {"fill": 0, "marg": 1, "lt": 2, "walk": 3, "reweight": 4, "seg": 5, "rwseg": 6}
 
 
 class GretelHipError(RuntimeError):

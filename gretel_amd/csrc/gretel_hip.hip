@@ -1125,9 +1125,13 @@ static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
     if (lds_emit > set_emit[dv]) { hipFuncSetAttribute((const void *)k_emit<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_emit); set_emit[dv] = lds_emit; }
     P.patch_off = (int)off;
     P.rws = 1;
-    prof_begin(h, GH_K_SEG);
+    prof_begin(h, GH_K_RWSEG);
     hipLaunchKernelGGL((k_rwseg<T, LC, COL>), dim3(S), dim3(SEG_THREADS), lds, h->stream, P, Q);
-    prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
+    // the extension's conditional lookups + what the reweight of a path reads and writes (the figure GH_K_REWEIGHT quotes)
+    const int wl = h->W < LC ? h->W : LC;
+    prof_end(h, GH_K_RWSEG, (double)N * (double)LC * CELL * esize(h) +
+             (double)(N + 1) * ((double)h->W * 2.0 * esize(h) + 1.0 + CELL * esize(h) + 2 * 64 + 88 + 8) +
+             (double)N * ((double)wl * 7 * esize(h) + (double)LC * LT_ROW * 8.0));
     hipLaunchKernelGGL((k_scan<LC, false>), dim3(G1), dim3(SEG_THREADS), lds_scan, h->stream, P);
     hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, h->stream, P);
 }

@@ -194,8 +194,9 @@ int gh_coverage_sites(int device, const int32_t *ref_start, const int64_t *off, 
  * gh_profile_enable(h, k): k = 0 off; k >= 1 brackets every k-th launch of each kernel with a pair of events
  * (an event between two kernels costs the stream a ~10 us bubble, so a timed region samples with k > 1). */
 /* GH_K_WALK: the whole path extension of one path (one serial walker launch, or k_seg + k_scan + k_emit);
- * GH_K_SEG: k_seg alone, the largest kernel of the segment-parallel extension */
-enum { GH_K_FILL = 0, GH_K_MARG = 1, GH_K_LT = 2, GH_K_WALK = 3, GH_K_REWEIGHT = 4, GH_K_SEG = 5, GH_K_COUNT = 6 };
+ * GH_K_SEG: k_seg alone, the largest kernel of the segment-parallel extension (inside gh_spin: the first path only);
+ * GH_K_RWSEG: k_rwseg alone -- the reweight of path k-1 and the k_seg of path k in one launch (every later path of a gh_spin) */
+enum { GH_K_FILL = 0, GH_K_MARG = 1, GH_K_LT = 2, GH_K_WALK = 3, GH_K_REWEIGHT = 4, GH_K_SEG = 5, GH_K_RWSEG = 6, GH_K_COUNT = 7 };
 int gh_profile_enable(gh_t *h, int on);
 int gh_profile_reset(gh_t *h);
 int gh_profile_get(gh_t *h, int kernel, double *total_ms, int64_t *launches);

@@ -67,18 +67,15 @@ def main():
     head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
     out = {"git_head": head, "cost_cycles_per_wave_instruction": {"valu_f64": 4, "valu": 2, "lds": 0, "salu": 0, "vmem": 0, "wait": 0},
            "note": "costs: wave64 on a SIMD-32; LDS / scalar / branch instructions issue beside the VALU when four waves share a SIMD", "L": {}}
-    for lc in range(1, 7):
-        m = re.search(r"^_Z5k_segILi%dELb0EEv10seg_params:.*?^\.Lfunc_end" % lc, text, re.S | re.M)
-        if not m:
-            continue
-        lines = m.group(0).split("\n")
+    def two_loops(lines):
         per_radix = {}
         nexts, walks = [], []
         for a, b in loops_of(lines):
             ops = body(lines, a, b)
             kinds = collections.Counter(klass(o) for o in ops)
-            if any(o == "v_add_f64" for o in ops) and kinds["valu_f64"] >= 8:
-                nexts.append((a, ops, kinds))
+            if any(o == "v_add_f64" for o in ops) and kinds["valu_f64"] >= 8 and not kinds["vmem"] and \
+                    not any(o.startswith(("v_fma_f64", "v_mul_f64", "v_div", "v_rcp")) for o in ops):
+                nexts.append((a, ops, kinds))       # (adds and compares only: the reweight loops of k_rwseg take logarithms and touch memory)
             elif any(o in ("ds_read_u8", "ds_read_u16", "ds_read_u8_d16", "ds_read_u16_d16", "ds_read_u8_d16_hi") for o in ops) and not any(o.startswith("global_store") for o in ops[:3]):
                 walks.append((a, ops, kinds))
         # seg_body<4> is emitted in front of seg_body<5>
@@ -88,7 +85,18 @@ def main():
                 cyc = sum(out["cost_cycles_per_wave_instruction"][k] * v for k, v in kinds.items())
                 per_radix.setdefault(radix, {})[name] = {"instructions": len(ops), "by_class": dict(kinds), "issue_cycles_per_iteration": cyc,
                                                          "by_opcode": dict(collections.Counter(ops).most_common(12))}
-        out["L"][str(lc)] = per_radix
+        return per_radix
+
+    for lc in range(1, 7):
+        m = re.search(r"^_Z5k_segILi%dELb0EEv10seg_params:.*?^\.Lfunc_end" % lc, text, re.S | re.M)
+        if m:
+            out["L"][str(lc)] = two_loops(m.group(0).split("\n"))
+    # k_rwseg<float, L, false>: the same two loops as compiled inside the fused kernel (the reweight of the path before runs in front)
+    out["rwseg"] = {"L": {}}
+    for lc in range(1, 7):
+        m = re.search(r"^_Z7k_rwsegIfLi%dELb0EEv10seg_params10rws_params:.*?^\.Lfunc_end" % lc, text, re.S | re.M)
+        if m:
+            out["rwseg"]["L"][str(lc)] = two_loops(m.group(0).split("\n"))
     # the candidate-pool walker (lag counts 6..24): instructions per step of its unrolled block loop (LC steps per trip)
     out["cwalk"] = {"cost_cycles_per_instruction": {"one_wave_per_simd": 5.0, "two_waves_per_simd": 2.5},
                     "note": "one wavefront walks 16 pool entries; a lone wave issues an instruction every ~5 cycles (scratch/ubench6/7.hip), "
