@@ -1224,7 +1224,7 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     const int stride = (slot >= 0 && h->spin_partial_stride > nb) ? h->spin_partial_stride : nb;
     if (slot < 0) { int rc_ = ensure_partial(h, nb, 1); if (rc_) return rc_; }
     double *partial = h->partial + (slot > 0 ? (size_t)slot * stride : 0);
-    if (slot >= 0 && stride > nb) HIPCHK(hipMemsetAsync(partial + nb, 0, sizeof(double) * (size_t)(stride - nb), h->stream));
+    if (slot >= 0 && stride > nb && !h->rws) HIPCHK(hipMemsetAsync(partial + nb, 0, sizeof(double) * (size_t)(stride - nb), h->stream));
     // in a spin the walker re-armed the flags when it finished; a lone reweight does it here
     if (!use_state) hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, h->stream, h->dstate, (const win_desc *)nullptr, 0);
     // with a valid conditional table (conditional A or B, no marginal term) the kernel also rewrites the table rows
@@ -1296,11 +1296,20 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     return GH_OK;
 }
 
-static int reset_spin_state(gh_handle *h)
+// the control words a spin starts from (stop, hole_at, n_done; lt_stale, cw_unres) and, for k_rwseg, the partial sums of the
+// removed mass, in one launch instead of two small copies and a memset with a dispatch gap each
+__global__ void k_spin_reset(dev_state *st, double *partial, size_t n)
 {
-    int zeros[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h->dstate, zeros, sizeof zeros, hipMemcpyHostToDevice, h->stream));
-    return GH_OK;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += stride) partial[q] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->stop = 0; st->hole_at = 0; st->n_done = 0; st->lt_stale = 0; st->cw_unres = 0; }
+}
+
+static int reset_spin_state(gh_handle *h, double *partial = nullptr, size_t n = 0)
+{
+    const int blocks = n ? (int)((n + 1023) / 1024 > 256 ? 256 : (n + 1023) / 1024) : 1;
+    hipLaunchKernelGGL(k_spin_reset, dim3(blocks), dim3(256), 0, h->stream, h->dstate, partial, n);
+    return post_launch(h, "k_spin_reset");
 }
 
 // ---- candidate-pool segment walk (cwalk.hpp): L = 6 .. 16, spins -------------------------------
@@ -1623,6 +1632,35 @@ static int results_to_host(gh_handle *h, uint8_t *paths_out, const uint8_t *d_pa
     return GH_OK;
 }
 
+// The end of a spin in ONE wait: the device state and the results of the `launched` paths go to pinned staging together
+// (how many of them are complete is only known from the state); stage_deliver then hands n_done of them to the caller.
+// Returns 1 when there is no pinned memory to be had (the caller takes the two-step way).
+static int state_and_results_to_stage(gh_handle *h, dev_state *hs, const uint8_t *d_paths, size_t n1, const gh_path_rec *d_recs, int launched)
+{
+    const size_t pb = n1 * (size_t)launched, rb = sizeof(gh_path_rec) * (size_t)launched, need = pb + rb + sizeof(dev_state) + 64;
+    if (need > h->stage_cap) {
+        if (h->stage) hipHostFree(h->stage);
+        h->stage = nullptr; h->stage_cap = 0;
+        const size_t cap = need + need / 2 + 4096;
+        if (hipHostMalloc((void **)&h->stage, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->stage = nullptr; return 1; }
+        h->stage_cap = cap;
+    }
+    const size_t rec_off = (pb + 63) & ~(size_t)63;
+    HIPCHK(hipMemcpyAsync(h->stage + rec_off + rb, h->dstate, sizeof(dev_state), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage + rec_off, d_recs, rb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->stage, d_paths, pb, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    memcpy(hs, h->stage + rec_off + rb, sizeof(dev_state));
+    return GH_OK;
+}
+
+static void stage_deliver(gh_handle *h, uint8_t *paths_out, size_t n1, gh_path_rec *recs, int launched, int n_done)
+{
+    const size_t rec_off = (n1 * (size_t)launched + 63) & ~(size_t)63;
+    memcpy(paths_out, h->stage, n1 * (size_t)n_done);
+    memcpy(recs, h->stage + rec_off, sizeof(gh_path_rec) * (size_t)n_done);
+}
+
 // The spin of lag counts 6 .. 24: segments walked from candidate pools (cwalk.hpp).  The paths are queued a few at a
 // time: a path whose chain stays open after the queued rounds idles the kernels behind it; the host then queues more
 // rounds for that one path, and if its chain is still open hands it to the serial walker (whose states join the pools)
@@ -1848,7 +1886,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     uint8_t *d_paths = h->spin_paths;
     gh_path_rec *d_recs = h->spin_recs;
     hipError_t e = hipSuccess;
-    rc = reset_spin_state(h);
+    rc = GH_OK;
     bool seg = seg_ok(h->wmode, h->L);
     h->seg6 = false;
     if (rc == GH_OK && !seg && h->wmode == WM_SEG && h->L == SEG_MAX_L_NARROW && !(getenv("GH_SEG6") && atoi(getenv("GH_SEG6")) == 0)) {
@@ -1918,21 +1956,13 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     if (h->rws && rws_S > nb) nb = rws_S;                       // ... k_rwseg leaves one partial sum per segment
     h->spin_partial_stride = nb;
     if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);       // L only changes through gh_set_L / gh_fill, never inside a spin
-    if (rc == GH_OK && h->rws) {
-        // (every slot is summed over the whole stride: what a kernel with fewer workgroups leaves untouched must read 0)
-        e = hipMemsetAsync(h->partial, 0, sizeof(double) * (size_t)nb * max_paths, h->stream);
-        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
-    }
+    // (k_rwseg: every slot is summed over the whole stride: what a kernel with fewer workgroups leaves untouched must read 0)
+    if (rc == GH_OK) rc = reset_spin_state(h, h->rws ? h->partial : nullptr, h->rws ? (size_t)nb * max_paths : 0);
     // Segment-parallel walks with a conditional table that the fused reweight keeps current (conditional A/B, no marginal
     // term): no k_lt between two paths.  Its only job there is to notice that a candidate mask moved (a count reached
     // zero; rare) and rebuild the table; instead the next k_seg sees the flag k_marg left, marks the table stale and the
     // rest of the queue does nothing.  The host then rebuilds and queues the remaining paths again.
     const bool optimistic = seg && !h->lt_full;
-    if (rc == GH_OK && seg) {
-        const int zero = 0;
-        e = hipMemcpyAsync(&h->dstate->lt_stale, &zero, sizeof zero, hipMemcpyHostToDevice, h->stream);
-        if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
-    }
     dev_state hs;
     memset(&hs, 0, sizeof hs);
     int first = 0;
@@ -1981,8 +2011,17 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             rc = post_launch(h, "k_reweight_finish_all");
         }
         if (rc != GH_OK) break;
-        e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        // state and results in one wait (the results of a queue that has to be taken up again are fetched in vain: rare)
+        bool staged = false;
+        if (launched > 0) {
+            const int sr = state_and_results_to_stage(h, &hs, d_paths, n1, d_recs, launched);
+            if (sr < 0) { rc = sr; break; }
+            staged = sr == GH_OK;
+        }
+        if (!staged) {
+            e = hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        }
         if (getenv("GH_PRINT_STATE"))
             fprintf(stderr, "gh_spin: stop %d hole_at %d n_done %d first_hole %d cur_hole %d lt_stale %d cm_same %d narrow %d ranked %d\n", hs.stop, hs.hole_at,
                     hs.n_done, hs.first_hole, hs.cur_hole, hs.lt_stale, hs.cm_same, hs.narrow, hs.ranked);
@@ -1993,7 +2032,10 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             if (e == hipSuccess) { first = hs.n_done; h->spin_requeues++; continue; }
         }
         if (e != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
-        else if (hs.n_done > 0) rc = results_to_host(h, paths_out, d_paths, n1 * hs.n_done, recs, d_recs, sizeof(gh_path_rec) * hs.n_done);
+        else if (hs.n_done > 0) {
+            if (staged && hs.n_done <= launched) stage_deliver(h, paths_out, n1, recs, launched, hs.n_done);
+            else rc = results_to_host(h, paths_out, d_paths, n1 * hs.n_done, recs, d_recs, sizeof(gh_path_rec) * hs.n_done);
+        }
         break;
     }
     h->spin_partial_stride = 0;

@@ -333,19 +333,17 @@ class Hansel:
         """gretel/cmd.py:148-179 on the device.  Returns dict(n, hole_at, paths uint8[n][N+1],
         hp_current, hp_original, ratio, magnitude)."""
         self._ensure()
-        paths = np.zeros((max_paths, self.n + 1), dtype=np.uint8)
-        recs = (_lib.gh_path_rec * max(1, max_paths))()
+        # (gh_spin writes rows 0 .. n-1 of both; gh_path_rec is five doubles -- include/gretel_hip.h)
+        paths = np.empty((max_paths, self.n + 1), dtype=np.uint8)
+        recs = np.empty((max(1, max_paths), C.sizeof(_lib.gh_path_rec) // 8), dtype=np.float64)
         n, hole = C.c_int(), C.c_int()
-        check(self._lib.gh_spin(self._h, int(max_paths), float(min_remove), _p(paths), recs, C.byref(n), C.byref(hole)))
+        check(self._lib.gh_spin(self._h, int(max_paths), float(min_remove), _p(paths), _p(recs), C.byref(n), C.byref(hole)))
         k = n.value
         if k:
             self.is_weighted = True
-        return dict(n=k, hole_at=hole.value, paths=paths[:k],
-                    hp_current=np.array([recs[q].hp_current for q in range(k)]),
-                    hp_original=np.array([recs[q].hp_original for q in range(k)]),
-                    ratio=np.array([recs[q].ratio for q in range(k)]),
-                    magnitude=np.array([recs[q].magnitude for q in range(k)]),
-                    min_marginal=np.array([recs[q].min_marginal for q in range(k)]))
+        r = recs[:k]
+        return dict(n=k, hole_at=hole.value, paths=paths[:k], hp_current=r[:, 0].copy(), hp_original=r[:, 1].copy(),
+                    ratio=r[:, 2].copy(), magnitude=r[:, 3].copy(), min_marginal=r[:, 4].copy())
 
     def path_symbols(self, indices):
         return [self.symbols[int(q)] for q in indices]
