@@ -2507,7 +2507,11 @@ extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
     if (out[3] == 3) { out[0] = (uint64_t)h->spin_requeues; out[1] = 0; out[2] = 0; }
     if (out[3] == 4) { out[0] = (uint64_t)h->spin_requeues; out[1] = (uint64_t)h->cw_stat[1]; out[2] = (uint64_t)h->cw_stat[2]; }
     if (getenv("GH_PRINT_STAMPS"))      // diagnostic builds (-DSEG_STAMPS / -DGH_STAMPS)
-        fprintf(stderr, "stamps: %llu %llu %llu %llu\n", hs.dbg8[1] - hs.dbg8[0], hs.dbg8[2] - hs.dbg8[1], hs.dbg8[3] - hs.dbg8[2], hs.dbg8[4] - hs.dbg8[3]);
+    {
+        fprintf(stderr, "stamps:");
+        for (int q = 1; q < 12 && hs.dbg8[q] >= hs.dbg8[q - 1] && hs.dbg8[q - 1]; q++) fprintf(stderr, " %llu", hs.dbg8[q] - hs.dbg8[q - 1]);
+        fprintf(stderr, "\n");
+    }
     return GH_OK;
 }
 

@@ -73,7 +73,7 @@ struct dev_state {
     int cw_need;     // k_cscan: most rounds a path needed to close its chain since the host last cleared this (sizes the rounds queued per path)
     unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
-    unsigned long long dbg8[5];  // -DGH_STAMPS / -DSEG_STAMPS builds: cycles per segment of the code
+    unsigned long long dbg8[12]; // -DGH_STAMPS / -DSEG_STAMPS / -DRWS_STAMPS builds: cycles per segment of the code
 };
 
 struct dev_ctl {

@@ -5,9 +5,15 @@
 
 #define SEG_THREADS 1024
 // diagnostic builds only (-DSEG_STAMPS): s_memtime at the phase boundaries of k_seg's workgroup 0 into st->dbg8
-#ifdef SEG_STAMPS
+// (-DRWS_STAMPS: k_rwseg's workgroup 100 -- the reweight phases in slots 0..5, its k_seg phases behind them)
+#if defined(RWS_STAMPS)
+#define RWS_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 100 && threadIdx.x == 0) P.st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SEG_STAMP(i) RWS_STAMP(6 + (i))
+#elif defined(SEG_STAMPS)
+#define RWS_STAMP(i)
 #define SEG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) P.st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define RWS_STAMP(i)
 #define SEG_STAMP(i)
 #endif
 // -DRW_STAMPS: the same inside k_rw's workgroup 100 (every stamp waits for the memory operations issued before it)

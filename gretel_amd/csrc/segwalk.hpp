@@ -107,6 +107,9 @@ struct seg_patch {
     int col[SEG_MAX_L_NARROW][SEG_MAX_L_NARROW];               // the column, -1 = none
     unsigned rmask[SEG_MAX_L_NARROW][SEG_MAX_L_NARROW];        // the digit rows that exist
     int colmode;
+    // marginal term: log10 marginal of the halo positions after the reweight, by candidate rank (R = 4) and by symbol (R = 5) --
+    // rinfo / minfo of those positions are being rewritten by the neighbour while this workgroup stages
+    double lm4[SEG_MAX_L_NARROW][4], lm5[SEG_MAX_L_NARROW][5];
 };
 
 template <int R, int LC, bool TRACK>
@@ -157,6 +160,8 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
                 for (int b = 0; b < R; b++) v[b] = src[b];
                 if (P.mt && l == 0) {
                     const double *lm = R == 4 ? P.rinfo + (size_t)(i + 1) * RINFO : P.minfo + (size_t)(i + 1) * MINFO;
+                    // (k_rwseg: position i + 1 in front of the segment belongs to the neighbour, who is rewriting it: from the patch)
+                    if (patch && c0 == t0 && t0 > 0 && ii + 1 < LC) lm = R == 4 ? patch->lm4[ii + 1] : patch->lm5[ii + 1];
 #pragma unroll
                     for (int b = 0; b < R; b++) v[b] = lm[b] + v[b];
                 }
@@ -179,6 +184,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
                         if (P.mt && l == 0) {
                             const int i = t0 + 1 - LC + hp;
                             const double *lm = R == 4 ? P.rinfo + (size_t)(i + 1) * RINFO : P.minfo + (size_t)(i + 1) * MINFO;
+                            if (hp + 1 < LC) lm = R == 4 ? patch->lm4[hp + 1] : patch->lm5[hp + 1];
                             v = lm[col] + v;
                         }
                         Gs[((size_t)(hp * LC + l) * R + b) * R + col] = v;
@@ -191,6 +197,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
                     if (P.mt && l == 0) {
                         const int i = t0 + 1 - LC + hp;
                         const double *lm = R == 4 ? P.rinfo + (size_t)(i + 1) * RINFO : P.minfo + (size_t)(i + 1) * MINFO;
+                        if (hp + 1 < LC) lm = R == 4 ? patch->lm4[hp + 1] : patch->lm5[hp + 1];
                         v = lm[b] + v;
                     }
                     Gs[((size_t)(hp * LC + l) * R + d) * R + b] = v;
@@ -1095,6 +1102,26 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
 // (seg_params::rws).  COL (conditionals C, E): the cell's column instead of its row, the band blocks of the workgroup's positions
 // staged in LDS, the patch carries columns.  Lane groups of 8 (W <= 8), at most 128 positions per workgroup with the halo: gh_spin checks.
 // -------------------------------------------------------------------------------------------------------------
+// minimum over the 64 lanes of a wavefront, in every lane, without LDS: a minimum does not mind seeing a value twice, so the
+// exchanges are the cheap DPP patterns (neighbour, other pair, other quad, other half of the row of 16), then the four rows
+__device__ __forceinline__ double lane_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+    double x;
+    x = dpp_f64<0xB1>(v); v = x < v ? x : v;          // quad_perm [1,0,3,2]
+    x = dpp_f64<0x4E>(v); v = x < v ? x : v;          // quad_perm [2,3,0,1]
+    x = dpp_f64<0x141>(v); v = x < v ? x : v;         // row_half_mirror
+    x = dpp_f64<0x140>(v); v = x < v ? x : v;         // row_mirror
+    const double r0 = lane_f64(v, 0), r1 = lane_f64(v, 16), r2 = lane_f64(v, 32), r3 = lane_f64(v, 48);
+    const double a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+    return b < a ? b : a;
+}
+
 struct rws_params {
     void *band;
     double *cnt, *marg, *minfo, *rinfo, *G;
@@ -1114,25 +1141,18 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     const symmap sm = P.sm;
     dev_state *st = P.st;
     double *sred = reinterpret_cast<double *>(smem);                  // [SEG_THREADS] scratch (k_seg's regions are not in use yet)
-    if (tid < SEG_MAX_L_NARROW) patch->row6[tid] = -1;               // (the barriers of the reduction below lie between this and the halo lanes' writes)
+    if (tid < SEG_MAX_L_NARROW) patch->row6[tid] = -1;
     if (tid < SEG_MAX_L_NARROW * SEG_MAX_L_NARROW) { (&patch->col[0][0])[tid] = -1; (&patch->rmask[0][0])[tid] = 0u; }
     if (tid == 0) patch->colmode = COL ? 1 : 0;
     const int R = c.ranked != 0 ? 4 : 5;
     const seg_geom g = seg_geometry(N, L, R);
-    // ---- the path's minimum marginal over the segments (k_rw) ------------------------------------------------------
-    double v0 = INFINITY;
-    for (int q = tid; q < g.S; q += SEG_THREADS) { const double v = P.segmin[q]; if (v < v0) v0 = v; }
-    sred[tid] = v0;
-    __syncthreads();
-    for (int q = SEG_THREADS / 2; q > 0; q >>= 1) {
-        if (tid < q && sred[tid + q] < sred[tid]) sred[tid] = sred[tid + q];
-        __syncthreads();
-    }
-    const double minm = sred[0];
-    __syncthreads();
-    const double ratio = minm < Q.min_remove ? Q.min_remove : minm;
-    if (sblk == 0 && tid == 0) seg_finish(st, Q.rec, N, minm, Q.min_remove);
     if (sblk >= g.S) { if (tid == 0) Q.partial[sblk] = 0.0; return false; }
+    RWS_STAMP(0);
+    // ---- the path's minimum marginal over the segments: every wavefront takes it for itself -- a few loads per lane, issued with
+    // the loads of the path, the cells and the masks, then lane exchanges (wave_min_f64): no barrier, no LDS
+    double vs[7];                                                     // (at most 400 segments: seg_geometry)
+#pragma unroll
+    for (int k = 0; k < 7; k++) { const int q = (tid & 63) + 64 * k; vs[k] = q < g.S ? P.segmin[q] : INFINITY; }
     // ---- this workgroup's positions: the halo (recomputed, nothing stored), then its own ---------------------------
     const int t0 = sblk * g.seglen;
     const int t1 = t0 + g.seglen < N ? t0 + g.seglen : N;
@@ -1187,6 +1207,16 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     T rrow[NSYM];
 #pragma unroll
     for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? blk[run0 + (size_t)x * rstride] : (T)0;
+    double v0 = vs[0];
+#pragma unroll
+    for (int k = 1; k < 7; k++) v0 = vs[k] < v0 ? vs[k] : v0;
+    const double minm = wave_min_f64(v0);
+    RWS_STAMP(1);
+    // (the patch was armed by lanes of wavefront 0 and is written by the halo lanes, which are lanes of wavefront 0 too: in order)
+    static_assert(SEG_MAX_L_NARROW * 8 <= 64 && SEG_MAX_L_NARROW * SEG_MAX_L_NARROW <= 64, "halo lane groups and the patch's arming lanes in one wavefront");
+    const double ratio = minm < Q.min_remove ? Q.min_remove : minm;
+    if (sblk == 0 && tid == 0) seg_finish(st, Q.rec, N, minm, Q.min_remove);
+    RWS_STAMP(2);
     double removed = 0.0;
     int na = -1, nb = -1;
     T nval = (T)0;
@@ -1263,6 +1293,22 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
             if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
             if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
             if (p >= 1 && cand == 0) hole_p = p;
+        }
+    }
+    RWS_STAMP(3);
+    if (halo && act && P.mt) {
+        // the marginal term of the halo positions, as the owner writes it to rinfo / minfo in this launch
+        if (s < NSYM) {
+            if ((VALID_MASK >> s) & 1) {
+                const double m = (cs[s] > 0 && tot != 0.0) ? cs[s] / tot : 0.0;
+                const int b5 = a6_of_sym(sm, s);
+                const double lm = gh_log10(m);
+                if (b5 < 5) patch->lm5[slot][b5] = lm;
+                const int r = __popc(cm5 & ((1u << b5) - 1u));
+                if (((cand >> s) & 1u) && r < 4) patch->lm4[slot][r] = lm;
+            }
+        } else {
+            for (int r = __popc(cm5); r < 4; r++) patch->lm4[slot][r] = 0.0;
         }
     }
     // ---- the table row of lag d0 (k_rw's table_row): to G for an own position, into the patch for a halo position ---------
@@ -1373,20 +1419,30 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
             }
         }
     }
+    RWS_STAMP(4);
     // ---- flags, removed mass ---------------------------------------------------------------------------------------
     __shared__ unsigned s_flags;
     __shared__ int s_hole;
+    __shared__ double s_part[32];
     if (tid == 0) { s_flags = 0; s_hole = 0x7fffffff; }
     sred[tid] = removed;
     __syncthreads();
     if (flag_bits) atomicOr(&s_flags, flag_bits);
     if (hole_p != 0x7fffffff) atomicMin(&s_hole, hole_p);
-    for (int q = SEG_THREADS / 2; q > 0; q >>= 1) {
-        if (tid < q) sred[tid] += sred[tid + q];
-        __syncthreads();
+    // two levels in a fixed order instead of a tree of ten barriers: 32 threads sum every 32nd value of the lanes that hold
+    // positions, one thread sums the 32
+    if (tid < 32) {
+        const int nact = 8 * (nh + nown);
+        double a2 = 0.0;
+        for (int q = tid; q < nact; q += 32) a2 += sred[q];
+        s_part[tid] = a2;
     }
+    __syncthreads();
     if (tid == 0) {
-        Q.partial[sblk] = sred[0];
+        double tot_removed = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) tot_removed += s_part[q];
+        Q.partial[sblk] = tot_removed;
         const unsigned f = s_flags;
         if (f & 1u) atomicAnd(&st->cm_same, 0);
         if (f & 2u) atomicAnd(&st->nodel, 0);
@@ -1396,6 +1452,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     // what this workgroup stored (G rows, marginals) is read back by its own k_seg part
     __threadfence_block();
     __syncthreads();
+    RWS_STAMP(5);
     return true;
 }
 
