@@ -20,6 +20,7 @@ python3 bench.py --config C5 --steps 2 --warmup 1 > $out/bench_c5.json 2> $out/b
 python3 bench.py --gpus 2 --backend gloo --share-gpu --steps 3 --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err
 python3 bench.py --batch 256 --steps 1 --warmup 1 > $out/bench_batch256.json 2> $out/bench_batch256.err
 GH_FUSE=1 python3 bench.py --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_three_launches.json 2> $out/bench_three_launches.err
+GH_RWSEG=0 python3 bench.py --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_four_launches.json 2> $out/bench_four_launches.err
 python3 scratch/l_sweep.py > $out/l_sweep.txt 2>&1
 if [ "${2:-}" = "cpu-full" ]; then
   python3 bench.py --config C2 --steps 2 --cpu-full --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_c2_cpu_full.json 2> $out/bench_c2_cpu_full.err
