@@ -183,6 +183,7 @@ struct gh_reads {
     int span_pos;     // sorted tables: widest run of positions one workgroup of k_fill_sorted (FILL_RPB reads) covers
 };
 #define FILL_RPB 2048     /* reads per workgroup of k_fill_sorted */
+#define FILL_PAIRS_MIN_K 10   /* k_fill_pairs (32 lanes per read) from this many SNPs in the longest read */
 
 static inline size_t esize(const gh_handle *h) { return h->cfg.storage == GH_STORAGE_F64 ? 8 : 4; }
 
@@ -595,6 +596,16 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
                 hipLaunchKernelGGL(k_fill_sorted<float>, dim3(gb), dim3(block), lds, h->stream, (float *)h->band, h->N, h->W,
                                    r->rank, r->off, r->bases, r->n_reads, rpb, max_pos, r->max_k, use_end_sentinels, h->dstate);
             }
+        } else if (r->max_k >= FILL_PAIRS_MIN_K && r->max_k <= 32 && !(getenv("GH_FILL_PAIRS") && atoi(getenv("GH_FILL_PAIRS")) == 0)) {
+            // long reads, sparse tensor: 32 lanes per read (k_fill_pairs)
+            int64_t nbp = (r->n_reads * 32 + block - 1) / block;
+            if (nbp > 256 * 64) nbp = 256 * 64;
+            if (h->cfg.storage == GH_STORAGE_F64)
+                hipLaunchKernelGGL(k_fill_pairs<double>, dim3((unsigned)nbp), dim3(block), 0, h->stream, (double *)h->band,
+                                   h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);
+            else
+                hipLaunchKernelGGL(k_fill_pairs<float>, dim3((unsigned)nbp), dim3(block), 0, h->stream, (float *)h->band,
+                                   h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);
         } else if (h->cfg.storage == GH_STORAGE_F64)
             hipLaunchKernelGGL(k_fill<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (double *)h->band,
                                h->N, h->W, r->rank, r->off, r->bases, r->n_reads, use_end_sentinels, h->dstate);

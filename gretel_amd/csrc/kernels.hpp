@@ -265,6 +265,64 @@ k_fill(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_fill_pairs: the same pair loop with 32 lanes per read -- lane g takes the pairs (i, i + g + 1), i ascending.  For long reads
+// (tens of SNPs each, a wide band: C5) the tensor is sparse -- fewer observations than cells, nothing to privatise in LDS -- and
+// one thread per read sends the 64 atomics of a wavefront to 64 positions 196 W bytes apart.  Here the atomics of one step go to
+// the cells (i, i + d), d = 1 .. k - 1, of ONE from-position and from-symbol: W x 7 consecutive elements of the band.
+// Reads of at most 32 SNPs (the host checks).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_fill_pairs(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank,
+             const int64_t *__restrict__ off, const uint8_t *__restrict__ bases, int64_t n_reads,
+             int use_end_sentinels, dev_state *st)
+{
+    __shared__ unsigned long long s_acc[3];
+    if (threadIdx.x < 3) s_acc[threadIdx.x] = 0;
+    __syncthreads();
+    const int g = threadIdx.x & 31;
+    const bool upper = (threadIdx.x & 32) != 0;
+    const int64_t grp0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5, ngrp = ((int64_t)gridDim.x * blockDim.x) >> 5;
+    unsigned long long slices = 0, crumbs = 0, covered = 0;
+    for (int64_t r = grp0; r < n_reads; r += ngrp) {
+        const int64_t o0 = off[r];
+        const int k = (int)(off[r + 1] - o0);
+        if (!(k > 1)) continue;                                  // util.py:230 (the same for the 32 lanes of the read)
+        const int rk = rank[r];
+        const int c = g < k ? bases[o0 + g] : 'N';
+        const int sym = c_sym_of_char[c];
+        const unsigned long long bad64 = __ballot(g < k && sym < 0), cov64 = __ballot(g < k && c != 'N' && c != '_');
+        const unsigned bad = upper ? (unsigned)(bad64 >> 32) : (unsigned)bad64, cov = upper ? (unsigned)(cov64 >> 32) : (unsigned)cov64;
+        if (g == 0) { slices++; covered += __popc(cov); }       // util.py:233, 239
+        if (bad) { if (g == 0) atomicAdd(&st->fill[3], 1ULL); continue; }
+        for (int i = 0; i < k - 1; i++) {
+            const int a = __shfl(sym, i, 32);
+            if (a == SYM_US || a == SYM_N) continue;             // util.py:258
+            const int j = i + g + 1;
+            const int b = __shfl(sym, j < k ? j : 0, 32);
+            if (j >= k) continue;
+            if (i == 0 && j == 1 && rk == 0) {                   // util.py:262
+                add_obs(band, N, W, SYM_US, a, 0, 1, &st->fill[4]);
+                add_obs(band, N, W, a, b, 1, 2, &st->fill[4]);
+            } else if ((j + rk + 1) == N && (j - i) == 1) {      // util.py:271
+                add_obs(band, N, W, a, b, N - 1, N, &st->fill[4]);
+                add_obs(band, N, W, b, SYM_US, N, N + 1, &st->fill[4]);
+            } else {                                             // util.py:279
+                add_obs(band, N, W, a, b, i + rk + 1, j + rk + 1, &st->fill[4]);
+                if (use_end_sentinels && j == k - 1 && (j - i) == 1)          // util.py:283
+                    add_obs(band, N, W, b, SYM_US, j + rk + 1, j + rk + 2, &st->fill[4]);
+            }
+            crumbs++;
+        }
+    }
+    if (slices) atomicAdd(&s_acc[0], slices);
+    if (crumbs) atomicAdd(&s_acc[1], crumbs);
+    if (covered) atomicAdd(&s_acc[2], covered);
+    __syncthreads();
+    if (threadIdx.x < 3 && s_acc[threadIdx.x]) atomicAdd(&st->fill[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fill_sorted: the same pair loop for a support table sorted by rank (what a coordinate-sorted
 // BAM gives).  A workgroup owns a contiguous run of reads, so all its observations fall into a
 // narrow slice of positions: it counts them in LDS (integer adds) and flushes the slice once
