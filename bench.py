@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--storage", default="f32", choices=["f32", "f64"], help="storage dtype of the tensor (gh_config.storage)")
     ap.add_argument("--cpu-full", action="store_true", help="CPU baseline as BASELINE.md section 3 plans it: the Python oracle on the "
                     "whole contig (C2: every path; C3: 3 paths; minutes), instead of the bounded sample of the default run")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed and send the control records through it even with ONE rank "
+                         "(a one-GPU box exercises RCCL's communicator, broadcast, gather and all-reduce that way)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="control-plane backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host sockets "
                          "(lets several ranks share one GPU: --share-gpu)")
@@ -375,7 +378,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm_dev = dev if args.backend == "nccl" else torch.device("cpu")     # where the control records live
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
@@ -391,7 +395,7 @@ def main():
     if args.paths <= 0:
         args.paths = 1000 if args.config == "C5" else 100
     desc = broadcast_descriptor(dict(paths=args.paths, steps=args.steps, warmup=args.warmup,
-                                     config={"C2": 2, "C3": 3, "C5": 5}[args.config]), comm_dev, world, rank)
+                                     config={"C2": 2, "C3": 3, "C5": 5}[args.config]), comm_dev, world, rank, force=use_dist)
     cfg_name = "C%d" % desc["config"]
     paths = desc["paths"]
 
@@ -407,11 +411,11 @@ def main():
         h.clear()
         stats = h.fill_from_support(None, None, None, reads_handle=reads)
         res = h.spin(paths)
-        gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank)
+        gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank, force=use_dist)
         return stats, res, gathered
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         h.sync()
@@ -435,7 +439,7 @@ def main():
     ev_empty_ms, ev_nop_ms = h.profile_overhead(30)      # what a bracket reads with nothing / an empty kernel inside
 
     tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if use_dist:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
@@ -543,7 +547,7 @@ def main():
                        "n_snps": n, "n_reads": table.n_reads, "L": L, "band": table.band, "paths": paths,
                        "parallelism": "%d independent window(s), one per rank; %s broadcast/gather of control records, no data-path collective"
                                       % (world, "RCCL" if args.backend == "nccl" else "gloo"),
-                       "backend": args.backend, "share_gpu": bool(args.share_gpu),
+                       "backend": args.backend, "share_gpu": bool(args.share_gpu), "control_records_through_torch_distributed": bool(use_dist),
                        "hansel_spec": dict(spec_kw, cand_order="ACGT-", offer_zero=False)},
             "edge_evals_per_s": hap_s * (cond_evals + rw_cells),
             "edge_evals_per_path": {"conditionals": cond_evals, "reweight_cells": rw_cells},
@@ -736,7 +740,7 @@ def main():
             out["cpu_baseline_c"] = cpu_baseline_c(table, 3 if n >= 5000 else 10)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,9 +21,10 @@ def windows_of_rank(n_windows, world, rank):
     return list(range(rank, n_windows, world))
 
 
-def broadcast_descriptor(desc, device, world, rank):
-    """Rank 0's run descriptor (small dict of ints) to every rank."""
-    if world == 1:
+def broadcast_descriptor(desc, device, world, rank, force=False):
+    """Rank 0's run descriptor (small dict of ints) to every rank.  force: go through torch.distributed even with one rank
+    (a one-GPU box can exercise RCCL's communicator and its broadcast / gather that way)."""
+    if world == 1 and not force:
         return {k: int(desc[k]) for k in DESC_KEYS}
     import torch
     import torch.distributed as dist
@@ -58,9 +59,9 @@ def unpack_result(paths, vals):
                 ratio=vals[:k, 2].copy(), magnitude=vals[:k, 3].copy())
 
 
-def gather_results(res, n_snps, max_paths, device, world, rank):
+def gather_results(res, n_snps, max_paths, device, world, rank, force=False):
     """All windows' records on rank 0 (list indexed by rank), None elsewhere."""
-    if world == 1:
+    if world == 1 and not force:
         return [res]
     import torch
     import torch.distributed as dist

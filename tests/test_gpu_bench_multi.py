@@ -79,3 +79,13 @@ def test_eight_ranks_on_one_gpu(tmp_path):
     assert eight["n_gpus"] == 8 and eight["scaling"] == "weak"
     assert abs(eight["value"] * eight["ms_per_step"] * 1e-3 * 2 - 8 * 2 * 10) < 1e-6 * 160
     _check_gathered(dump, 8, 10)
+
+
+def test_one_rank_through_rccl(tmp_path):
+    # what a one-GPU box can show of the RCCL path: the process group on backend nccl (= RCCL) with ONE rank, the run descriptor
+    # broadcast, the result records gathered and the timings all-reduced on cuda:0 -- the calls the driver's 8-rank launch makes
+    dump = str(tmp_path / "g1.npz")
+    one = _run(["--force-dist", "--backend", "nccl", "--dump-gathered", dump])
+    assert one["n_gpus"] == 1 and one["config"]["backend"] == "nccl" and one["config"]["control_records_through_torch_distributed"] is True
+    assert abs(one["value"] * one["ms_per_step"] * 1e-3 * 2 - 2 * 20) < 1e-6 * 40
+    _check_gathered(dump, 1, 20)

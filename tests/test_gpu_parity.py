@@ -284,6 +284,36 @@ def test_fill_sorted_and_shuffled_tables_agree():
     assert np.array_equal(h3.export_band(), o3.export_band())
 
 
+@pytest.mark.parametrize("k_max,lam", [(21, 10.0), (32, 24.0), (33, 24.0)])
+def test_fill_of_long_reads_three_ways(k_max, lam, monkeypatch):
+    # long reads over a wide band, where no LDS slice holds a workgroup's reads (C5's shape): 32 lanes per read (k_fill_pairs; reads
+    # of at most 32 SNPs), one thread per read (k_fill), and the oracle -- with '-', N and '_' bases, reads at rank 0 and up to the
+    # last SNP, with and without the end sentinels
+    t = make_support_table(6000, 24000, k=None, seed=21, k_lambda=lam, k_max=k_max)
+    rng = np.random.default_rng(3)
+    bases = t.bases.copy()
+    bases[rng.random(len(bases)) < 0.05] = ord('-')
+    bases[rng.random(len(bases)) < 0.03] = ord('N')
+    bases[rng.random(len(bases)) < 0.005] = ord('_')
+    assert int(np.diff(t.off).max()) == k_max and (t.rank == 0).any() and int((t.rank + np.diff(t.off)).max()) == t.n_snps
+    # (shuffled: a rank-sorted table of this size would be counted in LDS)
+    perm = rng.permutation(t.n_reads)
+    ks = np.diff(t.off)
+    rank = np.ascontiguousarray(t.rank[perm])
+    off = np.concatenate([[0], np.cumsum(ks[perm])]).astype(np.int64)
+    bases = np.concatenate([bases[t.off[i]:t.off[i + 1]] for i in perm])
+    from oracle.c_oracle import lib, _p
+    for sentinels in (False, True):
+        o = COracle(t.n_snps, t.band)
+        assert lib().orc_fill(o._h, _p(rank), _p(off), _p(bases), t.n_reads, int(sentinels)) == 0
+        want = o.export_band()
+        for pairs in ("1", "0"):
+            monkeypatch.setenv("GH_FILL_PAIRS", pairs)
+            h = Hansel(t.n_snps, band=t.band)
+            assert h.fill_from_support(rank, off, bases, use_end_sentinels=sentinels) == o.stats(), (sentinels, pairs)
+            assert np.array_equal(h.export_band(), want), (sentinels, pairs)
+
+
 def test_fill_after_spin_keeps_the_fill_accounting():
     # fill -> spin -> fill on one handle without clear(): the second fill's counters are deltas of the device
     # totals against the host mirror, which nothing but create/clear may reset (a stray reset inside gh_spin once
