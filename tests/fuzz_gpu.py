@@ -30,11 +30,15 @@ while time.time() < t_end:
             bases[rng.random(len(bases)) < 0.03] = ord('N')
         t.bases = bases
     storage = str(rng.choice(["f32", "f32", "f64"]))
-    mode = str(rng.choice(["A", "A", "B", "C", "D"]))
+    mode = str(rng.choice(["A", "A", "B", "C", "D", "E"]))
     mt = bool(rng.random() < 0.25)
+    # the other switches of the unpinned arithmetic: the order candidates are offered in, zero-count candidates
+    order = "".join(rng.permutation(list("ACGT-"))) if rng.random() < 0.25 else "ACGT-"
+    zero = bool(rng.random() < 0.15)
+    sw = dict(cand_order=order, offer_zero=zero)
     L = None if rng.random() < 0.4 else (int(rng.integers(1, 27)) if rng.random() < 0.85 else int(rng.integers(25, 48)))
     paths = int(rng.integers(1, 9))
-    desc = dict(n=n, reads=reads, k=k, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths)
+    desc = dict(n=n, reads=reads, k=k, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths, **sw)
     if k is not None and rng.random() < 0.12:
         # batched launch over 3 windows of one shape (same N, band, switches, L)
         ts = [t] + [make_support_table(n, reads, k=k, n_haps=int(rng.integers(1, 9)), err=err, seed=int(rng.integers(0, 1 << 30)))
@@ -42,8 +46,8 @@ while time.time() < t_end:
         if len({x.band for x in ts}) == 1:
             hs, os_ = [], []
             for x in ts:
-                hh = Hansel(x.n_snps, band=x.band, storage=storage, cond_mode=mode, marginal_term=mt)
-                oo = COracle(x.n_snps, x.band, storage, mode, mt)
+                hh = Hansel(x.n_snps, band=x.band, storage=storage, cond_mode=mode, marginal_term=mt, **sw)
+                oo = COracle(x.n_snps, x.band, storage, mode, mt, **sw)
                 assert hh.fill_from_support(x.rank, x.off, x.bases) == oo.fill(x)
                 hh.L = L if L is not None else 3; oo.L = hh.L
                 hs.append(hh); os_.append(oo)
@@ -60,8 +64,8 @@ while time.time() < t_end:
                     sys.exit(1)
             n_batch += 1
             continue
-    h = Hansel(t.n_snps, band=t.band, storage=storage, cond_mode=mode, marginal_term=mt)
-    o = COracle(t.n_snps, t.band, storage, mode, mt)
+    h = Hansel(t.n_snps, band=t.band, storage=storage, cond_mode=mode, marginal_term=mt, **sw)
+    o = COracle(t.n_snps, t.band, storage, mode, mt, **sw)
     try:
         assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t), "fill stats"
         if L is not None:

@@ -89,3 +89,27 @@ def test_one_rank_through_rccl(tmp_path):
     assert one["n_gpus"] == 1 and one["config"]["backend"] == "nccl" and one["config"]["control_records_through_torch_distributed"] is True
     assert abs(one["value"] * one["ms_per_step"] * 1e-3 * 2 - 2 * 20) < 1e-6 * 40
     _check_gathered(dump, 1, 20)
+
+
+def test_the_drivers_launcher_two_ranks(tmp_path):
+    # the driver's own launch line for N > 1 (python -m torch.distributed.run ... bench.py --gpus N ...: RANK / LOCAL_RANK /
+    # WORLD_SIZE / MASTER_* from the environment), here with gloo and both ranks on the one GPU of the test box
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dump = str(tmp_path / "gl.npz")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--config", "C2", "--paths", "20", "--backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-throughput-leg",
+                          "--no-spec-matrix", "--no-e2e", "--dump-gathered", dump], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                      # rank 0 prints the one line
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "weak"
+    assert abs(two["value"] * two["ms_per_step"] * 1e-3 * 2 - 2 * 2 * 20) < 1e-6 * 80
+    _check_gathered(dump, 2, 20)
