@@ -1085,7 +1085,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     if (rc) return rc;
     seg_params P;
     P.N = h->N; P.L = h->L; P.rearm = rearm; P.check_masks = check_masks;
-    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
+    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.nanp = h->cfg.marginal_term && h->cfg.offer_zero; P.sm = h->sm; P.st = h->dstate;
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
     P.rws = 0; P.W = h->W; P.esz = (int)esize(h); P.band = h->band; P.halo = h->rws ? h->seg_halo : nullptr; P.patch_off = 0;
@@ -1112,6 +1112,22 @@ static size_t rws_lds_bytes(int LC, bool five)
     return (b + 15) & ~(size_t)15;
 }
 
+// where the patch lies in k_rwseg's dynamic LDS for this handle (behind k_seg's regions for either radix and, under the column
+// conditionals, behind the staged band blocks of the workgroup's positions); the kernel needs this + sizeof(seg_patch)
+static size_t rws_patch_off(const gh_handle *h, int LC)
+{
+    const bool five = seg_radix_ok(5, LC);
+    const seg_geom g4 = seg_geometry(h->N, LC, 4), g5 = five ? seg_geometry(h->N, LC, 5) : g4;
+    size_t off = rws_lds_bytes(LC, five);
+    if (h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E) {
+        const int longest = g4.seglen > g5.seglen ? g4.seglen : g5.seglen;
+        const size_t need = (size_t)SEG_THREADS * 8 + (size_t)(longest + LC + 1) * NSYM * h->W * NSYM * esize(h);
+        if (need > off) off = (need + 15) & ~(size_t)15;
+    }
+    return off;
+}
+#define RWS_LDS_MAX (160 * 1024 - 1024)      /* what a workgroup may have of the CU's 160 KB, less the kernel's static variables */
+
 template <typename T, int LC, bool COL>
 static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
 {
@@ -1119,13 +1135,7 @@ static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
     const int N = h->N;
     const seg_geom g4 = seg_geometry(N, LC, 4), g5 = five ? seg_geometry(N, LC, 5) : g4;
     const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
-    size_t off = rws_lds_bytes(LC, five);
-    if (COL) {
-        // column mode stages the band blocks of the workgroup's positions (halo + own) behind the reduction scratch
-        const int longest = g4.seglen > g5.seglen ? g4.seglen : g5.seglen;
-        const size_t need = (size_t)SEG_THREADS * 8 + (size_t)(longest + LC + 1) * NSYM * h->W * NSYM * sizeof(T);
-        if (need > off) off = (need + 15) & ~(size_t)15;
-    }
+    const size_t off = rws_patch_off(h, LC);
     const size_t lds = off + sizeof(seg_patch);
     const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
     const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
@@ -1155,7 +1165,7 @@ static int launch_rwseg(gh_handle *h, const uint8_t *d_prev, gh_path_rec *d_prev
     if (rc) return rc;
     seg_params P;
     P.N = h->N; P.L = h->L; P.rearm = 1; P.check_masks = check_masks;
-    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.sm = h->sm; P.st = h->dstate;
+    P.G = h->lt; P.minfo = h->minfo; P.rinfo = h->rinfo; P.mt = h->cfg.marginal_term; P.nanp = h->cfg.marginal_term && h->cfg.offer_zero; P.sm = h->sm; P.st = h->dstate;
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
     P.rws = 1; P.W = h->W; P.esz = (int)esize(h); P.band = h->band; P.halo = h->seg_halo; P.patch_off = 0;
@@ -1951,7 +1961,10 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         const bool small = (five ? max2(emit_small_lds_bytes(h->N, h->L, 4), emit_small_lds_bytes(h->N, h->L, 5)) : emit_small_lds_bytes(h->N, h->L, 4)) <= 64 * 1024 &&
                            !(getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0);
         const int longest = g4.seglen > g5.seglen ? g4.seglen : g5.seglen;
-        if (!small && longest + h->L + 1 <= SEG_THREADS / 8 && (rc = alloc_seg(h)) == GH_OK) {
+        // (... and the kernel's LDS must fit: the column conditionals stage the band blocks of all those positions -- long
+        // segments of a wide band in binary64 do not)
+        if (!small && longest + h->L + 1 <= SEG_THREADS / 8 && rws_patch_off(h, h->L) + sizeof(seg_patch) <= RWS_LDS_MAX &&
+            (rc = alloc_seg(h)) == GH_OK) {
             rws_S = g4.S > g5.S ? g4.S : g5.S;
             const size_t need = (size_t)rws_S * h->L * NSYM * h->W * NSYM * esize(h);
             if (need > h->seg_halo_bytes) {

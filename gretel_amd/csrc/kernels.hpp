@@ -61,7 +61,7 @@ struct dev_state {
     int n_done;
     int scratch;
     int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish   } contiguous:
-    int nodel;       // stays non-zero while no position has '-' among its candidates (k_marg)     } re-armed
+    int nodel;       // stays non-zero while no position offers the LAST symbol of the candidate order ('-' by default): the depth-1 walker then works on four lanes per group (k_marg)  } re-armed
     int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one  } with one
     int narrow;      // stays non-zero while every position has at most 4 candidates (k_marg)      } memset
     int ranked;      // layout of G as k_lt last built it: 1 = rows/columns are candidate RANKS (see k_lt), 0 = symbols
@@ -565,7 +565,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
                 rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
             }
             if (p >= 1 && cand == 0) hole_p = p;
-            if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
+            if (p >= 1 && (cm5 & (1u << 4))) flag_bits |= 2u;      // the LAST symbol of the candidate order ('-' by default) is offered here
             if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
         }
     }

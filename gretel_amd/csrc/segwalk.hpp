@@ -40,6 +40,7 @@ struct seg_params {
     const double *minfo;      // [N+2][16]
     const double *rinfo;      // [N+2][8]: log10 marginal / marginal by candidate rank
     int mt;                   // gh_config.marginal_term: the edge weight starts with log10 marginal(b, t) (added in front of x1)
+    int nanp;                 // sums can be NaN (zero-count candidates offered AND the marginal term): seg_argmax
     symmap sm;
     dev_state *st;
     uint32_t *hist;           // [S][NW][NS] picks of every entry state, DPW per word, the first lowest
@@ -70,9 +71,19 @@ struct seg_params {
 // back for every input without NaNs (the sums are finite or -inf), with v_max_f64 where the scan needs two
 // v_cndmask per value it carries along.
 template <int R>
-__device__ __forceinline__ unsigned seg_argmax(const double (&v)[R])
+__device__ __forceinline__ unsigned seg_argmax(const double (&vin)[R], bool nanp = false)
 {
     static_assert(R == 4 || R == 5, "four ranks or five symbols");
+    double v[R];
+#pragma unroll
+    for (int b = 0; b < R; b++) v[b] = vin[b];
+    if (R == 5 && nanp) {
+        // a NaN (zero-count candidates WITH the marginal term: log10(0) + an infinite conditional) never wins the reference's
+        // scan unless it is offered first (below); inside a pair of the tournament it would shield its partner: x > NaN is false.
+        // -inf never wins either (nothing is greater than the incumbent through it), and the tournament is exact without NaNs.
+#pragma unroll
+        for (int b = 1; b < R; b++) v[b] = v[b] != v[b] ? -INFINITY : v[b];
+    }
     const bool c01 = v[1] > v[0], c23 = v[3] > v[2];
     const double m01 = vmax_f64(v[0], v[1]), m23 = vmax_f64(v[2], v[3]);
     const bool c = m23 > m01;
@@ -129,6 +140,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
     double *Gs = reinterpret_cast<double *>(smem);                 // [(CH + LC - 1)][LC][R][R]
     next_t *Nx = reinterpret_cast<next_t *>(Gs + (size_t)(CH + LC - 1) * LC * RR);   // [CH][NI]
     double *Ms = reinterpret_cast<double *>(smem + seg_lds_bytes(R, LC));            // [CH][R] marginal of column b at every target
+    const bool nanp = P.nanp != 0;
     double mn[SPT];                                                // minimum marginal of the picks, per entry state
 #pragma unroll
     for (int q = 0; q < SPT; q++) mn[q] = INFINITY;
@@ -260,7 +272,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
                         double v[R];
 #pragma unroll
                         for (int b = 0; b < R; b++) v[b] = LC >= 2 ? acc2[b] + xl[dL][b] : xl[dL][b];
-                        packed |= seg_argmax<R>(v) << (BITS * dL);
+                        packed |= seg_argmax<R>(v, nanp) << (BITS * dL);
                     }
                     Nx[(size_t)tl * NI + j + (SH ? dS * NJ : 0)] = (next_t)packed;
                 }
@@ -905,7 +917,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             // the window's flags: collected per workgroup in LDS, one global atomic per flag and workgroup (thousands of
             // positions and-ing the same word one by one cost 12 ns each: 0.2 ms per path in a window full of '-')
             if (cm_old != cmw) flag_bits |= 1u;                    // the conditional table must then be rebuilt in full
-            if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
+            if (p >= 1 && (cm5 & (1u << 4))) flag_bits |= 2u;      // the LAST symbol of the candidate order ('-' by default) is offered here
             if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
             if (p >= 1 && cand == 0) hole_p = p;
         }
@@ -1290,7 +1302,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
                 Q.rinfo[(size_t)p * RINFO + 4 + r] = INFINITY;
             }
             if (cm_old != cmw) flag_bits |= 1u;
-            if (p >= 1 && (cand & (1u << 5))) flag_bits |= 2u;
+            if (p >= 1 && (cm5 & (1u << 4))) flag_bits |= 2u;      // the LAST symbol of the candidate order ('-' by default) is offered here
             if (p >= 1 && __popc(cm5) > 4) flag_bits |= 4u;
             if (p >= 1 && cand == 0) hole_p = p;
         }

@@ -86,6 +86,16 @@ while time.time() < t_end:
         variants[v] = variants.get(v, 0) + 1
     except AssertionError as e:
         print("MISMATCH", e, desc, flush=True)
+        if n <= 20:
+            print(" table: rank", t.rank.tolist(), "off", t.off.tolist(), "bases", bytes(t.bases).decode(), flush=True)
+            try:
+                print(" gpu   ", [bytes(b"ACGTN-_"[q] for q in p).decode() for p in res["paths"]], res["hp_current"].tolist(), "variant", h.walk_clock()[3], flush=True)
+                print(" oracle", [bytes(b"ACGTN-_"[q] for q in p).decode() for p in ref["paths"]], ref["hp_current"].tolist(), flush=True)
+            except Exception as e2:
+                print(" (no detail: %r)" % (e2,), flush=True)
+        sys.exit(1)
+    except Exception as e:
+        print("ERROR", repr(e), desc, flush=True)
         sys.exit(1)
     n_cases += 1
 print("fuzz ok: %d cases + %d batched triples, walker variants %s" % (n_cases, n_batch, variants))

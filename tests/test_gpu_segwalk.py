@@ -225,3 +225,18 @@ def test_reweight_in_the_next_launch_with_a_hole_and_a_stale_table(monkeypatch):
     same(h.spin(1), o.spin(1))
     same(h.spin(2), o.spin(2))
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("n,k,mode,storage", [(20011, 5, "C", "f64"), (12000, 9, "E", "f64"), (20011, 9, "C", "f32")])
+def test_long_segments_under_the_column_conditionals(n, k, mode, storage):
+    # k_rwseg stages the band blocks of a workgroup's positions in LDS under conditionals C / E: segments of 79 positions of a
+    # wide band in binary64 do not fit 160 KB -- the spin must notice and keep the four launches (a launch with too much LDS
+    # fails with "invalid argument": found by the fuzz), with the same paths either way
+    t = make_support_table(n, n * 6, k=k, n_haps=4, seed=5)
+    h = Hansel(t.n_snps, band=t.band, cond_mode=mode, storage=storage)
+    o = COracle(t.n_snps, t.band, storage, mode)
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    res, ref = h.spin(5), o.spin(5)
+    assert res["n"] == ref["n"] == 5 and np.array_equal(res["paths"], ref["paths"])
+    assert res["hp_current"].tolist() == ref["hp_current"].tolist()
+    assert np.array_equal(h.export_band(), o.export_band())

@@ -129,3 +129,45 @@ def test_zero_count_candidates(kw, L, walk):
     assert np.array_equal(res["hp_current"], ref["hp_current"], equal_nan=True) and np.array_equal(res["hp_original"], ref["hp_original"], equal_nan=True)
     assert res["ratio"].tolist() == ref["ratio"].tolist() and np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0)
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("mode", ["C", "D", "E"])
+def test_a_nan_behind_the_first_candidate_never_wins(mode):
+    # windows of 2..5 SNPs, zero-count candidates offered with the marginal term: at the first positions the symbols never seen
+    # weigh NaN (-inf + inf).  gretel.py:166-174 keeps an incumbent unless something compares GREATER: a NaN in any place but
+    # the first never wins -- and must not shield the candidate behind it either (k_seg's arg-max is a tournament of pairs: a NaN
+    # in front of T once kept T out; found by the fuzz)
+    n_bad = 0
+    for n, seed in itertools.product((2, 3, 5), range(30)):
+        t = make_support_table(n, 44, k=2, n_haps=2, err=0.01, seed=seed, k_max=n)
+        h, o = make_pair(t, cond_mode=mode, marginal_term=True, offer_zero=True)
+        res, ref = h.spin(3), o.spin(3)
+        ok = res["n"] == ref["n"] and np.array_equal(res["paths"], ref["paths"]) and \
+            np.array_equal(res["hp_current"], ref["hp_current"], equal_nan=True)
+        n_bad += not ok
+    assert n_bad == 0
+
+
+@pytest.mark.parametrize("walk", ["spec", "spec1"])
+@pytest.mark.parametrize("order", ["TG-AC", "-TGCA", "CA-GT"])
+@pytest.mark.parametrize("L", [1, 2, 3])
+def test_serial_walkers_under_a_candidate_order(walk, order, L):
+    # the depth-1 walker works on four lanes per group while no position offers the fifth candidate -- the LAST symbol of the
+    # candidate order, not '-' as such (with '-' in the middle of the order the symbol in fifth place was never looked at:
+    # found by the fuzz through a batched launch at L = 1, where nothing else runs the depth-1 walker on a narrow window)
+    for seed in range(3):
+        t = make_support_table(17 + 40 * seed, 340 + 900 * seed, k=7, n_haps=8, err=0.05, seed=seed)
+        h, o = make_pair(t, L=L, walk=walk, cand_order=order)
+        same(h.spin(3), o.spin(3))
+        assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("order", ["TG-AC", "-TGCA"])
+@pytest.mark.parametrize("L", [1, 3])
+def test_batched_launches_under_a_candidate_order(order, L, monkeypatch):
+    from gretel_amd.hansel import HanselBatch
+    monkeypatch.setenv("GH_BATCH_STREAMS_MAX", "-1")          # kernels launched over all windows, not windows on their own streams
+    ts = [make_support_table(60, 1500, k=7, n_haps=6, err=0.03, seed=90 + q) for q in range(3)]
+    pairs = [make_pair(t, L=L, cand_order=order) for t in ts]
+    for res, (_, o) in zip(HanselBatch([h for h, _ in pairs]).spin(4), pairs):
+        same(res, o.spin(4))
