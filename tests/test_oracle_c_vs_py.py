@@ -54,6 +54,29 @@ def test_c_equals_python(mode, mt, storage, band, extra):
                 assert np.array_equal(band_c[i, d - 1], dense[:, :, i, i + d])
 
 
+@pytest.mark.parametrize("mode", ["C", "D", "E"])
+def test_nan_weights_c_equals_python(mode):
+    # zero-count candidates offered WITH the marginal term: at the first positions (V(0) = 0) the symbols never seen weigh
+    # NaN (-inf + inf).  gretel.py:166-174 replaces the incumbent only by something that compares GREATER, so a NaN wins exactly
+    # when it is offered first -- both restatements must read the loop that way (the HIP path is held to the C one)
+    n_nan = 0
+    for n, seed in [(2, 13), (2, 18), (3, 3), (3, 7), (3, 13), (5, 1), (5, 4)]:
+        t = make_support_table(n, 44, k=2, n_haps=2, err=0.01, seed=seed, k_max=n)
+        spec = HanselSpec(cond_mode=mode, marginal_term=True, offer_zero=True)
+        h = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, t.n_snps, spec, band=None)
+        G.fill_from_support(h, t.reads(), t.n_snps)
+        c = COracle(t.n_snps, t.band, "f32", mode, True, use_libm=True, offer_zero=True)
+        c.fill(t)
+        ew = h.get_edge_weights_at(1, [h.symbols_d['_']])
+        n_nan += sum(1 for v in ew.values() if v != v)
+        recs, _ = G.recover_paths(h, t.n_snps, 3)
+        r = c.spin(3)
+        assert r["n"] == len(recs)
+        assert paths_to_str(r["paths"]) == [x["path"] for x in recs]
+        assert np.array_equal(r["hp_current"], np.array([x["hp_current"] for x in recs]), equal_nan=True)
+    assert mode != "C" or n_nan > 0          # (C: V(0) + the column sum of a symbol never seen = 0; D's row sum and E's V(j) are not)
+
+
 def test_full_enumeration_equals_banded_enumeration():
     t = make_support_table(40, 800, k=3, seed=2)
     a = COracle(t.n_snps, t.band, use_libm=True)
