@@ -71,6 +71,23 @@ while time.time() < t_end:
         if L is not None:
             h.L = L; o.L = L
         assert h.gap_check() == o.gap_check(), "gap"
+        if rng.random() < 0.15:
+            # the reference's own loop (cmd.py:148-179): one generate_path, one reweight_hansel_from_path at a time
+            h.snapshot_original(); o.snapshot_original()
+            for it in range(paths):
+                pg, po = h.generate_path(), o.generate_path()
+                if po[0] is None:
+                    assert pg[0] is None and pg[1] == po[1], "lone path: hole %s %s" % (pg[1], po[1])
+                    break
+                assert pg[0] is not None and np.array_equal(pg[0], po[0]), "lone path %d" % it
+                assert np.array_equal(np.array(pg[1:]), np.array(po[1]), equal_nan=True), "lone path %d: likelihoods / minimum %s %s" % (it, pg[1:], po[1])
+                ratio = max(pg[3], 0.01) if pg[3] == pg[3] else 0.01
+                mg, mo = h.reweight_from_path(pg[0], ratio), o.reweight_path(po[0], ratio)
+                assert abs(mg - mo) <= 1e-10 * abs(mo), "lone reweight %d" % it
+            assert np.array_equal(h.export_band(), o.export_band()), "band after lone calls"
+            variants["lone"] = variants.get("lone", 0) + 1
+            n_cases += 1
+            continue
         res, ref = h.spin(paths), o.spin(paths)
         assert res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"], "n/hole %s %s" % ((res["n"], res["hole_at"]), (ref["n"], ref["hole_at"]))
         assert np.array_equal(res["paths"], ref["paths"]), "paths"
