@@ -64,10 +64,33 @@ while time.time() < t_end:
                     sys.exit(1)
             n_batch += 1
             continue
+    # the serial walkers instead of the segment-parallel / pool extension now and then (GH_WALK is read when a handle is created)
+    walk = str(rng.choice(["spec", "spec1", "src"])) if rng.random() < 0.1 else None
+    if walk:
+        os.environ["GH_WALK"] = walk
+    else:
+        os.environ.pop("GH_WALK", None)
     h = Hansel(t.n_snps, band=t.band, storage=storage, cond_mode=mode, marginal_term=mt, **sw)
+    os.environ.pop("GH_WALK", None)
     o = COracle(t.n_snps, t.band, storage, mode, mt, **sw)
+    sent = bool(rng.random() < 0.15)                     # the end sentinels of util.py:283
+    if rng.random() < 0.15:
+        # reads in any order (what an unsorted BAM gives): the scattered fills instead of the LDS-counting one
+        perm = rng.permutation(t.n_reads)
+        ks = np.diff(t.off)
+        t.bases = np.concatenate([t.bases[t.off[i]:t.off[i + 1]] for i in perm]) if t.n_reads else t.bases
+        t.off = np.concatenate([[0], np.cumsum(ks[perm])]).astype(np.int64)
+        t.rank = np.ascontiguousarray(t.rank[perm])
+    desc.update(walk=walk, sentinels=sent)
     try:
-        assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t), "fill stats"
+        if rng.random() < 0.1:
+            # a handle that has been used before: fill, spin, clear -- then the case proper
+            h.fill_from_support(t.rank, t.off, t.bases)
+            h.spin(2)
+            h.clear()
+        assert h.fill_from_support(t.rank, t.off, t.bases, use_end_sentinels=sent) == o.fill(t, use_end_sentinels=sent), "fill stats"
+        if rng.random() < 0.1:
+            h = h.copy()                                 # cmd.py:79: the spin runs on a copy of the filled tensor
         if L is not None:
             h.L = L; o.L = L
         assert h.gap_check() == o.gap_check(), "gap"
