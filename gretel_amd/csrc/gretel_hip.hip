@@ -1028,7 +1028,8 @@ static int alloc_seg(gh_handle *h)
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_smin, maps_b * 4);          // doubles where the maps hold 2-byte states
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmin, gmaps_b * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cm5snap, (size_t)h->N + 2);
-    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_min, CW_MAX_SEG * sizeof(double));
+    // (behind the segment minima: k_rwseg's flag words, one int2 per segment)
+    if (e == hipSuccess) e = hipMalloc((void **)&h->seg_min, CW_MAX_SEG * (sizeof(double) + sizeof(int2)));
     if (e == hipSuccess) e = hipMalloc((void **)&h->lmsel1, ((size_t)h->N + 2) * sizeof(double));
     if (e != hipSuccess) return fail(GH_ERR_NOMEM, "hipMalloc for the segment-parallel walk failed: %s", hipGetErrorString(e));
     h->seg_L = h->L;
@@ -1089,6 +1090,7 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
     P.rws = 0; P.W = h->W; P.esz = (int)esize(h); P.band = h->band; P.halo = h->rws ? h->seg_halo : nullptr; P.patch_off = 0;
+    P.rwflags = reinterpret_cast<int2 *>(h->seg_min + CW_MAX_SEG);
     P.path_out = d_path; P.lmsel = d_lmsel ? d_lmsel : h->lmsel1;      // (lmsel1 exists only behind alloc_seg)
     if (h->L < 1 || h->L > SEG_MAX_L_NARROW) return fail(GH_ERR_STATE, "segment-parallel walk needs L <= %d", SEG_MAX_L_NARROW);
     prof_begin(h, GH_K_WALK);
@@ -1153,6 +1155,15 @@ static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
     prof_end(h, GH_K_RWSEG, (double)N * (double)LC * CELL * esize(h) +
              (double)(N + 1) * ((double)h->W * 2.0 * esize(h) + 1.0 + CELL * esize(h) + 2 * 64 + 88 + 8) +
              (double)N * ((double)wl * 7 * esize(h) + (double)LC * LT_ROW * 8.0));
+    // short memories / small windows: every segment map fits the LDS of the emitting workgroup, which composes them itself and
+    // takes k_scan's look at what the reweight found as well: two launches per path
+    const size_t lds_small = five ? max2(emit_small_lds_bytes(N, LC, 4), emit_small_lds_bytes(N, LC, 5)) : emit_small_lds_bytes(N, LC, 4);
+    if (lds_small <= 64 * 1024 && !(getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0)) {
+        static std::atomic<size_t> set_small[64];
+        if (lds_small > set_small[dv]) { hipFuncSetAttribute((const void *)k_emit_small<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small); set_small[dv] = lds_small; }
+        hipLaunchKernelGGL((k_emit_small<LC>), dim3(S), dim3(SEG_THREADS), lds_small, h->stream, P);
+        return;
+    }
     hipLaunchKernelGGL((k_scan<LC, false>), dim3(G1), dim3(SEG_THREADS), lds_scan, h->stream, P);
     hipLaunchKernelGGL((k_emit<LC>), dim3(S), dim3(SEG_THREADS), lds_emit, h->stream, P);
 }
@@ -1169,6 +1180,7 @@ static int launch_rwseg(gh_handle *h, const uint8_t *d_prev, gh_path_rec *d_prev
     P.hist = h->seg_hist; P.maps = h->seg_maps; P.pmaps = h->seg_pmaps; P.gmaps = h->seg_gmaps; P.segmin = h->seg_min;
     P.smin = h->seg_smin; P.gmin = h->seg_gmin; P.cm5snap = h->cm5snap;
     P.rws = 1; P.W = h->W; P.esz = (int)esize(h); P.band = h->band; P.halo = h->seg_halo; P.patch_off = 0;
+    P.rwflags = reinterpret_cast<int2 *>(h->seg_min + CW_MAX_SEG);
     P.path_out = d_path; P.lmsel = d_lmsel;
     rws_params Q;
     Q.band = h->band; Q.cnt = h->cnt; Q.marg = h->marg; Q.minfo = h->minfo; Q.rinfo = h->need_rinfo ? h->rinfo : nullptr; Q.G = h->lt;
@@ -1950,8 +1962,8 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             }
         }
     }
-    // k_rwseg (segwalk.hpp): the reweight of a path rides in the k_seg launch of the next one.  Row conditionals, lane groups of 8,
-    // windows whose k_scan / k_emit are separate launches, at most 128 positions per workgroup with the halo.
+    // k_rwseg (segwalk.hpp): the reweight of a path rides in the k_seg launch of the next one.  Lane groups of 8 (bands up to 8),
+    // at most 128 positions per workgroup with the halo; behind it k_scan + k_emit, or k_emit_small alone in small windows.
     h->rws = false;
     int rws_S = 0;
     if (rc == GH_OK && seg && !h->fuse && !h->lt_full && rw_lanes(h) == 8 &&
@@ -1963,7 +1975,9 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
         const int longest = g4.seglen > g5.seglen ? g4.seglen : g5.seglen;
         // (... and the kernel's LDS must fit: the column conditionals stage the band blocks of all those positions -- long
         // segments of a wide band in binary64 do not)
-        if (!small && longest + h->L + 1 <= SEG_THREADS / 8 && rws_patch_off(h, h->L) + sizeof(seg_patch) <= RWS_LDS_MAX &&
+        // (small windows -- k_emit_small behind k_rwseg, two launches per path -- unless GH_RWSEG_SMALL=0)
+        const bool small_ok = !(getenv("GH_RWSEG_SMALL") && atoi(getenv("GH_RWSEG_SMALL")) == 0);
+        if ((!small || small_ok) && longest + h->L + 1 <= SEG_THREADS / 8 && rws_patch_off(h, h->L) + sizeof(seg_patch) <= RWS_LDS_MAX &&
             (rc = alloc_seg(h)) == GH_OK) {
             rws_S = g4.S > g5.S ? g4.S : g5.S;
             const size_t need = (size_t)rws_S * h->L * NSYM * h->W * NSYM * esize(h);

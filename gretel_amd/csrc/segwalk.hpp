@@ -60,7 +60,54 @@ struct seg_params {
     const void *band;
     void *halo;               // [S][LC][7][W][7] elements
     int patch_off;            // k_rwseg: byte offset of the halo rows in its dynamic LDS (behind k_seg's regions for either radix)
+    // what the reweight inside k_rwseg found, one entry per workgroup: .x = bit 0 a candidate mask moved, bit 1 the last symbol of the
+    // candidate order is offered somewhere, bit 2 a position has five candidates; .y = its first position without a candidate.
+    // Plain stores, overwritten by every launch: the next launch (k_scan, or k_emit_small in small windows) reduces them -- no
+    // atomics on the control words, nothing to re-arm between two launches that both touch them
+    int2 *rwflags;            // [S]
 };
+
+// (every wavefront for itself, at the start of a kernel: every thread takes part)
+__device__ __forceinline__ int2 rws_flags_reduce(const int2 *fl, int S)
+{
+    const int lane = threadIdx.x & 63;
+    int f = 0, hole = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {                              // (at most 400 segments: seg_geometry)
+        const int q = lane + 64 * k;
+        if (q < S) { const int2 v = fl[q]; f |= v.x; hole = v.y < hole ? v.y : hole; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        f |= __shfl_xor(f, o);
+        const int h2 = __shfl_xor(hole, o);
+        hole = h2 < hole ? h2 : hole;
+    }
+    return make_int2(f, hole);
+}
+
+// what k_seg's look at the flags of the last reweight is behind k_rwseg (they only stand when that launch has ended): the control
+// words as the reweight's atomics would have left them, the hole, a stale table.  Returns false when the table is stale (the
+// caller returns); `hole` = the first position without a candidate.  Thread 0 of workgroup 0 writes, everybody decides alike.
+__device__ __forceinline__ bool rws_take_flags(const seg_params &P, dev_state *st, int S, int &hole)
+{
+    int2 fr = rws_flags_reduce(P.rwflags, S);
+    if (fr.y == 0x7fffffff) fr.y = 0x7f7f7f7f;                 // (no hole: the value the armed control word holds)
+    hole = fr.y;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (first) {
+        if (fr.x & 1) st->cm_same = 0;
+        if (fr.x & 2) st->nodel = 0;
+        if (fr.x & 4) st->narrow = 0;
+        if (fr.y < st->first_hole) st->first_hole = fr.y;
+    }
+    if (P.check_masks == 2 || (P.check_masks && (fr.x & 1))) {
+        if (first) st->lt_stale = 1;
+        return false;
+    }
+    if (first) st->cur_hole = fr.y;
+    return true;
+}
 
 // -------------------------------------------------------------------------------------------------------------
 // k_seg
@@ -406,12 +453,8 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
     int cur_hole = c.cur_hole;
     if (P.rws) {
         // behind k_rwseg the flags of the reweight only stand now: k_seg's look at them happens here
-        if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
-            return;
-        }
-        cur_hole = c.first_hole;
-        if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
+        const int S = seg_geometry(P.N, LC, c.ranked != 0 ? 4 : 5).S;
+        if (!rws_take_flags(P, st, S, cur_hole)) return;
     }
     // (a path that ends in a hole is followed by no k_marg: the flags must stand, as after the serial walkers)
     if (P.rearm && cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -564,13 +607,20 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit_small(seg_params P)
     dev_state *st = P.st;
     const dev_ctl c = load_ctl(st);
     if (c.stop || c.lt_stale) return;
+    int cur_hole = c.cur_hole;
+    if (P.rws) {
+        // behind k_rwseg (two launches per path in small windows): k_scan's look at what the reweight found happens here, in
+        // every workgroup for itself -- nobody reads the control words the first thread rewrites
+        const int S = seg_geometry(P.N, LC, c.ranked != 0 ? 4 : 5).S;
+        if (!rws_take_flags(P, st, S, cur_hole)) return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         st->dbg[3] = 3;
         // (k_scan's other job: the flags for the reweight that follows -- every k_seg workgroup has read them: it ran in the launch before)
-        if (P.rearm && c.cur_hole > P.N) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
+        if (P.rearm && cur_hole > P.N) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
     }
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC, true>(P, seg_smem, c.cur_hole);
-    else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC, true>(P, seg_smem, c.cur_hole);
+    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC, true>(P, seg_smem, cur_hole);
+    else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC, true>(P, seg_smem, cur_hole);
 }
 
 // what the serial walkers' bookkeeper does at the end of a walk: hole -> stop, else the record and the ratio the
@@ -1158,7 +1208,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     if (tid == 0) patch->colmode = COL ? 1 : 0;
     const int R = c.ranked != 0 ? 4 : 5;
     const seg_geom g = seg_geometry(N, L, R);
-    if (sblk >= g.S) { if (tid == 0) Q.partial[sblk] = 0.0; return false; }
+    if (sblk >= g.S) { if (tid == 0) { Q.partial[sblk] = 0.0; P.rwflags[sblk] = make_int2(0, 0x7fffffff); } return false; }
     RWS_STAMP(0);
     // ---- the path's minimum marginal over the segments: every wavefront takes it for itself -- a few loads per lane, issued with
     // the loads of the path, the cells and the masks, then lane exchanges (wave_min_f64): no barrier, no LDS
@@ -1455,11 +1505,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
 #pragma unroll
         for (int q = 0; q < 32; q++) tot_removed += s_part[q];
         Q.partial[sblk] = tot_removed;
-        const unsigned f = s_flags;
-        if (f & 1u) atomicAnd(&st->cm_same, 0);
-        if (f & 2u) atomicAnd(&st->nodel, 0);
-        if (f & 4u) atomicAnd(&st->narrow, 0);
-        if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
+        P.rwflags[sblk] = make_int2((int)s_flags, s_hole);         // (the next launch reduces them: rws_take_flags)
     }
     // what this workgroup stored (G rows, marginals) is read back by its own k_seg part
     __threadfence_block();
