@@ -66,15 +66,18 @@ def gather_results(res, n_snps, max_paths, device, world, rank, force=False):
     import torch
     import torch.distributed as dist
     paths, vals = pack_result(res, n_snps, max_paths)
-    tp = torch.from_numpy(paths).to(device)
-    tv = torch.from_numpy(vals).to(device)
-    if rank == 0:
-        gp = [torch.empty_like(tp) for _ in range(world)]
-        gv = [torch.empty_like(tv) for _ in range(world)]
-    else:
-        gp = gv = None
-    dist.gather(tp, gp, dst=0)
-    dist.gather(tv, gv, dst=0)
+    # ONE collective per window and step: the path bytes and the records' doubles travel in one byte buffer
+    nb_p, nb_v = paths.size, vals.size * 8
+    buf = np.empty(nb_p + nb_v, dtype=np.uint8)
+    buf[:nb_p] = paths.ravel()
+    buf[nb_p:] = vals.view(np.uint8).ravel()
+    tb = torch.from_numpy(buf).to(device)
+    gb = [torch.empty_like(tb) for _ in range(world)] if rank == 0 else None
+    dist.gather(tb, gb, dst=0)
     if rank != 0:
         return None
-    return [unpack_result(p.cpu().numpy(), v.cpu().numpy()) for p, v in zip(gp, gv)]
+    out = []
+    for g in gb:
+        a = g.cpu().numpy()
+        out.append(unpack_result(a[:nb_p].reshape(paths.shape), a[nb_p:].copy().view(np.float64).reshape(vals.shape)))
+    return out
