@@ -62,8 +62,9 @@ struct seg_params {
     int patch_off;            // k_rwseg: byte offset of the halo rows in its dynamic LDS (behind k_seg's regions for either radix)
     // what the reweight inside k_rwseg found, one entry per workgroup: .x = bit 0 a candidate mask moved, bit 1 the last symbol of the
     // candidate order is offered somewhere, bit 2 a position has five candidates; .y = its first position without a candidate.
-    // Plain stores, overwritten by every launch: the next launch (k_scan, or k_emit_small in small windows) reduces them -- no
-    // atomics on the control words, nothing to re-arm between two launches that both touch them
+    // Plain stores, overwritten by every launch: in small windows the next launch, k_emit_small, reduces them in every workgroup --
+    // it is also the launch that re-arms the control words, which its workgroups therefore must not read (k_scan, alone between
+    // two launches, reads the control words)
     int2 *rwflags;            // [S]
 };
 
@@ -170,7 +171,9 @@ struct seg_patch {
     double lm4[SEG_MAX_L_NARROW][4], lm5[SEG_MAX_L_NARROW][5];
 };
 
-template <int R, int LC, bool TRACK>
+// (NANP: sums can be NaN -- a separate instantiation: the sanitising selects in the arg-max of the 5^L loop cost the wide window a third
+// of its speed when they hung on a run-time flag)
+template <int R, int LC, bool TRACK, bool NANP = false>
 __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *smem, const seg_patch *patch = nullptr)
 {
     typedef typename seg_radix<R>::next_t next_t;
@@ -187,7 +190,7 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
     double *Gs = reinterpret_cast<double *>(smem);                 // [(CH + LC - 1)][LC][R][R]
     next_t *Nx = reinterpret_cast<next_t *>(Gs + (size_t)(CH + LC - 1) * LC * RR);   // [CH][NI]
     double *Ms = reinterpret_cast<double *>(smem + seg_lds_bytes(R, LC));            // [CH][R] marginal of column b at every target
-    const bool nanp = P.nanp != 0;
+    constexpr bool nanp = NANP;
     double mn[SPT];                                                // minimum marginal of the picks, per entry state
 #pragma unroll
     for (int q = 0; q < SPT; q++) mn[q] = INFINITY;
@@ -391,7 +394,10 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
     // the flags k_marg left for this path; k_scan re-arms them for the next k_marg, k_emit reads the copy
     if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC, TRACK>(P, seg_smem);
-    else if constexpr (seg_radix_ok(5, LC)) seg_body<5, LC, TRACK>(P, seg_smem);      // (beyond: the host only launches this for ranked tables)
+    else if constexpr (seg_radix_ok(5, LC)) {                  // (beyond: the host only launches this for ranked tables)
+        if (P.nanp) seg_body<5, LC, TRACK, true>(P, seg_smem);
+        else seg_body<5, LC, TRACK, false>(P, seg_smem);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -452,9 +458,14 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
     if (c.stop || c.lt_stale) return;
     int cur_hole = c.cur_hole;
     if (P.rws) {
-        // behind k_rwseg the flags of the reweight only stand now: k_seg's look at them happens here
-        const int S = seg_geometry(P.N, LC, c.ranked != 0 ? 4 : 5).S;
-        if (!rws_take_flags(P, st, S, cur_hole)) return;
+        // behind k_rwseg the flags of the reweight only stand now: k_seg's look at them happens here (from the control words the
+        // reweight's atomics left: reducing the workgroups' flag words as k_emit_small does costs this kernel a round trip, 0.85 us)
+        if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
+            return;
+        }
+        cur_hole = c.first_hole;
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
     }
     // (a path that ends in a hole is followed by no k_marg: the flags must stand, as after the serial walkers)
     if (P.rearm && cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1505,7 +1516,14 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
 #pragma unroll
         for (int q = 0; q < 32; q++) tot_removed += s_part[q];
         Q.partial[sblk] = tot_removed;
-        P.rwflags[sblk] = make_int2((int)s_flags, s_hole);         // (the next launch reduces them: rws_take_flags)
+        // for k_scan the control words (atomics, rare: something moved), for k_emit_small -- where the launch that reads them is
+        // the launch that re-arms them -- the workgroup's flag word (rws_take_flags)
+        const unsigned f = s_flags;
+        if (f & 1u) atomicAnd(&st->cm_same, 0);
+        if (f & 2u) atomicAnd(&st->nodel, 0);
+        if (f & 4u) atomicAnd(&st->narrow, 0);
+        if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
+        P.rwflags[sblk] = make_int2((int)f, s_hole);
     }
     // what this workgroup stored (G rows, marginals) is read back by its own k_seg part
     __threadfence_block();
@@ -1528,7 +1546,10 @@ __global__ void __launch_bounds__(SEG_THREADS) k_rwseg(seg_params P, rws_params 
     seg_patch *patch = reinterpret_cast<seg_patch *>(seg_smem + P.patch_off);
     if (!rwseg_reweight<T, LC, COL>(P, Q, c, seg_smem, patch)) return;
     if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC, false>(P, seg_smem, patch);
-    else if constexpr (seg_radix_ok(5, LC)) seg_body<5, LC, false>(P, seg_smem, patch);
+    else if constexpr (seg_radix_ok(5, LC)) {
+        if (P.nanp) seg_body<5, LC, false, true>(P, seg_smem, patch);
+        else seg_body<5, LC, false, false>(P, seg_smem, patch);
+    }
 }
 
 // lone gh_generate_path: no k_marg<T,true> follows, so the record is closed here
