@@ -579,7 +579,8 @@ def main():
                                                                    "rocprofv3's average for the same kernel (profiles/) lies between the raw and the net reading"},
                          "extension_ms_per_path_hip_events": walk_ms,
                          "walker_variant": {4: "candidate-pool segments (k_cwalk/k_clink/k_cscan rounds + k_cemit)",
-                                            3: "segment-parallel (k_seg + k_scan + k_emit)", 2: "serial, depth-2 speculation",
+                                            3: ("segment-parallel (k_rwseg: reweight of the path before + k_seg; k_scan + k_emit, or k_emit_small alone in small windows)"
+                                                if fused_rw else "segment-parallel (k_seg + k_scan + k_emit)"), 2: "serial, depth-2 speculation",
                                             1: "serial, depth-1 speculation, no '-' candidates", 0: "serial, depth-1 speculation"}.get(variant),
                          "walker_cycles_per_step": (cyc / nsteps) if (nsteps and variant <= 2) else None,
                          "issue_model": issue_model,
