@@ -91,12 +91,20 @@ def kernel_source_sha():
 
 
 def seg_geometry(n, L, R):
-    """gretel_amd/csrc/seg_geom.hpp: states, entries per position, positions per segment, segments."""
+    """gretel_amd/csrc/seg_geom.hpp: states, entries per position, positions per segment, segments, groups."""
     ns = R ** L
     g2 = max(1, min(16, (65536 if ns > 3125 else 32768) // ns))
     smax = (25 if 2048 < ns <= 3125 else 16) * g2
     seglen = max((n + smax - 1) // smax, 8)
-    return dict(NS=ns, NI=ns // R, seglen=seglen, S=(n + seglen - 1) // seglen)
+    S = (n + seglen - 1) // seglen
+    return dict(NS=ns, NI=ns // R, seglen=seglen, S=S, G1=(S + g2 - 1) // g2)
+
+
+def small_window(n, L, R):
+    """seg_geom.hpp, emit_small_lds_bytes <= 64 KB: every segment map fits the emitting workgroup's LDS -- k_emit_small instead of
+    k_scan + k_emit (one launch less per path)."""
+    g = seg_geometry(n, L, R)
+    return (g["G1"] + g["S"]) * g["NS"] * 2 + 16 <= 64 * 1024
 
 
 def issue_model_seg(n, L, ranked, clock_ghz, measured_ms, rw_bytes=None):
@@ -528,7 +536,9 @@ def main():
         b_rw = 8.0 * n * min(table.band, n)
         step_bytes = b_fill + paths * (b_ext + b_rw)
         step_s = dt_max / desc["steps"]
-        kernels_per_path = (3 if fused_rw else 4) if segwalk else (None if variant == 4 else 2)
+        ranked_w = not bool((h.candidate_masks()[1:] == 0x2F).any())
+        small_w = segwalk and small_window(n, L, 4 if ranked_w else 5) and os.environ.get("GH_EMIT_SMALL", "1") != "0"
+        kernels_per_path = ((3 if fused_rw else 4) - (1 if small_w else 0)) if segwalk else (None if variant == 4 else 2)
         out = {
             "metric": "haplotypes/sec + SNP-edge-evals/sec on 10k-SNP synthetic contig",
             "value": hap_s,
@@ -588,7 +598,8 @@ def main():
                                   "vector-ALU bound, then LDS-latency bound in the state walk), so its HBM traffic stays far below the "
                                   "bandwidth roofline by construction; a path is %s "
                                   "about 4 us of each is launch + first-touch latency; see DESIGN.md section 4"
-                                  % ("3 dependent kernels (k_rwseg: the reweight of the path before + k_seg; k_scan; k_emit) of 5-21 us,"
+                                  % (("2 dependent kernels (k_rwseg: the reweight of the path before + k_seg; k_emit_small) of 8-10 us,"
+                                      if small_w else "3 dependent kernels (k_rwseg: the reweight of the path before + k_seg; k_scan; k_emit) of 5-21 us,")
                                      if fused_rw else "4 dependent kernels (k_seg, k_scan, k_emit, k_rw) of 5-12 us each,"))
                                  if segwalk else
                                  ("each segment of the window is walked from a pool of candidate entry states by one wavefront per 16 "
