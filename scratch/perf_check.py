@@ -27,7 +27,8 @@ d, r = line(["--config", "C5", "--steps", "1", "--warmup", "1", "--no-throughput
 rows.append(("C5 haplotypes/s", d["value"], r["value"]))
 bad = 0
 for name, now, was in rows:
-    flag = "" if now >= (1 - tol) * was else "   <-- REGRESSION"
+    t = max(tol, 0.15) if "256 windows" in name else tol       # (that leg reads 121k..136k on the same build)
+    flag = "" if now >= (1 - t) * was else "   <-- REGRESSION"
     bad += bool(flag)
     print("%-28s %10.0f   committed %10.0f   %+5.1f %%%s" % (name, now, was, 100 * (now / was - 1), flag))
 sys.exit(1 if bad else 0)
