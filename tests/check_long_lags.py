@@ -1,3 +1,4 @@
+"""Test infrastructure (calls the oracle): C5's contig at lag counts 16, 17, 20, 24 against the C oracle, with timings."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

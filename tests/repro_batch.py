@@ -1,4 +1,4 @@
-"""Batched recovery under candidate orders: which route / switch mismatches the C oracle (GPU box, repo root)."""
+"""Test infrastructure (calls the oracle; run from the repo root on the GPU box).  Batched recovery under candidate orders: which route / switch mismatches the C oracle (GPU box, repo root)."""
 import os, sys, itertools
 sys.path.insert(0, ".")
 import numpy as np

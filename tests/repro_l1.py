@@ -1,3 +1,4 @@
+"""Test infrastructure (calls the oracle; run from the repo root on the GPU box): the serial walkers at L = 1..3 under a candidate order."""
 import os, sys, itertools
 sys.path.insert(0, ".")
 import numpy as np

@@ -1,4 +1,4 @@
-"""Tiny windows under every switch: first mismatch against the C oracle, with details (GPU box, repo root)."""
+"""Test infrastructure (calls the oracle; run from the repo root on the GPU box).  Tiny windows under every switch: first mismatch against the C oracle, with details (GPU box, repo root)."""
 import sys, itertools
 sys.path.insert(0, ".")
 import numpy as np
