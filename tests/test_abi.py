@@ -52,6 +52,22 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle/" in txt.replace("oracle/hansel_ref.py", "").replace("oracle/gretel_ref.py", ""):
                     bad.append(f)
     assert not bad, bad
+    # ... nor do the measurement scripts (scratch/, profiles/): whatever calls the oracle lives under tests/; bench.py only in its
+    # cpu_baseline legs, __graft_entry__.py only in smoke()
+    for d in ("scratch", "profiles"):
+        for f in os.listdir(os.path.join(ROOT, d)):
+            if f.endswith((".py", ".sh")):
+                txt = open(os.path.join(ROOT, d, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
+                    bad.append(d + "/" + f)
+    assert not bad, bad
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)(from|import)\s+oracle\b", b, flags=re.M):
+        fn = re.findall(r"^def (\w+)", b[:m.start()], flags=re.M)[-1]
+        assert fn.startswith("cpu_baseline"), fn
+    g = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for m in re.finditer(r"^(\s*)(from|import)\s+oracle\b", g, flags=re.M):
+        assert re.findall(r"^def (\w+)", g[:m.start()], flags=re.M)[-1] == "smoke"
 
 
 def test_io_library_exports_its_header():
