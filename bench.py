@@ -78,6 +78,20 @@ def self_launch(args):
     sys.exit(max(abs(rc) for rc in rcs))
 
 
+_JSON_FD = None
+
+
+def emit_line(line):
+    """The one JSON line, to the stdout this process was started with (main() points descriptor 1 at stderr meanwhile)."""
+    data = (line + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+        return
+    while data:
+        data = data[os.write(_JSON_FD, data):]
+
+
 def kernel_source_sha():
     """Identity of the build a profile was taken with: a hash over the kernel sources (the GPU box has no .git)."""
     import glob
@@ -341,7 +355,7 @@ def bench_batch(args, cfg_name, paths, desc, rank, world, local, dev):
         bp = batch.profile_get()
         rw = bp["reweight"]
         rw_ms = rw["ms"] / max(1, rw["launches"])
-        print(json.dumps({
+        emit_line(json.dumps({
             "roofline": {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)",
                          "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
                          "algorithmic_bytes_per_launch": rw["bytes_per_launch"],
@@ -369,6 +383,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)                   # never returns
     args.gpus = world
+    # stdout carries ONE line, the JSON: whatever a library writes to file descriptor 1 on its own (RCCL prints a version banner
+    # there when its first communicator comes up, through C stdio, so it would land BEHIND the line) goes to stderr instead
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -419,7 +439,7 @@ def main():
         h.clear()
         stats = h.fill_from_support(None, None, None, reads_handle=reads)
         res = h.spin(paths)
-        gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank, force=use_dist)
+        gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank, force=use_dist, copy=False)
         return stats, res, gathered
 
     def fence():
@@ -751,7 +771,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_python(table, min(args.cpu_snps, n), n)
             out["cpu_baseline_c"] = cpu_baseline_c(table, 3 if n >= 5000 else 10)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-        print(json.dumps(out))
+        emit_line(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -59,25 +59,73 @@ def unpack_result(paths, vals):
                 ratio=vals[:k, 2].copy(), magnitude=vals[:k, 3].copy())
 
 
-def gather_results(res, n_snps, max_paths, device, world, rank, force=False):
-    """All windows' records on rank 0 (list indexed by rank), None elsewhere."""
+class _GatherBuffers:
+    """What a gather needs, allocated once per shape: a (pinned) host staging buffer and its device twin on every rank, on
+    rank 0 one [world][bytes] tensor to gather into and its (pinned) host twin.  Per step that leaves one packing pass, one
+    asynchronous upload, the collective, and on rank 0 ONE download of all windows -- no per-rank copies."""
+
+    def __init__(self, nb_p, nb_v, device, world, rank):
+        import torch
+        self.nb_p, self.nb_v = nb_p, nb_v
+        self.off_v = (nb_p + 7) & ~7                              # the records' doubles start 8-byte aligned
+        nbytes = self.off_v + nb_v
+        cuda = device.type == "cuda"
+        self.cuda = cuda
+        self.send_host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=cuda)
+        self.send_np = self.send_host.numpy()
+        self.send_dev = torch.empty(nbytes, dtype=torch.uint8, device=device) if cuda else self.send_host
+        self.recv_dev = self.recv_host = None
+        if rank == 0:
+            self.recv_dev = torch.empty((world, nbytes), dtype=torch.uint8, device=device)
+            self.recv_host = torch.empty((world, nbytes), dtype=torch.uint8, pin_memory=True) if cuda else self.recv_dev
+
+
+_gather_cache = {}
+
+
+def gather_results(res, n_snps, max_paths, device, world, rank, force=False, copy=True):
+    """All windows' records on rank 0 (list indexed by rank), None elsewhere.  ONE collective per window and step: the path
+    bytes and the records' doubles travel in one byte buffer.  copy=False: the returned arrays are views of a buffer the next
+    call overwrites (bench.py, which looks at one step's results at a time)."""
     if world == 1 and not force:
         return [res]
     import torch
     import torch.distributed as dist
-    paths, vals = pack_result(res, n_snps, max_paths)
-    # ONE collective per window and step: the path bytes and the records' doubles travel in one byte buffer
-    nb_p, nb_v = paths.size, vals.size * 8
-    buf = np.empty(nb_p + nb_v, dtype=np.uint8)
-    buf[:nb_p] = paths.ravel()
-    buf[nb_p:] = vals.view(np.uint8).ravel()
-    tb = torch.from_numpy(buf).to(device)
-    gb = [torch.empty_like(tb) for _ in range(world)] if rank == 0 else None
-    dist.gather(tb, gb, dst=0)
+    n1 = n_snps + 1
+    key = (n_snps, max_paths, str(device), world, rank)
+    b = _gather_cache.get(key)
+    if b is None:
+        b = _gather_cache[key] = _GatherBuffers(max_paths * n1, (max_paths + 1) * 4 * 8, device, world, rank)
+    # pack (pack_result's layout) straight into the staging buffer
+    k = int(res["n"])
+    pv = b.send_np[:b.nb_p].reshape(max_paths, n1)
+    vv = b.send_np[b.off_v:b.off_v + b.nb_v].view(np.float64).reshape(max_paths + 1, 4)
+    if k:
+        pv[:k] = res["paths"]
+        vv[:k, 0] = res["hp_current"]
+        vv[:k, 1] = res["hp_original"]
+        vv[:k, 2] = res["ratio"]
+        vv[:k, 3] = res["magnitude"]
+    pv[k:] = 255
+    vv[k:max_paths] = 0.0
+    vv[max_paths] = (k, res["hole_at"], 0.0, 0.0)
+    if b.cuda:
+        b.send_dev.copy_(b.send_host, non_blocking=True)         # (stream-ordered: the collective is queued behind it)
+    dist.gather(b.send_dev, [b.recv_dev[r] for r in range(world)] if rank == 0 else None, dst=0)
     if rank != 0:
         return None
+    if b.cuda:
+        b.recv_host.copy_(b.recv_dev, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    a = b.recv_host.numpy()
     out = []
-    for g in gb:
-        a = g.cpu().numpy()
-        out.append(unpack_result(a[:nb_p].reshape(paths.shape), a[nb_p:].copy().view(np.float64).reshape(vals.shape)))
+    for r in range(world):
+        paths = a[r, :b.nb_p].reshape(max_paths, n1)
+        vals = a[r, b.off_v:b.off_v + b.nb_v].view(np.float64).reshape(max_paths + 1, 4)
+        if copy:
+            out.append(unpack_result(paths, vals))
+        else:
+            kk = int(vals[max_paths, 0])
+            out.append(dict(n=kk, hole_at=int(vals[max_paths, 1]), paths=paths[:kk], hp_current=vals[:kk, 0], hp_original=vals[:kk, 1],
+                            ratio=vals[:kk, 2], magnitude=vals[:kk, 3]))
     return out

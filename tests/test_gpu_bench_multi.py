@@ -22,6 +22,9 @@ def _run(extra, paths="20"):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
+    # stdout carries that line and nothing else (RCCL's version banner, printed through C stdio when the first communicator
+    # comes up, once landed behind it)
+    assert out.stdout.strip().splitlines() == lines, out.stdout
     return json.loads(lines[0])
 
 
