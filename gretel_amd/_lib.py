@@ -70,6 +70,8 @@ def load():
     sigs = {
         "gh_device_count": [P(i32)],
         "gh_device_clock_khz": [i32, P(i32)],
+        "gh_log10_device": [i32, vp, vp, C.c_int64],
+        "gh_log10_host": [vp, vp, C.c_int64],
         "gh_create": [P(gh_config), P(vp)],
         "gh_destroy": [vp],
         "gh_copy": [vp, P(vp)],
@@ -134,6 +136,18 @@ def device_clock_khz(device=-1):
     k = C.c_int(0)
     check(load().gh_device_clock_khz(int(device), C.byref(k)))
     return k.value
+
+
+def log10_many(x, device=None):
+    """log10 as the kernels evaluate it (include/gh_detlog.h): on the GPU `device`, or (None) the same source on the host."""
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    if device is None:
+        check(load().gh_log10_host(x.ctypes.data, y.ctypes.data, x.size))
+    else:
+        check(load().gh_log10_device(int(device), x.ctypes.data, y.ctypes.data, x.size))
+    return y
 
 
 def device_count():

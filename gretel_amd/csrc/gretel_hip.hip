@@ -276,6 +276,40 @@ extern "C" int gh_device_clock_khz(int device, int *khz)
     return GH_OK;
 }
 
+// log10 as the kernels evaluate it (include/gh_detlog.h), over an array: what tests/test_gpu_detlog.py holds to the host's libm
+__global__ void k_log10_many(const double *__restrict__ x, double *__restrict__ y, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = gh_log10(x[i]);
+}
+
+extern "C" int gh_log10_device(int device, const double *x, double *y, int64_t n)
+{
+    if (!x || !y || n < 0) return fail(GH_ERR_ARG, "null argument");
+    if (n == 0) return GH_OK;
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    double *dx = nullptr, *dy = nullptr;
+    HIPCHK(hipMalloc(&dx, n * sizeof(double)));
+    if (hipMalloc(&dy, n * sizeof(double)) != hipSuccess) { hipFree(dx); return fail(GH_ERR_HIP, "hipMalloc"); }
+    int rc = GH_OK;
+    if (hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(GH_ERR_HIP, "hipMemcpy");
+    if (rc == GH_OK) {
+        k_log10_many<<<dim3((unsigned)((n + 255) / 256)), dim3(256)>>>(dx, dy, n);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(y, dy, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(GH_ERR_HIP, "k_log10_many");
+    }
+    hipFree(dx); hipFree(dy);
+    return rc;
+}
+
+// the same function compiled for the host (no device touched): the restatement itself against the running libm
+extern "C" int gh_log10_host(const double *x, double *y, int64_t n)
+{
+    if (!x || !y || n < 0) return fail(GH_ERR_ARG, "null argument");
+    for (int64_t i = 0; i < n; i++) y[i] = gh_log10(x[i]);
+    return GH_OK;
+}
+
 static void free_handle(gh_handle *h)
 {
     if (!h) return;
@@ -1187,6 +1221,7 @@ static int launch_rwseg(gh_handle *h, const uint8_t *d_prev, gh_path_rec *d_prev
     Q.nvalid = h->nvalid; Q.cmask = h->cmask; Q.path = d_prev; Q.min_remove = min_remove;
     Q.partial = h->partial + (size_t)prev_slot * h->spin_partial_stride;
     Q.rec = d_prev_rec; Q.cond_mode = h->cfg.cond_mode; Q.offer_zero = h->cfg.offer_zero;
+    if (h->L < 1 || h->L > SEG_MAX_L_NARROW) return fail(GH_ERR_STATE, "k_rwseg needs L <= %d", SEG_MAX_L_NARROW);   // before the bracket opens
     prof_begin(h, GH_K_WALK);
     const bool f64 = h->cfg.storage == GH_STORAGE_F64;
     const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;
@@ -1982,10 +2017,13 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
             rws_S = g4.S > g5.S ? g4.S : g5.S;
             const size_t need = (size_t)rws_S * h->L * NSYM * h->W * NSYM * esize(h);
             if (need > h->seg_halo_bytes) {
-                HIPCHK(hipStreamSynchronize(h->stream));
-                hipFree(h->seg_halo); h->seg_halo = nullptr; h->seg_halo_bytes = 0;
-                if (hipMalloc(&h->seg_halo, need) != hipSuccess) rc = fail(GH_ERR_NOMEM, "hipMalloc failed");
-                else h->seg_halo_bytes = need;
+                // (no early return from here on: the cleanup at the end of this function resets fuse / rws / the stride)
+                if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: %s", hipGetErrorString(e));
+                else {
+                    hipFree(h->seg_halo); h->seg_halo = nullptr; h->seg_halo_bytes = 0;
+                    if (hipMalloc(&h->seg_halo, need) != hipSuccess) rc = fail(GH_ERR_NOMEM, "hipMalloc failed");
+                    else h->seg_halo_bytes = need;
+                }
             }
             h->rws = rc == GH_OK;
         }

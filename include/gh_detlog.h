@@ -1,23 +1,40 @@
 /*
- * gh_detlog.h -- a bit-reproducible double-precision log10 for host and device.
+ * gh_detlog.h -- the host's log10, bit for bit, on host and device.
  *
  * Why: Gretel's path extension picks the arg-max of sums of log10(conditional)
  * (reference gretel/gretel.py:155-174) and accumulates log10(marginal)
- * (gretel/gretel.py:185-186).  The reference calls libm's log10 through
- * Python's math.log10.  libm (glibc) and the GPU math library (ocml) are both
- * "within an ulp or so" but not bit-identical to each other, so a near tie
- * could resolve differently on the two sides and the recovered SNP sequence
- * would stop being bit-exact.  This header gives ONE sequence of IEEE-754
- * binary64 operations (+, -, *, / and integer bit moves; no fma contraction --
- * compile with -ffp-contract=off) that gcc on x86-64 and hipcc on gfx950
- * evaluate identically.  Error < 1 ulp (tests/test_detlog.py checks it against
- * a 50-digit reference and against libm).
+ * (gretel/gretel.py:185-186).  The reference calls libm's log10 through Python's
+ * math.log10 (gretel/gretel.py:2).  Candidates whose evidence is mathematically
+ * equal but arrives through different operands (the same counts in another order,
+ * a.b = c.d) end up an ulp or two apart -- or exactly tied -- depending on how
+ * every single log10 was rounded: tests/test_log10_audit.py counts such steps
+ * (86 within 4 ulp among 1.2e8, next to 11 000 exact ties), and a log10 that is
+ * merely "accurate to an ulp" decides about one step in 5e6 differently from
+ * libm -- one path in a hundred at 50 000 SNPs (rounds 1-3 shipped such a log10;
+ * profiles/r4_log10_audit_fdlibm.json is its census).  So this header is not
+ * another log10: it is glibc's, restated operation by operation --
  *
- * Algorithm: the classic argument reduction x = 2^k * (1+f),
- * sqrt(2)/2 < 1+f < sqrt(2), log(1+f) = f - f^2/2 + s*(f^2/2 + R(s^2)),
- * s = f/(2+f), R a degree-7 minimax polynomial (Sun fdlibm's published
- * coefficients), followed by a hi/lo split multiplication by 1/ln(10) and
- * addition of k*log10(2) in two pieces.
+ *   log10(x):  glibc sysdeps/ieee754/dbl-64/e_log10.c (__ieee754_log10):
+ *              x = 2^k m, m in [1,2) for k >= 0, [0.5,1) for k < 0 (y = k or k+1);
+ *              (y*log10_2lo + ivln10*log(m)) + y*log10_2hi, plain multiplies and adds;
+ *   log(m):    glibc sysdeps/ieee754/dbl-64/e_log.c (__log, glibc >= 2.28; Szabolcs
+ *              Nagy's table-driven log), in the form x86-64 hosts with FMA run it
+ *              (the ifunc picks __log_fma wherever the CPU has FMA and AVX2: every
+ *              x86-64 server since 2013): r = fma(z, 1/c, -1) and the fused
+ *              multiply-adds exactly where that build has them (read off the
+ *              instruction sequence of Ubuntu GLIBC 2.35-0ubuntu3.11's libm.so.6);
+ *   table:     include/gh_logtab.inc, glibc's __log_data.tab (tools/gen_logtab.py).
+ *
+ * Every operation below is an IEEE-754 binary64 +, -, *, or an EXPLICIT fma;
+ * compile with -ffp-contract=off so the compiler adds none of its own.  gcc on
+ * x86-64 and hipcc on gfx950 then evaluate it identically, and identically to
+ * the libm it restates: tests/test_detlog.py compares it with the running libm
+ * on 4e7 arguments (every exponent, the near-one interval, every table
+ * interval's edges, the operands the hot path produces) on the CPU, and the GPU
+ * suite compares the device function with the host's libm the same way
+ * (tests/test_gpu_detlog.py).  On a host whose libm takes another road (no FMA;
+ * a glibc before 2.28; another libc) that test says so -- the reference's own
+ * answers on near-ties differ between such hosts too.
  *
  * Special cases: +0/-0 -> -inf, x<0 -> nan, +inf -> +inf, nan -> nan.
  */
@@ -36,62 +53,92 @@
 GH_HD uint64_t gh_d2u(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 GH_HD double gh_u2d(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
 
-/* the arithmetic of gh_log10 for a normal, positive, finite x (k0 = exponent carried in by the caller's
- * subnormal scaling); straight-line code, so that several calls interleave on the GPU */
+/* { 1/c, log c } per subinterval: glibc's __log_data.tab */
+static const double gh_logtab_host[256] = {
+#include "gh_logtab.inc"
+};
+#if defined(__HIPCC__)
+__device__ static const double gh_logtab_dev[256] = {
+#include "gh_logtab.inc"
+};
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GH_LOGTAB gh_logtab_dev
+#else
+#define GH_LOGTAB gh_logtab_host
+#endif
+
+/* glibc's log() for 0.5 <= x < 2 (what its log10 hands it), the FMA build */
+GH_HD double gh_log_reduced(double x)
+{
+    const uint64_t ix = gh_d2u(x);
+    /* 1 - 0x1p-4 <= x < 1 + 0x1.09p-4: a polynomial in r = x - 1, its leading terms in two pieces */
+    if (ix - 0x3fee000000000000ULL < 0x0003090000000000ULL) {
+        const double B0 = -0x1.0000000000000p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3,
+                     B3 = 0x1.999999995dd0cp-3, B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de30p-3,
+                     B6 = -0x1.fffffa4423d65p-4, B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4,
+                     B9 = 0x1.78182f7afd085p-4, B10 = -0x1.5521375d145cdp-4;
+        if (ix == 0x3ff0000000000000ULL) return 0.0;
+        const double r = x - 1.0;
+        const double r2 = r * r;
+        const double r3 = r * r2;
+        double a = __builtin_fma(r, B2, B1);
+        double b = __builtin_fma(r, B5, B4);
+        double c = __builtin_fma(r, B8, B7);
+        a = __builtin_fma(r2, B3, a);
+        b = __builtin_fma(r2, B6, b);
+        c = __builtin_fma(r2, B9, c);
+        c = __builtin_fma(r3, B10, c);
+        double y = __builtin_fma(c, r3, b);
+        y = __builtin_fma(y, r3, a);
+        /* rhi = the top 26 bits of r; hi + lo = r - rhi*rhi/2 */
+        const double t = __builtin_fma(r, 0x1p27, r);
+        const double rhi = __builtin_fma(-0x1p27, r, t);
+        const double rlo = r - rhi;
+        const double rr = rhi * rhi;
+        const double hi = __builtin_fma(rr, B0, r);
+        double lo = __builtin_fma(rr, B0, r - hi);
+        lo = __builtin_fma(B0 * rlo, r + rhi, lo);
+        y = __builtin_fma(y, r3, lo);
+        return hi + y;
+    }
+    const double ln2hi = 0x1.62e42fefa3800p-1, ln2lo = 0x1.ef35793c76730p-45;
+    const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3,
+                 A3 = 0x1.999b324f10111p-3, A4 = -0x1.55575e506c89fp-3;
+    /* x = 2^k z, z in [0x1.6p-1, 0x1.6p0), split into 128 intervals; log x = k ln2 + log c + log1p(z/c - 1) */
+    const uint64_t tmp = ix - 0x3fe6000000000000ULL;
+    const int i = (int)((tmp >> 45) & 127);
+    const int32_t k = (int32_t)((int64_t)tmp >> 52);
+    const double z = gh_u2d(ix - (tmp & 0xfff0000000000000ULL));
+    const double kd = (double)k;
+    const double invc = GH_LOGTAB[2 * i], logc = GH_LOGTAB[2 * i + 1];
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double w = __builtin_fma(kd, ln2hi, logc);
+    const double hi = w + r;
+    const double lo = __builtin_fma(kd, ln2lo, (w - hi) + r);
+    const double r2 = r * r;
+    const double p = __builtin_fma(r, A2, A1);
+    const double q = __builtin_fma(r, A4, A3);
+    const double lo2 = __builtin_fma(r2, A0, lo);
+    const double pq = __builtin_fma(q, r2, p);
+    const double y = __builtin_fma(r * r2, pq, lo2);
+    return y + hi;
+}
+
+/* log10 of a normal, positive, finite x (k0 = exponent carried in by the caller's subnormal scaling):
+ * glibc's __ieee754_log10 behind its special cases */
 GH_HD double gh_log10_normal(double x, int32_t k0)
 {
-    const double ivln10hi = 4.34294481878168880939e-01;   /* 0x3fdbcb7b15200000 */
-    const double ivln10lo = 2.50829467116452752298e-11;   /* 0x3dbb9438ca9aadd5 */
-    const double log10_2hi = 3.01029995663611771306e-01;  /* 0x3FD34413509F6000 */
-    const double log10_2lo = 3.69423907715893078616e-13;  /* 0x3D59FEF311F12B36 */
-    const double Lg1 = 6.666666666666735130e-01;
-    const double Lg2 = 3.999999999940941908e-01;
-    const double Lg3 = 2.857142874366239149e-01;
-    const double Lg4 = 2.222219843214978396e-01;
-    const double Lg5 = 1.818357216161805012e-01;
-    const double Lg6 = 1.531383769920937332e-01;
-    const double Lg7 = 1.479819860511658591e-01;
-
-
-    uint64_t u = gh_d2u(x);
-    int32_t hx = (int32_t)(u >> 32);
-    uint32_t lx = (uint32_t)u;
-    int32_t k = k0;
-
-    k += (hx >> 20) - 1023;
-    hx &= 0x000fffff;
-    int32_t i = (hx + 0x95f64) & 0x100000;       /* 1 iff mantissa > sqrt(2) */
-    u = ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32) | lx;   /* normalise x or x/2 */
-    x = gh_u2d(u);
-    k += (i >> 20);
-    double y = (double)k;
-    double f = x - 1.0;
-    double hfsq = 0.5 * f * f;
-
-    /* r = log(1+f) - f + f*f/2 */
-    double s = f / (2.0 + f);
-    double z = s * s;
-    double w = z * z;
-    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
-    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
-    double R = t2 + t1;
-    double r = s * (hfsq + R);
-
-    /* hi + lo = f - hfsq + r, hi with its low 32 bits cleared */
-    double hi = f - hfsq;
-    hi = gh_u2d(gh_d2u(hi) & 0xffffffff00000000ULL);
-    double lo = (f - hi) - hfsq + r;
-
-    double val_hi = hi * ivln10hi;
-    double y2 = y * log10_2hi;
-    double val_lo = y * log10_2lo + (lo + hi) * ivln10lo + lo * ivln10hi;
-
-    /* extra-precision sum y2 + val_hi */
-    double ww = y2 + val_hi;
-    val_lo += (y2 - ww) + val_hi;
-    val_hi = ww;
-
-    return val_lo + val_hi;
+    const double ivln10 = 0x1.bcb7b1526e50ep-2;       /* 1/ln 10 */
+    const double log10_2hi = 0x1.34413509f6000p-2;
+    const double log10_2lo = 0x1.9fef311f12b36p-42;
+    const uint64_t u = gh_d2u(x);
+    const int32_t k = k0 + (int32_t)(u >> 52) - 1023;
+    const int32_t i = (int32_t)((uint32_t)k >> 31);               /* 1 iff k < 0: then m in [0.5, 1) and y = k + 1 */
+    const double m = gh_u2d((u & 0x000fffffffffffffULL) | ((uint64_t)(0x3ff - i) << 52));
+    const double y = (double)(k + i);
+    const double z = y * log10_2lo + ivln10 * gh_log_reduced(m);
+    return z + y * log10_2hi;
 }
 
 /* 1 iff gh_log10(x) takes the straight-line path: 2^-1022 <= x < inf */
@@ -120,7 +167,7 @@ GH_HD double gh_log10(double x)
     }
     if (hx >= 0x7ff00000)
         return x + x;                            /* inf or nan */
-    return gh_log10_normal(x, k);                /* log10(1) comes out as +0 by itself */
+    return gh_log10_normal(x, k);
 }
 
 

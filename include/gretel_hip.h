@@ -90,6 +90,13 @@ int gh_device_count(int *n);
 /* peak shader clock of a device in kHz (bench.py prices its instruction-issue floors with it) */
 int gh_device_clock_khz(int device, int *khz);
 
+/* log10 as every kernel evaluates it: include/gh_detlog.h, glibc's log10 restated so that the arg-max of
+ * gretel/gretel.py:159-174 and the sums of gretel/gretel.py:185-186 see the very doubles math.log10 (gretel/gretel.py:2)
+ * gives the reference.  gh_log10_device runs it on the GPU over an array, gh_log10_host is the same source compiled
+ * for the host (touches no device): the tests hold both to the running libm. */
+int gh_log10_device(int device, const double *x, double *y, int64_t n);
+int gh_log10_host(const double *x, double *y, int64_t n);
+
 /* Hansel.init_matrix(['A','C','G','T','N','-','_'], ['N','_'], N) -- gretel/util.py:83.
  * Allocates the zeroed banded tensor [(N+2)][band][7][7] in HBM. */
 int gh_create(const gh_config *cfg, gh_t **out);

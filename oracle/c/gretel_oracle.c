@@ -25,9 +25,10 @@
  * whenever no read carries SNPs further apart than `band` (zero is a fixed point
  * of reweight), so results are identical.
  *
- * log10: `use_libm=1` calls libm's log10 (what Python's math.log10 calls);
- * `use_libm=0` uses include/gh_detlog.h, the bit-reproducible log10 that the
- * HIP kernels also use (see that header for why).
+ * log10: `use_libm=1` (the default of oracle/c_oracle.py) calls libm's log10 -- what Python's
+ * math.log10 calls, i.e. the reference's (gretel/gretel.py:2); `use_libm=0` uses include/gh_detlog.h,
+ * the restatement of glibc's log10 the HIP kernels evaluate.  The two are the same function bit for bit
+ * (tests/test_detlog.py); orc_audit_* below evaluates them side by side over whole spins.
  */
 #include <math.h>
 #include <stdint.h>
@@ -52,7 +53,28 @@ typedef struct orc {
     void *h;                    /* live matrix    [(n+2)*band*49] */
     void *h0;                   /* hansel.copy()  (gretel/cmd.py:79) */
     int64_t reweight_calls;
+    struct orc_audit *audit;    /* orc_audit_begin(): both log10s in lock-step (below) */
 } orc_t;
+
+/* What a spin looks like when libm's log10 (the reference's: math.log10, gretel/gretel.py:2,185-186) and the
+ * one of include/gh_detlog.h (the HIP kernels') are evaluated side by side on the SAME state.
+ * The spin follows the handle's own log (use_libm); a step where the other log would have picked another symbol
+ * is a FLIP.  No flip in a spin => both logs recover the same paths, ratios and tensor (induction over the steps:
+ * same tensor and same prefix => same candidates; no log enters the reweight).  The census counts how close the
+ * steps came: margin = best - second-best edge weight, in ulps of |best|. */
+#define ORC_AUDIT_BINS 8        /* exact tie | <4 | <16 | <64 | <256 | <1024 | <2^20 | rest  (ulps of |best|) */
+typedef struct orc_audit {
+    int64_t steps;              /* steps with >= 2 candidates */
+    int64_t flips;              /* the two logs disagree on the pick */
+    int64_t order_diffs;        /* ... of which: weights tie exactly under one log and not under the other */
+    int64_t nan_steps;          /* a NaN weight among the candidates */
+    int64_t margin_bins[ORC_AUDIT_BINS];
+    int64_t first_flip_path, first_flip_snp;
+    double min_margin_ulps;     /* smallest non-zero margin seen */
+    double max_abs_dhp_cur, max_abs_dhp_orig;   /* per path: |hp(libm) - hp(det)| */
+    double max_abs_dw;          /* largest |w_libm - w_det| over all finite candidate weights */
+    int64_t paths;
+} orc_audit_t;
 
 static const int VALID[5] = {0, 1, 2, 3, 5};   /* A C G T -  (unsymbols N,_ excluded) */
 
@@ -152,7 +174,24 @@ orc_t *orc_create(int n, int band, int storage, int cond_mode, int marginal_term
 void orc_destroy(orc_t *o)
 {
     if (!o) return;
-    free(o->h); free(o->h0); free(o);
+    free(o->h); free(o->h0); free(o->audit); free(o);
+}
+
+int orc_audit_begin(orc_t *o)
+{
+    if (!o->audit) o->audit = (orc_audit_t *)malloc(sizeof(orc_audit_t));
+    if (!o->audit) return -1;
+    memset(o->audit, 0, sizeof(orc_audit_t));
+    o->audit->first_flip_path = o->audit->first_flip_snp = -1;
+    o->audit->min_margin_ulps = INFINITY;
+    return 0;
+}
+
+int orc_audit_get(const orc_t *o, orc_audit_t *out)
+{
+    if (!o->audit) return -1;
+    *out = *o->audit;
+    return 0;
 }
 
 void orc_set_L(orc_t *o, int L) { o->L = L; }
@@ -325,11 +364,88 @@ int orc_edge_weights(const orc_t *o, int p, const uint8_t *path, double w[NSYM])
     return mask;
 }
 
+static double lg_with(double x, int use_libm)
+{
+    if (use_libm) return x == 0.0 ? -INFINITY : log10(x);
+    return gh_log10(x);
+}
+
+/* gretel.py:166-174 over weights w[] */
+static int pick_first_wins(const orc_t *o, int mask, const double w[NSYM])
+{
+    int next_m = -1;
+    double next_v = 0.0;
+    for (int q = 0; q < 5; q++) {
+        int b = o->order[q];
+        if (!(mask & (1 << b))) continue;
+        if (next_m < 0) { next_v = w[b]; next_m = b; }
+        else if (w[b] > next_v) { next_v = w[b]; next_m = b; }
+    }
+    return next_m;
+}
+
+/* one step of the audit: the edge weights of orc_edge_weights() once more with the OTHER log10 (same conditionals, same
+ * order of additions), the two picks compared, the margin of the handle's own weights binned */
+static void audit_step(orc_t *o, int p, const uint8_t *path, int mask, const double w[NSYM], int pick, int path_no)
+{
+    orc_audit_t *a = o->audit;
+    int ncand = 0;
+    for (int q = 0; q < 5; q++) if (mask & (1 << VALID[q])) ncand++;
+    if (ncand < 2) return;
+    a->steps++;
+    double c[8], w2[NSYM];
+    counts_m(o, o->h, p, c);
+    int lmax = o->L < p ? o->L : p;
+    int other = !o->use_libm, any_nan = 0;
+    for (int q = 0; q < 5; q++) {
+        int b = VALID[q];
+        w2[b] = 0.0;
+        if (!(mask & (1 << b))) continue;
+        double acc = 0.0;
+        if (o->marginal_term) acc += lg_with((c[b] > 0 && c[7] != 0.0) ? c[b] / c[7] : 0.0, other);
+        for (int l = 1; l <= lmax; l++)
+            acc += lg_with(orc_conditional(o, path[p - l], b, p - l, p), other);
+        w2[b] = acc;
+        if (w[b] != w[b] || w2[b] != w2[b]) any_nan = 1;
+        else if (isfinite(w[b]) && isfinite(w2[b])) {
+            double d = fabs(w[b] - w2[b]);
+            if (d > a->max_abs_dw) a->max_abs_dw = d;
+        }
+    }
+    if (any_nan) a->nan_steps++;
+    int pick2 = pick_first_wins(o, mask, w2);
+    if (pick2 != pick) {
+        a->flips++;
+        if (a->first_flip_path < 0) { a->first_flip_path = path_no; a->first_flip_snp = p; }
+        /* an exact tie under one log only? */
+        double b1 = w[pick], b2 = w2[pick2];
+        if (w[pick2] == b1 || w2[pick] == b2) a->order_diffs++;
+    }
+    /* margin of the handle's own weights */
+    double best = w[pick], second = -INFINITY;
+    for (int q = 0; q < 5; q++) {
+        int b = VALID[q];
+        if (!(mask & (1 << b)) || b == pick) continue;
+        if (w[b] > second) second = w[b];      /* a NaN never compares greater: it is no runner-up */
+    }
+    if (best != best || second != second || !isfinite(best)) return;
+    double m = best - second;            /* >= 0 */
+    double ulp = nextafter(fabs(best), INFINITY) - fabs(best);
+    double mu = isfinite(second) ? m / ulp : INFINITY;
+    int bin;
+    if (mu == 0.0) bin = 0;
+    else if (mu < 4) bin = 1; else if (mu < 16) bin = 2; else if (mu < 64) bin = 3; else if (mu < 256) bin = 4;
+    else if (mu < 1024) bin = 5; else if (mu < 1048576.0) bin = 6; else bin = 7;
+    a->margin_bins[bin]++;
+    if (mu > 0.0 && mu < a->min_margin_ulps) a->min_margin_ulps = mu;
+}
+
 /* gretel/gretel.py:102-189.  path has n+1 entries (symbol indices), path[0] = '_'.
  * Returns 0, or the SNP (>=1) at which no branch could be selected. */
 int orc_generate_path(orc_t *o, uint8_t *path, double *hp_cur, double *hp_orig, double *min_marg)
 {
     double running = 0.0, running_uw = 0.0, mn = INFINITY;
+    double running2 = 0.0, running_uw2 = 0.0;         /* audit: the same sums under the other log */
     const void *m0 = o->h0 ? o->h0 : o->h;
     path[0] = SYM_US;
     for (int snp = 1; snp <= o->n; snp++) {
@@ -348,7 +464,19 @@ int orc_generate_path(orc_t *o, uint8_t *path, double *hp_cur, double *hp_orig, 
         if (m < mn) mn = m;
         running += lg(o, m);                          /* gretel.py:185 */
         running_uw += lg(o, marginal_m(o, m0, next_m, snp));   /* gretel.py:186 */
+        if (o->audit) {
+            audit_step(o, snp, path, mask, w, next_m, (int)o->audit->paths);
+            running2 += lg_with(m, !o->use_libm);
+            running_uw2 += lg_with(marginal_m(o, m0, next_m, snp), !o->use_libm);
+        }
         path[snp] = (uint8_t)next_m;
+    }
+    if (o->audit) {
+        orc_audit_t *a = o->audit;
+        double d1 = fabs(running - running2), d2 = fabs(running_uw - running_uw2);
+        if (d1 > a->max_abs_dhp_cur) a->max_abs_dhp_cur = d1;
+        if (d2 > a->max_abs_dhp_orig) a->max_abs_dhp_orig = d2;
+        a->paths++;
     }
     *hp_cur = running; *hp_orig = running_uw; *min_marg = mn;
     return 0;

@@ -59,6 +59,8 @@ def lib():
         L.orc_spin.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.orc_gap_check.argtypes = [vp]
         L.orc_export_band.argtypes = [vp, vp]
+        L.orc_audit_begin.argtypes = [vp]
+        L.orc_audit_get.argtypes = [vp, vp]
         L.orc_log10.restype = dbl
         L.orc_log10.argtypes = [dbl, i32]
         L.orc_log10_many.argtypes = [vp, vp, i64, i32]
@@ -70,8 +72,19 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+AUDIT_BINS = ("tie", "<4", "<16", "<64", "<256", "<1024", "<2^20", "rest")
+
+
+class _Audit(C.Structure):
+    # struct orc_audit of oracle/c/gretel_oracle.c
+    _fields_ = [("steps", C.c_int64), ("flips", C.c_int64), ("order_diffs", C.c_int64), ("nan_steps", C.c_int64),
+                ("margin_bins", C.c_int64 * 8), ("first_flip_path", C.c_int64), ("first_flip_snp", C.c_int64),
+                ("min_margin_ulps", C.c_double), ("max_abs_dhp_cur", C.c_double), ("max_abs_dhp_orig", C.c_double),
+                ("max_abs_dw", C.c_double), ("paths", C.c_int64)]
+
+
 class COracle:
-    def __init__(self, n, band, storage="f32", cond_mode="A", marginal_term=False, use_libm=False,
+    def __init__(self, n, band, storage="f32", cond_mode="A", marginal_term=False, use_libm=True,
                  cand_order="ACGT-", offer_zero=False):
         self.n, self.band = n, max(1, band)
         self._h = lib().orc_create(n, self.band, 0 if storage == "f32" else 1,
@@ -165,6 +178,20 @@ class COracle:
         done = lib().orc_spin(self._h, max_paths, _p(paths), _p(hc), _p(ho), _p(ra), _p(mg), C.byref(hole))
         return dict(n=done, hole_at=hole.value, paths=paths[:done], hp_current=hc[:done],
                     hp_original=ho[:done], ratio=ra[:done], magnitude=mg[:done])
+
+    def audit_begin(self):
+        """From here on every generate_path evaluates BOTH log10s (libm's = the reference's math.log10, and
+        include/gh_detlog.h's = the kernels') on the same state and counts the steps they would decide differently."""
+        if lib().orc_audit_begin(self._h):
+            raise MemoryError
+
+    def audit(self):
+        a = _Audit()
+        if lib().orc_audit_get(self._h, C.byref(a)):
+            raise RuntimeError("audit_begin() was not called")
+        d = {k: getattr(a, k) for k, _ in _Audit._fields_ if k != "margin_bins"}
+        d["margin_ulps"] = dict(zip(AUDIT_BINS, list(a.margin_bins)))
+        return d
 
     def gap_check(self):
         return lib().orc_gap_check(self._h)

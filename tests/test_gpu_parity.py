@@ -1,7 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
 Integer/byte/index results are bit-exact; the path likelihoods are bit-exact against the C
-oracle (same deterministic log10) and within 1e-9 of the Python/libm restatement (the bar in
-BASELINE.json is 1e-6); the removed mass is a parallel sum, checked to 1e-12 relative."""
+oracle AND the Python restatement, both on libm's log10 -- the kernels' log10 (include/gh_detlog.h) is that
+function (the bar in BASELINE.json is 1e-6); the removed mass is a parallel sum, checked to 1e-12 relative."""
 import os
 
 import numpy as np
@@ -25,7 +25,7 @@ def _pair(t, storage="f32", mode="A", mt=False, band=None, L=None):
     band = band or t.band
     h = Hansel(t.n_snps, band=band, storage=storage, cond_mode=mode, marginal_term=mt)
     st = h.fill_from_support(t.rank, t.off, t.bases)
-    o = COracle(t.n_snps, band, storage, mode, mt, use_libm=False)
+    o = COracle(t.n_snps, band, storage, mode, mt, use_libm=True)
     assert o.fill(t) == st
     assert o.L == h.L
     if L is not None:
@@ -73,8 +73,8 @@ def test_fixture_end_to_end_matches_python_oracle():
     for rec in recs:
         path, prob, mn = gretel.generate_path(v["N"], h, orig)
         assert "".join(str(x) for x in path) == rec["path"]
-        assert abs(prob["hp_current"] - rec["hp_current"]) < 1e-9
-        assert abs(prob["hp_original"] - rec["hp_original"]) < 1e-9
+        assert prob["hp_current"] == rec["hp_current"]
+        assert prob["hp_original"] == rec["hp_original"]
         mn = max(mn, 0.01)
         assert abs(mn - rec["ratio"]) < 1e-12
         mag = gretel.reweight_hansel_from_path(h, path, mn)
@@ -201,8 +201,8 @@ def test_spin_matches_python_oracle_small():
     recs, _ = G.recover_paths(ph, t.n_snps, 12)
     res = h.spin(12)
     assert [Hansel.path_str(p) for p in res["paths"]] == [r["path"] for r in recs]
-    assert np.allclose(res["hp_current"], [r["hp_current"] for r in recs], rtol=0, atol=1e-9)
-    assert np.allclose(res["hp_original"], [r["hp_original"] for r in recs], rtol=0, atol=1e-9)
+    assert res["hp_current"].tolist() == [r["hp_current"] for r in recs]
+    assert res["hp_original"].tolist() == [r["hp_original"] for r in recs]
     assert np.allclose(res["magnitude"], [r["magnitude"] for r in recs], rtol=1e-12)
     assert np.array_equal(h.export_dense(), ph.dense().astype(np.float64))
 
@@ -321,7 +321,7 @@ def test_fill_after_spin_keeps_the_fill_accounting():
     t1 = make_support_table(200, 6000, k=4, seed=21)
     t2 = make_support_table(200, 5000, k=4, seed=22)
     h = Hansel(t1.n_snps, band=t1.band)
-    o = COracle(t1.n_snps, t1.band, use_libm=False)
+    o = COracle(t1.n_snps, t1.band, use_libm=True)
     assert h.fill_from_support(t1.rank, t1.off, t1.bases) == o.fill(t1)
     _same_spin(h.spin(7), o.spin(7))                      # first spin allocates the result buffers
     assert h.fill_from_support(t2.rank, t2.off, t2.bases) == o.fill(t2)
