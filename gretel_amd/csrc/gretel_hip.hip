@@ -1162,7 +1162,7 @@ static size_t rws_patch_off(const gh_handle *h, int LC)
     }
     return off;
 }
-#define RWS_LDS_MAX (160 * 1024 - 1024)      /* what a workgroup may have of the CU's 160 KB, less the kernel's static variables */
+#define RWS_LDS_MAX (160 * 1024 - 3 * 1024 - 512)      /* what a workgroup may have of the CU's 160 KB, less the kernel's static variables */
 
 template <typename T, int LC, bool COL>
 static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)

@@ -175,6 +175,15 @@ __device__ __forceinline__ double dpp_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+// log10's table (include/gh_detlog.h: 128 x { 1/c, log c }, 2 KB) in LDS: the kernels that take logarithms between two
+// dependent memory round trips (k_marg<T,true>, k_rw, k_rwseg) read it there -- from global memory the lookup is one more
+// round trip in the chain (k_rwseg +0.8 us, the batched k_marg<T,true> +0.2 ms per launch, measured).  A barrier between
+// logtab_stage() and the first logarithm.
+__device__ __forceinline__ void logtab_stage(double *t)
+{
+    for (int q = threadIdx.x; q < 256; q += blockDim.x) t[q] = gh_logtab_dev[q];
+}
+
 // hansel conditional, shared by the table builder and the per-call lookup
 template <typename T>
 __device__ __forceinline__ double log_conditional(const T *__restrict__ band, int W, int cond_mode,
@@ -440,6 +449,8 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
        double *G, int L, int cond_mode, const double *segmin, gh_path_rec *seg_rec, symmap sm, int offer_zero, double *rinfo)
 {
     __shared__ double s_red[256];
+    __shared__ double s_logtab[256];
+    logtab_stage(s_logtab);
     bool live = true;
     double seg_ratio = 0.0;
     if (RW && segmin) {
@@ -468,6 +479,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         live = !st->stop;
     }
     if (RW && use_state_ratio && !segmin && st->stop) live = false;
+    __syncthreads();                                           // s_logtab stands
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int p = t >> 3, s = t & 7;
     const bool act = live && p <= N;
@@ -535,7 +547,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
     double my_m = 0.0, my_lm = 0.0;
     if (s < NSYM) {
         my_m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
-        if ((VALID_MASK >> s) & 1) my_lm = gh_log10(my_m);
+        if ((VALID_MASK >> s) & 1) my_lm = gh_log10_tab(my_m, s_logtab, GH_LOG_SERIAL);
     }
     if (act) {
         if (s < NSYM) {
@@ -617,10 +629,10 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
                 odd |= !gh_log10_is_normal(xq[b5]);
             }
 #pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal(xq[b5], 0);
+            for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal_tab(xq[b5], 0, s_logtab, GH_LOG_SERIAL);
             if (odd) {
 #pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10(xq[b5]);
+                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_tab(xq[b5], s_logtab, GH_LOG_SERIAL);
             }
             if (!ranked) {
 #pragma unroll

@@ -717,7 +717,9 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
      gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage, fuse_params fz, int fuse_lds)
 {
     __shared__ double s_red[256];
+    __shared__ double s_logtab[256];
     extern __shared__ __align__(16) unsigned char rw_smem_all[];
+    logtab_stage(s_logtab);                                 // (the barriers of the minimum's reduction stand between this and the first logarithm)
     const int tid = threadIdx.x;
     constexpr int PPB = 256 / LP;                           // positions per workgroup
     constexpr bool fused = FUSED;                           // (a compile-time switch: the prologue's registers cost the plain kernel a wave per SIMD)
@@ -956,7 +958,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             marg[(size_t)p * 8 + s] = m;
             if ((VALID_MASK >> s) & 1) {
                 const int b5 = a6_of_sym(sm, s);
-                const double lm = gh_log10(m);
+                const double lm = gh_log10_tab(m, s_logtab, GH_LOG_BOTH);
                 minfo[(size_t)p * MINFO + b5] = lm;
                 minfo[(size_t)p * MINFO + 5 + b5] = m;
                 const int r = __popc(cm5 & ((1u << b5) - 1u));
@@ -1008,10 +1010,10 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             odd |= !gh_log10_is_normal(xq[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) v[q] = gh_log10_normal(xq[q], 0);
+        for (int q = 0; q < 6; q++) v[q] = gh_log10_normal_tab(xq[q], 0, s_logtab, GH_LOG_BOTH);
         if (odd) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) v[q] = gh_log10(xq[q]);
+            for (int q = 0; q < 6; q++) v[q] = gh_log10_tab(xq[q], s_logtab, GH_LOG_BOTH);
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) {
@@ -1079,10 +1081,10 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
 #pragma unroll
             for (int q = 0; q < LT_ROW; q++) odd |= !gh_log10_is_normal(xq[q]);
 #pragma unroll
-            for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_normal(xq[q], 0);
+            for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_normal_tab(xq[q], 0, s_logtab, GH_LOG_BOTH);
             if (odd) {
 #pragma unroll
-                for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10(xq[q]);
+                for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_tab(xq[q], s_logtab, GH_LOG_BOTH);
             }
             if (sm.fwd == 0x53210u) {
                 // the default order: compact index q IS the q-th valid symbol -- the row is put together in registers and leaves
@@ -1214,6 +1216,8 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     const symmap sm = P.sm;
     dev_state *st = P.st;
     double *sred = reinterpret_cast<double *>(smem);                  // [SEG_THREADS] scratch (k_seg's regions are not in use yet)
+    __shared__ double s_logtab[256];
+    logtab_stage(s_logtab);
     if (tid < SEG_MAX_L_NARROW) patch->row6[tid] = -1;
     if (tid < SEG_MAX_L_NARROW * SEG_MAX_L_NARROW) { (&patch->col[0][0])[tid] = -1; (&patch->rmask[0][0])[tid] = 0u; }
     if (tid == 0) patch->colmode = COL ? 1 : 0;
@@ -1310,6 +1314,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     }
     na = __shfl(na, 0, 8); nb = __shfl(nb, 0, 8);
     nval = (T)__shfl((double)nval, 0, 8);
+    __syncthreads();                                                  // s_logtab stands (staged at the top: nobody waits here for memory)
     // ---- marginals of position p (k_marg / k_rw: same order of operations) ----------------------------------------------
     unsigned flag_bits = 0;
     int hole_p = 0x7fffffff;
@@ -1343,7 +1348,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
             Q.marg[(size_t)p * 8 + s] = m;
             if ((VALID_MASK >> s) & 1) {
                 const int b5 = a6_of_sym(sm, s);
-                const double lm = gh_log10(m);
+                const double lm = gh_log10_tab(m, s_logtab, GH_LOG_BOTH);
                 Q.minfo[(size_t)p * MINFO + b5] = lm;
                 Q.minfo[(size_t)p * MINFO + 5 + b5] = m;
                 const int r = __popc(cm5 & ((1u << b5) - 1u));
@@ -1375,7 +1380,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
             if ((VALID_MASK >> s) & 1) {
                 const double m = (cs[s] > 0 && tot != 0.0) ? cs[s] / tot : 0.0;
                 const int b5 = a6_of_sym(sm, s);
-                const double lm = gh_log10(m);
+                const double lm = gh_log10_tab(m, s_logtab, GH_LOG_BOTH);
                 if (b5 < 5) patch->lm5[slot][b5] = lm;
                 const int r = __popc(cm5 & ((1u << b5) - 1u));
                 if (((cand >> s) & 1u) && r < 4) patch->lm4[slot][r] = lm;
@@ -1407,10 +1412,10 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
                     odd |= !gh_log10_is_normal(xq[q]);
                 }
 #pragma unroll
-                for (int q = 0; q < 6; q++) v[q] = gh_log10_normal(xq[q], 0);
+                for (int q = 0; q < 6; q++) v[q] = gh_log10_normal_tab(xq[q], 0, s_logtab, GH_LOG_BOTH);
                 if (odd) {
 #pragma unroll
-                    for (int q = 0; q < 6; q++) v[q] = gh_log10(xq[q]);
+                    for (int q = 0; q < 6; q++) v[q] = gh_log10_tab(xq[q], s_logtab, GH_LOG_BOTH);
                 }
                 unsigned rmask = 0;
 #pragma unroll
@@ -1455,10 +1460,10 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
 #pragma unroll
                 for (int q = 0; q < LT_ROW; q++) odd |= !gh_log10_is_normal(xq[q]);
 #pragma unroll
-                for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_normal(xq[q], 0);
+                for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_normal_tab(xq[q], 0, s_logtab, GH_LOG_BOTH);
                 if (odd) {
 #pragma unroll
-                    for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10(xq[q]);
+                    for (int q = 0; q < LT_ROW; q++) v[q] = gh_log10_tab(xq[q], s_logtab, GH_LOG_BOTH);
                 }
 #pragma unroll
                 for (int q = 0; q < LT_ROW; q++) out[q] = -INFINITY;

@@ -68,17 +68,29 @@ __device__ static const double gh_logtab_dev[256] = {
 #define GH_LOGTAB gh_logtab_host
 #endif
 
-/* glibc's log() for 0.5 <= x < 2 (what its log10 hands it), the FMA build */
-GH_HD double gh_log_reduced(double x)
+/* how a caller wants the logarithm scheduled (a compile-time constant at every call; the VALUES never depend on it):
+ * GH_LOG_BOTH   evaluate both branches of log() and select -- straight-line code, several logarithms interleave (k_rwseg, k_rw:
+ *               the logarithms sit in a chain of dependent steps of one workgroup and there are registers to spare);
+ * GH_LOG_SERIAL one logarithm after the other, the branch taken as a branch (k_marg<T,true>, k_lt: a wave per SIMD more is
+ *               worth more than instruction-level parallelism -- five interleaved logarithms cost 13 VGPRs). */
+#define GH_LOG_BOTH 1
+#define GH_LOG_SERIAL 2
+/* glibc's log() for 0.5 <= x < 2 (what its log10 hands it), the FMA build.  glibc branches on the argument; here both
+ * (mode & GH_LOG_BOTH) both branches are evaluated and one is selected (the same operations on the same operands either
+ * way): straight-line code, so that the five or six logarithms a lane of k_rw / k_rwseg takes interleave.
+ * tab = { 1/c, log c } x 128 (gh_logtab_*: the kernels hand in their copy in LDS). */
+GH_HD double gh_log_reduced_tab(double x, const double *tab, int mode)
 {
+    const int both = (mode & GH_LOG_BOTH) != 0;
     const uint64_t ix = gh_d2u(x);
-    /* 1 - 0x1p-4 <= x < 1 + 0x1.09p-4: a polynomial in r = x - 1, its leading terms in two pieces */
-    if (ix - 0x3fee000000000000ULL < 0x0003090000000000ULL) {
+    /* (a) 1 - 0x1p-4 <= x < 1 + 0x1.09p-4: a polynomial in r = x - 1, its leading terms in two pieces (x = 1 gives +0 by itself) */
+    const int near_one = ix - 0x3fee000000000000ULL < 0x0003090000000000ULL;
+    double y_near = 0.0;
+    if (both || near_one) {
         const double B0 = -0x1.0000000000000p-1, B1 = 0x1.5555555555577p-2, B2 = -0x1.ffffffffffdcbp-3,
                      B3 = 0x1.999999995dd0cp-3, B4 = -0x1.55555556745a7p-3, B5 = 0x1.24924a344de30p-3,
                      B6 = -0x1.fffffa4423d65p-4, B7 = 0x1.c7184282ad6cap-4, B8 = -0x1.999eb43b068ffp-4,
                      B9 = 0x1.78182f7afd085p-4, B10 = -0x1.5521375d145cdp-4;
-        if (ix == 0x3ff0000000000000ULL) return 0.0;
         const double r = x - 1.0;
         const double r2 = r * r;
         const double r3 = r * r2;
@@ -100,34 +112,38 @@ GH_HD double gh_log_reduced(double x)
         double lo = __builtin_fma(rr, B0, r - hi);
         lo = __builtin_fma(B0 * rlo, r + rhi, lo);
         y = __builtin_fma(y, r3, lo);
-        return hi + y;
+        y_near = hi + y;
     }
-    const double ln2hi = 0x1.62e42fefa3800p-1, ln2lo = 0x1.ef35793c76730p-45;
-    const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3,
-                 A3 = 0x1.999b324f10111p-3, A4 = -0x1.55575e506c89fp-3;
-    /* x = 2^k z, z in [0x1.6p-1, 0x1.6p0), split into 128 intervals; log x = k ln2 + log c + log1p(z/c - 1) */
-    const uint64_t tmp = ix - 0x3fe6000000000000ULL;
-    const int i = (int)((tmp >> 45) & 127);
-    const int32_t k = (int32_t)((int64_t)tmp >> 52);
-    const double z = gh_u2d(ix - (tmp & 0xfff0000000000000ULL));
-    const double kd = (double)k;
-    const double invc = GH_LOGTAB[2 * i], logc = GH_LOGTAB[2 * i + 1];
-    const double r = __builtin_fma(z, invc, -1.0);
-    const double w = __builtin_fma(kd, ln2hi, logc);
-    const double hi = w + r;
-    const double lo = __builtin_fma(kd, ln2lo, (w - hi) + r);
-    const double r2 = r * r;
-    const double p = __builtin_fma(r, A2, A1);
-    const double q = __builtin_fma(r, A4, A3);
-    const double lo2 = __builtin_fma(r2, A0, lo);
-    const double pq = __builtin_fma(q, r2, p);
-    const double y = __builtin_fma(r * r2, pq, lo2);
-    return y + hi;
+    /* (b) x = 2^k z, z in [0x1.6p-1, 0x1.6p0), split into 128 intervals; log x = k ln2 + log c + log1p(z/c - 1) */
+    double y_main = 0.0;
+    if (both || !near_one) {
+        const double ln2hi = 0x1.62e42fefa3800p-1, ln2lo = 0x1.ef35793c76730p-45;
+        const double A0 = -0x1.0000000000001p-1, A1 = 0x1.555555551305bp-2, A2 = -0x1.fffffffeb4590p-3,
+                     A3 = 0x1.999b324f10111p-3, A4 = -0x1.55575e506c89fp-3;
+        const uint64_t tmp = ix - 0x3fe6000000000000ULL;
+        const int i = (int)((tmp >> 45) & 127);
+        const int32_t k = (int32_t)((int64_t)tmp >> 52);
+        const double z = gh_u2d(ix - (tmp & 0xfff0000000000000ULL));
+        const double kd = (double)k;
+        const double invc = tab[2 * i], logc = tab[2 * i + 1];
+        const double r = __builtin_fma(z, invc, -1.0);
+        const double w = __builtin_fma(kd, ln2hi, logc);
+        const double hi = w + r;
+        const double lo = __builtin_fma(kd, ln2lo, (w - hi) + r);
+        const double r2 = r * r;
+        const double p = __builtin_fma(r, A2, A1);
+        const double q = __builtin_fma(r, A4, A3);
+        const double lo2 = __builtin_fma(r2, A0, lo);
+        const double pq = __builtin_fma(q, r2, p);
+        const double y = __builtin_fma(r * r2, pq, lo2);
+        y_main = y + hi;
+    }
+    return near_one ? y_near : y_main;
 }
 
 /* log10 of a normal, positive, finite x (k0 = exponent carried in by the caller's subnormal scaling):
  * glibc's __ieee754_log10 behind its special cases */
-GH_HD double gh_log10_normal(double x, int32_t k0)
+GH_HD double gh_log10_normal_tab(double x, int32_t k0, const double *tab, int mode)
 {
     const double ivln10 = 0x1.bcb7b1526e50ep-2;       /* 1/ln 10 */
     const double log10_2hi = 0x1.34413509f6000p-2;
@@ -137,9 +153,14 @@ GH_HD double gh_log10_normal(double x, int32_t k0)
     const int32_t i = (int32_t)((uint32_t)k >> 31);               /* 1 iff k < 0: then m in [0.5, 1) and y = k + 1 */
     const double m = gh_u2d((u & 0x000fffffffffffffULL) | ((uint64_t)(0x3ff - i) << 52));
     const double y = (double)(k + i);
-    const double z = y * log10_2lo + ivln10 * gh_log_reduced(m);
-    return z + y * log10_2hi;
+    const double z = y * log10_2lo + ivln10 * gh_log_reduced_tab(m, tab, mode);
+    const double out = z + y * log10_2hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (mode & GH_LOG_SERIAL) __builtin_amdgcn_sched_barrier(0);
+#endif
+    return out;
 }
+GH_HD double gh_log10_normal(double x, int32_t k0) { return gh_log10_normal_tab(x, k0, GH_LOGTAB, GH_LOG_SERIAL); }
 
 /* 1 iff gh_log10(x) takes the straight-line path: 2^-1022 <= x < inf */
 GH_HD int gh_log10_is_normal(double x)
@@ -148,7 +169,7 @@ GH_HD int gh_log10_is_normal(double x)
     return hx >= 0x00100000 && hx < 0x7ff00000;
 }
 
-GH_HD double gh_log10(double x)
+GH_HD double gh_log10_tab(double x, const double *tab, int mode)
 {
     const double two54 = 1.80143985094819840000e+16;      /* 2^54 */
     uint64_t u = gh_d2u(x);
@@ -167,8 +188,9 @@ GH_HD double gh_log10(double x)
     }
     if (hx >= 0x7ff00000)
         return x + x;                            /* inf or nan */
-    return gh_log10_normal(x, k);
+    return gh_log10_normal_tab(x, k, tab, mode);
 }
+GH_HD double gh_log10(double x) { return gh_log10_tab(x, GH_LOGTAB, GH_LOG_SERIAL); }
 
 
 #endif /* GH_DETLOG_H */
