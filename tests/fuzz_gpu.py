@@ -19,10 +19,13 @@ variants = {}
 while time.time() < t_end:
     n = int(rng.choice([4000, 7777, 12000, 20011])) if big else int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
     k = int(rng.integers(2, min(n, 12) + 1)) if rng.random() < 0.7 else None
+    # reads of up to 21 SNPs mostly (C5's shape), up to 33 / 64 now and then: bands beyond the 32 lanes of the wide reweight kernels
+    kmx = int(rng.choice([21, 21, 21, 33, 48, 64]))
+    lam = 10.0 if kmx == 21 else float(rng.choice([10.0, kmx * 0.6]))
     n_haps = int(rng.integers(1, 9))
     err = float(rng.choice([0.0, 0.0, 0.01, 0.05]))
     reads = int(max(20, n * rng.integers(4, 12 if big else 40)))
-    t = make_support_table(n, reads, k=k, n_haps=n_haps, err=err, seed=int(rng.integers(0, 1 << 30)), k_max=min(21, n))
+    t = make_support_table(n, reads, k=k, n_haps=n_haps, err=err, seed=int(rng.integers(0, 1 << 30)), k_max=min(kmx, n), k_lambda=lam)
     if rng.random() < 0.4:
         bases = t.bases.copy()
         bases[rng.random(len(bases)) < rng.choice([0.02, 0.1, 0.3])] = ord('-')
@@ -38,7 +41,7 @@ while time.time() < t_end:
     sw = dict(cand_order=order, offer_zero=zero)
     L = None if rng.random() < 0.4 else (int(rng.integers(1, 27)) if rng.random() < 0.85 else int(rng.integers(25, 48)))
     paths = int(rng.integers(1, 9))
-    desc = dict(n=n, reads=reads, k=k, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths, **sw)
+    desc = dict(n=n, reads=reads, k=k, k_max=kmx, k_lambda=lam, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths, **sw)
     if k is not None and rng.random() < 0.12:
         # batched launch over 3 windows of one shape (same N, band, switches, L)
         ts = [t] + [make_support_table(n, reads, k=k, n_haps=int(rng.integers(1, 9)), err=err, seed=int(rng.integers(0, 1 << 30)))
