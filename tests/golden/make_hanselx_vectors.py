@@ -47,6 +47,12 @@ def windows():
     bases[np.random.default_rng(5).random(len(bases)) < 0.06] = ord('-')      # some positions with five candidates
     t.bases = bases
     out.append(("synth_70_kvar_dels", t.n_snps, list(t.reads())))
+    # reads of 7 SNPs: util.py:333 sets L = 7 -- beyond the lag counts the HIP path enumerates (its candidate pools walk this one)
+    t = make_support_table(60, 700, k=7, seed=11)
+    out.append(("synth_60_k7_L7", t.n_snps, list(t.reads())))
+    # reads of up to 13 SNPs: observations up to 12 positions apart (a band wider than the 8-lane reweight groups), L = 10
+    t = make_support_table(64, 420, k=None, seed=13, k_lambda=10.0, k_min=6, k_max=13)
+    out.append(("synth_64_k13_band12", t.n_snps, list(t.reads())))
     return out
 
 

@@ -66,3 +66,29 @@ def test_hip_reproduces_golden(case):
     assert res["ratio"].tolist() == [x["ratio"] for x in case["records"]]
     assert np.allclose(res["magnitude"], [x["magnitude"] for x in case["records"]], rtol=1e-12, atol=0)
     assert abs(h.export_band().sum() - case["final_sum"]) <= 1e-9 * case["final_sum"]
+
+
+HANSELX = os.path.join(GOLDEN, "hanselx_vectors.json")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(HANSELX), reason="tests/golden/hanselx_vectors.json absent (made by make_hanselx_vectors.py where "
+                    "hanselx==0.0.92 is importable): the HIP path is held to the oracle only until then")
+def test_hip_reproduces_the_real_hanselx_vectors():
+    """The day the pinning kit has run: what the REAL package and the reference's own gretel.py answered (five paths per
+    window: the fixture, L = 4, five-candidate positions, L = 7 -- the candidate pools --, a band of 12), through the product path
+    under its default spec.  Paths bit-exact, likelihoods within 1e-6 (BASELINE.json), ratios within 1e-12."""
+    from gretel_amd.hansel import Hansel as DevHansel
+    vec = json.load(open(HANSELX))
+    for w in vec["windows"]:
+        t = _T([(int(r), s) for r, s in w["reads"]])
+        h = DevHansel(w["n_snps"], band=t.band)
+        assert list(h.fill_from_support(t.rank, t.off, t.bases)) == w["stats"], w["name"]
+        assert h.L == w["L"], w["name"]
+        res = h.spin(len(w["records"]) or 1)
+        assert [DevHansel.path_str(p) for p in res["paths"]] == [x["path"] for x in w["records"]], w["name"]
+        want = lambda k: np.array([float.fromhex(x[k][1]) for x in w["records"]])
+        assert np.allclose(res["hp_current"], want("hp_current"), rtol=0, atol=1e-6), w["name"]
+        assert np.allclose(res["hp_original"], want("hp_original"), rtol=0, atol=1e-6), w["name"]
+        assert np.allclose(res["ratio"], want("ratio"), rtol=1e-12, atol=0), w["name"]
+        assert np.allclose(res["magnitude"], want("magnitude"), rtol=1e-9, atol=0), w["name"]
