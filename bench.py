@@ -722,6 +722,35 @@ def main():
                 del hw, rw
             except Exception as exc:
                 out["wide_window"] = {"error": repr(exc)}
+            # ... and with deletions at 1 % of the POSITIONS (a deletion column here and there: what a real pileup shows): the
+            # mixed-radix state space (segmix.hpp) -- a few hundred states more behind each such column instead of 5^L everywhere
+            try:
+                import copy
+                from gretel_amd.synth import sprinkle_deletions
+                ts_ = copy.copy(table)
+                ts_.bases = table.bases.copy()
+                sprinkle_deletions(ts_, 0.01, seed=4321)
+                hw = Hansel(n, band=table.band, device=local)
+                rw = DeviceReads(hw, ts_.rank, ts_.off, ts_.bases)
+                hw.fill_from_support(None, None, None, reads_handle=rw)
+                hw.spin(10)
+                wide = int((hw.candidate_masks()[1:] == 0x2F).sum())
+                hw.clear()
+                hw.fill_from_support(None, None, None, reads_handle=rw)
+                torch.cuda.synchronize()
+                t0w = time.perf_counter()
+                rwres = hw.spin(paths)
+                dtw = time.perf_counter() - t0w
+                clk = hw.walk_clock()
+                out["wide_window_sparse"] = {"value": rwres["n"] / dtw, "unit": "haplotypes/s", "ms_per_path": dtw / max(1, rwres["n"]) * 1e3,
+                                             "positions_with_5_candidates": wide, "walker_variant": clk[3],
+                                             "state_space": {4: "candidate ranks (4^L)", 5: "symbols (5^L)", 6: "mixed radix"}.get(clk[1], clk[1]),
+                                             "most_states_per_target": clk[2],
+                                             "note": "same contig, '-' on 30 %% of the reads at 1 %% of the positions: %d of %d positions show A, C, G, T "
+                                                     "and '-'; one spin of %d paths (fill not included)" % (wide, n, paths)}
+                del hw, rw
+            except Exception as exc:
+                out["wide_window_sparse"] = {"error": repr(exc)}
         if world == 1 and not args.no_spec_matrix:
             # the switches of the Hansel arithmetic the reference leaves to hanselx: the same step
             # (clear + fill + `paths` spins) under every conditional x marginal term x storage.  Every spec runs the same

@@ -803,6 +803,15 @@ static bool seg_ok(int wm, int L);
 // (k_lt); the segment-parallel walks want the bare conditionals and add lm themselves
 // derived = false (the candidate pools' looks): the depth-2 serial walker's tables Ht / Yt are left alone -- nobody reads them
 // until a serial walk, in front of which the table is rebuilt in full anyway (45 us per look at C5 otherwise)
+// the mixed-radix state space (segmix.hpp) for this handle?  L = 5 over the segment-parallel extension; not where every symbol is
+// offered everywhere (five candidates at every position: nothing to gain) and not inside a spin of the opt-in GH_FUSE flow, whose
+// k_seg / k_scan / k_rw carry the minima over the enumerated states
+static bool mixed_allowed(const gh_handle *h)
+{
+    static const bool off = getenv("GH_MIXED") && atoi(getenv("GH_MIXED")) == 0;
+    return !off && !h->fuse && h->L == SEGM_L && h->wmode == WM_SEG && !h->cfg.offer_zero;
+}
+
 static int ensure_lt(gh_handle *h, bool baked = false, bool derived = true)
 {
     int rc = ensure_marg(h);
@@ -833,6 +842,12 @@ static int ensure_lt(gh_handle *h, bool baked = false, bool derived = true)
     prof_end(h, GH_K_LT, inc ? 8.0
                              : (double)h->N * ((double)wl * CELL * esize(h) + (double)h->L * LT_BLK * 8.0));
     { int rc_ = post_launch(h, "k_lt"); if (rc_) return rc_; }
+    // mixed radix for the segment-parallel extension (segmix.hpp): how many states enter a target at most, taken whenever the table
+    // may have been rebuilt (k_lt zeroes it then; behind an incremental refresh the old bound stands: candidates only disappear)
+    if (mixed_allowed(h)) {
+        hipLaunchKernelGGL(k_classify, dim3((unsigned)((h->N + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t *)h->cmask, h->N, h->L, h->dstate);
+        int rc_ = post_launch(h, "k_classify"); if (rc_) return rc_;
+    }
     h->dirty_lt = false;
     h->lt_inc_path = nullptr;
     h->lt_baked = want_baked;
@@ -908,7 +923,7 @@ extern "C" int gh_gap_check(gh_t *h, int *first_gap)
     if (set_dev(h)) return GH_ERR_HIP;
     int rc = ensure_marg(h);
     if (rc) return rc;
-    int *d_gap = &h->dstate->scratch;
+    int *d_gap = reinterpret_cast<int *>(&h->dstate->fill[5]);      // (a spare word of the state)
     int big = 0x7fffffff;
     HIPCHK(hipMemcpyAsync(d_gap, &big, 4, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_gap, dim3((h->N + 1 + 255) / 256), dim3(256), 0, h->stream, h->cnt, h->N, d_gap);
@@ -1041,6 +1056,15 @@ static void launch_walk_any(int wm, int N, int L, walk_params P, hipStream_t str
 
 // ---- segment-parallel walk ---------------------------------------------------------------------
 static size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+// the largest value of f(class) over the state spaces a lag count can be walked in: 4 (ranked), 5 (symbols, L <= 5), 6 (mixed radix, L = 5);
+// which one applies is decided on the device (seg_class), the host sizes for all
+template <typename F> static size_t max_cls(int L, F f)
+{
+    size_t m = f(4);
+    if (seg_radix_ok(5, L)) m = max2(m, f(5));
+    if (L == SEGM_L) m = max2(m, f(SEG_CLS_MIXED));
+    return m;
+}
 
 static int alloc_seg(gh_handle *h)
 {
@@ -1051,10 +1075,10 @@ static int alloc_seg(gh_handle *h)
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
     h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr;
     // the layout is decided on the device (st->ranked): size for both (L = 6: ranked tables only, see gh_spin)
-    const seg_geom g4 = seg_geometry(h->N, h->L, 4), g5 = seg_radix_ok(5, h->L) ? seg_geometry(h->N, h->L, 5) : g4;
-    const size_t hist_b = max2((size_t)g4.S * g4.NW * g4.NS, (size_t)g5.S * g5.NW * g5.NS) * 4;
-    const size_t maps_b = max2((size_t)g4.S * g4.NS, (size_t)g5.S * g5.NS) * 2;
-    const size_t gmaps_b = max2((size_t)g4.G1 * g4.NS, (size_t)g5.G1 * g5.NS) * 2;
+    const int N_ = h->N, L_ = h->L;
+    const size_t hist_b = max_cls(L_, [&](int R) { const seg_geom g = seg_geometry(N_, L_, R); return (size_t)g.S * g.NW * g.NS; }) * 4;
+    const size_t maps_b = max_cls(L_, [&](int R) { const seg_geom g = seg_geometry(N_, L_, R); return (size_t)g.S * g.NS; }) * 2;
+    const size_t gmaps_b = max_cls(L_, [&](int R) { const seg_geom g = seg_geometry(N_, L_, R); return (size_t)g.G1 * g.NS; }) * 2;
     hipError_t e = hipMalloc((void **)&h->seg_hist, hist_b);
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_maps, maps_b);
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_pmaps, maps_b + 16);        // (+ slack: 16-byte copies in k_rw)
@@ -1075,15 +1099,13 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
 {
     hipStream_t stream = h->stream;
     const int N = h->N, dev = h->dev;
-    constexpr bool five = seg_radix_ok(5, LC);
-    const seg_geom g4 = seg_geometry(N, LC, 4), g5 = five ? seg_geometry(N, LC, 5) : g4;
-    const size_t lds_seg = five ? max2(seg_lds_total(4, LC), seg_lds_total(5, LC)) : seg_lds_total(4, LC);
-    const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
-    const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
+    const size_t lds_seg = max_cls(LC, [&](int R) { return seg_lds_total(R, LC); });
+    const size_t lds_scan = max_cls(LC, [&](int R) { return scan_lds_bytes(N, LC, R); });
+    const size_t lds_emit = max_cls(LC, [&](int R) { return emit_lds_bytes(N, LC, R); });
     // per instantiation and device: raise the dynamic-LDS limit once, not on every launch
     static std::atomic<size_t> set_seg[64], set_scan[64], set_emit[64], set_segt[64], set_scant[64];      // (gh_batch_spin runs gh_spin on several host threads)
     const int dv = dev & 63;
-    const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
+    const int S = (int)max_cls(LC, [&](int R) { return (size_t)seg_geometry(N, LC, R).S; }), G1 = (int)max_cls(LC, [&](int R) { return (size_t)seg_geometry(N, LC, R).G1; });
     if (h->fuse) {
         // spins without k_emit: k_seg / k_scan also carry the minimum marginals (TRACK), k_rw chains the group maps itself
         if (lds_seg > set_segt[dv]) { hipFuncSetAttribute((const void *)k_seg<LC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg); set_segt[dv] = lds_seg; }
@@ -1102,7 +1124,7 @@ static void launch_seg_lc(gh_handle *h, const seg_params &P)
     // algorithmic bytes of k_seg: the conditional lookups of the extension (L history cells per step)
     prof_end(h, GH_K_SEG, (double)N * (double)LC * CELL * esize(h));
     // short memories / small windows: every segment map fits the LDS of the emitting workgroup, which composes them itself
-    const size_t lds_small = five ? max2(emit_small_lds_bytes(N, LC, 4), emit_small_lds_bytes(N, LC, 5)) : emit_small_lds_bytes(N, LC, 4);
+    const size_t lds_small = max_cls(LC, [&](int R) { return emit_small_lds_bytes(N, LC, R); });
     static const bool no_small = getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0;
     if (lds_small <= 64 * 1024 && !no_small) {
         static std::atomic<size_t> set_small[64];
@@ -1143,7 +1165,8 @@ static int launch_seg_walk(gh_handle *h, uint8_t *d_path, double *d_lmsel, int r
 // ---- k_rwseg: reweight of the path before + this path's k_seg in one launch, then k_scan, k_emit (segwalk.hpp) ----------
 static size_t rws_lds_bytes(int LC, bool five)
 {
-    size_t b = five ? max2(seg_lds_total(4, LC), seg_lds_total(5, LC)) : seg_lds_total(4, LC);
+    (void)five;
+    size_t b = max_cls(LC, [&](int R) { return seg_lds_total(R, LC); });
     if (b < (size_t)SEG_THREADS * 8) b = (size_t)SEG_THREADS * 8;      // the reweight phase's reduction scratch
     return (b + 15) & ~(size_t)15;
 }
@@ -1169,12 +1192,12 @@ static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
 {
     constexpr bool five = seg_radix_ok(5, LC);
     const int N = h->N;
-    const seg_geom g4 = seg_geometry(N, LC, 4), g5 = five ? seg_geometry(N, LC, 5) : g4;
-    const int S = g4.S > g5.S ? g4.S : g5.S, G1 = g4.G1 > g5.G1 ? g4.G1 : g5.G1;
+    (void)five;
+    const int S = (int)max_cls(LC, [&](int R) { return (size_t)seg_geometry(N, LC, R).S; }), G1 = (int)max_cls(LC, [&](int R) { return (size_t)seg_geometry(N, LC, R).G1; });
     const size_t off = rws_patch_off(h, LC);
     const size_t lds = off + sizeof(seg_patch);
-    const size_t lds_scan = five ? max2(scan_lds_bytes(N, LC, 4), scan_lds_bytes(N, LC, 5)) : scan_lds_bytes(N, LC, 4);
-    const size_t lds_emit = five ? max2(emit_lds_bytes(N, LC, 4), emit_lds_bytes(N, LC, 5)) : emit_lds_bytes(N, LC, 4);
+    const size_t lds_scan = max_cls(LC, [&](int R) { return scan_lds_bytes(N, LC, R); });
+    const size_t lds_emit = max_cls(LC, [&](int R) { return emit_lds_bytes(N, LC, R); });
     static std::atomic<size_t> set_rws[64], set_scan[64], set_emit[64];
     const int dv = h->dev & 63;
     if (lds > set_rws[dv]) { hipFuncSetAttribute((const void *)k_rwseg<T, LC, COL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_rws[dv] = lds; }
@@ -1191,7 +1214,7 @@ static void launch_rwseg_lc(gh_handle *h, seg_params P, const rws_params &Q)
              (double)N * ((double)wl * 7 * esize(h) + (double)LC * LT_ROW * 8.0));
     // short memories / small windows: every segment map fits the LDS of the emitting workgroup, which composes them itself and
     // takes k_scan's look at what the reweight found as well: two launches per path
-    const size_t lds_small = five ? max2(emit_small_lds_bytes(N, LC, 4), emit_small_lds_bytes(N, LC, 5)) : emit_small_lds_bytes(N, LC, 4);
+    const size_t lds_small = max_cls(LC, [&](int R) { return emit_small_lds_bytes(N, LC, R); });
     if (lds_small <= 64 * 1024 && !(getenv("GH_EMIT_SMALL") && atoi(getenv("GH_EMIT_SMALL")) == 0)) {
         static std::atomic<size_t> set_small[64];
         if (lds_small > set_small[dv]) { hipFuncSetAttribute((const void *)k_emit_small<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small); set_small[dv] = lds_small; }
@@ -1993,6 +2016,8 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
                 if ((!small || force) && seg_radix_ok(R, h->L) && rw_fuse_lds_bytes(h->N, h->L, R, ppb, h->W) <= 64 * 1024 && (rc = alloc_seg(h)) == GH_OK) {
                     h->fuse = true;
                     h->fuse_lds = rw_fuse_lds_bytes(h->N, h->L, R, ppb, h->W);
+                    // (this spin walks the enumerated states: whatever k_classify found before the flow was chosen does not apply)
+                    if (hipMemsetAsync(&h->dstate->maxstates, 0, sizeof(int), h->stream) != hipSuccess) rc = fail(GH_ERR_HIP, "gh_spin failed: hipMemsetAsync");
                 }
             }
         }
@@ -2580,7 +2605,13 @@ extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
     HIPCHK(hipMemcpyAsync(&hs, h->dstate, sizeof hs, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     out[0] = hs.dbg[0]; out[1] = hs.dbg[1]; out[2] = hs.dbg[2]; out[3] = hs.dbg[3];
-    if (out[3] == 3) { out[0] = (uint64_t)h->spin_requeues; out[1] = 0; out[2] = 0; }
+    if (out[3] == 3) {
+        // out[1]: the state space the extension walked -- 4 ranks, 5 symbols, 6 mixed radix (seg_class, from the same control words);
+        // out[2]: the most states entering a target as k_classify found them (0: not taken)
+        out[0] = (uint64_t)h->spin_requeues;
+        out[1] = hs.ranked ? 4u : ((h->L == SEGM_L && hs.maxstates > 0 && hs.maxstates <= SEGM_NS) ? (uint64_t)SEG_CLS_MIXED : 5u);
+        out[2] = (uint64_t)hs.maxstates;
+    }
     if (out[3] == 4) { out[0] = (uint64_t)h->spin_requeues; out[1] = (uint64_t)h->cw_stat[1]; out[2] = (uint64_t)h->cw_stat[2]; }
     if (getenv("GH_PRINT_STAMPS"))      // diagnostic builds (-DSEG_STAMPS / -DGH_STAMPS)
     {

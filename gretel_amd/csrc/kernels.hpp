@@ -59,7 +59,7 @@ struct dev_state {
     int stop;        // set at a hole: later launches of the spin become no-ops
     int hole_at;
     int n_done;
-    int scratch;
+    int maxstates;   // k_classify: the most states that enter any target as a mixed-radix number (product of the candidate counts of L consecutive positions); 0 = not taken / mixed radix not allowed
     int first_hole;  // smallest snp in [1,N] without a candidate (k_marg), else INT_MAX-ish   } contiguous:
     int nodel;       // stays non-zero while no position offers the LAST symbol of the candidate order ('-' by default): the depth-1 walker then works on four lanes per group (k_marg)  } re-armed
     int cm_same;     // stays non-zero while k_marg finds every candidate mask equal to the previous one  } with one
@@ -77,7 +77,7 @@ struct dev_state {
 };
 
 struct dev_ctl {
-    int stop, hole_at, n_done, scratch, first_hole, nodel, cm_same, narrow, ranked, cur_hole, lt_stale, cw_unres;
+    int stop, hole_at, n_done, maxstates, first_hole, nodel, cm_same, narrow, ranked, cur_hole, lt_stale, cw_unres;
     double ratio;
     int cw_open_at, cw_need;
 };
@@ -85,6 +85,15 @@ static_assert(sizeof(dev_ctl) == 64 && offsetof(dev_state, fill) == 64, "control
 
 // all control words at once (call before the kernel's first store)
 __device__ __forceinline__ dev_ctl load_ctl(const dev_state *st) { return *reinterpret_cast<const dev_ctl *>(st); }
+
+// which state space the segment-parallel extension walks (segwalk.hpp, segmix.hpp): 4 = candidate ranks of the ranked table
+// layout (every position offers at most four), 6 = mixed radix over the five-symbol layout (few positions offer five: k_classify
+// found every target within SEGM_NS states), 5 = all 5^L symbol histories
+__device__ __forceinline__ int seg_class(const dev_ctl &c, int L)
+{
+    if (c.ranked != 0) return 4;
+    return (L == SEGM_L && c.maxstates > 0 && c.maxstates <= SEGM_NS) ? SEG_CLS_MIXED : 5;
+}
 
 // Batched launches (gh_batch_*): one entry per window; a kernel launched with `wd != nullptr` takes its
 // window from blockIdx.y (blockIdx.x for the walkers) and its buffers from wd[window].
@@ -458,7 +467,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
         // Every workgroup reduces it for itself (<= 256 values, exact in any order); workgroup 0 closes the record the
         // way the serial walkers' bookkeeper does.  ratio_arg carries the clamp (cmd.py:157-160).
         const dev_ctl c = load_ctl(st);
-        const int nseg = seg_geometry(N, L, c.ranked != 0 ? 4 : 5).S;
+        const int nseg = seg_geometry(N, L, seg_class(c, L)).S;
         s_red[threadIdx.x] = (int)threadIdx.x < nseg ? segmin[threadIdx.x] : INFINITY;
         __syncthreads();
         for (int q = 128; q > 0; q >>= 1) {
@@ -679,6 +688,25 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
 }
 
 // batched launches: re-arm the words k_marg min/and-reduces into (single windows use a memset)
+// the most states that enter any target when a state is the last L picks as candidate ranks: max over t of the product of
+// the candidate counts of positions t-L+1 .. t (a position without candidates, or in front of the window, counts 1)
+__global__ void __launch_bounds__(256) k_classify(const uint32_t *__restrict__ cmask, int N, int L, dev_state *st)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x + 1;
+    int prod = 0;
+    if (t <= N) {
+        prod = 1;
+        for (int l = 0; l < L; l++) {
+            const int p = t - l;
+            const int r = p >= 1 ? __popc(CM_CAND(cmask[p])) : 1;
+            prod *= r > 0 ? r : 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(prod, o); prod = x > prod ? x : prod; }
+    if ((threadIdx.x & 63) == 0 && prod > 0) atomicMax(&st->maxstates, prod);
+}
+
 __global__ void k_rearm(dev_state *st, const win_desc *wd, int skip_if_stopped)
 {
     if (wd) st = wd[blockIdx.x].st;
@@ -846,7 +874,7 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term /* = b
     // tie-breaking over ranks is first-wins over symbols, so the depth-2 walker (4 symbols) also serves windows
     // with '-' candidates; its bookkeeper maps ranks back through the candidate bits of minfo.
     const bool ranked = allow_ranked && st->narrow != 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->ranked = ranked ? 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->ranked = ranked ? 1 : 0; st->maxstates = 0; }      // (k_classify follows a rebuild)
     const size_t total = (size_t)(N + LT_PAD) * 6 * L * LT_ROW;
     for (size_t t = gtid; t < total; t += gsize) {
         const int b5 = (int)(t % LT_ROW);

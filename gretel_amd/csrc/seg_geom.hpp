@@ -28,18 +28,35 @@
 // the five-symbol radix at this lag count?  (R = 4: always)
 __host__ __device__ constexpr bool seg_radix_ok(int R, int L) { return R == 4 ? L <= SEG_MAX_L_NARROW : L <= SEG_MAX_L; }
 
+// MIXED radix (class 6, segmix.hpp): a window of the five-symbol layout in which only a few positions offer five candidates.
+// A state is the last L picks as candidate RANKS in a mixed-radix number -- the digit of position p has radix R_p = the number
+// of candidates there -- so the states entering a target number prod R_p over its L predecessors (1024 where all have four,
+// 1280 behind one position with five) instead of 5^L = 3125 everywhere.  The window qualifies when that product stays within
+// SEGM_NS at every target (k_classify, dev_state.maxstates); segments and groups are cut like the ranked layout's.
+#define SEG_CLS_MIXED 6
+#define SEGM_NS 2048           /* state budget per target (2 states per thread) */
+#define SEGM_L 5               /* the lag count that has the instantiation: 5^5 against 4^5 is where the radix costs 3x */
+#define SEGM_CH 40             /* targets per LDS chunk at most (whole words of 10 picks) */
+#define SEGM_NXCAP (24 * 1024) /* Next entries (2 bytes) per chunk; a target has at most SEGM_NS of them: 10 targets always fit */
+#define SEGM_MAXITEMS 512      /* (target, block of 64 tasks) work items per chunk */
+#define SEGM_ROW 6              /* doubles per staged table row: five columns and one of padding, so that rows start 16-byte aligned */
+
 template <int R> struct seg_radix;
 template <> struct seg_radix<4> { typedef uint8_t next_t;  static constexpr int BITS = 2, DPW = 16; };   // 4 picks of 2 bits per entry
 template <> struct seg_radix<5> { typedef uint16_t next_t; static constexpr int BITS = 3, DPW = 10; };   // 5 picks of 3 bits
+template <> struct seg_radix<6> { typedef uint16_t next_t; static constexpr int BITS = 3, DPW = 10; };   // mixed: up to 5 picks of 3 bits
 // (DPW: picks per 32-bit word of hist)
-__host__ __device__ constexpr int seg_dpw(int R) { return R == 4 ? 16 : 10; }
+__host__ __device__ constexpr int seg_dpw(int R) { return R == 4 ? 16 : 10; }      // (mixed: 10)
 
 __host__ __device__ constexpr int seg_ipow(int b, int e) { int r = 1; for (int i = 0; i < e; i++) r *= b; return r; }
+// states per target the buffers of a class are laid out for
+__host__ __device__ constexpr int seg_ns(int R, int L) { return R == SEG_CLS_MIXED ? SEGM_NS : seg_ipow(R, L); }
 
 // positions per LDS chunk of k_seg: the slice of G ((c + L - 1) sources x L lags x R x R doubles) and the chunk's
 // Next tables (c x R^(L-1) entries) within 96 KB, at most 64
 __host__ __device__ constexpr int seg_chunk(int R, int L)
 {
+    if (R == SEG_CLS_MIXED) return SEGM_CH;
     const int NI = seg_ipow(R, L - 1), sz = R == 4 ? 1 : 2;
     int c = 64;
     while (c > 8 && ((c + L - 1) * L * R * R * 8 + c * NI * sz + c * R * 8) > 96 * 1024) c -= 8;
@@ -57,8 +74,8 @@ struct seg_geom {
 __host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
 {
     seg_geom g;
-    g.NS = seg_ipow(R, L);
-    g.NI = g.NS / R;
+    g.NS = seg_ns(R, L);
+    g.NI = R == SEG_CLS_MIXED ? g.NS : g.NS / R;
     int g2 = (g.NS > 3125 ? 65536 : 32768) / g.NS;      // one group's maps (G2 x NS x 2 bytes) within 64 KB of LDS (128 KB for 4^6 states)
     if (g2 > 16) g2 = 16;
     if (g2 < 1) g2 = 1;
@@ -79,9 +96,11 @@ __host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
 // the slice of G and the Next tables (rounded up to 8 bytes: the marginal table of the chunk follows)
 __host__ __device__ constexpr size_t seg_lds_bytes(int R, int L)
 {
+    // mixed: the ranked slice (five rows x five columns per source and lag), the Next entries, the per-target tables (segmix.hpp)
+    if (R == SEG_CLS_MIXED) return (size_t)(SEGM_CH + L - 1) * L * 5 * SEGM_ROW * 8 + (size_t)SEGM_NXCAP * 2 + (size_t)SEGM_CH * 64 + 1024;
     return ((size_t)(seg_chunk(R, L) + L - 1) * L * R * R * 8 + (size_t)seg_chunk(R, L) * seg_ipow(R, L - 1) * (R == 4 ? 1 : 2) + 7) & ~(size_t)7;
 }
-__host__ __device__ constexpr size_t seg_lds_total(int R, int L) { return seg_lds_bytes(R, L) + (size_t)seg_chunk(R, L) * R * 8; }
+__host__ __device__ constexpr size_t seg_lds_total(int R, int L) { return seg_lds_bytes(R, L) + (R == SEG_CLS_MIXED ? 0 : (size_t)seg_chunk(R, L) * R * 8); }
 __host__ __device__ inline size_t scan_lds_bytes(int N, int L, int R)
 {
     const seg_geom g = seg_geometry(N, L, R);

@@ -169,6 +169,9 @@ struct seg_patch {
     // marginal term: log10 marginal of the halo positions after the reweight, by candidate rank (R = 4) and by symbol (R = 5) --
     // rinfo / minfo of those positions are being rewritten by the neighbour while this workgroup stages
     double lm4[SEG_MAX_L_NARROW][4], lm5[SEG_MAX_L_NARROW][5];
+    // candidate bits (compact order) after the reweight of every position this workgroup holds -- the halo first (slots 0 .. L-1,
+    // workgroups behind the first), then its own: the mixed-radix extension ranks its digits through them (segmix.hpp)
+    uint8_t cmall[SEG_THREADS / 8];
 };
 
 // (NANP: sums can be NaN -- a separate instantiation: the sanitising selects in the arg-max of the 5^L loop cost the wide window a third
@@ -378,6 +381,8 @@ __device__ __forceinline__ void seg_body(const seg_params &P, unsigned char *sme
     SEG_STAMP(4);
 }
 
+#include "segmix.hpp"
+
 template <int LC, bool TRACK>
 __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
 {
@@ -393,8 +398,10 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
     }
     // the flags k_marg left for this path; k_scan re-arms them for the next k_marg, k_emit reads the copy
     if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC, TRACK>(P, seg_smem);
+    const int cls = __builtin_amdgcn_readfirstlane(seg_class(c, LC));
+    if (cls == 4) seg_body<4, LC, TRACK>(P, seg_smem);
     else if constexpr (seg_radix_ok(5, LC)) {                  // (beyond: the host only launches this for ranked tables)
+        if constexpr (LC == SEGM_L && !TRACK) { if (cls == SEG_CLS_MIXED) { seg_body_mixed<LC, false>(P, seg_smem); return; } }
         if (P.nanp) seg_body<5, LC, TRACK, true>(P, seg_smem);
         else seg_body<5, LC, TRACK, false>(P, seg_smem);
     }
@@ -406,7 +413,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_seg(seg_params P)
 template <int R, int LC, bool TRACK>
 __device__ __forceinline__ void scan_body(const seg_params &P, unsigned char *smem)
 {
-    constexpr int NS = seg_ipow(R, LC);
+    constexpr int NS = seg_ns(R, LC);
     const seg_geom g = seg_geometry(P.N, LC, R);
     const int grp = blockIdx.x, tid = threadIdx.x;
     if (grp >= g.G1) return;
@@ -414,7 +421,14 @@ __device__ __forceinline__ void scan_body(const seg_params &P, unsigned char *sm
     const int n = (s_lo + g.G2 <= g.S ? g.G2 : g.S - s_lo);
     uint16_t *M = reinterpret_cast<uint16_t *>(smem);              // [n][NS]
     const uint16_t *src = P.maps + (size_t)s_lo * NS;
-    for (int e = tid; e < n * NS; e += SEG_THREADS) M[e] = src[e];
+    if constexpr (NS % 8 == 0) {
+        // (16 bytes per thread and trip: a map of 2048 states two bytes at a time was most of what this kernel did)
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(M);
+        for (int e = tid; e < n * (NS / 8); e += SEG_THREADS) d4[e] = s4[e];
+    } else {
+        for (int e = tid; e < n * NS; e += SEG_THREADS) M[e] = src[e];
+    }
     // the candidate bits of this group's positions as this path's kernels see them: the reweight behind rewrites them
     // while its neighbours still map ranks to symbols (k_rw without k_emit reads this copy)
     if (TRACK) {
@@ -471,8 +485,12 @@ __global__ void __launch_bounds__(SEG_THREADS) k_scan(seg_params P)
     if (P.rearm && cur_hole > P.N && blockIdx.x == 0 && threadIdx.x == 0) {
         st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f;
     }
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) scan_body<4, LC, TRACK>(P, seg_smem);
-    else if constexpr (seg_radix_ok(5, LC)) scan_body<5, LC, TRACK>(P, seg_smem);
+    const int cls = __builtin_amdgcn_readfirstlane(seg_class(c, LC));
+    if (cls == 4) scan_body<4, LC, TRACK>(P, seg_smem);
+    else if constexpr (seg_radix_ok(5, LC)) {
+        if constexpr (LC == SEGM_L && !TRACK) { if (cls == SEG_CLS_MIXED) { scan_body<SEG_CLS_MIXED, LC, false>(P, seg_smem); return; } }
+        scan_body<5, LC, TRACK>(P, seg_smem);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -485,7 +503,7 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
 {
     constexpr int BITS = seg_radix<R>::BITS, DPW = seg_radix<R>::DPW;
     constexpr unsigned MASK = (1u << BITS) - 1u;
-    constexpr int NS = seg_ipow(R, LC);
+    constexpr int NS = seg_ns(R, LC);
     __shared__ int s_sigma;
     __shared__ double s_min[SEG_THREADS / 64];
     const seg_geom g = seg_geometry(P.N, LC, R);
@@ -517,6 +535,15 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
         const uint32_t *src = reinterpret_cast<const uint32_t *>(P.maps);
         uint32_t *dst = reinterpret_cast<uint32_t *>(MS);
         for (int e = tid; e < s * NS / 2 + 1; e += SEG_THREADS) dst[e] = src[e];
+    } else if constexpr (NS % 8 == 0) {
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(P.gmaps);
+        uint4 *d4 = reinterpret_cast<uint4 *>(GM);
+        for (int e = tid; e < grp * (NS / 8); e += SEG_THREADS) d4[e] = g4[e];
+        if (q > 0) {
+            const uint4 *p4 = reinterpret_cast<const uint4 *>(P.pmaps + (size_t)s * NS);
+            uint4 *m4 = reinterpret_cast<uint4 *>(PM);
+            for (int e = tid; e < NS / 8; e += SEG_THREADS) m4[e] = p4[e];
+        }
     } else {
         for (int e = tid; e < grp * NS; e += SEG_THREADS) GM[e] = P.gmaps[e];
         if (q > 0) {
@@ -570,7 +597,7 @@ __device__ __forceinline__ void emit_body(const seg_params &P, unsigned char *sm
         int b5 = (int)((word >> (BITS * (tl % DPW))) & MASK);
         const double r16[16] = {row[0].x, row[0].y, row[1].x, row[1].y, row[2].x, row[2].y, row[3].x, row[3].y,
                                 row[4].x, row[4].y, row[5].x, row[5].y, row[6].x, row[6].y, row[7].x, row[7].y};
-        if (R == 4) {                                               // rank -> symbol through the candidate bits
+        if (R != 5) {                                               // rank -> symbol through the candidate bits (ranked layout, mixed radix)
             b5 = nth_set5((uint32_t)__double_as_longlong(r16[10]), b5);
             if (b5 < 0) b5 = 0;     // cannot happen for a decided position
         }
@@ -606,8 +633,12 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit(seg_params P)
     const dev_ctl c = load_ctl(st);
     if (c.stop || c.lt_stale) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->dbg[3] = 3;      // gh_debug_walk_clock: variant 3 = segment-parallel
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC>(P, seg_smem, c.cur_hole);
-    else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC>(P, seg_smem, c.cur_hole);
+    const int cls = __builtin_amdgcn_readfirstlane(seg_class(c, LC));
+    if (cls == 4) emit_body<4, LC>(P, seg_smem, c.cur_hole);
+    else if constexpr (seg_radix_ok(5, LC)) {
+        if constexpr (LC == SEGM_L) { if (cls == SEG_CLS_MIXED) { emit_body<SEG_CLS_MIXED, LC>(P, seg_smem, c.cur_hole); return; } }
+        emit_body<5, LC>(P, seg_smem, c.cur_hole);
+    }
 }
 
 // k_scan and k_emit in one launch where the window's maps fit the LDS (emit_body<.., true>)
@@ -622,7 +653,7 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit_small(seg_params P)
     if (P.rws) {
         // behind k_rwseg (two launches per path in small windows): k_scan's look at what the reweight found happens here, in
         // every workgroup for itself -- nobody reads the control words the first thread rewrites
-        const int S = seg_geometry(P.N, LC, c.ranked != 0 ? 4 : 5).S;
+        const int S = seg_geometry(P.N, LC, seg_class(c, LC)).S;
         if (!rws_take_flags(P, st, S, cur_hole)) return;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -630,8 +661,12 @@ __global__ void __launch_bounds__(SEG_THREADS) k_emit_small(seg_params P)
         // (k_scan's other job: the flags for the reweight that follows -- every k_seg workgroup has read them: it ran in the launch before)
         if (P.rearm && cur_hole > P.N) { st->first_hole = 0x7f7f7f7f; st->nodel = 0x7f7f7f7f; st->cm_same = 0x7f7f7f7f; st->narrow = 0x7f7f7f7f; }
     }
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) emit_body<4, LC, true>(P, seg_smem, cur_hole);
-    else if constexpr (seg_radix_ok(5, LC)) emit_body<5, LC, true>(P, seg_smem, cur_hole);
+    const int cls = __builtin_amdgcn_readfirstlane(seg_class(c, LC));
+    if (cls == 4) emit_body<4, LC, true>(P, seg_smem, cur_hole);
+    else if constexpr (seg_radix_ok(5, LC)) {
+        if constexpr (LC == SEGM_L) { if (cls == SEG_CLS_MIXED) { emit_body<SEG_CLS_MIXED, LC, true>(P, seg_smem, cur_hole); return; } }
+        emit_body<5, LC, true>(P, seg_smem, cur_hole);
+    }
 }
 
 // what the serial walkers' bookkeeper does at the end of a walk: hole -> stop, else the record and the ratio the
@@ -654,7 +689,7 @@ __device__ __forceinline__ void seg_finish(dev_state *st, gh_path_rec *rec, int 
 
 __device__ __forceinline__ int seg_count(const dev_state *st, int N, int L)
 {
-    return seg_geometry(N, L, st->ranked != 0 ? 4 : 5).S;
+    return seg_geometry(N, L, seg_class(load_ctl(st), L)).S;
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -740,7 +775,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         for (size_t q = tid; q < nv; q += 256) dst[q] = src[q];
     }
     const dev_ctl c = load_ctl(st);
-    const int Rr = c.ranked != 0 ? 4 : 5;
+    const int Rr = seg_class(c, L);                         // (the fused flow never runs over the mixed radix: mixed_allowed)
     const seg_geom sg = seg_geometry(N, L, Rr);
     const int nseg = nseg_arg > 0 ? nseg_arg : sg.S;
     double my_segmin = INFINITY;                            // (<= 512 segments: two per thread at most)
@@ -1221,7 +1256,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
     if (tid < SEG_MAX_L_NARROW) patch->row6[tid] = -1;
     if (tid < SEG_MAX_L_NARROW * SEG_MAX_L_NARROW) { (&patch->col[0][0])[tid] = -1; (&patch->rmask[0][0])[tid] = 0u; }
     if (tid == 0) patch->colmode = COL ? 1 : 0;
-    const int R = c.ranked != 0 ? 4 : 5;
+    const int R = seg_class(c, L);
     const seg_geom g = seg_geometry(N, L, R);
     if (sblk >= g.S) { if (tid == 0) { Q.partial[sblk] = 0.0; P.rwflags[sblk] = make_int2(0, 0x7fffffff); } return false; }
     RWS_STAMP(0);
@@ -1374,6 +1409,7 @@ __device__ __forceinline__ bool rwseg_reweight(const seg_params &P, const rws_pa
         }
     }
     RWS_STAMP(3);
+    if (act && s == 0) patch->cmall[slot] = (uint8_t)cm5;           // (the mixed-radix extension ranks its digits through these)
     if (halo && act && P.mt) {
         // the marginal term of the halo positions, as the owner writes it to rinfo / minfo in this launch
         if (s < NSYM) {
@@ -1550,8 +1586,10 @@ __global__ void __launch_bounds__(SEG_THREADS) k_rwseg(seg_params P, rws_params 
     }
     seg_patch *patch = reinterpret_cast<seg_patch *>(seg_smem + P.patch_off);
     if (!rwseg_reweight<T, LC, COL>(P, Q, c, seg_smem, patch)) return;
-    if (__builtin_amdgcn_readfirstlane(c.ranked) != 0) seg_body<4, LC, false>(P, seg_smem, patch);
+    const int cls = __builtin_amdgcn_readfirstlane(seg_class(c, LC));
+    if (cls == 4) seg_body<4, LC, false>(P, seg_smem, patch);
     else if constexpr (seg_radix_ok(5, LC)) {
+        if constexpr (LC == SEGM_L) { if (cls == SEG_CLS_MIXED) { seg_body_mixed<LC, true>(P, seg_smem, patch); return; } }
         if (P.nanp) seg_body<5, LC, false, true>(P, seg_smem, patch);
         else seg_body<5, LC, false, false>(P, seg_smem, patch);
     }

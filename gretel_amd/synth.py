@@ -127,3 +127,22 @@ def make_config(name, seed=0, **over):
     cfg = dict(CONFIGS[name])
     cfg.update(over)
     return make_support_table(seed=seed, **cfg)
+
+
+def sprinkle_deletions(table, frac_positions, frac_reads=0.3, seed=0):
+    """'-' at a fraction of the SNP POSITIONS (on `frac_reads` of the reads that cover them): what a real pileup shows where
+    some haplotypes carry a deletion -- a few columns of the window with five candidates (A, C, G, T and '-'), the rest
+    with at most four.  (Replacing a fraction of all BASES, as bench.py's wide_window does, leaves hardly a column without.)
+    Returns the positions (1-based SNP numbers) that got deletions; `table.bases` is replaced."""
+    rng = np.random.default_rng(seed)
+    n = table.n_snps
+    npos = max(1, int(round(frac_positions * n)))
+    pos = np.sort(rng.choice(np.arange(1, n + 1), size=npos, replace=False))
+    ks = np.diff(table.off)
+    read_of = np.repeat(np.arange(table.n_reads, dtype=np.int64), ks)
+    snp = table.rank[read_of].astype(np.int64) + (np.arange(len(table.bases), dtype=np.int64) - table.off[read_of]) + 1
+    hit = np.isin(snp, pos) & (rng.random(len(table.bases)) < frac_reads)
+    bases = table.bases.copy()
+    bases[hit] = ord('-')
+    table.bases = bases
+    return pos

@@ -213,7 +213,9 @@ int gh_profile_overhead(gh_t *h, int reps, double out[2]);
  * out[1] = the same interval in 100 MHz ticks (s_memrealtime), out[2] = steps it executed, out[3] = the variant
  * that ran (2 = depth-2 speculation, 1 = depth 1 without '-' candidates, 0 = depth 1 with them; 3 = segment-parallel
  * walk, which has no single walker wave: then out[0] = how often the last gh_spin rebuilt the conditional table and
- * queued its remaining paths again because a candidate mask moved, out[1] = out[2] = 0; 4 = candidate-pool segments
+ * queued its remaining paths again because a candidate mask moved, out[1] = the state space it enumerated (4: candidate
+ * ranks of a window whose positions offer at most four; 5: all symbol histories; 6: mixed radix -- few positions offer five),
+ * out[2] = the most states that enter a target as a mixed-radix number (0: not taken); 4 = candidate-pool segments
  * (L = 6..24): out[0] = re-queues of the last gh_spin, out[1] = paths this handle handed to the serial walker so far,
  * out[2] = walk/scan rounds it queued so far) */
 int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
