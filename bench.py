@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--config", default="C3", choices=["C2", "C3", "C5"])
     ap.add_argument("--paths", type=int, default=0, help="paths per step (default: 100; C5: 1000 = BASELINE.md's deep reweight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--blocking-gather", action="store_true", help="gather a step's records inside the step (a blocking collective + copies) "
+                    "instead of while the next step runs")
     ap.add_argument("--no-throughput-leg", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="throughput mode: this many independent windows per GPU in one batched launch")
     ap.add_argument("--cpu-snps", type=int, default=3000, help="SNP prefix used for the Python CPU baseline sample")
@@ -417,7 +419,7 @@ def main():
 
     from gretel_amd.hansel import Hansel, DeviceReads
     from gretel_amd.synth import make_config
-    from gretel_amd.dist import broadcast_descriptor, gather_results
+    from gretel_amd.dist import broadcast_descriptor, gather_results, ResultExchange
 
     # rank 0 decides the run, everybody learns it over RCCL
     if args.paths <= 0:
@@ -435,14 +437,31 @@ def main():
     h = Hansel(table.n_snps, band=table.band, device=local, **spec_kw)
     reads = DeviceReads(h, table.rank, table.off, table.bases)   # inputs resident in HBM before timing
 
+    # The records of a step go to rank 0 while the next step runs (gretel_amd.dist.ResultExchange: spin writes into a pinned
+    # slot, upload + gather + download ride on a side stream); --blocking-gather keeps the collective inside the step.
+    ex = None if args.blocking_gather else ResultExchange(table.n_snps, paths, comm_dev, world, rank, force=use_dist)
+
     def step():
         h.clear()
         stats = h.fill_from_support(None, None, None, reads_handle=reads)
-        res = h.spin(paths)
-        gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank, force=use_dist, copy=False)
+        if ex is None:
+            res = h.spin(paths)
+            gathered = gather_results(res, table.n_snps, paths, comm_dev, world, rank, force=use_dist, copy=False)
+            return stats, res, gathered
+        pv, rv = ex.buffers()
+        res = h.spin(paths, out_paths=pv, out_recs=rv)
+        ex.submit(res["n"], res["hole_at"])
+        # what rank 0 looks at is the step before this one (its records have had a whole step to arrive)
+        gathered = ex.collect() if len(ex.queue) > 1 else None
         return stats, res, gathered
 
+    drained = {}
+
     def fence():
+        if ex is not None:
+            last = ex.drain()                           # (inside the timed region: the last step's records are on rank 0)
+            if last is not None:
+                drained["last"] = last
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -462,6 +481,8 @@ def main():
         n_paths_local += res["n"]
     fence()
     dt = time.perf_counter() - t0
+    if ex is not None:
+        gathered = drained.get("last")                  # the last timed step's records, every rank's (rank 0)
     prof = h.profile_get()
     h.profile_enable(0)
     ev_empty_ms, ev_nop_ms = h.profile_overhead(30)      # what a bracket reads with nothing / an empty kernel inside
@@ -578,6 +599,8 @@ def main():
                        "parallelism": "%d independent window(s), one per rank; %s broadcast/gather of control records, no data-path collective"
                                       % (world, "RCCL" if args.backend == "nccl" else "gloo"),
                        "backend": args.backend, "share_gpu": bool(args.share_gpu), "control_records_through_torch_distributed": bool(use_dist),
+                       "gather": "blocking, inside the step (--blocking-gather)" if ex is None else
+                                 "overlapped: a step's records reach rank 0 on a side stream while the next step runs (ResultExchange); the last step's inside the timed region",
                        "hansel_spec": dict(spec_kw, cand_order="ACGT-", offer_zero=False)},
             "edge_evals_per_s": hap_s * (cond_evals + rw_cells),
             "edge_evals_per_path": {"conditionals": cond_evals, "reweight_cells": rw_cells},

@@ -113,6 +113,9 @@ def gather_results(res, n_snps, max_paths, device, world, rank, force=False, cop
         b.send_dev.copy_(b.send_host, non_blocking=True)         # (stream-ordered: the collective is queued behind it)
     dist.gather(b.send_dev, [b.recv_dev[r] for r in range(world)] if rank == 0 else None, dst=0)
     if rank != 0:
+        # the staging buffer is packed again by the next call: the upload and the collective that read it must be through
+        if b.cuda:
+            torch.cuda.current_stream().synchronize()
         return None
     if b.cuda:
         b.recv_host.copy_(b.recv_dev, non_blocking=True)
@@ -129,3 +132,118 @@ def gather_results(res, n_snps, max_paths, device, world, rank, force=False, cop
             out.append(dict(n=kk, hole_at=int(vals[max_paths, 1]), paths=paths[:kk], hp_current=vals[:kk, 0], hp_original=vals[:kk, 1],
                             ratio=vals[:kk, 2], magnitude=vals[:kk, 3]))
     return out
+
+
+class ResultExchange:
+    """gather_results with the collective OFF the critical path (bench.py's default; `--blocking-gather` keeps the form above).
+
+    The records of a step travel while the next step runs: `buffers()` hands out views of a pinned staging slot that
+    Hansel.spin writes its results into directly (no packing pass), `submit()` queues upload + gather + (rank 0) download of that
+    slot on a side stream and returns at once, `collect()` waits for the OLDEST outstanding submission and returns what rank 0
+    gathered (None elsewhere).  Two slots: a slot is handed out again only when its previous submission has been collected, so
+    no buffer is rewritten while a copy or the collective may still read it.  Every rank submits once per step, in step order:
+    the collectives match across ranks.  Wire format per window: paths u8[max_paths][N+1], gh_path_rec f64[max_paths][5],
+    f64[2] = (n, hole_at)."""
+
+    NREC = 5
+
+    def __init__(self, n_snps, max_paths, device, world, rank, force=False, slots=2):
+        import torch
+        self.n1, self.max_paths, self.device, self.world, self.rank = n_snps + 1, max_paths, device, world, rank
+        self.active = world > 1 or force
+        self.cuda = device.type == "cuda"
+        self.nb_p = max_paths * self.n1
+        self.off_r = (self.nb_p + 7) & ~7
+        self.nb_r = max(1, max_paths) * self.NREC * 8
+        self.off_t = self.off_r + self.nb_r
+        self.nbytes = self.off_t + 16
+        self.slots = []
+        for _ in range(slots):
+            host = torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=self.cuda)
+            sl = dict(host=host, np=host.numpy(), pending=None)
+            if self.active:
+                sl["dev"] = torch.empty(self.nbytes, dtype=torch.uint8, device=device) if self.cuda else host
+                sl["recv_list"] = None
+                if rank == 0:
+                    sl["recv_dev"] = torch.empty((world, self.nbytes), dtype=torch.uint8, device=device)
+                    sl["recv_host"] = torch.empty((world, self.nbytes), dtype=torch.uint8, pin_memory=True) if self.cuda else sl["recv_dev"]
+                    sl["recv_list"] = [sl["recv_dev"][r] for r in range(world)]
+                if self.cuda:
+                    sl["event"] = torch.cuda.Event()
+            self.slots.append(sl)
+        self.side = torch.cuda.Stream(device=device) if (self.cuda and self.active) else None
+        self.next_slot = 0
+        self.queue = []                 # submitted, not yet collected: (slot index, n, hole_at)
+
+    def _views(self, a):
+        paths = a[:self.nb_p].reshape(self.max_paths, self.n1)
+        recs = a[self.off_r:self.off_r + self.nb_r].view(np.float64).reshape(max(1, self.max_paths), self.NREC)
+        tail = a[self.off_t:self.off_t + 16].view(np.float64)
+        return paths, recs, tail
+
+    def buffers(self):
+        """(paths, recs) views of the slot the next submit() sends: hand them to Hansel.spin(out_paths=, out_recs=)."""
+        sl = self.slots[self.next_slot]
+        while any(q[0] == self.next_slot for q in self.queue):      # its last submission is still out: finish the oldest first
+            self._finish(self.queue.pop(0), keep=False)
+        p, r, _ = self._views(sl["np"])
+        return p, r
+
+    def submit(self, n, hole_at):
+        import torch
+        import torch.distributed as dist
+        si = self.next_slot
+        sl = self.slots[si]
+        self.next_slot = (si + 1) % len(self.slots)
+        _, _, tail = self._views(sl["np"])
+        tail[0], tail[1] = float(n), float(hole_at)
+        if self.active:
+            recv = sl["recv_list"]
+            if self.cuda:
+                with torch.cuda.stream(self.side):
+                    sl["dev"].copy_(sl["host"], non_blocking=True)
+                    work = dist.gather(sl["dev"], recv, dst=0, async_op=True)
+                    work.wait()                                   # (the side stream waits, not the host)
+                    if self.rank == 0:
+                        sl["recv_host"].copy_(sl["recv_dev"], non_blocking=True)
+                    sl["event"].record(self.side)
+                sl["pending"] = sl["event"]
+            else:
+                sl["pending"] = dist.gather(sl["dev"], recv, dst=0, async_op=True)
+        self.queue.append((si, int(n), int(hole_at)))
+
+    def _finish(self, q, keep=True):
+        si, n, hole = q
+        sl = self.slots[si]
+        if self.active and sl["pending"] is not None:
+            if self.cuda:
+                sl["pending"].synchronize()
+            else:
+                sl["pending"].wait()
+            sl["pending"] = None
+        if not keep or (self.active and self.rank != 0):
+            return None
+        if not self.active:
+            rows = [self._views(sl["np"])]
+        else:
+            a = sl["recv_host"].numpy()
+            rows = [self._views(a[r]) for r in range(self.world)]
+        out = []
+        for paths, recs, tail in rows:
+            k = int(tail[0])
+            out.append(dict(n=k, hole_at=int(tail[1]), paths=paths[:k], hp_current=recs[:k, 0], hp_original=recs[:k, 1],
+                            ratio=recs[:k, 2], magnitude=recs[:k, 3], min_marginal=recs[:k, 4]))
+        return out
+
+    def collect(self):
+        """Results of the oldest outstanding submission (views of buffers that the submission after next overwrites); None on
+        ranks other than 0, and when nothing is outstanding."""
+        if not self.queue:
+            return None
+        return self._finish(self.queue.pop(0))
+
+    def drain(self):
+        last = None
+        while self.queue:
+            last = self._finish(self.queue.pop(0))
+        return last

@@ -329,13 +329,26 @@ class Hansel:
         self.is_weighted = True
         return out.value
 
-    def spin(self, max_paths=100, min_remove=0.01):
+    def spin(self, max_paths=100, min_remove=0.01, out_paths=None, out_recs=None):
         """gretel/cmd.py:148-179 on the device.  Returns dict(n, hole_at, paths uint8[n][N+1],
-        hp_current, hp_original, ratio, magnitude)."""
+        hp_current, hp_original, ratio, magnitude).  out_paths uint8[max_paths][N+1] / out_recs float64[max_paths][5]: write the
+        results there (C-contiguous; e.g. views of a pinned buffer that a gather sends on, gretel_amd.dist.ResultExchange) --
+        `paths` of the returned dict is then a view of out_paths."""
         self._ensure()
         # (gh_spin writes rows 0 .. n-1 of both; gh_path_rec is five doubles -- include/gretel_hip.h)
-        paths = np.empty((max_paths, self.n + 1), dtype=np.uint8)
-        recs = np.empty((max(1, max_paths), C.sizeof(_lib.gh_path_rec) // 8), dtype=np.float64)
+        nrec = C.sizeof(_lib.gh_path_rec) // 8
+        if out_paths is not None:
+            if out_paths.dtype != np.uint8 or out_paths.shape != (max_paths, self.n + 1) or not out_paths.flags.c_contiguous:
+                raise ValueError("out_paths must be a C-contiguous uint8[%d][%d]" % (max_paths, self.n + 1))
+            paths = out_paths
+        else:
+            paths = np.empty((max_paths, self.n + 1), dtype=np.uint8)
+        if out_recs is not None:
+            if out_recs.dtype != np.float64 or out_recs.shape != (max(1, max_paths), nrec) or not out_recs.flags.c_contiguous:
+                raise ValueError("out_recs must be a C-contiguous float64[%d][%d]" % (max(1, max_paths), nrec))
+            recs = out_recs
+        else:
+            recs = np.empty((max(1, max_paths), nrec), dtype=np.float64)
         n, hole = C.c_int(), C.c_int()
         check(self._lib.gh_spin(self._h, int(max_paths), float(min_remove), _p(paths), _p(recs), C.byref(n), C.byref(hole)))
         k = n.value

@@ -59,6 +59,87 @@ WORKER = textwrap.dedent('''
 ''')
 
 
+EX_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, %r)
+    from gretel_amd import dist as gdist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    n_snps, max_paths, steps = 8, 4, 5
+    ex = gdist.ResultExchange(n_snps, max_paths, dev, world, rank)
+
+    def fake(step, r):          # what Hansel.spin would leave in the slot: k paths, their records
+        rng = np.random.default_rng(1000 * step + r)
+        k = 1 + (step + r) %% max_paths
+        return k, rng.integers(0, 7, (k, n_snps + 1), dtype=np.uint8), rng.random((k, 5))
+
+    def check(step, g):           # (at once: what collect() returns are views of buffers the submission after next overwrites)
+        if rank != 0:
+            assert g is None
+            return
+        assert g is not None and len(g) == world
+        for r in range(world):
+            k, paths, recs = fake(step, r)
+            assert g[r]["n"] == k and g[r]["hole_at"] == 7 * r + step, (step, r, g[r]["n"], g[r]["hole_at"])
+            assert np.array_equal(g[r]["paths"], paths) and np.array_equal(g[r]["hp_current"], recs[:, 0])
+            assert np.array_equal(g[r]["magnitude"], recs[:, 3]) and np.array_equal(g[r]["min_marginal"], recs[:, 4])
+
+    checked = 0
+    for step in range(steps):
+        pv, rv = ex.buffers()
+        k, paths, recs = fake(step, rank)
+        pv[:k] = paths; rv[:k] = recs
+        ex.submit(k, 7 * rank + step)
+        if len(ex.queue) > 1:
+            check(step - 1, ex.collect())       # the step before this one
+            checked += 1
+    check(steps - 1, ex.drain())
+    assert not ex.queue and checked == steps - 1
+    if rank == 0:
+        print("EXCHANGE_OK")
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def _run_world2(tmp_path, text, marker):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w.py"
+    script.write_text(text)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert marker in outs[0]
+
+
+def test_overlapped_exchange_world2(tmp_path):
+    # ResultExchange: five steps through two slots, every step's records of both ranks arrive on rank 0, in step order, one step late
+    _run_world2(tmp_path, EX_WORKER % ROOT, "EXCHANGE_OK")
+
+
+def test_exchange_with_one_rank_needs_no_process_group():
+    import torch
+    ex = gdist.ResultExchange(6, 3, torch.device("cpu"), 1, 0)
+    for step in range(4):
+        pv, rv = ex.buffers()
+        pv[:2] = step
+        rv[:2] = 0.5 * step
+        ex.submit(2, 0)
+        if len(ex.queue) > 1:
+            g = ex.collect()
+            assert len(g) == 1 and g[0]["n"] == 2 and (g[0]["paths"] == step - 1).all() and (g[0]["ratio"] == 0.5 * (step - 1)).all()
+    g = ex.drain()
+    assert (g[0]["paths"] == 3).all()
+
+
 def test_broadcast_and_gather_world2(tmp_path):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
