@@ -287,7 +287,7 @@ class _gio_table(C.Structure):
 class gio_stats(C.Structure):
     _fields_ = [("compressed_bytes", C.c_int64), ("blocks", C.c_int64), ("records", C.c_int64), ("reads_kept", C.c_int64),
                 ("used_index", C.c_int32), ("libdeflate", C.c_int32), ("threads", C.c_int32), ("reframed", C.c_int32),
-                ("seconds", C.c_double)]
+                ("seconds", C.c_double), ("depth_dropped", C.c_int64)]
 
 
 def native_last_stats():
@@ -307,6 +307,8 @@ def io_lib():
         L.gio_ref_len.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int64)]
         L.gio_support_table_from_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int,
                                                  C.POINTER(_gio_table)]
+        L.gio_support_table_from_bam_depth.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_int32,
+                                                       C.POINTER(_gio_table)]
         L.gio_table_free.argtypes = [C.POINTER(_gio_table)]
         L.gio_last_stats.argtypes = [C.POINTER(gio_stats)]
         L.gio_last_stats.restype = None
@@ -323,14 +325,18 @@ def native_ref_len(bam_path, contig):
     return out.value
 
 
-def native_support_table(bam_path, contig, start_pos, end_pos, region, stepper="samtools"):
+PYSAM_MAX_DEPTH = 8000          # bam.pileup's default, which the reference inherits (gretel/util.py:137 passes no max_depth)
+
+
+def native_support_table(bam_path, contig, start_pos, end_pos, region, stepper="samtools", max_depth=PYSAM_MAX_DEPTH):
+    """max_depth: the pileup's read-buffer cap (pysam's default 8000; 0 or None: keep every read)."""
     L = io_lib()
     reg = np.ascontiguousarray(np.asarray(region) != 0, dtype=np.uint8)
     if len(reg) < end_pos + 1:
         reg = np.concatenate([reg, np.zeros(end_pos + 1 - len(reg), dtype=np.uint8)])
     t = _gio_table()
-    rc = L.gio_support_table_from_bam(bam_path.encode(), contig.encode(), int(start_pos), int(end_pos),
-                                      reg.ctypes.data, int(stepper == "all"), C.byref(t))
+    rc = L.gio_support_table_from_bam_depth(bam_path.encode(), contig.encode(), int(start_pos), int(end_pos),
+                                            reg.ctypes.data, int(stepper == "all"), int(max_depth or 0), C.byref(t))
     if rc:
         msg = L.gio_last_error().decode()
         raise (KeyError if rc == -5 else IOError)(msg)

@@ -36,8 +36,8 @@ def build_parser():
     p.add_argument("-@", "--threads", type=int, default=1, help="accepted for compatibility (the fill runs on the GPU)")
     p.add_argument("--debugreads", type=str, default="", help="A newline delimited list of read names to output debug data when parsing the BAM")
     p.add_argument("--debugpos", type=str, default="", help="A newline delimited list of 1-indexed genomic positions to output debug data when parsing the BAM")
-    p.add_argument("--max-depth", type=int, default=0, help="drop reads that start where this many are already open, as the pileup the "
-                   "reference inherits does at pysam's default of 8000 (0 = keep every read; > 0 switches to the Python BAM decoder)")
+    p.add_argument("--max-depth", type=int, default=8000, help="read-buffer cap of the pileup: reads beyond it at a position are dropped, as "
+                   "the pysam pileup the reference runs on does at its default of 8000 (0 = keep every read) [default: 8000]")
     p.add_argument("--debughpos", type=str, default=",", help="comma delimited 1-indexed SNP ranks to print branch weights for")
     p.add_argument("--dumpmatrix", type=str, default=None, help="dump the Hansel tensor (.npz) to this path")
     p.add_argument("--dumpsnps", type=str, default=None, help="dump the SNP positions to this path")

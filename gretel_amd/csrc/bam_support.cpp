@@ -352,6 +352,7 @@ private:
 // ---------------------------------------------------------------------------------------------
 struct bam_header {
     std::vector<std::pair<std::string, int64_t>> refs;
+    bool sorted = false;        // @HD ... SO:coordinate
 };
 
 static int read_header(bgzf_stream &z, bam_header &h, const char *path)
@@ -361,6 +362,15 @@ static int read_header(bgzf_stream &z, bam_header &h, const char *path)
     if (l_text < 0) return fail(-4, "bad BAM header");
     z.consume(8);
     if (z.ensure((size_t)l_text + 4) < (int64_t)l_text + 4) return fail(-4, "truncated BAM header");
+    {
+        // the first header line says whether the records are in coordinate order (then a scan may stop behind its window)
+        const char *tx = (const char *)z.ptr();
+        const size_t n = (size_t)l_text;
+        size_t eol = 0;
+        while (eol < n && tx[eol] != '\n') eol++;
+        const std::string first(tx, eol);
+        h.sorted = first.compare(0, 3, "@HD") == 0 && first.find("SO:coordinate") != std::string::npos;
+    }
     z.consume((size_t)l_text);
     const int32_t n_ref = rd32(z.ptr());
     z.consume(4);
@@ -517,7 +527,7 @@ static int parse_record(const uint8_t *r, int32_t block_size, bam_rec &out)
 static const char SEQ[] = "=ACMGRSVTWYHKDBN";
 
 static int gio_support_table_from_bam_impl(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
-                                           const uint8_t *region, int stepper_all, gio_table *out)
+                                           const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out)
 {
     if (!bam_path || !contig || !region || !out || end_pos < 0) return fail(-1, "bad argument");
     memset(out, 0, sizeof *out);
@@ -635,7 +645,11 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     // the record.  Only the key table (first-seen order of the rows, util.py:191-207) is sequential: it takes the
     // records of a batch in file order from the threads' parts.
     struct kept { uint64_t h; int32_t rank; uint32_t key_off, key_len, ch_off, ch_len; };
+    // max_depth: what the pileup's read buffer sees of a record, in file order -- every record the stepper lets through that
+    // overlaps the fetched region, whether or not it shows a SNP: start, reference end, and the row it would open (-1: none)
+    struct depth_cand { int32_t pos, end, kept_idx; };
     struct part {
+        bigvec<depth_cand> cands;
         bigvec<kept> recs;
         bigvec<uint8_t> chars;
         bigvec<char> keys;
@@ -655,7 +669,26 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         const int flag = b.flag;
         if (b.ref_id != tid || (flag & (0x4 | 0x100 | 0x200 | 0x400))) return 0;
         if (!stepper_all && (flag & 0x1) && !(flag & 0x2)) return 0;        // orphans, stepper "samtools"
-        if (b.l_seq == 0) return 0;
+        // what the pileup's buffer counts: the record's reference span (bam_endpos: a read that consumes none spans one base),
+        // if it overlaps the fetched region [start_pos - 1, end_pos)
+        auto depth_note = [&](int64_t ref_end, int32_t kept_idx) {
+            if (max_depth <= 0) return;
+            const int64_t e = ref_end > (int64_t)b.pos ? ref_end : (int64_t)b.pos + 1;
+            if ((int64_t)b.pos < (int64_t)end_pos && e > (int64_t)start_pos - 1)
+                o.cands.push_back(depth_cand{b.pos, (int32_t)(e > 0x7fffffff ? 0x7fffffff : e), kept_idx});
+        };
+        if (b.l_seq == 0) {
+            if (max_depth > 0) {
+                int64_t r = b.pos;
+                for (int c = 0; c < b.n_cigar; c++) {
+                    const uint32_t v = rdu32(b.cigar + 4 * (size_t)c);
+                    const int op = v & 15;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) r += v >> 4;
+                }
+                depth_note(r, -1);
+            }
+            return 0;
+        }
 
         // walk the CIGAR the way htslib's pileup resolves it, column by column over the SNP positions
         const size_t ch0 = o.chars.size();
@@ -686,10 +719,11 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         }
         int64_t leftmost = (int64_t)b.pos + 1;                              // util.py:162
         if (leftmost < start_pos) {                                         // util.py:165-171
-            if (leftmost + qalen < start_pos) { o.chars.resize(ch0); return 0; }
+            if (leftmost + qalen < start_pos) { o.chars.resize(ch0); depth_note(ref, -1); return 0; }
             leftmost = start_pos;
         }
-        if (o.chars.size() == ch0) return 0;
+        if (o.chars.size() == ch0) { depth_note(ref, -1); return 0; }
+        depth_note(ref, (int32_t)o.recs.size());
         int one_or_two = 0;
         if (flag & 0x1) one_or_two = (flag & 0x40) ? 1 : ((flag & 0x80) ? 2 : 0);
         // "<qname>_<flag>_<1|2|0>", util.py:160 (snprintf here was a third of the whole decode)
@@ -754,6 +788,9 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         return (size_t)-1;
     };
     std::vector<std::vector<uint32_t>> lists;                               // [part][partition] -> gids, per batch
+    // the depth cap's state across batches: the position the iterator stands on, the reads that entered, their ends
+    int64_t dc_pos = -1, dc_base = -1, dc_exp_upto = 0, dc_accepted = 0, dc_expired = 0;
+    std::vector<uint32_t> dc_ends;                                          // [end - dc_base] reads that entered and end there
     bool done = false;
     bool front_to_back = false;                                             // this batch again on one thread (a guessed start was wrong)
     while (!done) {
@@ -848,6 +885,50 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             if (P.err) return fail(P.err, "%s", P.msg.c_str());
             if (P.stop) done = true;
             n_valid = t + 1;
+        }
+        // pysam's pileup keeps at most max_depth reads in its buffer (bam.pileup's default 8000, gretel/util.py:137 passes none):
+        // htslib's bam_plp_push drops a read that starts at the position the iterator stands on while the buffer holds more
+        // than maxcnt nodes.  In file order: the FIRST read of a position is pushed while the iterator still stands on an
+        // earlier one and always enters; every later read of that position finds the buffer holding the reads that entered and
+        // end behind position - 1 (the columns up to there have been produced and have released the rest) plus the list's
+        // sentinel node, and is dropped when that is more than max_depth.  One pass over the batch's records, the ends in a
+        // histogram (the starts ascend: what has expired is a running sum).
+        if (max_depth > 0) {
+            for (int t = 0; t < n_valid; t++) {
+                part &P = *kept_parts[p0 + (size_t)t];
+                bool any = false;
+                for (size_t ci = 0; ci < P.cands.size(); ci++) {
+                    const depth_cand &c = P.cands[ci];
+                    bool drop = false;
+                    if ((int64_t)c.pos != dc_pos) {
+                        dc_pos = c.pos;                                      // (the iterator moves here once this read is in)
+                    } else {
+                        while (dc_exp_upto < (int64_t)c.pos) {              // reads that end at or before pos - 1 ... end <= pos - 1
+                            const int64_t x = dc_exp_upto - dc_base;
+                            if (x >= 0 && (size_t)x < dc_ends.size()) dc_expired += dc_ends[(size_t)x];
+                            dc_exp_upto++;
+                        }
+                        drop = dc_accepted - dc_expired + 1 > (int64_t)max_depth;
+                    }
+                    if (drop) {
+                        g_stats.depth_dropped++;
+                        if (c.kept_idx >= 0) { P.recs[(size_t)c.kept_idx].ch_len = 0xffffffffu; any = true; }
+                        continue;
+                    }
+                    if (dc_base < 0) { dc_base = c.pos; dc_exp_upto = c.pos; }
+                    const size_t x = (size_t)((int64_t)c.end - dc_base);
+                    if (x >= dc_ends.size()) dc_ends.resize(x + 4096, 0);
+                    dc_ends[x]++;
+                    dc_accepted++;
+                }
+                if (any) {
+                    size_t w = 0;
+                    for (size_t i = 0; i < P.recs.size(); i++)
+                        if (P.recs[i].ch_len != 0xffffffffu) P.recs[w++] = P.recs[i];
+                    P.recs.resize(w);
+                }
+                bigvec<depth_cand>().swap(P.cands);
+            }
         }
         // gids of this batch: the parts' records behind one another
         std::vector<size_t> gbase((size_t)n_valid + 1, info.size());
@@ -1043,7 +1124,9 @@ static int gio_count_coverage_impl(const char *bam_path, const char *contig, int
         bam_rec b;
         if ((rc = parse_record(z.ptr() + 4, block_size, b))) return rc;
         z.consume(4 + (size_t)block_size);
-        if (indexed && (b.ref_id > tid || (b.ref_id == tid && b.pos >= stop))) break;
+        // (an index, or a header that declares coordinate order: nothing behind the window can matter -- without either every
+        // record of the file is visited, once per call)
+        if ((indexed || hd.sorted) && (b.ref_id > tid || (b.ref_id == tid && b.pos >= stop))) break;
         if (b.ref_id != tid || (b.flag & 0x4)) continue;                  // other contig / unmapped
         if (b.l_seq == 0) continue;
         int64_t ref = b.pos, q = 0;
@@ -1116,7 +1199,9 @@ static int gio_match_runs_impl(const char *bam_path, const char *contig, int32_t
         bam_rec b;
         if ((rc = parse_record(z.ptr() + 4, block_size, b))) return rc;
         z.consume(4 + (size_t)block_size);
-        if (indexed && (b.ref_id > tid || (b.ref_id == tid && b.pos >= stop))) break;
+        // (an index, or a header that declares coordinate order: nothing behind the window can matter -- without either every
+        // record of the file is visited, once per call)
+        if ((indexed || hd.sorted) && (b.ref_id > tid || (b.ref_id == tid && b.pos >= stop))) break;
         if (b.ref_id != tid || (b.flag & 0x4) || b.l_seq == 0) continue;
         int64_t ref = b.pos, q = 0;
         for (int c = 0; c < b.n_cigar; c++) {
@@ -1161,10 +1246,19 @@ extern "C" int gio_ref_len(const char *bam_path, const char *contig, int64_t *le
     catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
 }
 
+extern "C" int gio_support_table_from_bam_depth(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                                                const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out)
+{
+    try { return gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, max_depth, out); }
+    catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
+    catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
+}
+
 extern "C" int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
                                           const uint8_t *region, int stepper_all, gio_table *out)
 {
-    try { return gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, out); }
+    // (the reference passes no max_depth to bam.pileup, gretel/util.py:137: pysam's default applies)
+    try { return gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, GIO_PYSAM_MAX_DEPTH, out); }
     catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
     catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
 }

@@ -25,7 +25,10 @@ def coverage_on_gpu(bam, contig, start0, end, depth=0, device=-1, want_counts=Fa
     counts = np.zeros((4, n), dtype=np.int32) if want_counts else None
     # one window of the contig at a time: the decoder hands over one byte per aligned base, and a deep BAM over a whole
     # contig would not fit the host (the reference streams into a 4 x length array, snpper.py:29).  The runs are clipped to
-    # the window and a position's counts only need the reads that cover it, so the windows are independent.
+    # the window and a position's counts only need the reads that cover it, so the windows are independent.  Each window is
+    # one call of the decoder: with a .bai next to the BAM it starts at the window and stops behind it; without one it reads
+    # from the start of the file and stops behind the window if the header declares coordinate order (SO:coordinate) -- an
+    # unindexed, unsorted BAM is read in full once per 1 Mbp window (the reference makes one pass: index or sort such input).
     for w0 in range(start0, end, window):
         w1 = min(end, w0 + window)
         ref, off, codes = bamio.native_match_runs(bam, contig, w0, w1)

@@ -15,8 +15,11 @@ util.py:235-238 -- by walking the CIGAR the way htslib's pileup resolves it.  Th
 loop itself (util.py:226-286) and the counters / L (util.py:329-333) run on the GPU
 (`Hansel.fill_from_support` -> k_fill).
 
+pysam's pileup keeps at most max_depth = 8000 reads in its buffer by default and the reference passes no other value
+(util.py:137): both decoders apply that cap by htslib's rule (include/gretel_io.h; `max_depth=0` / `--max-depth 0` keeps
+every read).
+
 Known divergences from pysam's pileup, all irrelevant to the synthetic configs:
-  * no max_depth cap (pysam default 8000);
   * stepper "samtools" is modelled as: drop UNMAP/SECONDARY/QCFAIL/DUP reads and
     paired reads that are not properly paired (ignore_orphans); stepper "all"
     (reference --pepper, gretel/cmd.py:39,78) only drops the four flags;
@@ -171,7 +174,11 @@ def _support_of_read(rec, region, start_pos, end_pos, positions=None):
             if hi1 >= lo1:
                 chars.extend("-" * int(region[lo1:hi1 + 1].sum()))
                 if positions is not None:
-                    positions.extend((int(pos1), "-") for pos1 in np.flatnonzero(region[lo1:hi1 + 1]) + lo1)
+                    # util.py:180-182 prints "-" * (abs(p_read.indel) + 1): pysam's indel at a deleted column is the length of the
+                    # insertion that follows it (only behind the deletion's last base, when the next operation inserts), else 0
+                    nxt_ins = cig[ci + 1][1] if ci + 1 < len(cig) and cig[ci + 1][0] == 1 else 0
+                    positions.extend((int(pos1), "-" * ((nxt_ins if int(pos1) == ref + ln else 0) + 1))
+                                     for pos1 in np.flatnonzero(region[lo1:hi1 + 1]) + lo1)
             ref += ln
         elif op == 1:                             # I
             q += ln
@@ -182,17 +189,21 @@ def _support_of_read(rec, region, start_pos, end_pos, positions=None):
     return rec.pos + 1, qalen, chars
 
 
+PYSAM_MAX_DEPTH = 8000
+
+
 def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper="samtools",
-                           decoder="native", max_depth=0, debug_reads=None, debug_pos=None, debug_out=None):
+                           decoder="native", max_depth=PYSAM_MAX_DEPTH, debug_reads=None, debug_pos=None, debug_out=None):
     """The pileup half of load_from_bam (gretel/util.py:137-209) -> support table arrays.
     decoder="native": libgretel_io.so (C++/zlib, include/gretel_io.h); "python": the pure-Python restatement
     below (same rules; kept as the readable specification and as a cross-check in the tests).
-    max_depth > 0 (python decoder only, opt-in): drop a read that starts where that many kept reads are already open --
-    what the pileup the reference inherits does at pysam's default of 8000 (gretel/util.py:137 passes none).
+    max_depth: the read-buffer cap of the pileup the reference inherits (pysam's default 8000, gretel/util.py:137 passes none;
+    0: keep every read), by htslib's rule in both decoders: the first read of a position always enters; a later one is dropped
+    when the reads that entered and end behind position - 1, plus the list's sentinel node, number more than max_depth.
     debug_reads / debug_pos: the prints of gretel/util.py:211-224 (python decoder), to debug_out (default stdout)."""
-    if decoder == "native" and not (max_depth or debug_reads or debug_pos):
+    if decoder == "native" and not (debug_reads or debug_pos):
         from . import bamio
-        return bamio.native_support_table(bam_path, target_contig, start_pos, end_pos, vcf_handler["region"], stepper)
+        return bamio.native_support_table(bam_path, target_contig, start_pos, end_pos, vcf_handler["region"], stepper, max_depth)
     refs, records = read_bam(bam_path)
     names = [n for n, _ in refs]
     if target_contig not in names:
@@ -202,8 +213,7 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
     csum = np.concatenate([[0], np.cumsum(region)])          # csum[x] = sum(region[0:x])
     reads = {}
     order = []
-    import heapq
-    open_ends = []                                   # max_depth: reference ends of the kept reads still open
+    dc_pos, dc_ends, dc_accepted = None, [], 0      # max_depth: where the pileup iterator stands, the ends of the reads that entered
     dbg = {}                                         # key -> (query name, [(pos, sequence)]) for --debugreads / --debugpos
     want_dbg = bool(debug_reads) or bool(debug_pos)
     for rec in records:
@@ -211,18 +221,29 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
             continue
         if stepper == "samtools" and (rec.flag & 0x1) and not (rec.flag & 0x2):
             continue
+        if max_depth and max_depth > 0:
+            # htslib bam_plp_push (what pysam's bam.pileup(max_depth=...) sets): see include/gretel_io.h
+            end = rec.pos + sum(ln for op, ln in rec.cigar if op in (0, 2, 3, 7, 8))
+            end = end if end > rec.pos else rec.pos + 1
+            if rec.pos < end_pos and end > start_pos - 1:         # the fetch only brings records that overlap the region
+                if rec.pos != dc_pos:
+                    dc_pos = rec.pos                              # the first read of a position always enters
+                else:
+                    alive = dc_accepted - sum(1 for e in dc_ends if e <= rec.pos - 1)
+                    if alive + 1 > max_depth:
+                        continue
+                dc_ends.append(end)
+                dc_accepted += 1
+                if len(dc_ends) > 4 * max_depth + 64:             # (forget the expired ones now and then)
+                    keep = [e for e in dc_ends if e > rec.pos - 1]
+                    dc_accepted -= len(dc_ends) - len(keep)
+                    dc_ends = keep
         if rec.l_seq == 0:
             continue
         one_or_two = 0
         if rec.flag & 0x1:
             one_or_two = 1 if rec.flag & 0x40 else (2 if rec.flag & 0x80 else 0)
         key = "%s_%s_%d" % (rec.name, str(rec.flag), one_or_two)          # util.py:160
-        if max_depth > 0:
-            while open_ends and open_ends[0] <= rec.pos:
-                heapq.heappop(open_ends)
-            if len(open_ends) >= max_depth:
-                continue
-            heapq.heappush(open_ends, rec.pos + sum(ln for op, ln in rec.cigar if op in (0, 2, 3, 7, 8)))
         plist = [] if want_dbg else None
         leftmost, qalen, chars = _support_of_read(rec, region, start_pos, end_pos, plist)
         if leftmost < start_pos:                                          # util.py:165-171
@@ -260,7 +281,8 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
 
 
 def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_end_sentinels=False,
-                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", decoder="native", max_depth=0, **hansel_kw):
+                  n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", decoder="native", max_depth=PYSAM_MAX_DEPTH,
+                  **hansel_kw):
     """gretel/util.py:33-335.  Returns a device-backed Hansel with n_slices, n_crumbs and L set.
     n_threads is the reference's number of BAM iterator processes (util.py:288-326): the native decoder runs its own
     threads and the fill is one kernel, so the value changes nothing here -- said once on stderr when it is not 1."""

@@ -14,7 +14,13 @@
  *   rank = number of SNPs in [1, LEFTMOST)                   util.py:198
  *   stepper "samtools": UNMAP/SECONDARY/QCFAIL/DUP reads and paired-but-not-proper reads are
  *   dropped; stepper "all" (--pepper, cmd.py:39,78) keeps the latter.
- * Not reproduced: pysam's max_depth cap (8000).
+ *   pysam's max_depth: bam.pileup keeps at most 8000 reads in its buffer by default and the reference passes no other value
+ *   (util.py:137) -- on amplicon-depth data reads are silently dropped.  gio_support_table_from_bam applies that default;
+ *   gio_support_table_from_bam_depth takes the cap as an argument (<= 0: none).  The rule is htslib's (bam_plp_push): a read is
+ *   dropped when it starts at the position the pileup iterator stands on while the buffer holds more than max_depth nodes --
+ *   so the first read of a position always enters, and a later one is dropped when the reads that entered and end behind
+ *   position - 1, plus the list's sentinel node, number more than max_depth.  (One pileup over the whole window, as the
+ *   reference runs with its default of one BAM worker; with -@ > 1 it runs one pileup per block, util.py:288-326.)
  *
  * The BAM is streamed (BGZF blocks inflated in parallel batches; libdeflate when its runtime library is present,
  * zlib otherwise) and, like the reference's pysam fetch, uses the index next to it when there is one (<bam>.bai or
@@ -50,6 +56,7 @@ typedef struct {
     int32_t threads;
     int32_t reframed;           /* batches done again front to back because a thread's guessed first record was none */
     double seconds;             /* wall time of the call */
+    int64_t depth_dropped;      /* records the max_depth cap dropped */
 } gio_stats;
 
 const char *gio_last_error(void);
@@ -62,8 +69,12 @@ int gio_ref_len(const char *bam_path, const char *contig, int64_t *len);
 /* region: uint8[end_pos + 1], region[p] != 0 <=> 1-based position p is a SNP (VCF_h["region"],
  * util.py:393-403).  Reads appear in the order the pileup first meets them (file order).
  * Returns 0 or a negative error code; the table is released with gio_table_free. */
+#define GIO_PYSAM_MAX_DEPTH 8000
 int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
                                const uint8_t *region, int stepper_all, gio_table *out);
+/* the same with the pileup's read-buffer cap as an argument (max_depth <= 0: no cap) */
+int gio_support_table_from_bam_depth(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                                     const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out);
 void gio_table_free(gio_table *t);
 
 /* pysam's bam.count_coverage(contig, start0, stop, quality_threshold=0, read_callback='nofilter') as

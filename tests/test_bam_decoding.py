@@ -144,3 +144,71 @@ def test_debug_prints_and_depth_cap(capsys):
     assert 0 < len(r1[0]) < len(ref[0])
     r9 = util.support_table_from_bam(BAM, 'hoot', 1, 20, v, max_depth=8000)
     assert np.array_equal(r9[2], ref[2])
+
+
+def _depth_bam(tmp_path, reads):
+    bam = str(tmp_path / "deep.bam")
+    vcf = str(tmp_path / "deep.vcf.gz")
+    bamio.write_bam(bam, [("c", 400)], reads)
+    bamio.write_vcf_gz(vcf, "c", [20, 30, 40, 50, 60])
+    return bam, vcf
+
+
+def _rows(t):
+    rank, off, bases = t
+    return [(int(rank[i]), bases[off[i]:off[i + 1]].tobytes().decode()) for i in range(len(rank))]
+
+
+def test_max_depth_drops_what_the_pileup_buffer_would(tmp_path):
+    # pysam's bam.pileup keeps at most max_depth reads in its buffer (default 8000; the reference passes none, util.py:137);
+    # htslib's rule (bam_plp_push): a read is dropped when it starts where the iterator stands while the buffer holds more than
+    # max_depth nodes -- the first read of a position always enters; a later one sees the reads that entered and end behind
+    # position - 1, plus the list's sentinel.  Here by hand with max_depth = 3:
+    #   pos 10: r0 enters (first), r1 (buffer: r0 + sentinel = 2 <= 3) enters, r2 (r0 r1 + 1 = 3) enters, r3 (3 + 1 = 4 > 3) DROPPED,
+    #           r4 dropped likewise;
+    #   pos 11: r5 is the first of its position: enters although four are open; r6 (r0 r1 r2 r5 + 1 = 5) dropped;
+    #   pos 200: r0..r2 and r5 have ended (their ends <= 199): r7 enters (first), r8 (r7 + 1 = 2) enters.
+    seq = "ACGTACGTAC" * 6
+    reads = [("r%d" % i, 0, 0, 10, 60, "60M", seq) for i in range(5)]
+    reads += [("r5", 0, 0, 11, 60, "60M", seq), ("r6", 0, 0, 11, 60, "60M", seq)]
+    reads += [("r7", 0, 0, 200, 60, "60M", seq), ("r8", 0, 0, 200, 60, "60M", seq)]
+    bam, vcf = _depth_bam(tmp_path, reads)
+    v = util.process_vcf(vcf, "c", 1, 400)
+    for dec in ("native", "python"):
+        assert len(_rows(util.support_table_from_bam(bam, "c", 1, 400, v, decoder=dec, max_depth=0))) == 7        # r7, r8 show no SNP
+        assert len(_rows(util.support_table_from_bam(bam, "c", 1, 400, v, decoder=dec))) == 7                     # 8000: nothing dropped
+        got = _rows(util.support_table_from_bam(bam, "c", 1, 400, v, decoder=dec, max_depth=3))
+        assert len(got) == 4, (dec, got)                                                                          # r0 r1 r2 r5
+        assert got[:3] == [(0, "".join(seq[p - 11] for p in (20, 30, 40, 50, 60)))] * 3
+        assert got[3] == (0, "".join(seq[p - 12] for p in (20, 30, 40, 50, 60)))
+    util.support_table_from_bam(bam, "c", 1, 400, v, decoder="native", max_depth=3)
+    assert bamio.native_last_stats()["depth_dropped"] == 3
+
+
+def test_max_depth_native_equals_python_on_a_deep_pileup(tmp_path):
+    # 3 000 reads of mixed lengths piled on a 300-base contig, caps from 5 to 400: the two decoders drop the same reads
+    rng = np.random.default_rng(7)
+    pos = np.sort(rng.integers(0, 250, size=3000))
+    reads = []
+    for i, p in enumerate(pos):
+        ln = int(rng.integers(20, 120))
+        cig = "%dM" % ln if rng.random() < 0.8 else "%dM%dD%dM" % (ln // 2, int(rng.integers(1, 9)), ln - ln // 2)
+        flag = 0 if rng.random() < 0.9 else int(rng.choice([4, 256, 1, 3, 1024]))
+        reads.append(("q%d" % i, flag, 0, int(p), 60, cig, "".join(rng.choice(list("ACGT"), size=ln))))
+    bam, vcf = _depth_bam(tmp_path, reads)
+    v = util.process_vcf(vcf, "c", 1, 300)
+    full = _rows(util.support_table_from_bam(bam, "c", 1, 300, v, decoder="native", max_depth=0))
+    last = 0
+    for cap in (5, 37, 150, 400):
+        a = util.support_table_from_bam(bam, "c", 1, 300, v, decoder="native", max_depth=cap)
+        b = util.support_table_from_bam(bam, "c", 1, 300, v, decoder="python", max_depth=cap)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), cap
+        assert last <= len(a[0]) < len(full)               # a larger buffer keeps more reads; every one of these caps drops some
+        last = len(a[0])
+    # a window that starts inside the pile: only records overlapping it reach the buffer
+    for cap in (5, 60):
+        a = util.support_table_from_bam(bam, "c", 45, 300, util.process_vcf(vcf, "c", 45, 300), decoder="native", max_depth=cap)
+        b = util.support_table_from_bam(bam, "c", 45, 300, util.process_vcf(vcf, "c", 45, 300), decoder="python", max_depth=cap)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), cap
