@@ -117,6 +117,7 @@ struct gh_handle {
     double *seg_smin, *seg_gmin;   // minimum marginal per (segment, entry state) / per (group, entry state)
     uint8_t *cm5snap;      // [N+2] candidate bits as the last k_seg saw them
     size_t fuse_lds;       // LDS of k_rw's fused prologue for this spin's state space
+    bool band_zero;        // the tensor holds nothing but zeros (gh_create, gh_clear; until something is added): k_fill_own may store instead of add
     void *seg_halo;        // k_rwseg: per segment, the band blocks of the L positions in front of it (k_emit's copy)
     size_t seg_halo_bytes;
     bool rws;              // inside a gh_spin whose paths run as k_rwseg + k_scan + k_emit (segwalk.hpp)
@@ -181,6 +182,9 @@ struct gh_reads {
     int max_k;
     bool sorted;      // ranks ascend: k_fill_sorted applies
     int span_pos;     // sorted tables: widest run of positions one workgroup of k_fill_sorted (FILL_RPB reads) covers
+    int64_t dens128;  // sorted tables: the most reads whose ranks fall into any 128 consecutive positions (k_fill_own's counter width)
+    int64_t *first_at; // sorted tables: [n_first] first_at[p] = the first read whose rank is >= p (first_at[n_first - 1] = n_reads)
+    int n_first;
 };
 #define FILL_RPB 2048     /* reads per workgroup of k_fill_sorted */
 #define FILL_PAIRS_MIN_K 10   /* k_fill_pairs (32 lanes per read) from this many SNPs in the longest read */
@@ -396,7 +400,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->seg6 = false;
     h->ew_buf = nullptr;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = true;      // (the allocation is zeroed below / above: gh_create)
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
     h->prof = 0;
@@ -465,7 +469,7 @@ extern "C" int gh_clear(gh_t *h)
     memset(&h->stats, 0, sizeof h->stats);
     h->stats.L = 1;
     h->L = 1;
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = true;
     h->have_orig = false;
     h->cw_ready = false; h->cw_off = false;
     return GH_OK;
@@ -484,6 +488,7 @@ extern "C" int gh_copy(const gh_t *src, gh_t **out)
     if (e != hipSuccess) { free_handle(h); return fail(GH_ERR_HIP, "copy failed: %s", hipGetErrorString(e)); }
     h->L = src->L;
     h->stats = src->stats;
+    h->band_zero = src->band_zero;
     *out = h;
     return GH_OK;
 }
@@ -550,15 +555,43 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
             const int span = rank[q1 - 1] - rank[q0] + r->max_k + 1;      // the slice k_fill_sorted counts in LDS
             if (span > r->span_pos) r->span_pos = span;
         }
+    r->dens128 = 0;
+    r->first_at = nullptr; r->n_first = 0;
+    std::vector<int64_t> first_at;
+    if (r->sorted && n_reads > 0 && rank[0] >= 0) {
+        // where the reads of every rank start (k_fill_own's workgroups find their reads with two lookups instead of a bisection
+        // of 20 dependent loads each)
+        const int64_t top = (int64_t)rank[n_reads - 1] + 2;
+        if (top <= ((int64_t)1 << 28)) {
+            first_at.assign((size_t)top, n_reads);
+            int64_t q = 0;
+            for (int64_t p = 0; p < top; p++) {
+                while (q < n_reads && rank[q] < p) q++;
+                first_at[(size_t)p] = q;
+            }
+        }
+    }
+    if (r->sorted) {
+        int64_t lo = 0;
+        for (int64_t q = 0; q < n_reads; q++) {
+            while (rank[q] - rank[lo] >= 128) lo++;
+            if (q - lo + 1 > r->dens128) r->dens128 = q - lo + 1;
+        }
+    }
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void **)&r->rank, (size_t)(n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->off, (size_t)(n_reads + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->bases, (size_t)(r->n_bases ? r->n_bases : 1));
+    if (e == hipSuccess && !first_at.empty()) {
+        e = hipMalloc((void **)&r->first_at, first_at.size() * 8);
+        if (e == hipSuccess) e = hipMemcpy(r->first_at, first_at.data(), first_at.size() * 8, hipMemcpyHostToDevice);
+        r->n_first = (int)first_at.size();
+    }
     if (e == hipSuccess && n_reads) e = hipMemcpy(r->rank, rank, (size_t)n_reads * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && n_reads) e = hipMemcpy(r->off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess && r->n_bases) e = hipMemcpy(r->bases, bases, (size_t)r->n_bases, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        hipFree(r->rank); hipFree(r->off); hipFree(r->bases);
+        hipFree(r->rank); hipFree(r->off); hipFree(r->bases); hipFree(r->first_at);
         delete r;
         return fail(GH_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
@@ -570,7 +603,7 @@ extern "C" int gh_reads_free(gh_reads_t *r)
 {
     if (!r) return GH_OK;
     hipSetDevice(r->dev);
-    hipFree(r->rank); hipFree(r->off); hipFree(r->bases);
+    hipFree(r->rank); hipFree(r->off); hipFree(r->bases); hipFree(r->first_at);
     delete r;
     return GH_OK;
 }
@@ -618,7 +651,41 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
             if (max_pos > 1024) max_pos = 1024;
             if (r->span_pos > 0 && r->span_pos < max_pos) max_pos = r->span_pos > r->max_k + 8 ? r->span_pos : r->max_k + 8;
         }
-        if (max_pos >= r->max_k + 8) {
+        // rank-sorted tables: the tensor cut by owner (k_fill_own) -- no global atomics -- when a slice of from-positions wide enough
+        // to keep the overlap between neighbours small fits the LDS: P positions x W x 49 counters of 2 bytes (4 where a workgroup
+        // may see 65 536 reads).  GH_FILL_OWN=0 keeps the older fills (the tests run them against each other).
+        int own_P = 0;
+        bool own_half = true;
+        if (r->sorted && r->first_at && !no_sorted && !(getenv("GH_FILL_OWN") && atoi(getenv("GH_FILL_OWN")) == 0)) {
+            int P = (h->N + 2 + 1023) / 1024;                    // about a thousand workgroups ...
+            if (P < 2 * r->max_k) P = 2 * r->max_k;              // ... that visit a read 1.5 times at most
+            if (P < 8) P = 8;
+            // the reads one workgroup can see: ranks within P + max_k positions
+            const int64_t win = (int64_t)((P + r->max_k + 127) / 128 + 1) * r->dens128;
+            own_half = win < 65536 && !(getenv("GH_FILL_OWN_WIDE") && atoi(getenv("GH_FILL_OWN_WIDE")));      // (the tests force the 4-byte counters)
+            const size_t per_pos = (size_t)h->W * CELL * (own_half ? 2 : 4);
+            const int P_lds = (int)((150 * 1024 - FILL_OWN_SYMS) / per_pos);
+            if (P > P_lds) P = P_lds;
+            if (P >= r->max_k && P >= 8 && r->max_k <= FILL_OWN_SYMS) own_P = P;               // (narrower: every read would be visited by many workgroups)
+        }
+        if (own_P > 0) {
+            const unsigned gb = (unsigned)((h->N + 2 + own_P - 1) / own_P);
+            const size_t sym_off = (((size_t)own_P * h->W * CELL * (own_half ? 2 : 4)) + 15) & ~(size_t)15;
+            const size_t lds = sym_off + FILL_OWN_SYMS;
+#define FILL_OWN(T_, CT_, Z_, G_) do {                                                                                                   \
+                hipFuncSetAttribute((const void *)k_fill_own<T_, CT_, Z_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+                hipLaunchKernelGGL((k_fill_own<T_, CT_, Z_, G_>), dim3(gb), dim3(1024), lds, h->stream, (T_ *)h->band, h->N, h->W, r->rank,  \
+                                   r->off, r->bases, r->n_reads, own_P, r->max_k, use_end_sentinels, h->dstate, r->first_at, r->n_first, (int)sym_off); \
+            } while (0)
+            // lanes per read: one for short reads, four / eight for long ones (a lane takes every G-th from-index of its read)
+#define FILL_OWN_G(T_, CT_, Z_) do { if (r->max_k <= 8) FILL_OWN(T_, CT_, Z_, 1); else if (r->max_k <= 32) FILL_OWN(T_, CT_, Z_, 4); else FILL_OWN(T_, CT_, Z_, 8); } while (0)
+#define FILL_OWN_Z(T_, CT_) do { if (h->band_zero) FILL_OWN_G(T_, CT_, true); else FILL_OWN_G(T_, CT_, false); } while (0)
+            if (h->cfg.storage == GH_STORAGE_F64) { if (own_half) FILL_OWN_Z(double, uint16_t); else FILL_OWN_Z(double, uint32_t); }
+            else { if (own_half) FILL_OWN_Z(float, uint16_t); else FILL_OWN_Z(float, uint32_t); }
+#undef FILL_OWN_G
+#undef FILL_OWN_Z
+#undef FILL_OWN
+        } else if (max_pos >= r->max_k + 8) {
             const unsigned gb = (unsigned)((r->n_reads + rpb - 1) / rpb);
             const size_t lds = (size_t)max_pos * h->W * CELL * sizeof(unsigned);
             if (h->cfg.storage == GH_STORAGE_F64) {
@@ -649,7 +716,7 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         prof_end(h, GH_K_FILL, bytes);
         { int rc_ = post_launch(h, "k_fill"); if (rc_) return rc_; }
     }
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; if (r->n_reads > 0) h->band_zero = false;
     h->cw_ready = false; h->cw_off = false;
     int rc = pull_fill_state(h, "gh_fill");
     if (h->stats.n_slices > 0) {                                   // util.py:333
@@ -720,7 +787,7 @@ extern "C" int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const i
             hipLaunchKernelGGL(k_add_batch<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
         else
             hipLaunchKernelGGL(k_add_batch<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
-        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = false;
         int64_t s0 = h->stats.n_slices, c0 = h->stats.n_crumbs, v0 = h->stats.covered_snps;
         rc = pull_fill_state(h, "gh_add_batch");
         h->stats.n_slices = s0; h->stats.n_crumbs = c0; h->stats.covered_snps = v0;
@@ -2467,7 +2534,7 @@ extern "C" int gh_import_band(gh_t *h, const double *in)
         hipLaunchKernelGGL(k_import<float>, dim3(nb), dim3(256), 0, h->stream, (float *)h->band, d, n, h->W);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(d);
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = false;
     if (e != hipSuccess) return fail(GH_ERR_HIP, "import failed: %s", hipGetErrorString(e));
     return GH_OK;
 }

@@ -341,6 +341,196 @@ k_fill_pairs(T *__restrict__ band, int N, int W, const int32_t *__restrict__ ran
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_fill_own: the pair loop for a rank-sorted table with the tensor cut by OWNER.  Workgroup g owns the from-positions
+// [g P, g P + P): it visits every read that can observe something from one of them (ranks in [g P - max_k, g P + P), found by
+// bisection of the rank column), counts what falls into its slice with integer LDS atomics (2-byte counters where no
+// workgroup sees 65 536 reads, 4-byte otherwise) and flushes the slice ONCE with plain read-modify-writes of consecutive
+// cells -- nobody else writes them.  No global atomic at all: k_fill_pairs sends one float atomic per observation into a
+// tensor that is mostly zeros (C5: 10 M atomics, 0.35 ms); here the cost is what the slice's bytes cost to read and write
+// (C5: 2 x 206 MB), whatever the number of observations, and a read is visited (P + max_k) / P times.  The read counters
+// (slices, covered SNPs, crumbs, bad symbols, out-of-band pairs) are taken by the workgroup that owns the read's rank.
+// Same integers as the other fills; cells whose count is zero are not touched.
+// ---------------------------------------------------------------------------------------------
+#define FILL_OWN_SYMS (16 * 1024)      /* bytes of LDS for the bases of a chunk of reads */
+template <typename T, typename CT, bool ZERO, int G>
+__global__ void __launch_bounds__(1024)
+k_fill_own(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank, const int64_t *__restrict__ off,
+           const uint8_t *__restrict__ bases, int64_t n_reads, int P, int max_k, int use_end_sentinels, dev_state *st,
+           const int64_t *__restrict__ first_at, int n_first, int sym_off)
+{
+    extern __shared__ unsigned own_slice[];          // [n_pos][7][W][7] counters of CT, the band's layout; at sym_off bytes: the chunk's bases
+    __shared__ unsigned long long s_acc[5];
+    __shared__ long long s_range[2];
+    constexpr bool HALF = sizeof(CT) == 2;
+    const int s0 = blockIdx.x * P;
+    int n_pos = N + 2 - s0;
+    if (n_pos > P) n_pos = P;
+    if (n_pos < 1) return;
+    const int n_cells = n_pos * W * CELL;
+    const int n_words = HALF ? (n_cells + 1) / 2 : n_cells;
+    {
+        uint4 *z4 = reinterpret_cast<uint4 *>(own_slice);          // (the allocation is rounded up to 16 bytes)
+        for (int q = threadIdx.x; q < (n_words + 3) / 4; q += blockDim.x) z4[q] = make_uint4(0, 0, 0, 0);
+    }
+    if (threadIdx.x < 5) s_acc[threadIdx.x] = 0;
+    if (threadIdx.x < 2) {
+        // first read with rank >= s0 - max_k (lane 0) / first read with rank > s0 + P - 1 (lane 1): the host's table of where
+        // every rank starts (a bisection of the rank column is 20 dependent loads the whole workgroup waits for)
+        long long want = threadIdx.x == 0 ? (long long)s0 - max_k : (long long)s0 + P;
+        if (want < 0) want = 0;
+        if (want > n_first - 1) want = n_first - 1;
+        s_range[threadIdx.x] = first_at[want];
+    }
+    __syncthreads();
+    auto count = [&](int a, int b, int i, int j, bool mine, unsigned long long &oob) {
+        const int d = j - i;
+        if (d < 1 || d > W || i < 0 || j > N + 1) { if (mine) oob++; return; }
+        const int li = i - s0;
+        if (li < 0 || li >= n_pos) return;
+        const unsigned c = (unsigned)bidx(W, (size_t)li, d, a, b);
+        if (HALF) atomicAdd(&own_slice[c >> 1], 1u << (16 * (c & 1)));
+        else atomicAdd(&own_slice[c], 1u);
+    };
+    unsigned long long slices = 0, crumbs = 0, covered = 0, badr = 0, oob = 0;
+    // The workgroup's reads in chunks whose bases fit FILL_OWN_SYMS bytes of LDS: the bases go there first, as symbol codes
+    // (one coalesced pass over a contiguous run of the table; 255 = not a symbol) -- a thread that fetches the two bases of each
+    // of its read's k (k - 1) / 2 pairs from memory is a chain of several hundred dependent loads (C5: 0.3 ms of 0.3).
+    // Within a chunk the lanes of a wavefront take reads far apart (row x of a 64-row matrix over the chunk's reads):
+    // neighbours in a rank-sorted table start at the same positions and carry the same haplotypes -- their LDS atomics
+    // would hit the same counters.
+    unsigned char *syms = reinterpret_cast<unsigned char *>(own_slice) + sym_off;
+    const long long chunk_reads = FILL_OWN_SYMS / (max_k > 0 ? max_k : 1);
+    for (long long c_lo = s_range[0]; c_lo < s_range[1]; c_lo += chunk_reads) {
+        const long long c_hi = c_lo + chunk_reads < s_range[1] ? c_lo + chunk_reads : s_range[1];
+        const int64_t b_lo = off[c_lo], b_hi = off[c_hi];
+        __syncthreads();                                         // (the chunk before is done with syms)
+        for (int64_t q = threadIdx.x; q < b_hi - b_lo; q += blockDim.x) {
+            const int sc = c_sym_of_char[bases[b_lo + q]];
+            syms[q] = (unsigned char)(sc < 0 ? 255 : sc);
+        }
+        __syncthreads();
+        // G lanes per read (1 for short reads, up to 8 for long ones): lane g takes the from-indices i = g, g + G, ... and for
+        // each the pairs (i, j > i).  Every pair adds H[a, b, i + rk + 1, j + rk + 1] (util.py:279-280 -- and that IS the second
+        // observation of the rank-0 case, util.py:267, and the first of the last-SNP case, util.py:274); only ADJACENT pairs
+        // add a second one: (_, a, 0, 1) for the first pair of a read at rank 0 (util.py:262-266), (b, _, N, N + 1) where the
+        // pair ends on the last SNP (util.py:271-275), the end sentinel (b, _, j + rk + 1, j + rk + 2) behind a read's last
+        // pair when asked for (util.py:283-286) -- in that order of precedence.  A from-position outside the slice needs no
+        // loop over j at all.
+        const long long n_mine = c_hi - c_lo;
+        const long long cols = (n_mine + 63) / 64;
+#if defined(FILL_OWN_DBG) && FILL_OWN_DBG == 1
+        if (n_mine >= 0) continue;
+#endif
+        for (long long xg = threadIdx.x; xg < cols * 64 * G; xg += blockDim.x) {
+            const int g = (int)(xg % G);
+            const long long x = xg / G;
+            const long long rr = (x & 63) * cols + (x >> 6);
+            if (rr >= n_mine) continue;
+            const long long r = c_lo + rr;
+            const int64_t o0 = off[r];
+            const int k = (int)(off[r + 1] - o0);
+            if (!(k > 1)) continue;                                  // util.py:230
+            const int rk = rank[r];
+            const bool mine = rk >= s0 && rk < s0 + P && g == 0;     // this lane counts the read itself
+            const unsigned char *s = syms + (o0 - b_lo);
+            bool bad = false;
+            unsigned cov = 0;
+            for (int i = 0; i < k; i++) {
+                const int c = s[i];
+                if (c == 255) bad = true;
+                if (c != SYM_N && c != SYM_US) cov++;                // util.py:239
+            }
+            if (mine) { slices++; covered += cov; }                  // util.py:233
+            if (bad) { if (mine) badr++; continue; }
+            const bool own_read = rk >= s0 && rk < s0 + P;           // (crumbs and out-of-band pairs: by the workgroup that owns the read, any lane)
+            for (int i = g; i < k - 1; i += G) {
+                const int a = s[i];
+                if (a == SYM_US || a == SYM_N) continue;             // util.py:258
+                if (own_read) crumbs += (unsigned)(k - 1 - i);
+                const int pi = i + rk + 1;                           // the from-position of every pair of this i
+                // the adjacent pair's second observation
+                {
+                    const int j = i + 1, b = s[j];
+                    if (i == 0 && rk == 0) count(SYM_US, a, 0, 1, own_read, oob);
+                    else if (j + rk + 1 == N) count(b, SYM_US, N, N + 1, own_read, oob);
+                    else if (use_end_sentinels && j == k - 1) count(b, SYM_US, j + rk + 1, j + rk + 2, own_read, oob);
+                }
+                const int li = pi - s0;
+                const int jmax = k - 1 < i + W ? k - 1 : i + W;      // pairs further apart than the band: out of band
+                if (own_read && k - 1 > i + W) oob += (unsigned)(k - 1 - (i + W));
+                if (li < 0 || li >= n_pos) continue;
+                const unsigned base = (unsigned)__mul24(__mul24(li, NSYM) + a, W) * NSYM;        // bidx(W, li, 1, a, 0)
+                for (int j = i + 1; j <= jmax; j++) {
+                    if (j + rk + 1 > N + 1) { if (own_read) oob++; continue; }
+                    const unsigned c = base + (unsigned)(j - i - 1) * NSYM + (unsigned)s[j];
+                    if (HALF) atomicAdd(&own_slice[c >> 1], 1u << (16 * (c & 1)));
+                    else atomicAdd(&own_slice[c], 1u);
+                }
+            }
+        }
+    }
+    {
+        // the five counters: summed over the wavefront first (a thousand threads adding to five LDS words one after the other
+        // cost more than the pair loop of a short-read window)
+        unsigned long long v5[5] = {slices, crumbs, covered, badr, oob};
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            unsigned lo = (unsigned)v5[q], hi = (unsigned)(v5[q] >> 32);
+            unsigned long long t = v5[q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = (unsigned)t; hi = (unsigned)(t >> 32);
+                const unsigned lo2 = __shfl_xor(lo, o), hi2 = __shfl_xor(hi, o);
+                t += ((unsigned long long)hi2 << 32) | lo2;
+            }
+            if ((threadIdx.x & 63) == 0 && t) atomicAdd(&s_acc[q], t);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 5 && s_acc[threadIdx.x]) atomicAdd(&st->fill[threadIdx.x], s_acc[threadIdx.x]);
+    // flush: consecutive lanes -> consecutive cells, each owned by this workgroup alone; four cells per lane and trip (16 or 32
+    // bytes), eight trips' loads in flight before the first addition -- one cell per trip behind an `if` was a chain of
+    // dependent round trips (C5: 0.6 ms).  ZERO: the tensor is known to hold zeros (gh_clear / gh_create): stores only.
+    T *dst = band + (size_t)s0 * W * CELL;
+#if defined(FILL_OWN_DBG) && FILL_OWN_DBG == 2
+    if (n_cells > 0) return;
+#endif
+    auto cnt_at = [&](int q) -> unsigned { return HALF ? (own_slice[q >> 1] >> (16 * (q & 1))) & 0xffffu : own_slice[q]; };
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    const int n_quads = n_cells / 4;                              // (n_cells = n_pos * W * 49: the tail below takes the rest)
+    constexpr int UN = 8;
+    for (int q0 = threadIdx.x; q0 < n_quads; q0 += blockDim.x * UN) {
+        vec4 v[UN];
+        unsigned c[UN][4];
+        bool any[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int q = q0 + u * blockDim.x;
+            any[u] = false;
+            if (q < n_quads) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) { c[u][e] = cnt_at(4 * q + e); any[u] |= c[u][e] != 0; }
+                if (!ZERO && any[u]) v[u] = *reinterpret_cast<const vec4 *>(dst + 4 * (size_t)q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int q = q0 + u * blockDim.x;
+            if (q < n_quads && any[u]) {
+                vec4 w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[e] = ZERO ? (T)c[u][e] : v[u][e] + (T)c[u][e];
+                *reinterpret_cast<vec4 *>(dst + 4 * (size_t)q) = w;
+            }
+        }
+    }
+    for (int q = 4 * n_quads + threadIdx.x; q < n_cells; q += blockDim.x) {
+        const unsigned c1 = cnt_at(q);
+        if (c1) dst[q] = ZERO ? (T)c1 : dst[q] + (T)c1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fill_sorted: the same pair loop for a support table sorted by rank (what a coordinate-sorted
 // BAM gives).  A workgroup owns a contiguous run of reads, so all its observations fall into a
 // narrow slice of positions: it counts them in LDS (integer adds) and flushes the slice once
