@@ -130,7 +130,6 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
             }
             return a6;
         };
-#ifndef SEGM_LOADS_LATE
 #pragma unroll
         for (int k = 0; k < TRIPS; k++) {
             const int e = tid + k * SEG_THREADS;
@@ -138,20 +137,27 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
             a6st[k] = load_row(ec / (4 * LC), (ec >> 2) % LC, ec & 3, wst[k], lmst[k]);
             if (e != ec) a6st[k] = -1;
         }
-#endif
         // (0) the candidate bits of the chunk's positions and, per target, radices / entries / work items (wavefront 0)
         if (tid < CH + LC) cmc[tid] = (uint8_t)cm_of(c0 + 1 - LC + tid);
         segm_lds_barrier();
         if (wave == 0) {
             unsigned rd = 0, NI = 1, NJ = 1;
+            unsigned ls = LC - 1;                                  // the lag whose digit a task loops over besides the oldest: see (1b)
             if (lane < avail) {
+                unsigned rmax = 0;
 #pragma unroll
                 for (int l = 0; l <= LC; l++) {
                     const unsigned r = (unsigned)segm_radix(cmc[lane + LC - l]);
                     rd |= r << (3 * l);
-                    if (l >= 1 && l <= LC - 1) NI *= r;
-                    if (l >= 1 && l <= LC - 2) NJ *= r;
+                    if (l >= 1 && l <= LC - 1) { NI *= r; if (r > rmax) rmax = r; }
                 }
+                // the looped lag: L - 1 unless a younger digit has a larger radix (the lanes then enumerate the three narrow ones)
+                if (((rd >> (3 * (LC - 1))) & 7u) < rmax) {
+#pragma unroll
+                    for (int l = LC - 2; l >= 1; l--)
+                        if (((rd >> (3 * l)) & 7u) == rmax) ls = (unsigned)l;
+                }
+                NJ = NI / ((rd >> (3 * ls)) & 7u);
             }
             // entries in front of target `lane` (inclusive scan over the lanes that hold a target)
             const unsigned inc = segm_scan(lane < avail ? NI : 0u);
@@ -163,16 +169,13 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
             if (lane < nc) {
                 rad[lane] = rd; nit[lane] = NI; nxo[lane] = inc - NI; ito[lane] = iinc - items;
                 winf[lane] = make_uint2(NI | ((rd & 7u) << 12) | ((inc - NI) << 15), __float_as_uint(1.0f / (float)NI));
-                const unsigned r1 = (rd >> 3) & 7u, r2 = (rd >> 6) & 7u;
-                // ceil(2^15 / r) for r = 1..5 without a division (everybody waits for this wavefront)
+                // the two youngest of the three lags the lanes enumerate, and ceil(2^15 / r) of their radices without a division
+                // (everybody waits for this wavefront)
+                const unsigned la = ls == 1u ? 2u : 1u, lb = ls <= 2u ? 3u : 2u;
+                const unsigned ra = (rd >> (3 * la)) & 7u, rb = (rd >> (3 * lb)) & 7u;
                 auto rcp15 = [](unsigned r) { return r == 1u ? 32768u : (r == 2u ? 16384u : (r == 3u ? 10923u : (r == 4u ? 8192u : 6554u))); };
-                const unsigned mg = rcp15(r1) | (rcp15(r2) << 16);
-#ifdef SEGM_ITEMS_OLD
-                mgc[lane] = mg;
-                for (unsigned q = 0; q < items; q++) reinterpret_cast<uint8_t *>(iti + 2 * CH)[iinc - items + q] = (uint8_t)lane;
-#else
-                for (unsigned q = 0; q < items; q++) iti[iinc - items + q] = make_uint4((unsigned)lane | (q << 8), rd, mg, inc - NI);
-#endif
+                const unsigned mg = rcp15(ra) | (rcp15(rb) << 16);
+                for (unsigned q = 0; q < items; q++) iti[iinc - items + q] = make_uint4((unsigned)lane | (q << 8) | (ls << 16), rd, mg, inc - NI);
             }
             if (lane == nc - 1) { nxo[nc] = inc; ito[nc] = iinc; ctl[0] = nc; ctl[1] = (int)iinc; }
         }
@@ -194,15 +197,6 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
         // beyond: -inf.  Sources c0+1-LC .. c0+nc-1 (slot ii), every lag; a row that does not exist, or whose target lies behind
         // the chunk, is never read: zeros (a source in front of the window: its terms ARE +0.0).
         const int nsrc = nc + LC - 1;
-#ifdef SEGM_LOADS_LATE
-#pragma unroll
-        for (int k = 0; k < TRIPS; k++) {
-            const int e = tid + k * SEG_THREADS;
-            const int ec = e < nsrc * LC * 4 ? e : 0;
-            a6st[k] = load_row(ec / (4 * LC), (ec >> 2) % LC, ec & 3, wst[k], lmst[k]);
-            if (e != ec) a6st[k] = -1;
-        }
-#endif
         auto store_row = [&](int ii, int l, int d, int a6, double (&w)[5], const double (&lmv)[5]) __attribute__((always_inline)) {
             const int jj = ii + l + 1;                             // the target position i + l + 1 in cmc
             double *dst = Gs + ((size_t)(ii * LC + l) * 5 + d) * RS;
@@ -264,53 +258,51 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
         }
         __syncthreads();
         SEG_STAMP(1);
-        // (1b) Next for every (target, valid state): work item = (target, 64 tasks); a task takes the young digits d_1 .. d_{L-2}
-        // as given and loops over d_{L-1} and d_L itself, as seg_body does -- up to each digit's radix.  Lag l of chunk-local
-        // target tl comes from slot tl + LC - l.
+        // (1b) Next for every (target, valid state).  A work item is (target, 64 tasks): a task takes three of the digits
+        // d_1 .. d_{L-1} as given and loops over the fourth and over the oldest, d_L, itself, as seg_body does.  The fourth is
+        // d_{L-1} unless a younger position has more candidates -- then that one: behind ONE five-candidate position the lanes
+        // still enumerate 4 x 4 x 4 = 64 combinations, one item per target (five of the six targets behind such a position
+        // would otherwise need a second item of 16 tasks, and the wavefront that draws it a fourth round: the launch waits for
+        // it).  Whatever the loop order, the sum of a state is built lag ascending -- acc = x_1; acc += x_2; ... -- like
+        // everywhere.  Lag l of chunk-local target tl comes from slot tl + LC - l.
         for (int it = wave; it < nitems; it += SEG_THREADS / 64) {
-#ifdef SEGM_ITEMS_OLD
-            const uint8_t *itl8 = reinterpret_cast<const uint8_t *>(iti + 2 * CH);
-            const int tl = __builtin_amdgcn_readfirstlane((int)itl8[it]);
-            const unsigned rd = (unsigned)__builtin_amdgcn_readfirstlane((int)rad[tl]);
-            const int jb = it - __builtin_amdgcn_readfirstlane((int)ito[tl]);
-            const unsigned mg = (unsigned)__builtin_amdgcn_readfirstlane((int)mgc[tl]);
-            const unsigned nx0 = (unsigned)__builtin_amdgcn_readfirstlane((int)nxo[tl]);
-#else
             const uint4 info = iti[it];
             const int tl = __builtin_amdgcn_readfirstlane((int)(info.x & 0xffu));
-            const int jb = __builtin_amdgcn_readfirstlane((int)(info.x >> 8));
+            const int jb = __builtin_amdgcn_readfirstlane((int)((info.x >> 8) & 0xffu));
+            const unsigned ls = (unsigned)__builtin_amdgcn_readfirstlane((int)(info.x >> 16));
             const unsigned rd = (unsigned)__builtin_amdgcn_readfirstlane((int)info.y);
             const unsigned mg = (unsigned)__builtin_amdgcn_readfirstlane((int)info.z);
             const unsigned nx0 = (unsigned)__builtin_amdgcn_readfirstlane((int)info.w);
-#endif
             const unsigned r0 = rd & 7u, r1 = (rd >> 3) & 7u, r2 = (rd >> 6) & 7u, r3 = (rd >> 9) & 7u, r4 = (rd >> 12) & 7u, r5 = (rd >> 15) & 7u;
-            const unsigned NJ = r1 * r2 * r3;
+            // the lags the lanes enumerate (ascending) and the looped one; M_l = the weight of digit d_l in the entry index
+            const unsigned la = ls == 1u ? 2u : 1u, lb = ls <= 2u ? 3u : 2u, lc = ls == 4u ? 3u : 4u;
+            const unsigned M2 = r1, M3 = r1 * r2, M4 = M3 * r3;
+            auto radix = [&](unsigned l) { return l == 1u ? r1 : (l == 2u ? r2 : (l == 3u ? r3 : r4)); };
+            auto weight = [&](unsigned l) { return l == 1u ? 1u : (l == 2u ? M2 : (l == 3u ? M3 : M4)); };
+            const unsigned ra = radix(la), rb = radix(lb), rc = radix(lc), rs = radix(ls);
+            const unsigned NJ = ra * rb * rc;
             const unsigned j = (unsigned)jb * 64u + (unsigned)lane;
             if (j < NJ) {
                 // (radices are 1..5, j < 125: the quotients through exact reciprocal multiplies, ceil(2^15 / r) made by wavefront 0)
                 const unsigned q1 = __umul24(j, mg & 0xffffu) >> 15;
-                const unsigned d1 = j - __umul24(q1, r1);
-                const unsigned d3 = __umul24(q1, mg >> 16) >> 15;
-                const unsigned d2 = q1 - __umul24(d3, r2);
-                uint16_t *out = Nx + nx0 + j;
+                const unsigned da = j - __umul24(q1, ra);
+                const unsigned dc = __umul24(q1, mg >> 16) >> 15;
+                const unsigned db = q1 - __umul24(dc, rb);
+                uint16_t *out = Nx + nx0 + __umul24(da, weight(la)) + __umul24(db, weight(lb)) + __umul24(dc, weight(lc));
+                const unsigned Ms = weight(ls);
+                auto row_of = [&](unsigned l, unsigned d) { return Gs + ((size_t)((tl + LC - (int)l) * LC + ((int)l - 1)) * 5 + d) * RS; };
                 // (the whole task by the target's candidate count: four columns are read, added and compared where it offers four)
                 auto rest = [&](auto br_) __attribute__((always_inline)) {
                     constexpr int BR = decltype(br_)::value;
-                    double acc[BR];
+                    double xa[BR], xb[BR], xc[BR];
                     {
-                        const double *row1 = Gs + ((size_t)((tl + LC - 1) * LC + 0) * 5 + d1) * RS;
-                        const double *row2 = Gs + ((size_t)((tl + LC - 2) * LC + 1) * 5 + d2) * RS;
-                        const double *row3 = Gs + ((size_t)((tl + LC - 3) * LC + 2) * 5 + d3) * RS;
+                        const double *pa = row_of(la, da), *pb = row_of(lb, db), *pc = row_of(lc, dc);
 #pragma unroll
-                        for (int b = 0; b < BR; b++) acc[b] = row1[b];
-#pragma unroll
-                        for (int b = 0; b < BR; b++) acc[b] = acc[b] + row2[b];
-#pragma unroll
-                        for (int b = 0; b < BR; b++) acc[b] = acc[b] + row3[b];
+                        for (int b = 0; b < BR; b++) { xa[b] = pa[b]; xb[b] = pb[b]; xc[b] = pc[b]; }
                     }
-                    // Digits 0..3 of the two oldest positions run straight-line, whatever their radices (a row beyond a radix holds
-                    // zeros or stale numbers: what is computed from it is not stored, or lands in bits nobody reads) -- a branch per
-                    // digit would put every LDS read behind its own wait; only the fifth value of a digit, rare, is conditional.
+                    // Digits 0..3 of the looped lag and of the oldest run straight-line, whatever their radices (a row beyond a radix
+                    // holds zeros or stale numbers: what is computed from it is not stored, or lands in bits nobody reads) -- a branch
+                    // per digit would put every LDS read behind its own wait; only the fifth value of a digit, rare, is conditional.
                     double xl[5][BR];                              // lag L, every value of d_L
 #pragma unroll
                     for (int dL = 0; dL < 4; dL++) {
@@ -323,11 +315,7 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
 #pragma unroll
                         for (int b = 0; b < BR; b++) xl[4][b] = row[b];
                     }
-                    auto one_dS = [&](int dS) __attribute__((always_inline)) {
-                        const double *row = Gs + ((size_t)((tl + 1) * LC + (LC - 2)) * 5 + dS) * RS;
-                        double acc2[BR];
-#pragma unroll
-                        for (int b = 0; b < BR; b++) acc2[b] = acc[b] + row[b];
+                    auto oldest = [&](const double (&acc2)[BR], int dS) __attribute__((always_inline)) {
                         unsigned packed = 0;
 #pragma unroll
                         for (int dL = 0; dL < 4; dL++) {
@@ -342,11 +330,42 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
                             for (int b = 0; b < BR; b++) v[b] = acc2[b] + xl[4][b];
                             packed |= seg_argmax<BR>(v, false) << (BITS * 4);
                         }
-                        if ((unsigned)dS < r4) out[dS * NJ] = (uint16_t)packed;
+                        if ((unsigned)dS < rs) out[__umul24((unsigned)dS, Ms)] = (uint16_t)packed;
                     };
+                    if (ls == 4u) {
+                        // the looped lag is the last of the four: the three in front are summed once
+                        double acc[BR];
 #pragma unroll
-                    for (int dS = 0; dS < 4; dS++) one_dS(dS);
-                    if (r4 == 5u) one_dS(4);
+                        for (int b = 0; b < BR; b++) acc[b] = (xa[b] + xb[b]) + xc[b];
+                        auto one = [&](int dS) __attribute__((always_inline)) {
+                            const double *row = row_of(4u, (unsigned)dS);
+                            double acc2[BR];
+#pragma unroll
+                            for (int b = 0; b < BR; b++) acc2[b] = acc[b] + row[b];
+                            oldest(acc2, dS);
+                        };
+#pragma unroll
+                        for (int dS = 0; dS < 4; dS++) one(dS);
+                        if (rs == 5u) one(4);
+                    } else {
+                        // a younger lag is looped: its term takes its place in the lag-ascending sum of every state
+                        auto one = [&](int dS) __attribute__((always_inline)) {
+                            const double *row = row_of(ls, (unsigned)dS);
+                            double acc2[BR];
+#pragma unroll
+                            for (int b = 0; b < BR; b++) {
+                                const double x = row[b];
+                                const double t1 = ls == 1u ? x : xa[b];
+                                const double t2 = ls == 1u ? xa[b] : (ls == 2u ? x : xb[b]);
+                                const double t3 = ls <= 2u ? xb[b] : x;
+                                acc2[b] = ((t1 + t2) + t3) + xc[b];
+                            }
+                            oldest(acc2, dS);
+                        };
+#pragma unroll
+                        for (int dS = 0; dS < 4; dS++) one(dS);
+                        if (rs == 5u) one(4);
+                    }
                 };
                 if (r0 == 5u) rest(std::integral_constant<int, 5>{});
                 else rest(std::integral_constant<int, 4>{});

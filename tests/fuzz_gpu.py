@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from gretel_amd.hansel import Hansel, HanselBatch
-from gretel_amd.synth import make_support_table
+from gretel_amd.synth import make_support_table, sprinkle_deletions
 from oracle.c_oracle import COracle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -32,6 +32,11 @@ while time.time() < t_end:
         if rng.random() < 0.3:
             bases[rng.random(len(bases)) < 0.03] = ord('N')
         t.bases = bases
+    sparse = False
+    if rng.random() < 0.15 and n >= 17:
+        # deletions at a few POSITIONS only (a five-candidate column here and there): the mixed-radix state space at L = 5
+        sprinkle_deletions(t, float(rng.choice([0.004, 0.02, 0.06])), frac_reads=float(rng.choice([0.1, 0.3, 0.6])), seed=int(rng.integers(0, 1 << 30)))
+        sparse = True
     storage = str(rng.choice(["f32", "f32", "f64"]))
     mode = str(rng.choice(["A", "A", "B", "C", "D", "E"]))
     mt = bool(rng.random() < 0.25)
@@ -40,8 +45,10 @@ while time.time() < t_end:
     zero = bool(rng.random() < 0.15)
     sw = dict(cand_order=order, offer_zero=zero)
     L = None if rng.random() < 0.4 else (int(rng.integers(1, 27)) if rng.random() < 0.85 else int(rng.integers(25, 48)))
+    if sparse and rng.random() < 0.8:
+        L = 5
     paths = int(rng.integers(1, 9))
-    desc = dict(n=n, reads=reads, k=k, k_max=kmx, k_lambda=lam, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths, **sw)
+    desc = dict(n=n, reads=reads, k=k, k_max=kmx, k_lambda=lam, sparse_dels=sparse, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths, **sw)
     if k is not None and rng.random() < 0.12:
         # batched launch over 3 windows of one shape (same N, band, switches, L)
         ts = [t] + [make_support_table(n, reads, k=k, n_haps=int(rng.integers(1, 9)), err=err, seed=int(rng.integers(0, 1 << 30)))
@@ -125,8 +132,11 @@ while time.time() < t_end:
         # a second spin on the reweighted tensor (tables rebuilt / reused)
         res2, ref2 = h.spin(2), o.spin(2)
         assert res2["n"] == ref2["n"] and np.array_equal(res2["paths"], ref2["paths"]), "second spin"
-        v = h.walk_clock()[3] if res["n"] else -1
+        clk = h.walk_clock() if res["n"] else (0, 0, 0, -1)
+        v = clk[3]
         variants[v] = variants.get(v, 0) + 1
+        if v == 3 and clk[1] == 6:
+            variants["mixed"] = variants.get("mixed", 0) + 1
     except AssertionError as e:
         print("MISMATCH", e, desc, flush=True)
         if n <= 20:
