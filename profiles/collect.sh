@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles of one round, to be run on the GPU box from the repo root:
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r3'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r4'
 # Kernel trace and the PMC passes are separate runs (never combined with other trace domains); rocprofv3 is given python3
 # directly.  Back in the build container the summaries are made from gpurun_out/prof_<round>/ (where git is):
 #   cp gpurun_out/prof_r3/bench_default.json profiles/r3_bench_default.json   (... c2, c5, batch256, 2 ranks, fused)
@@ -10,7 +10,7 @@
 #   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc_b256 > profiles/r3_pmc_traffic_batch256.json
 #   python profiles/seg_isa_count.py > profiles/r3_seg_isa.json          (no GPU needed)
 set -u
-R=${1:-r3}
+R=${1:-r4}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
@@ -22,6 +22,13 @@ python3 bench.py --batch 256 --steps 1 --warmup 1 > $out/bench_batch256.json 2> 
 GH_FUSE=1 python3 bench.py --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_three_launches.json 2> $out/bench_three_launches.err
 GH_RWSEG=0 python3 bench.py --no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_four_launches.json 2> $out/bench_four_launches.err
 python3 scratch/l_sweep.py > $out/l_sweep.txt 2>&1
+# the fills alone (HIP events), and the sparse-deletion window (mixed radix) beside the plain one and the five-symbol radix
+for c in C2 C3 C5; do python3 scratch/fill_time.py $c 2>&1 | tail -2; done > $out/fill_times.txt
+(python3 scratch/mixed_try.py 0.01; GH_MIXED=0 python3 scratch/mixed_try.py 0.01; python3 scratch/mixed_try.py 0) > $out/mixed_radix.txt 2>&1
+Q0="--no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix --steps 30 --warmup 3"
+for a in "" "--force-dist" "--force-dist --blocking-gather" "" "--force-dist" "--force-dist --blocking-gather"; do
+  python3 bench.py $Q0 $a 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s %.0f hap/s %.4f ms/step' % (sys.argv[1], d['value'], d['ms_per_step']))" "[$a]"
+done > $out/gather_cost.txt 2>&1
 if [ "${2:-}" = "cpu-full" ]; then
   python3 bench.py --config C2 --steps 2 --cpu-full --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_c2_cpu_full.json 2> $out/bench_c2_cpu_full.err
   python3 bench.py --steps 2 --cpu-full --no-throughput-leg --no-e2e --no-spec-matrix > $out/bench_c3_cpu_full.json 2> $out/bench_c3_cpu_full.err
@@ -31,6 +38,8 @@ Q="--no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 $Q > $out/bench_under_rocprof.json 2> $out/kt.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c5 -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --steps 1 --warmup 1 $Q > $out/bench_c5_under_rocprof.json 2> $out/kt_c5.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_b256 -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --batch 256 --steps 1 --warmup 1 > $out/bench_batch256_under_rocprof.json 2> $out/kt_b256.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_sparse -o kt -- python3 $GRAFT_REPO_ROOT/scratch/mixed_try.py 0.01 > $out/kt_sparse.txt 2> $out/kt_sparse.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --config C2 --steps 3 --warmup 1 $Q > $out/bench_c2_under_rocprof.json 2> $out/kt_c2.err
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 $Q > $out/pmc_$c.json 2> $out/pmc_$c.err
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_c5_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --paths 100 --steps 1 --warmup 0 $Q > $out/pmc_c5_$c.json 2> $out/pmc_c5_$c.err

@@ -1,6 +1,6 @@
 """scratch: time the fill alone (HIP events of the library's own bracket) for a config: python scratch/fill_time.py C5"""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gretel_amd.hansel import Hansel, DeviceReads
 from gretel_amd.synth import make_config
 t = make_config(sys.argv[1])

@@ -1,6 +1,6 @@
 """scratch: the sparse-deletion window under the mixed radix, timed; GH_MIXED=0 for the five-symbol radix on the same window."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, copy
 from gretel_amd.hansel import Hansel
 from gretel_amd.synth import make_config, sprinkle_deletions
