@@ -2,7 +2,7 @@
 
 FETCH_SIZE / WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced
 reads (MI355X_MICROARCH.md, HBM / rocprofv3 section), hence the x2.  Usage:
-    python profiles/pmc_summarize.py gpurun_out/prof_r3 [pmc] > profiles/r3_pmc_traffic.json
+    python profiles/pmc_summarize.py gpurun_out/prof_r4 [pmc] > profiles/r4_pmc_traffic.json
 (second argument: the prefix of the two pass directories, pmc -> pmc_FETCH_SIZE / pmc_WRITE_SIZE; pmc_c5, pmc_b256 likewise).
 The summary records the build it belongs to: kernel_source_sha (what bench.py printed in that very run: a hash over the
 kernel sources, the GPU box has no .git) and the git HEAD of the tree the summary is made in -- bench.py quotes a
@@ -57,4 +57,4 @@ def main(root, prefix="pmc"):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r3", sys.argv[2] if len(sys.argv) > 2 else "pmc")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r4", sys.argv[2] if len(sys.argv) > 2 else "pmc")

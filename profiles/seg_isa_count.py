@@ -1,6 +1,6 @@
 """Instruction budget of k_seg (the dominant kernel of the headline config), counted in the ISA hipcc emits -- no GPU needed:
 
-    python profiles/seg_isa_count.py > profiles/r3_seg_isa.json
+    python profiles/seg_isa_count.py > profiles/r4_seg_isa.json
 
 k_seg<L> is bound by vector-ALU issue, not by HBM: per position it evaluates Next[t][state] for all R^L states (binary64 adds,
 compares, selects) and then walks all R^L entry states through the segment by table lookups.  The two inner loops are found in
@@ -78,9 +78,26 @@ def main():
                 nexts.append((a, ops, kinds))       # (adds and compares only: the reweight loops of k_rwseg take logarithms and touch memory)
             elif any(o in ("ds_read_u8", "ds_read_u16", "ds_read_u8_d16", "ds_read_u16_d16", "ds_read_u8_d16_hi") for o in ops) and not any(o.startswith("global_store") for o in ops[:3]):
                 walks.append((a, ops, kinds))
-        # seg_body<4> is emitted in front of seg_body<5>
-        for name, lst in (("next_table_loop", nexts), ("state_walk_loop", walks)):
-            for q, (a, ops, kinds) in enumerate(sorted(lst)[:2]):
+        # which loop belongs to which radix, by what it does rather than by where the compiler put it (round 4: the four-rank
+        # body is emitted LAST): the Next-table loop of seg_body<4> has the fewest binary64 operations, the five-symbol one the
+        # next more (the NaN-safe instantiation and the mixed-radix body are larger still); the state walk of seg_body<4> reads
+        # one-byte entries, the five-symbol one two-byte entries
+        def has(t, *prefixes):
+            return any(o.startswith(prefixes) for o in t[1])
+        mixed = lambda t: has(t, "v_readfirstlane", "v_readlane")            # the mixed-radix body hands its radices round in scalar registers
+        n4 = [t for t in nexts if has(t, "ds_write_b8") and not mixed(t)]     # one-byte Next entries: four ranks
+        # (two-byte entries: the NaN-safe five-symbol instantiation is the largest, the plain one the second largest; what is smaller belongs to other bodies)
+        n5 = sorted((t for t in nexts if has(t, "ds_write_b16") and not mixed(t)), key=lambda t: -t[2]["valu_f64"])[1:2]
+        # (the walk of a whole word of picks: the longest of the loops that read entries -- the shorter ones are its tails)
+        w4 = sorted((t for t in walks if has(t, "ds_read_u8") and not mixed(t) and not has(t, "ds_write")), key=lambda t: -len(t[1]))
+        w5 = sorted((t for t in walks if has(t, "ds_read_u16") and not mixed(t) and not has(t, "ds_write")), key=lambda t: -len(t[1]))
+        picks = {"next_table_loop": [n4[0] if n4 else None, n5[0] if n5 else None],
+                 "state_walk_loop": [w4[0] if w4 else None, w5[0] if w5 else None]}
+        for name, lst in picks.items():
+            for q, t in enumerate(lst):
+                if t is None:
+                    continue
+                a, ops, kinds = t
                 radix = "R4" if q == 0 else "R5"
                 cyc = sum(out["cost_cycles_per_wave_instruction"][k] * v for k, v in kinds.items())
                 per_radix.setdefault(radix, {})[name] = {"instructions": len(ops), "by_class": dict(kinds), "issue_cycles_per_iteration": cyc,

@@ -1,6 +1,6 @@
 """Quick regression check of the headline figures against the committed profiles (GPU box, repo root):
     python scratch/perf_check.py [tolerance]        # default: flags anything more than 7 % below the committed figure
-Runs bench.py for C3 (with the five-candidate window leg), C2 and a short C5 and compares with profiles/r3_bench_*.json."""
+Runs bench.py for C3 (with the five-candidate window leg), C2 and a short C5 and compares with profiles/r4_bench_*.json."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tol = float(sys.argv[1]) if len(sys.argv) > 1 else 0.07
@@ -13,7 +13,7 @@ def line(args):
 
 
 def ref(name):
-    return json.loads(open(os.path.join(ROOT, "profiles", "r3_bench_%s.json" % name)).read().strip().splitlines()[-1])
+    return json.loads(open(os.path.join(ROOT, "profiles", "r4_bench_%s.json" % name)).read().strip().splitlines()[-1])
 
 
 rows = []
