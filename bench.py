@@ -99,8 +99,7 @@ def kernel_source_sha():
     import glob
     import hashlib
     hh = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "gretel_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h")) +
-                   glob.glob(os.path.join(ROOT, "include", "*.inc")))
+    files = sorted(glob.glob(os.path.join(ROOT, "gretel_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
     for f in files:
         hh.update(os.path.basename(f).encode())
         hh.update(open(f, "rb").read())
