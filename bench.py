@@ -487,6 +487,8 @@ def main():
     h.profile_enable(0)
     ev_empty_ms, ev_nop_ms = h.profile_overhead(30)      # what a bracket reads with nothing / an empty kernel inside
 
+    if ex is not None:
+        ex.close()                                      # (the worker thread: no collective of its own may run beside the ones below)
     tt = torch.tensor([dt, float(n_paths_local)], dtype=torch.float64, device=comm_dev)
     if use_dist:
         tmax = tt.clone()

@@ -139,7 +139,8 @@ class ResultExchange:
 
     The records of a step travel while the next step runs: `buffers()` hands out views of a pinned staging slot that
     Hansel.spin writes its results into directly (no packing pass), `submit()` queues upload + gather + (rank 0) download of that
-    slot on a side stream and returns at once, `collect()` waits for the OLDEST outstanding submission and returns what rank 0
+    slot on a side stream -- from a worker thread, so that the caller does not even pay the host side of the collective -- and
+    returns at once, `collect()` waits for the OLDEST outstanding submission and returns what rank 0
     gathered (None elsewhere).  Two slots: a slot is handed out again only when its previous submission has been collected, so
     no buffer is rewritten while a copy or the collective may still read it.  Every rank submits once per step, in step order:
     the collectives match across ranks.  Wire format per window: paths u8[max_paths][N+1], gh_path_rec f64[max_paths][5],
@@ -148,6 +149,8 @@ class ResultExchange:
     NREC = 5
 
     def __init__(self, n_snps, max_paths, device, world, rank, force=False, slots=2):
+        import queue as queue_mod
+        import threading
         import torch
         self.n1, self.max_paths, self.device, self.world, self.rank = n_snps + 1, max_paths, device, world, rank
         self.active = world > 1 or force
@@ -160,7 +163,8 @@ class ResultExchange:
         self.slots = []
         for _ in range(slots):
             host = torch.empty(self.nbytes, dtype=torch.uint8, pin_memory=self.cuda)
-            sl = dict(host=host, np=host.numpy(), pending=None)
+            sl = dict(host=host, np=host.numpy(), done=threading.Event(), error=None)
+            sl["done"].set()
             if self.active:
                 sl["dev"] = torch.empty(self.nbytes, dtype=torch.uint8, device=device) if self.cuda else host
                 sl["recv_list"] = None
@@ -174,6 +178,11 @@ class ResultExchange:
         self.side = torch.cuda.Stream(device=device) if (self.cuda and self.active) else None
         self.next_slot = 0
         self.queue = []                 # submitted, not yet collected: (slot index, n, hole_at)
+        self._thread = None
+        if self.active:
+            self._jobs = queue_mod.Queue()
+            self._thread = threading.Thread(target=self._worker, name="gretel-result-exchange", daemon=True)
+            self._thread.start()
 
     def _views(self, a):
         paths = a[:self.nb_p].reshape(self.max_paths, self.n1)
@@ -190,37 +199,57 @@ class ResultExchange:
         return p, r
 
     def submit(self, n, hole_at):
-        import torch
-        import torch.distributed as dist
         si = self.next_slot
         sl = self.slots[si]
         self.next_slot = (si + 1) % len(self.slots)
         _, _, tail = self._views(sl["np"])
         tail[0], tail[1] = float(n), float(hole_at)
         if self.active:
-            recv = sl["recv_list"]
-            if self.cuda:
-                with torch.cuda.stream(self.side):
-                    sl["dev"].copy_(sl["host"], non_blocking=True)
-                    work = dist.gather(sl["dev"], recv, dst=0, async_op=True)
-                    work.wait()                                   # (the side stream waits, not the host)
-                    if self.rank == 0:
-                        sl["recv_host"].copy_(sl["recv_dev"], non_blocking=True)
-                    sl["event"].record(self.side)
-                sl["pending"] = sl["event"]
-            else:
-                sl["pending"] = dist.gather(sl["dev"], recv, dst=0, async_op=True)
+            # the torch calls (upload, collective, download: ~0.1 ms of host time) are made by a worker thread: the caller goes
+            # straight on to its next step -- its time is spent inside the C library, which releases the interpreter lock
+            sl["done"].clear()
+            self._jobs.put(si)
         self.queue.append((si, int(n), int(hole_at)))
+
+    def _worker(self):
+        import torch
+        import torch.distributed as dist
+        while True:
+            si = self._jobs.get()
+            if si is None:
+                return
+            sl = self.slots[si]
+            try:
+                recv = sl["recv_list"]
+                if self.cuda:
+                    with torch.cuda.stream(self.side):
+                        sl["dev"].copy_(sl["host"], non_blocking=True)
+                        dist.gather(sl["dev"], recv, dst=0)
+                        if self.rank == 0:
+                            sl["recv_host"].copy_(sl["recv_dev"], non_blocking=True)
+                        sl["event"].record(self.side)
+                    sl["event"].synchronize()
+                else:
+                    dist.gather(sl["dev"], recv, dst=0)
+            except BaseException as exc:           # (handed to the thread that collects)
+                sl["error"] = exc
+            sl["done"].set()
+
+    def close(self):
+        if self.active and self._thread is not None:
+            self.drain()
+            self._jobs.put(None)
+            self._thread.join()
+            self._thread = None
 
     def _finish(self, q, keep=True):
         si, n, hole = q
         sl = self.slots[si]
-        if self.active and sl["pending"] is not None:
-            if self.cuda:
-                sl["pending"].synchronize()
-            else:
-                sl["pending"].wait()
-            sl["pending"] = None
+        if self.active:
+            sl["done"].wait()
+            if sl.get("error") is not None:
+                exc, sl["error"] = sl["error"], None
+                raise exc
         if not keep or (self.active and self.rank != 0):
             return None
         if not self.active:
