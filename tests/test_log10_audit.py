@@ -94,17 +94,17 @@ def test_the_audit_sees_an_exact_tie():
     # the census itself on a case done by hand: two candidates with identical evidence tie exactly, the order decides
     from oracle.c_oracle import COracle
     from gretel_amd.synth import SupportTable
-    reads = ["AC", "AG"] * 3
+    reads = ["AAC", "AAG"] * 3
     bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
-    t = SupportTable(2, np.zeros(len(reads), np.int32), np.arange(0, 2 * len(reads) + 1, 2, dtype=np.int64), bases,
-                     np.zeros((1, 2), np.uint8), np.ones(1))
-    o = COracle(2, 1, use_libm=True)
+    t = SupportTable(3, np.zeros(len(reads), np.int32), np.arange(0, 3 * len(reads) + 1, 3, dtype=np.int64), bases,
+                     np.zeros((1, 3), np.uint8), np.ones(1))
+    o = COracle(3, 2, use_libm=True)
     o.fill(t)
     o.audit_begin()
     r = o.spin(1)
     a = o.audit()
-    assert r["n"] == 1 and a["margin_ulps"]["tie"] == 1 and a["flips"] == 0      # C and G tie at SNP 2; C is offered first
-    assert r["paths"][0].tolist() == [6, 0, 1]
+    assert r["n"] == 1 and a["margin_ulps"]["tie"] == 1 and a["flips"] == 0      # C and G tie at SNP 3; C is offered first
+    assert r["paths"][0].tolist() == [6, 0, 0, 1]
 
 
 if __name__ == "__main__":
