@@ -71,6 +71,7 @@ def load():
         "gh_device_count": [P(i32)],
         "gh_device_clock_khz": [i32, P(i32)],
         "gh_log10_device": [i32, vp, vp, C.c_int64],
+        "gh_debug_segment_stamps": [vp, vp, i32],
         "gh_log10_host": [vp, vp, C.c_int64],
         "gh_create": [P(gh_config), P(vp)],
         "gh_destroy": [vp],

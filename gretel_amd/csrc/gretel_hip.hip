@@ -2689,6 +2689,17 @@ extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
     return GH_OK;
 }
 
+// diagnostic builds (-DRWS_STAMPS_ALL): the stamps every k_rwseg workgroup of the last launch left, 16 doubles per workgroup
+extern "C" int gh_debug_segment_stamps(gh_t *h, double *out, int n_workgroups)
+{
+    if (!h || !out || n_workgroups < 1) return fail(GH_ERR_ARG, "bad argument");
+    if (set_dev(h)) return GH_ERR_HIP;
+    if (!h->seg_smin) return fail(GH_ERR_STATE, "no segment-parallel walk has run on this handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->seg_smin, (size_t)n_workgroups * 16 * sizeof(double), hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
 extern "C" int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch)
 {
     if (!h || !bytes_per_launch || kernel < 0 || kernel >= GH_K_COUNT) return fail(GH_ERR_ARG, "bad argument");

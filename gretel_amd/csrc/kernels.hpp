@@ -879,7 +879,7 @@ k_marg(T *band, int N, int W, double *cnt, double *marg,
 
 // batched launches: re-arm the words k_marg min/and-reduces into (single windows use a memset)
 // the most states that enter any target when a state is the last L picks as candidate ranks: max over t of the product of
-// the candidate counts of positions t-L+1 .. t (a position without candidates, or in front of the window, counts 1)
+// the radices of positions t-L+1 .. t (segmix.hpp: 5 where a position offers five candidates, 4 everywhere else)
 __global__ void __launch_bounds__(256) k_classify(const uint32_t *__restrict__ cmask, int N, int L, dev_state *st)
 {
     const int t = blockIdx.x * 256 + threadIdx.x + 1;
@@ -888,8 +888,7 @@ __global__ void __launch_bounds__(256) k_classify(const uint32_t *__restrict__ c
         prod = 1;
         for (int l = 0; l < L; l++) {
             const int p = t - l;
-            const int r = p >= 1 ? __popc(CM_CAND(cmask[p])) : 1;
-            prod *= r > 0 ? r : 1;
+            prod *= (p >= 1 && __popc(CM_CAND(cmask[p])) == 5) ? 5 : 4;     // (segm_radix: 5 where five candidates are offered, else 4)
         }
     }
 #pragma unroll

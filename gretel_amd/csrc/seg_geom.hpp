@@ -6,7 +6,12 @@
 #define SEG_THREADS 1024
 // diagnostic builds only (-DSEG_STAMPS): s_memtime at the phase boundaries of k_seg's workgroup 0 into st->dbg8
 // (-DRWS_STAMPS: k_rwseg's workgroup 100 -- the reweight phases in slots 0..5, its k_seg phases behind them)
-#if defined(RWS_STAMPS)
+#if defined(RWS_STAMPS_ALL)
+// (-DRWS_STAMPS_ALL: EVERY workgroup of k_rwseg leaves its stamps, 16 per workgroup, in the (otherwise unused) smin buffer: which
+// workgroup a launch waits for, and in which phase -- gh_debug_segment_stamps reads them)
+#define RWS_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (threadIdx.x == 0) P.smin[(size_t)blockIdx.x * 16 + (i)] = (double)__builtin_amdgcn_s_memtime(); } while (0)
+#define SEG_STAMP(i) RWS_STAMP(6 + (i))
+#elif defined(RWS_STAMPS)
 #define RWS_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 100 && threadIdx.x == 0) P.st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define SEG_STAMP(i) RWS_STAMP(6 + (i))
 #elif defined(SEG_STAMPS)
@@ -97,7 +102,7 @@ __host__ __device__ inline seg_geom seg_geometry(int N, int L, int R)
 __host__ __device__ constexpr size_t seg_lds_bytes(int R, int L)
 {
     // mixed: the ranked slice (five rows x five columns per source and lag), the Next entries, the per-target tables (segmix.hpp)
-    if (R == SEG_CLS_MIXED) return (size_t)(SEGM_CH + L - 1) * L * 5 * SEGM_ROW * 8 + (size_t)SEGM_NXCAP * 2 + (size_t)SEGM_CH * 64 + 1024;
+    if (R == SEG_CLS_MIXED) return (size_t)(SEGM_CH + L - 1) * L * 5 * SEGM_ROW * 8 + (size_t)SEGM_NXCAP * 2 + (size_t)SEGM_CH * 64 + 1024 + 64;
     return ((size_t)(seg_chunk(R, L) + L - 1) * L * R * R * 8 + (size_t)seg_chunk(R, L) * seg_ipow(R, L - 1) * (R == 4 ? 1 : 2) + 7) & ~(size_t)7;
 }
 __host__ __device__ constexpr size_t seg_lds_total(int R, int L) { return seg_lds_bytes(R, L) + (R == SEG_CLS_MIXED ? 0 : (size_t)seg_chunk(R, L) * R * 8); }

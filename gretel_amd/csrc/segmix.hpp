@@ -4,7 +4,7 @@
 // candidates -- 3 125 states at L = 5 where the window without that position has 1 024: 2.3x per path for one '-' anywhere.
 // Here a state is the last L picks as candidate RANKS (rank r at position p = the r-th candidate of p in the order they are
 // offered in, gretel/gretel.py:166-174), written as a mixed-radix number whose digit for position p has radix
-//     R_p = number of candidates at p        (1 for a position without candidates, for position 0 = '_', and in front of it),
+//     R_p = 5 where p offers five candidates, 4 everywhere else (fewer candidates: the missing ranks are -inf columns),
 // so the states entering target t number C_t = prod_{l=1..L} R_{t-l}: 1 024 where the L positions behind t offer four, 1 280
 // behind one that offers five.  With d_l the digit of position t-l and M_1 = 1, M_{l+1} = M_l R_{t-l}:
 //     sigma_t = sum_l d_l M_l,      NI_t = M_L (the entries of target t: digits d_1 .. d_{L-1}; one entry holds the pick for
@@ -27,7 +27,11 @@
 #define SEGM_ROW_US 0x80u
 #define SEGM_NOPOS 0x40u
 
-__device__ __forceinline__ int segm_radix(unsigned cm) { const int r = __popc(cm & 31u); return r > 0 ? r : 1; }
+// the radix of a position's digit: 5 where it offers five candidates, 4 everywhere else -- also where it offers fewer, at
+// position 0 and in front of the window (ranks that do not exist are columns of -inf and rows nobody reaches, as in the
+// four-rank layout): every target out of sight of a five-candidate position then has the SAME radices and takes the fast
+// body of (1b), and its states are the 1 024 of the four-rank layout
+__device__ __forceinline__ int segm_radix(unsigned cm) { return __popc(cm & 31u) == 5 ? 5 : 4; }
 
 // first-wins arg-max over the first BR of five sums (BR = the target's candidate count, 4 or 5; fewer: the rest is -inf)
 template <int BR>
@@ -82,7 +86,8 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
     uint2 *winf = reinterpret_cast<uint2 *>(ctl + 2);
     // [2 CH] work items of the Next build, everything a wavefront needs of one in a single read: .x = target | block of 64 tasks << 8,
     // .y = the target's radices, .z = reciprocal multipliers of the two youngest radices, .w = where the target's entries start
-    uint4 *iti = reinterpret_cast<uint4 *>(winf + CH);             // [CH] what a step of the state walk needs of its target: .x = NI | R_t << 12 | offset << 15, .y = 1.0f / NI
+    uint4 *iti = reinterpret_cast<uint4 *>(winf + CH);
+    uint32_t *wfast = reinterpret_cast<uint32_t *>(iti + 2 * CH);     // [CH / 10] 1: every target of the word has four candidates and four-candidate predecessors             // [CH] what a step of the state walk needs of its target: .x = NI | R_t << 12 | offset << 15, .y = 1.0f / NI
 
     unsigned sigma[SPT];
     bool live[SPT];                                                // (threads beyond the entry states walk state 0 and store nothing)
@@ -111,9 +116,9 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
         // five candidates: a second pass.
         const bool halo_chunk = HASP && c0 == t0 && t0 > 0;
         constexpr int TRIPS = ((CH + LC - 1) * LC * 4 + SEG_THREADS - 1) / SEG_THREADS;
-        double wst[TRIPS][5], lmst[TRIPS][5];
+        double wst[TRIPS][5];
         int a6st[TRIPS];
-        auto load_row = [&](int ii, int l, int d, double (&w)[5], double (&lmv)[5]) __attribute__((always_inline)) -> int {
+        auto load_row = [&](int ii, int l, int d, double (&w)[5]) __attribute__((always_inline)) -> int {
             const int i = c0 + 1 - LC + ii;
             const unsigned cmi = cm_of(i);
             int a6 = (cmi & SEGM_ROW_US) ? 5 : nth_set5(cmi & 31u, d);
@@ -122,19 +127,13 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
             const double *src = P.G + (((size_t)ic * 6 + ac) * LC + l) * LT_ROW;
 #pragma unroll
             for (int b = 0; b < 5; b++) w[b] = src[b];
-            if (P.mt) {
-                // (the marginal term of lag 1: log10 marginal of the target's symbols, by symbol like the columns; added at store time)
-                const double *lm = P.minfo + (size_t)(ic + 1) * MINFO;
-#pragma unroll
-                for (int b = 0; b < 5; b++) lmv[b] = lm[b];
-            }
             return a6;
         };
 #pragma unroll
         for (int k = 0; k < TRIPS; k++) {
             const int e = tid + k * SEG_THREADS;
             const int ec = e < (avail + LC - 1) * LC * 4 ? e : 0;
-            a6st[k] = load_row(ec / (4 * LC), (ec >> 2) % LC, ec & 3, wst[k], lmst[k]);
+            a6st[k] = load_row(ec / (4 * LC), (ec >> 2) % LC, ec & 3, wst[k]);
             if (e != ec) a6st[k] = -1;
         }
         // (0) the candidate bits of the chunk's positions and, per target, radices / entries / work items (wavefront 0)
@@ -142,22 +141,14 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
         segm_lds_barrier();
         if (wave == 0) {
             unsigned rd = 0, NI = 1, NJ = 1;
-            unsigned ls = LC - 1;                                  // the lag whose digit a task loops over besides the oldest: see (1b)
             if (lane < avail) {
-                unsigned rmax = 0;
 #pragma unroll
                 for (int l = 0; l <= LC; l++) {
                     const unsigned r = (unsigned)segm_radix(cmc[lane + LC - l]);
                     rd |= r << (3 * l);
-                    if (l >= 1 && l <= LC - 1) { NI *= r; if (r > rmax) rmax = r; }
+                    if (l >= 1 && l <= LC - 1) NI *= r;
+                    if (l >= 1 && l <= LC - 2) NJ *= r;
                 }
-                // the looped lag: L - 1 unless a younger digit has a larger radix (the lanes then enumerate the three narrow ones)
-                if (((rd >> (3 * (LC - 1))) & 7u) < rmax) {
-#pragma unroll
-                    for (int l = LC - 2; l >= 1; l--)
-                        if (((rd >> (3 * l)) & 7u) == rmax) ls = (unsigned)l;
-                }
-                NJ = NI / ((rd >> (3 * ls)) & 7u);
             }
             // entries in front of target `lane` (inclusive scan over the lanes that hold a target)
             const unsigned inc = segm_scan(lane < avail ? NI : 0u);
@@ -165,19 +156,32 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
             const unsigned long long fits = __ballot(lane < avail && inc <= (unsigned)SEGM_NXCAP);
             int nc = __popcll(fits);                               // (the sums ascend: the lanes that fit are a prefix)
             if (nc < avail) nc = nc / DPW * DPW;
-            const unsigned items = lane < nc ? (NJ + 63u) / 64u : 0u, iinc = segm_scan(items);
+            // work items of (1b): the general ones (a target that sees a five-candidate position) FIRST -- they cost more than twice a
+            // fast one, and handed out in order every wavefront draws at most one of them before the fast ones fill the rounds
+            constexpr unsigned RD_ALL4_ = 4u | (4u << 3) | (4u << 6) | (4u << 9) | (4u << 12) | (4u << 15);
+            const bool general = lane < nc && rd != RD_ALL4_;
+            const unsigned items = lane < nc ? (NJ + 63u) / 64u : 0u;
+            const unsigned ginc = segm_scan(general ? items : 0u), finc = segm_scan(general ? 0u : items);
+            const unsigned gtot = (unsigned)__builtin_amdgcn_readlane((int)ginc, 63), ftot = (unsigned)__builtin_amdgcn_readlane((int)finc, 63);
+            const unsigned iinc = general ? ginc : gtot + finc;      // (inclusive end of this target's items in the list)
+            // words of the state walk whose ten targets are all of the fast kind: the walk takes seg_body<4>'s steps there
+            {
+                const unsigned long long gen64 = __ballot(general);
+                if (lane < (nc + DPW - 1) / DPW) {
+                    const unsigned long long m = ((1ull << DPW) - 1ull) << (lane * DPW);
+                    wfast[lane] = (gen64 & m) == 0ull && (lane + 1) * DPW <= nc ? 1u : 0u;
+                }
+            }
             if (lane < nc) {
                 rad[lane] = rd; nit[lane] = NI; nxo[lane] = inc - NI; ito[lane] = iinc - items;
                 winf[lane] = make_uint2(NI | ((rd & 7u) << 12) | ((inc - NI) << 15), __float_as_uint(1.0f / (float)NI));
-                // the two youngest of the three lags the lanes enumerate, and ceil(2^15 / r) of their radices without a division
-                // (everybody waits for this wavefront)
-                const unsigned la = ls == 1u ? 2u : 1u, lb = ls <= 2u ? 3u : 2u;
-                const unsigned ra = (rd >> (3 * la)) & 7u, rb = (rd >> (3 * lb)) & 7u;
+                // ceil(2^15 / r) of the two youngest radices without a division (everybody waits for this wavefront)
+                const unsigned r1 = (rd >> 3) & 7u, r2 = (rd >> 6) & 7u;
                 auto rcp15 = [](unsigned r) { return r == 1u ? 32768u : (r == 2u ? 16384u : (r == 3u ? 10923u : (r == 4u ? 8192u : 6554u))); };
-                const unsigned mg = rcp15(ra) | (rcp15(rb) << 16);
-                for (unsigned q = 0; q < items; q++) iti[iinc - items + q] = make_uint4((unsigned)lane | (q << 8) | (ls << 16), rd, mg, inc - NI);
+                const unsigned mg = rcp15(r1) | (rcp15(r2) << 16);
+                for (unsigned q = 0; q < items; q++) iti[iinc - items + q] = make_uint4((unsigned)lane | (q << 8), rd, mg, inc - NI);
             }
-            if (lane == nc - 1) { nxo[nc] = inc; ito[nc] = iinc; ctl[0] = nc; ctl[1] = (int)iinc; }
+            if (lane == nc - 1) { nxo[nc] = inc; ctl[0] = nc; ctl[1] = (int)(gtot + ftot); }
         }
         segm_lds_barrier();
         const int nc = ctl[0], nitems = ctl[1];
@@ -197,7 +201,7 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
         // beyond: -inf.  Sources c0+1-LC .. c0+nc-1 (slot ii), every lag; a row that does not exist, or whose target lies behind
         // the chunk, is never read: zeros (a source in front of the window: its terms ARE +0.0).
         const int nsrc = nc + LC - 1;
-        auto store_row = [&](int ii, int l, int d, int a6, double (&w)[5], const double (&lmv)[5]) __attribute__((always_inline)) {
+        auto store_row = [&](int ii, int l, int d, int a6, double (&w)[5]) __attribute__((always_inline)) {
             const int jj = ii + l + 1;                             // the target position i + l + 1 in cmc
             double *dst = Gs + ((size_t)(ii * LC + l) * 5 + d) * RS;
             if (a6 < 0 || jj >= nc + LC) {
@@ -226,10 +230,12 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
                 }
             }
             if (P.mt && l == 0) {
-                // the marginal term in front of the first addition: (0.0 + lm) + x1
+                // the marginal term in front of the first addition: (0.0 + lm) + x1 -- log10 marginal of the target's symbols, by symbol
+                // like the columns (fetched here: held across step (0) it cost ten registers of a kernel that has none to spare)
+                const double *lmp = P.minfo + (size_t)(c0 + 1 - LC + ii + 1) * MINFO;
 #pragma unroll
                 for (int b = 0; b < 5; b++) {
-                    double lm = lmv[b];
+                    double lm = lmp[b];
                     if constexpr (HASP) { if (halo_chunk && ii + 1 < LC) lm = patch->lm5[ii + 1][b]; }
                     w[b] = lm + w[b];
                 }
@@ -247,128 +253,115 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
 #pragma unroll
         for (int k = 0; k < TRIPS; k++) {
             const int e = tid + k * SEG_THREADS;
-            if (e < nsrc * LC * 4) store_row(e / (4 * LC), (e >> 2) % LC, e & 3, a6st[k], wst[k], lmst[k]);
+            if (e < nsrc * LC * 4) store_row(e / (4 * LC), (e >> 2) % LC, e & 3, a6st[k], wst[k]);
         }
         for (int e = tid; e < nsrc * LC; e += SEG_THREADS) {
             if (__popc(cmc[e / LC] & 31u) == 5) {
-                double w5[5], lm5v[5];
-                const int a6 = load_row(e / LC, e % LC, 4, w5, lm5v);
-                store_row(e / LC, e % LC, 4, a6, w5, lm5v);
+                double w5[5];
+                const int a6 = load_row(e / LC, e % LC, 4, w5);
+                store_row(e / LC, e % LC, 4, a6, w5);
             }
         }
         __syncthreads();
         SEG_STAMP(1);
-        // (1b) Next for every (target, valid state).  A work item is (target, 64 tasks): a task takes three of the digits
-        // d_1 .. d_{L-1} as given and loops over the fourth and over the oldest, d_L, itself, as seg_body does.  The fourth is
-        // d_{L-1} unless a younger position has more candidates -- then that one: behind ONE five-candidate position the lanes
-        // still enumerate 4 x 4 x 4 = 64 combinations, one item per target (five of the six targets behind such a position
-        // would otherwise need a second item of 16 tasks, and the wavefront that draws it a fourth round: the launch waits for
-        // it).  Whatever the loop order, the sum of a state is built lag ascending -- acc = x_1; acc += x_2; ... -- like
-        // everywhere.  Lag l of chunk-local target tl comes from slot tl + LC - l.
+        // (1b) Next for every (target, valid state).  A work item is (target, 64 tasks): a task takes the digits d_1 .. d_{L-2} as
+        // given and loops over d_{L-1} and the oldest, d_L, itself, as seg_body does.  Nearly every target of such a window has
+        // four candidates and four-candidate predecessors: those take seg_body<4>'s task body as it is -- digits by shifts, sixteen
+        // (d_{L-1}, d_L) pairs straight-line, the rows of lag L in registers.  A target that sees a five-candidate position takes
+        // the general body: radices from scalar registers, digits up to their radix, every row read from LDS where it is used
+        // (the registers the fast body fills are all this kernel has: held there as well, the rows of the general body spilled to
+        // scratch memory -- 176 bytes per lane, 8 us per launch, the first version of this file).  Either way the sum of a state is
+        // built lag ascending -- acc = x_1; acc += x_2; ... -- like everywhere.  Lag l of chunk-local target tl comes from slot
+        // tl + LC - l.
         for (int it = wave; it < nitems; it += SEG_THREADS / 64) {
             const uint4 info = iti[it];
             const int tl = __builtin_amdgcn_readfirstlane((int)(info.x & 0xffu));
             const int jb = __builtin_amdgcn_readfirstlane((int)((info.x >> 8) & 0xffu));
-            const unsigned ls = (unsigned)__builtin_amdgcn_readfirstlane((int)(info.x >> 16));
             const unsigned rd = (unsigned)__builtin_amdgcn_readfirstlane((int)info.y);
-            const unsigned mg = (unsigned)__builtin_amdgcn_readfirstlane((int)info.z);
             const unsigned nx0 = (unsigned)__builtin_amdgcn_readfirstlane((int)info.w);
-            const unsigned r0 = rd & 7u, r1 = (rd >> 3) & 7u, r2 = (rd >> 6) & 7u, r3 = (rd >> 9) & 7u, r4 = (rd >> 12) & 7u, r5 = (rd >> 15) & 7u;
-            // the lags the lanes enumerate (ascending) and the looped one; M_l = the weight of digit d_l in the entry index
-            const unsigned la = ls == 1u ? 2u : 1u, lb = ls <= 2u ? 3u : 2u, lc = ls == 4u ? 3u : 4u;
-            const unsigned M2 = r1, M3 = r1 * r2, M4 = M3 * r3;
-            auto radix = [&](unsigned l) { return l == 1u ? r1 : (l == 2u ? r2 : (l == 3u ? r3 : r4)); };
-            auto weight = [&](unsigned l) { return l == 1u ? 1u : (l == 2u ? M2 : (l == 3u ? M3 : M4)); };
-            const unsigned ra = radix(la), rb = radix(lb), rc = radix(lc), rs = radix(ls);
-            const unsigned NJ = ra * rb * rc;
+            auto row_of = [&](int l, unsigned d) { return Gs + ((size_t)((tl + LC - l) * LC + (l - 1)) * 5 + d) * RS; };
+            constexpr unsigned RD_ALL4 = 4u | (4u << 3) | (4u << 6) | (4u << 9) | (4u << 12) | (4u << 15);
+            if (rd == RD_ALL4) {
+                // ---- four candidates everywhere in sight: 64 tasks, one item
+                const unsigned j = (unsigned)lane;
+                const unsigned d1 = j & 3u, d2 = (j >> 2) & 3u, d3 = j >> 4;
+                double acc[4];
+                {
+                    const double *p1 = row_of(1, d1), *p2 = row_of(2, d2), *p3 = row_of(3, d3);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) acc[b] = (p1[b] + p2[b]) + p3[b];
+                }
+                double xl[4][4];
+#pragma unroll
+                for (int dL = 0; dL < 4; dL++) {
+                    const double *row = row_of(LC, (unsigned)dL);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) xl[dL][b] = row[b];
+                }
+                uint16_t *out = Nx + nx0 + j;
+#pragma unroll
+                for (int dS = 0; dS < 4; dS++) {
+                    const double *row = row_of(LC - 1, (unsigned)dS);
+                    double acc2[4];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) acc2[b] = acc[b] + row[b];
+                    unsigned packed = 0;
+#pragma unroll
+                    for (int dL = 0; dL < 4; dL++) {
+                        double v[4];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) v[b] = acc2[b] + xl[dL][b];
+                        packed |= seg_argmax<4>(v, false) << (BITS * dL);
+                    }
+                    out[dS * 64] = (uint16_t)packed;
+                }
+                continue;
+            }
+            // ---- the general body
+            const unsigned mg = (unsigned)__builtin_amdgcn_readfirstlane((int)info.z);
+            const unsigned r1 = (rd >> 3) & 7u, r2 = (rd >> 6) & 7u, r3 = (rd >> 9) & 7u, r4 = (rd >> 12) & 7u, r5 = (rd >> 15) & 7u;
+            const unsigned NJ = r1 * r2 * r3;
             const unsigned j = (unsigned)jb * 64u + (unsigned)lane;
             if (j < NJ) {
                 // (radices are 1..5, j < 125: the quotients through exact reciprocal multiplies, ceil(2^15 / r) made by wavefront 0)
                 const unsigned q1 = __umul24(j, mg & 0xffffu) >> 15;
-                const unsigned da = j - __umul24(q1, ra);
-                const unsigned dc = __umul24(q1, mg >> 16) >> 15;
-                const unsigned db = q1 - __umul24(dc, rb);
-                uint16_t *out = Nx + nx0 + __umul24(da, weight(la)) + __umul24(db, weight(lb)) + __umul24(dc, weight(lc));
-                const unsigned Ms = weight(ls);
-                auto row_of = [&](unsigned l, unsigned d) { return Gs + ((size_t)((tl + LC - (int)l) * LC + ((int)l - 1)) * 5 + d) * RS; };
-                // (the whole task by the target's candidate count: four columns are read, added and compared where it offers four)
-                auto rest = [&](auto br_) __attribute__((always_inline)) {
+                const unsigned d1 = j - __umul24(q1, r1);
+                const unsigned d3 = __umul24(q1, mg >> 16) >> 15;
+                const unsigned d2 = q1 - __umul24(d3, r2);
+                uint16_t *out = Nx + nx0 + j;
+                // (by the target's own candidate count: only the five-candidate position itself needs the fifth column)
+                auto body = [&](auto br_) __attribute__((always_inline)) {
                     constexpr int BR = decltype(br_)::value;
-                    double xa[BR], xb[BR], xc[BR];
+                    double acc[BR];
                     {
-                        const double *pa = row_of(la, da), *pb = row_of(lb, db), *pc = row_of(lc, dc);
+                        const double *p1 = row_of(1, d1), *p2 = row_of(2, d2), *p3 = row_of(3, d3);
 #pragma unroll
-                        for (int b = 0; b < BR; b++) { xa[b] = pa[b]; xb[b] = pb[b]; xc[b] = pc[b]; }
+                        for (int b = 0; b < BR; b++) acc[b] = (p1[b] + p2[b]) + p3[b];
                     }
-                    // Digits 0..3 of the looped lag and of the oldest run straight-line, whatever their radices (a row beyond a radix
-                    // holds zeros or stale numbers: what is computed from it is not stored, or lands in bits nobody reads) -- a branch
-                    // per digit would put every LDS read behind its own wait; only the fifth value of a digit, rare, is conditional.
-                    double xl[5][BR];                              // lag L, every value of d_L
+                    auto one_dS = [&](unsigned dS) __attribute__((always_inline)) {
+                        const double *row = row_of(LC - 1, dS);
+                        double acc2[BR];
 #pragma unroll
-                    for (int dL = 0; dL < 4; dL++) {
-                        const double *row = Gs + ((size_t)(tl * LC + (LC - 1)) * 5 + dL) * RS;
-#pragma unroll
-                        for (int b = 0; b < BR; b++) xl[dL][b] = row[b];
-                    }
-                    if (r5 == 5u) {
-                        const double *row = Gs + ((size_t)(tl * LC + (LC - 1)) * 5 + 4) * RS;
-#pragma unroll
-                        for (int b = 0; b < BR; b++) xl[4][b] = row[b];
-                    }
-                    auto oldest = [&](const double (&acc2)[BR], int dS) __attribute__((always_inline)) {
+                        for (int b = 0; b < BR; b++) acc2[b] = acc[b] + row[b];
                         unsigned packed = 0;
-#pragma unroll
-                        for (int dL = 0; dL < 4; dL++) {
+                        auto one_dL = [&](unsigned dL) __attribute__((always_inline)) {
+                            const double *rowL = row_of(LC, dL);
                             double v[BR];
 #pragma unroll
-                            for (int b = 0; b < BR; b++) v[b] = acc2[b] + xl[dL][b];
+                            for (int b = 0; b < BR; b++) v[b] = acc2[b] + rowL[b];
                             packed |= seg_argmax<BR>(v, false) << (BITS * dL);
-                        }
-                        if (r5 == 5u) {
-                            double v[BR];
+                        };
 #pragma unroll
-                            for (int b = 0; b < BR; b++) v[b] = acc2[b] + xl[4][b];
-                            packed |= seg_argmax<BR>(v, false) << (BITS * 4);
-                        }
-                        if ((unsigned)dS < rs) out[__umul24((unsigned)dS, Ms)] = (uint16_t)packed;
+                        for (int dL = 0; dL < 4; dL++) one_dL((unsigned)dL);       // (radices are 4 or 5: digits 0..3 always exist)
+                        if (r5 == 5u) one_dL(4u);
+                        out[dS * NJ] = (uint16_t)packed;
                     };
-                    if (ls == 4u) {
-                        // the looped lag is the last of the four: the three in front are summed once
-                        double acc[BR];
 #pragma unroll
-                        for (int b = 0; b < BR; b++) acc[b] = (xa[b] + xb[b]) + xc[b];
-                        auto one = [&](int dS) __attribute__((always_inline)) {
-                            const double *row = row_of(4u, (unsigned)dS);
-                            double acc2[BR];
-#pragma unroll
-                            for (int b = 0; b < BR; b++) acc2[b] = acc[b] + row[b];
-                            oldest(acc2, dS);
-                        };
-#pragma unroll
-                        for (int dS = 0; dS < 4; dS++) one(dS);
-                        if (rs == 5u) one(4);
-                    } else {
-                        // a younger lag is looped: its term takes its place in the lag-ascending sum of every state
-                        auto one = [&](int dS) __attribute__((always_inline)) {
-                            const double *row = row_of(ls, (unsigned)dS);
-                            double acc2[BR];
-#pragma unroll
-                            for (int b = 0; b < BR; b++) {
-                                const double x = row[b];
-                                const double t1 = ls == 1u ? x : xa[b];
-                                const double t2 = ls == 1u ? xa[b] : (ls == 2u ? x : xb[b]);
-                                const double t3 = ls <= 2u ? xb[b] : x;
-                                acc2[b] = ((t1 + t2) + t3) + xc[b];
-                            }
-                            oldest(acc2, dS);
-                        };
-#pragma unroll
-                        for (int dS = 0; dS < 4; dS++) one(dS);
-                        if (rs == 5u) one(4);
-                    }
+                    for (int dS = 0; dS < 4; dS++) one_dS((unsigned)dS);
+                    if (r4 == 5u) one_dS(4u);
                 };
-                if (r0 == 5u) rest(std::integral_constant<int, 5>{});
-                else rest(std::integral_constant<int, 4>{});
+                if ((rd & 7u) == 5u) body(std::integral_constant<int, 5>{});
+                else body(std::integral_constant<int, 4>{});
             }
         }
         __syncthreads();
@@ -388,27 +381,44 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
                 constexpr int SL = decltype(slots_)::value;
                 for (int tw = 0; tw < nc; tw += DPW) {
                     const int nu = nc - tw < DPW ? nc - tw : DPW;
-                    const uint2 wi = winf[tw + (lane < nu ? lane : 0)];
                     unsigned word[SL];
 #pragma unroll
                     for (int q = 0; q < SL; q++) word[q] = 0;
+                    if (__builtin_amdgcn_readfirstlane((int)wfast[tw / DPW]) != 0) {
+                        // ten targets with four candidates and four-candidate predecessors: NI = 256, R_t = 4, their entries lie
+                        // behind one another -- seg_body<4>'s step (shift, mask, one table read), nothing fetched per target
+                        const uint16_t *rows = Nx + __builtin_amdgcn_readfirstlane((int)nxo[tw]);
 #pragma unroll
-                    for (int u = 0; u < DPW; u++) {
-                        if (u < nu) {
-                            const unsigned ix = (unsigned)__builtin_amdgcn_readlane((int)wi.x, u);
-                            const float rcp = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)wi.y, u));
-                            const int negNI = -(int)(ix & 0xfffu);
-                            const unsigned r0 = (ix >> 12) & 7u;
-                            const uint16_t *rows = Nx + (ix >> 15);
-                            const float half = 0.5f * rcp;
+                        for (int u = 0; u < DPW; u++) {
 #pragma unroll
                             for (int q = 0; q < SL; q++) {
                                 const unsigned sg = sigma[q];
-                                const unsigned hi = (unsigned)__builtin_fmaf((float)sg, rcp, half);
-                                const unsigned idx = (unsigned)__mul24((int)hi, negNI) + sg;
-                                const unsigned d = ((unsigned)rows[idx] >> (BITS * hi)) & 7u;
+                                const unsigned hi = sg >> 8, idx = sg & 255u;
+                                const unsigned d = ((unsigned)rows[u * 256 + idx] >> (BITS * hi)) & 7u;
                                 word[q] |= d << (BITS * u);
-                                sigma[q] = __umul24(idx, r0) + d;
+                                sigma[q] = idx * 4u + d;
+                            }
+                        }
+                    } else {
+                        const uint2 wi = winf[tw + (lane < nu ? lane : 0)];
+#pragma unroll
+                        for (int u = 0; u < DPW; u++) {
+                            if (u < nu) {
+                                const unsigned ix = (unsigned)__builtin_amdgcn_readlane((int)wi.x, u);
+                                const float rcp = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)wi.y, u));
+                                const int negNI = -(int)(ix & 0xfffu);
+                                const unsigned r0 = (ix >> 12) & 7u;
+                                const uint16_t *rows = Nx + (ix >> 15);
+                                const float half = 0.5f * rcp;
+#pragma unroll
+                                for (int q = 0; q < SL; q++) {
+                                    const unsigned sg = sigma[q];
+                                    const unsigned hi = (unsigned)__builtin_fmaf((float)sg, rcp, half);
+                                    const unsigned idx = (unsigned)__mul24((int)hi, negNI) + sg;
+                                    const unsigned d = ((unsigned)rows[idx] >> (BITS * hi)) & 7u;
+                                    word[q] |= d << (BITS * u);
+                                    sigma[q] = __umul24(idx, r0) + d;
+                                }
                             }
                         }
                     }

@@ -219,6 +219,9 @@ int gh_profile_overhead(gh_t *h, int reps, double out[2]);
  * (L = 6..24): out[0] = re-queues of the last gh_spin, out[1] = paths this handle handed to the serial walker so far,
  * out[2] = walk/scan rounds it queued so far) */
 int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
+/* diagnostic builds only (-DRWS_STAMPS_ALL): the s_memtime stamps every k_rwseg workgroup of the last launch left at its phase
+ * boundaries, 16 doubles per workgroup (scratch/wg_stamps.py) -- which workgroup a launch waits for, and in which phase */
+int gh_debug_segment_stamps(gh_t *h, double *out, int n_workgroups);
 /* algorithmic bytes of the last launch of each kernel */
 int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch);
 
