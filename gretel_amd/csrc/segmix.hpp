@@ -338,22 +338,39 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
 #pragma unroll
                         for (int b = 0; b < BR; b++) acc[b] = (p1[b] + p2[b]) + p3[b];
                     }
+                    // (four columns: the rows of lag L for digits 0..3 in registers, as in the fast body -- 32 registers, which five
+                    // columns would not leave; the fifth value of a digit is read where it is used)
+                    constexpr int XL = BR == 4 ? 4 : 1;
+                    double xl[XL][BR];
+                    if constexpr (BR == 4) {
+#pragma unroll
+                        for (int dL = 0; dL < 4; dL++) {
+                            const double *rowL = row_of(LC, (unsigned)dL);
+#pragma unroll
+                            for (int b = 0; b < BR; b++) xl[dL][b] = rowL[b];
+                        }
+                    }
                     auto one_dS = [&](unsigned dS) __attribute__((always_inline)) {
                         const double *row = row_of(LC - 1, dS);
                         double acc2[BR];
 #pragma unroll
                         for (int b = 0; b < BR; b++) acc2[b] = acc[b] + row[b];
                         unsigned packed = 0;
-                        auto one_dL = [&](unsigned dL) __attribute__((always_inline)) {
-                            const double *rowL = row_of(LC, dL);
+                        auto one_dL = [&](unsigned dL, auto fromreg_) __attribute__((always_inline)) {
                             double v[BR];
+                            if constexpr (decltype(fromreg_)::value) {
 #pragma unroll
-                            for (int b = 0; b < BR; b++) v[b] = acc2[b] + rowL[b];
+                                for (int b = 0; b < BR; b++) v[b] = acc2[b] + xl[dL][b];
+                            } else {
+                                const double *rowL = row_of(LC, dL);
+#pragma unroll
+                                for (int b = 0; b < BR; b++) v[b] = acc2[b] + rowL[b];
+                            }
                             packed |= seg_argmax<BR>(v, false) << (BITS * dL);
                         };
 #pragma unroll
-                        for (int dL = 0; dL < 4; dL++) one_dL((unsigned)dL);       // (radices are 4 or 5: digits 0..3 always exist)
-                        if (r5 == 5u) one_dL(4u);
+                        for (int dL = 0; dL < 4; dL++) one_dL((unsigned)dL, std::integral_constant<bool, BR == 4>{});       // (radices are 4 or 5: digits 0..3 always exist)
+                        if (r5 == 5u) one_dL(4u, std::false_type{});
                         out[dS * NJ] = (uint16_t)packed;
                     };
 #pragma unroll
