@@ -1368,7 +1368,15 @@ static int ensure_partial(gh_handle *h, int nb, int slots)
 // path's partial sums in their own slot, the caller reduces all paths with one k_reweight_finish_all at the end.
 // k_rw's lane group: 32 lanes per position where the band or the lag count exceeds 8 (all distances and lags in one
 // round), else 8; blocks per path accordingly (also the stride of the per-path partial sums of the removed mass)
-static int rw_lanes(const gh_handle *h) { return (h->W > 8 || h->L > 8) ? 32 : 8; }
+// (16: row conditionals with bands up to 32 and at most 16 lags -- the distances beyond 16 take a second round, the table
+// entries are dealt out over the group anyway, and the marginals, 7 lanes of every group, cost a wavefront half as much)
+static int rw_lanes(const gh_handle *h)
+{
+    if (!(h->W > 8 || h->L > 8)) return 8;
+    const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;
+    static const bool no16 = getenv("GH_RW_LP16") && atoi(getenv("GH_RW_LP16")) == 0;
+    return (!col && h->W <= 32 && h->L <= 16 && !no16) ? 16 : 32;
+}
 static int rw_blocks(const gh_handle *h, bool seg) { return (int)(((size_t)(h->N + 1) * (seg ? rw_lanes(h) : 8) + 255) / 256); }
 
 // seg: the walk just before was segment-parallel: the kernel reduces the minimum marginal itself, clamps it to `ratio`
@@ -1398,8 +1406,10 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     do {                                                                                                                          \
         /* COL: the band block of the workgroup's positions staged in LDS when it fits (k_rw) */                                   \
         const size_t blk_b = (size_t)(256 / LP) * NSYM * h->W * NSYM * sizeof(T);                                                 \
-        const int stage = (COL && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0;    \
-        const size_t lds_b = fuse_lds + (stage ? blk_b : 0);                                                                      \
+        /* | 2: `cnt` holds the row sums of the band as it stands (k_rw takes the rows a reweight does not touch from there) */     \
+        const int stage = ((COL && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0) |  \
+                          ((!h->dirty_marg && !(getenv("GH_RW_CNT") && atoi(getenv("GH_RW_CNT")) == 0)) ? 2 : 0);                  \
+        const size_t lds_b = fuse_lds + ((stage & 1) ? blk_b : 0);                                                                \
         static std::atomic<size_t> set_lds[64];                                                                                   \
         if (lds_b > set_lds[h->dev & 63]) {                                                                                       \
             hipFuncSetAttribute((const void *)k_rw<T, LP, COL, FZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);      \
@@ -1411,7 +1421,7 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
     } while (0)
 #define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true, false); else GH_RW_LAUNCH(T, LP, false, false); } while (0)
 #define GH_RW_LAUNCHF(T) do { if (col) GH_RW_LAUNCH(T, 8, true, true); else GH_RW_LAUNCH(T, 8, false, true); } while (0)
-        const bool wide = rw_lanes(h) == 32;
+        const bool wide = rw_lanes(h) == 32, mid = rw_lanes(h) == 16;
         const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;      // the table entries a reweighted cell feeds: a column
         // behind k_seg + k_scan without a k_emit (h->fuse): the kernel finds its picks itself and writes the path to d_path / d_lmsel
         fuse_params fz;
@@ -1424,7 +1434,8 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         }
         if (fz.hist) {                                      // (three-launch spins: lane groups of 8 only, gh_spin decides)
             if (h->cfg.storage == GH_STORAGE_F64) GH_RW_LAUNCHF(double); else GH_RW_LAUNCHF(float);
-        } else if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
+        } else if (mid) { if (h->cfg.storage == GH_STORAGE_F64) GH_RW_LAUNCH(double, 16, false, false); else GH_RW_LAUNCH(float, 16, false, false); }
+        else if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
         else { if (wide) GH_RW_LAUNCH2(float, 32); else GH_RW_LAUNCH2(float, 8); }
 #undef GH_RW_LAUNCHF
 #undef GH_RW_LAUNCH2

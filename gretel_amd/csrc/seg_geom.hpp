@@ -23,7 +23,10 @@
 #endif
 // -DRW_STAMPS: the same inside k_rw's workgroup 100 (every stamp waits for the memory operations issued before it)
 #ifdef RW_STAMPS
-#define RW_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == 100 && threadIdx.x == 0) st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifndef RW_STAMP_BLOCK
+#define RW_STAMP_BLOCK 100
+#endif
+#define RW_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (blockIdx.x == RW_STAMP_BLOCK && threadIdx.x == 0) st->dbg8[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define RW_STAMP(i)
 #endif

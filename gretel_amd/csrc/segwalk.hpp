@@ -751,7 +751,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
      gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage, fuse_params fz, int fuse_lds)
 {
-    __shared__ double s_red[256];
+    __shared__ double s_min4[4], s_sum4[4];
     __shared__ double s_logtab[256];
     extern __shared__ __align__(16) unsigned char rw_smem_all[];
     logtab_stage(s_logtab);                                 // (the barriers of the minimum's reduction stand between this and the first logarithm)
@@ -765,7 +765,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     // from memory measured 6-12 us for k_rw<float, 8, true> at C3 (every line of the band, cold, one sector per lane).
     T *blk = reinterpret_cast<T *>(rw_smem);
     const size_t pos_elems = (size_t)NSYM * W * NSYM;
-    if (COL && stage) {
+    if (COL && (stage & 1)) {
         const int p0 = blockIdx.x * PPB;
         const int np = p0 + PPB <= N + 2 ? PPB : (N + 2 > p0 ? N + 2 - p0 : 0);
         typedef T vecT __attribute__((ext_vector_type(16 / sizeof(T))));
@@ -841,8 +841,15 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     }
     // this lane owns the table entries of lag d0: a row (every lag up to L), or a column (only where the cell changed)
     const bool lag_row = G && act && pp < N && d0 <= L && j0 <= N && (!COL || (mult0 > 0 && d0 <= W));
+    // the row sums of cell (p, p+1) = the counts at p.  A reweight moves one element of that cell, in the row of the path's symbol:
+    // every other row's sum is the one the pass before left in `cnt` (stage & 2: the host knows cnt to be current), and that
+    // row is the one lane 0 reads anyway -- one 64-byte line per position instead of seven (bands of 20: 384 of ~1000 bytes read)
+    const bool cnt_ok = !COL && (stage & 2);
     T crow[NSYM];
-    if (!(COL && stage)) {
+    double cold = 0.0;
+    if (cnt_ok) {
+        cold = (act && s < NSYM) ? cnt[(size_t)pp * 8 + s] : 0.0;
+    } else if (!(COL && (stage & 1))) {
 #pragma unroll
         for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? band[bidx(W, pp, 1, s, x)] : (T)0;      // cell (p, p+1), row s
     }
@@ -850,7 +857,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     uint32_t cm_t = 0;
     if (lag_row) { nv_t = nvalid[j0]; cm_t = CM_CAND(cmask[j0]); }
     const uint32_t cm_old = (act && s == 7) ? cmask[pp] : 0u;
-    static_assert(LP == 8 || LP == 32, "lane groups of 8 or 32");
+    static_assert(LP == 8 || LP == 16 || LP == 32, "lane groups of 8, 16 or 32");
     // ---- the path's minimum marginal, while round 1 is in flight ----------------------------------------------
     if (fused) {
         // (1) the start state through the group maps: the state that enters every group; and, through the prefix maps, every
@@ -898,14 +905,17 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             if (act && s == 0) fz.lmsel[p] = p == 0 ? 1.0 : lmv;       // ([0] = 1.0: k_hp still has this path's sums to take)
         }
     }
-    s_red[tid] = my_segmin;
-    __syncthreads();
-    for (int q = 128; q > 0; q >>= 1) {
-        if (tid < q && s_red[tid + q] < s_red[tid]) s_red[tid] = s_red[tid + q];
-        __syncthreads();
+    // (inside the wavefront by lane exchange, the four wavefronts through LDS: one barrier where a tree over 256 slots takes nine)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_xor(my_segmin, o);
+        my_segmin = w < my_segmin ? w : my_segmin;
     }
-    const double minm = s_red[0];
+    if ((tid & 63) == 0) s_min4[tid >> 6] = my_segmin;
     __syncthreads();
+    double minm = s_min4[0];
+#pragma unroll
+    for (int q = 1; q < 4; q++) minm = s_min4[q] < minm ? s_min4[q] : minm;
     RW_STAMP(1);
     const double ratio = minm < min_remove ? min_remove : minm;
     if (blockIdx.x == 0 && tid == 0) seg_finish(st, rec, N, minm, min_remove);
@@ -919,7 +929,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     // compiler waits for each of the seven strided loads before it issues the next: 7 round trips, 15 us for k_rw<float, 8, COL>)
     const T *runp = need_row ? rowp : band + bidx(W, pp, 1, 0, 0);      // (its own position's block)
     T rrow[NSYM];
-    if (COL && stage) {
+    if (COL && (stage & 1)) {
         // (the reduction above has passed barriers behind the staging stores)
         const T *lp = blk + (size_t)(tid / LP) * pos_elems;                // this position's block in LDS
 #pragma unroll
@@ -968,13 +978,22 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     int nv = 0;
     uint32_t cm = 0, cm5 = 0;
     T acc = (T)0;
+    double mine;
+    if (cnt_ok) {
+        // lane 0 holds the row of the path's symbol (the rewritten element in place): the same left-to-right sum in the storage type
 #pragma unroll
-    for (int x = 0; x < NSYM; x++) {
-        T v = crow[x];
-        if (s == na && x == nb) v = nval;                   // the element this group has just rewritten
-        acc = acc + v;
+        for (int x = 0; x < NSYM; x++) acc = acc + rrow[x];
+        const double suma = __shfl((double)acc, 0, LP);
+        mine = (s == na) ? suma : cold;
+    } else {
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) {
+            T v = crow[x];
+            if (s == na && x == nb) v = nval;               // the element this group has just rewritten
+            acc = acc + v;
+        }
+        mine = (double)acc;
     }
-    const double mine = (double)acc;
 #pragma unroll
     for (int x = 0; x < NSYM; x++) {
         cs[x] = __shfl(mine, x, LP);
@@ -1155,7 +1174,54 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
                 for (int rb = __popc(cj5); rb < LT_ROW; rb++) out[rb] = -INFINITY;
             }
         };
-        if (d0 <= L && row6 >= 0) table_row(d0, rrow, nv_t, cm_t);
+        if constexpr (LP >= 16) {
+            // Lane groups of 16 / 32 (bands or lag counts above 8): one lane per lag would leave the five divisions and logarithms of a
+            // row to L of 32 lanes -- at C5 (L = 11) a third of every wavefront works while this kernel is bound by exactly that
+            // arithmetic.  The rows go through LDS instead (same wavefront: no barrier) and the 5 L entries are dealt out over all the group's
+            // lanes; entry e = (lag - 1) * 5 + column lies at out[e], so the lanes' stores are one contiguous run.  Same division,
+            // same log10 on the same operands: the bits do not depend on the lane that computes them.
+            __shared__ T s_rows[256 / LP][LP][NSYM];
+            __shared__ double s_den[256 / LP][LP];
+            __shared__ uint32_t s_cmt[256 / LP][LP];
+            const int pl = tid / LP;
+            const int Lr = L < LP ? L : LP;
+            if (d0 <= Lr) {
+                T racc = (T)0;
+#pragma unroll
+                for (int x = 0; x < NSYM; x++) { s_rows[pl][s][x] = rrow[x]; racc = racc + rrow[x]; }      // zeros beyond the band
+                const double sum = (double)racc;
+                s_den[pl][s] = (cond_mode == GH_COND_A) ? (double)nv_t + sum : (cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
+                // the symbol behind each of the five columns of this lag, 4 bits each (15: no such candidate -> -inf)
+                uint32_t colsym = 0;
+#pragma unroll
+                for (int col = 0; col < LT_ROW; col++) {
+                    const int b5 = ranked ? nth_set5(cm5_of_cmask(sm, cm_t), col) : col;
+                    const int sy = b5 >= 0 ? vsym(sm, b5) : 0;
+                    colsym |= (uint32_t)((b5 >= 0 && ((cm_t >> sy) & 1u)) ? sy : 15) << (4 * col);
+                }
+                s_cmt[pl][s] = colsym;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (row6 >= 0) {
+                double *out = G + ((size_t)p * 6 + row6) * L * LT_ROW;
+                const bool row_live = a6 < 5 || p == 0;
+                for (int e = s; e < Lr * LT_ROW; e += LP) {
+                    const int l1 = e / LT_ROW, col = e - l1 * LT_ROW;
+                    double r = 0.0;
+                    if (p + l1 + 1 <= N && row_live) {
+                        const int sy = (int)((s_cmt[pl][l1] >> (4 * col)) & 15u);
+                        r = -INFINITY;
+                        if (sy != 15) {
+                            const double xq = (1.0 + (double)s_rows[pl][l1][sy]) / s_den[pl][l1];
+                            r = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_BOTH) : gh_log10_tab(xq, s_logtab, GH_LOG_BOTH);
+                        }
+                    }
+                    out[e] = r;
+                }
+            }
+        } else if (d0 <= L && row6 >= 0) table_row(d0, rrow, nv_t, cm_t);
         for (int l = d0 + LP; l <= L && row6 >= 0; l += LP) {    // lag counts above the lane group: the remaining lags, one by one
             T rowT[NSYM];
 #pragma unroll
@@ -1179,22 +1245,23 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     __shared__ unsigned s_flags;
     __shared__ int s_hole;
     if (tid == 0) { s_flags = 0; s_hole = 0x7fffffff; }
-    s_red[tid] = removed;
+    // (a fixed tree -- butterflies inside the wavefront, then the four wavefronts in order -- so the sum is the same from run to run)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o);
+    if ((tid & 63) == 0) s_sum4[tid >> 6] = removed;
     __syncthreads();
     if (flag_bits) atomicOr(&s_flags, flag_bits);
     if (hole_p != 0x7fffffff) atomicMin(&s_hole, hole_p);
-    for (int q = 128; q > 0; q >>= 1) {
-        if (tid < q) s_red[tid] += s_red[tid + q];
-        __syncthreads();
-    }
+    __syncthreads();
     if (tid == 0) {
-        partial[blockIdx.x] = s_red[0];
+        partial[blockIdx.x] = (s_sum4[0] + s_sum4[1]) + (s_sum4[2] + s_sum4[3]);
         const unsigned f = s_flags;
         if (f & 1u) atomicAnd(&st->cm_same, 0);
         if (f & 2u) atomicAnd(&st->nodel, 0);
         if (f & 4u) atomicAnd(&st->narrow, 0);
         if (s_hole != 0x7fffffff) atomicMin(&st->first_hole, s_hole);
     }
+    RW_STAMP(5);
 }
 
 // -------------------------------------------------------------------------------------------------------------
