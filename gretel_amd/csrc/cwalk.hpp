@@ -32,7 +32,10 @@
 
 #define CW_K 64                 /* pool entries per segment */
 #define CW_MIN_L 6
-#define CW_MAX_L 24             /* 2 bits per pick in a 64-bit state; beyond 24 lags the table slice of a chunk outgrows the LDS */
+#ifndef CW_CH_CAP
+#define CW_CH_CAP 40
+#endif
+#define CW_MAX_L 32             /* 2 bits per pick in a 64-bit state; 32 targets x 32 lags x 4 x 4 doubles are 128 KB of LDS */
 typedef unsigned long long cw_key;
 #define CW_MAX_SEG 512
 #define CW_MIN_LEN 32
@@ -62,23 +65,28 @@ __host__ __device__ inline cw_geom cw_geometry(int N, int L)
 #define CW_MAX_L5 21
 __host__ __device__ constexpr int cw_lanes(int R) { return R == 4 ? 4 : 8; }
 __host__ __device__ constexpr int cw_bits(int R) { return R == 4 ? 2 : 3; }
-// rows of a source staged in LDS: 0..3 of the ranked table; all six of the symbol table (rows 0..4 are used; six keep the
-// slice one contiguous, 16-byte-divisible run of G)
-__host__ __device__ constexpr int cw_rows(int R) { return R == 4 ? 4 : 6; }
-// positions per LDS chunk of k_cwalk: (c + L - 1) sources x rows x L lags x 5 columns of doubles within the budget
+// The slice of G a chunk of targets needs, in LDS TARGET-major (round 4): Gs[tl][lag - 1][row][col] = G[t - lag][row][lag - 1][col]
+// for the chunk's targets t = c0 + 1 + tl -- exactly the (source, lag) pairs the chunk reads, CH x L blocks of rows x columns.
+// (Rounds 2-3 copied whole source blocks as they lie in G -- (CH + L - 1) sources x L lags, of which a chunk reads the diagonal
+// band only: at 24 lags 16 targets per chunk, fewer than the L steps the unrolled walk takes at a time, and nothing beyond 24.)
+// rows / columns kept: the four ranks of the ranked table; the five symbols A C G T - of the symbol table
+__host__ __device__ constexpr int cw_rows(int R) { return R == 4 ? 4 : 5; }
+__host__ __device__ constexpr int cw_cols(int R) { return R == 4 ? 4 : 5; }
 __host__ __device__ constexpr int cw_lds_budget(int L, int R)
 {
     return R == 4 ? (L <= 13 ? 76 * 1024 : (L <= 17 ? 96 * 1024 : (L <= 19 ? 120 * 1024 : 150 * 1024)))
                   : (L <= 12 ? 76 * 1024 : (L <= 13 ? 96 * 1024 : (L <= 15 ? 120 * 1024 : 150 * 1024)));
 }
-// (+ 5 doubles per source slot: the log-marginals of its lag-1 target, for windows walked with the marginal term)
+// targets per LDS chunk of k_cwalk (+ 5 doubles per target: its log-marginals, for windows walked with the marginal term)
 __host__ __device__ constexpr int cw_chunk(int L, int R)
 {
-    int c = 64;
-    while (c > 2 && (c + L - 1) * (cw_rows(R) * L * 5 + 5) * 8 > cw_lds_budget(L, R)) c -= 1;
-    return c;
+    int c = cw_lds_budget(L, R) / ((L * cw_rows(R) * cw_cols(R) + 5) * 8);
+    // (the next chunk's slice waits in registers under the walk: from 18 lags on no more targets than a segment of the
+    // usual length has, or the walk's own registers go through the accumulator file)
+    if (L >= 18 && c > CW_CH_CAP) c = CW_CH_CAP > L ? CW_CH_CAP : L;
+    return c > 64 ? 64 : (c < 2 ? 2 : c);
 }
-__host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)(cw_chunk(L, R) + L - 1) * (cw_rows(R) * L * 5 + 5) * 8; }
+__host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)cw_chunk(L, R) * (L * cw_rows(R) * cw_cols(R) + 5) * 8; }
 
 struct cw_params {
     int N, L;
@@ -126,12 +134,6 @@ struct cw_params {
     int runon;                // k_cwalk: segments a walker may run on into behind its own (<= CW_RUNON)
     cw_key key0;              // key of the start state (0 in the packed mode)
 };
-
-// k_cwalk's LDS: the slice of G, then the log-marginal rows (one per source slot)
-__device__ __forceinline__ double *Gs_lm(unsigned char *smem, int CH, int LC, int rows)
-{
-    return reinterpret_cast<double *>(smem) + (size_t)(CH + LC - 1) * rows * LC * LT_ROW;
-}
 
 __device__ __forceinline__ cw_key cw_hash_digits(const uint8_t *d, int L)
 {
@@ -222,7 +224,8 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     if (!__syncthreads_or(live ? 1 : 0)) return;            // nothing new to walk in this segment
     constexpr int CH = cw_chunk(LC, R);
     constexpr cw_key SMASK = BITS * LC >= 64 ? ~0ull : ((1ull << (BITS * LC)) - 1ull);
-    double *Gs = reinterpret_cast<double *>(cw_smem);       // [(CH + LC - 1)][R][LC][5]: G's own layout, rows 0..R-1
+    constexpr int ROWS = cw_rows(R), COLS = cw_cols(R), ENT = ROWS * COLS;      // one (target, lag) block: rows x columns doubles
+    double *Gs = reinterpret_cast<double *>(cw_smem);       // [CH][LC][ROWS][COLS]
     cw_key sigma = live ? P.keys[(size_t)s * CW_K + q] : 0ull;
     int seg = s;                                            // the segment being walked: s, then (run-on) s + 1, ...
     int t0 = s * g.seglen;
@@ -234,73 +237,70 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     bool active = live;                                     // this lane group still walks
     int pslot = 0;                                          // run-on: the pending slot of pool `seg` this walk belongs to
     uint32_t *hdst = P.hist + (size_t)s * nw_e * CW_K + q;  // where its words of picks go (stride CW_K): the entry's own, or a pending slot's
-    // The slice of G a chunk needs: sources c0+1-LC .. c0+nc-1.  Rows 0..3 of a source are one contiguous run of 4*L*5
-    // doubles in G ([i][row][lag][col]) and go to LDS as they are (16-byte copies).  The loads of chunk k+1 are issued
-    // before chunk k is walked and stay in registers under the walk: their latency is off the critical path.
-    constexpr int ROWS = cw_rows(R);
-    constexpr int RUN = ROWS * LC * LT_ROW, RUN2 = RUN / 2;       // doubles / double2 per source
-    static_assert(RUN % 2 == 0, "16-byte copies");
-    constexpr int NV = ((CH + LC - 1) * RUN2 + NTHR - 1) / NTHR;
-    lds_v2d pre[NV];
-    // marginal term: the log-marginals of target i + 1 for every source slot (column b: rank or symbol, like G's columns),
-    // fetched with the slice, added in front of the lag-1 entries once the slice stands in LDS
-    constexpr int NLM = ((CH + LC - 1) * LT_ROW + NTHR - 1) / NTHR;
-    double *Lms = Gs_lm(cw_smem, CH, LC, ROWS);
+    // The slice of a chunk: for target t = c0 + 1 + tl and lag l the rows of source t - l at that lag -- a run of COLS doubles
+    // per (tl, l, row) in G ([i][row][lag][col]), copied as a unit.  Position 0 carries '_' whatever the digit says (row 5),
+    // positions in front of it add +0.0.  The loads of chunk k+1 are issued before chunk k is walked and stay in registers
+    // under the walk: their latency is off the critical path.
+    constexpr int UNITS = CH * LC * ROWS;
+    constexpr int NV = (UNITS + NTHR - 1) / NTHR;
+    double pre[NV][COLS];
+    // marginal term: the log-marginals of the chunk's targets (column b: rank or symbol, like G's columns), fetched with the
+    // slice, added in front of the lag-1 entries once the slice stands in LDS
+    constexpr int NLM = (CH * LT_ROW + NTHR - 1) / NTHR;
+    double *Lms = Gs + (size_t)CH * LC * ENT;
     double prelm[NLM];
     auto fetch = [&](int c0) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
-        const int i_lo = c0 + 1 - LC, total = (nc + LC - 1) * RUN2;
         if (P.mt) {
 #pragma unroll
             for (int k = 0; k < NLM; k++) {
                 const int e = tid + k * NTHR;
-                const int ii = e / LT_ROW, bb = e - ii * LT_ROW;
-                const int tgt = i_lo + ii + 1;
+                const int tl = e / LT_ROW, bb = e - tl * LT_ROW;
+                const int tgt = c0 + 1 + tl;
                 prelm[k] = 0.0;
-                if (ii < nc + LC - 1 && tgt >= 1 && tgt <= P.N && bb < R)
-                    prelm[k] = R == 4 ? P.rinfo[(size_t)tgt * RINFO + bb] : P.minfo[(size_t)tgt * MINFO + bb];
+                if (tl < nc && bb < R) prelm[k] = R == 4 ? P.rinfo[(size_t)tgt * RINFO + bb] : P.minfo[(size_t)tgt * MINFO + bb];
             }
         }
+        const int total = nc * LC * ROWS;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            const int e = tid + k * NTHR;
-            pre[k] = lds_v2d{0.0, 0.0};
-            if (e < total) {
-                const int ii = e / RUN2, r2 = e - ii * RUN2;
-                const int i = i_lo + ii;
-                if (i >= 1) pre[k] = *reinterpret_cast<const lds_v2d *>(P.G + (size_t)i * 6 * LC * LT_ROW + 2 * r2);
+            const int u = tid + k * NTHR;
+#pragma unroll
+            for (int cc = 0; cc < COLS; cc++) pre[k][cc] = 0.0;
+            if (u < total) {
+                const int row = u % ROWS, l1 = (u / ROWS) % LC, tl = u / (ROWS * LC);
+                const int i = c0 + tl - l1;                           // source of lag l1 + 1 at target c0 + 1 + tl
+                if (i >= 0) {
+                    const double *src = P.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * LC + l1) * LT_ROW;
+#pragma unroll
+                    for (int cc = 0; cc < COLS; cc++) pre[k][cc] = src[cc];
+                }
             }
         }
     };
     auto store = [&](int c0) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
-        const int i_lo = c0 + 1 - LC, total = (nc + LC - 1) * RUN2;
-        lds_v2d *dst = reinterpret_cast<lds_v2d *>(Gs);
+        const int total = nc * LC * ROWS;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
-            const int e = tid + k * NTHR;
-            if (e < total) dst[e] = pre[k];
-        }
-        if (i_lo <= 0) {                                          // position 0 carries '_' whatever the digit says (row 5)
-            __syncthreads();
-            const int ii0 = -i_lo;                                // its slot
-            for (int e = tid; e < RUN; e += NTHR) {
-                const int l = (e / LT_ROW) % LC, bb = e % LT_ROW;
-                Gs[(size_t)ii0 * RUN + e] = P.G[(size_t)(5 * LC + l) * LT_ROW + bb];
+            const int u = tid + k * NTHR;
+            if (u < total) {
+#pragma unroll
+                for (int cc = 0; cc < COLS; cc++) Gs[(size_t)u * COLS + cc] = pre[k][cc];
             }
         }
         if (P.mt) {
 #pragma unroll
             for (int k = 0; k < NLM; k++) {
                 const int e = tid + k * NTHR;
-                if (e < (nc + LC - 1) * LT_ROW) Lms[e] = prelm[k];
+                if (e < nc * LT_ROW) Lms[e] = prelm[k];
             }
             __syncthreads();
-            // lag 1 of slot ii, row r, column bb:  (0.0 + lm) + x1 -- the reference's first addition
-            for (int e = tid; e < (nc + LC - 1) * ROWS * LT_ROW; e += NTHR) {
-                const int bb = e % LT_ROW, r = (e / LT_ROW) % ROWS, ii = e / (LT_ROW * ROWS);
-                double *g = Gs + (size_t)ii * RUN + (size_t)r * LC * LT_ROW + bb;
-                *g = Lms[ii * LT_ROW + bb] + *g;
+            // lag 1 of target tl, row r, column bb:  (0.0 + lm) + x1 -- the reference's first addition
+            for (int e = tid; e < nc * ENT; e += NTHR) {
+                const int tl = e / ENT, rc = e - tl * ENT, bb = rc % COLS;
+                double *g = Gs + (size_t)tl * LC * ENT + rc;
+                *g = Lms[tl * LT_ROW + bb] + *g;
             }
         }
     };
@@ -312,13 +312,13 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
         store(c0);
         __syncthreads();
         if (c0 + CH < t1) fetch(c0 + CH);
-        // One step: lag l of chunk-local target tl comes from slot tl + LC - l, row = the pick made l positions ago:
-        // Gs[((slot * ROWS + row) * LC + (l - 1)) * 5 + b].  rowoff(l) = that pick's row offset in doubles.
+        // One step: lag l of chunk-local target tl, row = the pick made l positions ago:
+        // Gs[((tl * LC + (l - 1)) * ROWS + row) * COLS + b].  rowoff(l) = that pick's row offset in doubles.
         auto step = [&](int tl, auto rowoff) {
-            const double *base = Gs + (size_t)tl * RUN + bcol;
+            const double *base = Gs + (size_t)tl * LC * ENT + bcol;
             double x[LC];
 #pragma unroll
-            for (int l = 1; l <= LC; l++) x[l - 1] = base[((LC - l) * ROWS * LC + (l - 1)) * LT_ROW + rowoff(l)];
+            for (int l = 1; l <= LC; l++) x[l - 1] = base[(l - 1) * ENT + rowoff(l)];
             double acc = x[0];
 #pragma unroll
             for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
         // blocks of LC steps: the row offsets of the last LC picks sit in registers, slot k = the pick of the step that is
         // k (mod LC) into the block, so every index below is a compile-time constant (no shuffling of registers, no
         // bit-field extraction per lag); what is left of the chunk takes the offsets out of the state word
-        constexpr unsigned ROWD = LC * LT_ROW;                       // doubles per row
+        constexpr unsigned ROWD = COLS;                              // doubles per row of a (target, lag) block
         int tl = 0;
         if (nc >= LC) {
             unsigned dig[LC];

@@ -1609,6 +1609,8 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
 #define CW_CASE(n) case n: if (!h->cw_wide) launch_cwalk_lc<n, 4>(P, h->stream, g.S, h->dev); else launch_cwalk_lc<(n <= CW_MAX_L5 ? n : CW_MAX_L5), 5>(P, h->stream, g.S, h->dev); break;
             CW_CASE(6) CW_CASE(7) CW_CASE(8) CW_CASE(9) CW_CASE(10) CW_CASE(11) CW_CASE(12) CW_CASE(13) CW_CASE(14) CW_CASE(15) CW_CASE(16)
             CW_CASE(17) CW_CASE(18) CW_CASE(19) CW_CASE(20) CW_CASE(21) CW_CASE(22) CW_CASE(23) CW_CASE(24)
+            // (25..32 lags: over ranks only -- cw_digit_mode sends the symbol table beyond CW_MAX_L5 to k_cwalkg)
+            CW_CASE(25) CW_CASE(26) CW_CASE(27) CW_CASE(28) CW_CASE(29) CW_CASE(30) CW_CASE(31) CW_CASE(32)
 #undef CW_CASE
             default: return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_LG);
         }

@@ -34,7 +34,7 @@ def _same(res, ref):
     assert np.allclose(res["magnitude"], ref["magnitude"], rtol=1e-10, atol=0)
 
 
-@pytest.mark.parametrize("L", [-6, 6, 7, 8, 9, 10, 12, 13, 16, 17, 20, 24, 25, 31, 40])
+@pytest.mark.parametrize("L", [-6, 6, 7, 8, 9, 10, 12, 13, 16, 17, 18, 20, 24, 25, 31, 32, 33, 40])
 def test_every_lag_count(L, monkeypatch):
     # long-read-style reads (k ~ Poisson(10)); L = 9 and up also exercises the table rows beyond the eighth lag in k_rw.
     # L = 6 in a window without a five-candidate position enumerates its 4^6 states (variant 3); -6: the pools all the same
@@ -44,7 +44,7 @@ def test_every_lag_count(L, monkeypatch):
         want = 4
     else:
         want = 3 if L == 6 else 4
-    # (beyond 24 lags: k_cwalkg -- the table from global memory, states as bytes next to their hash)
+    # (beyond 32 lags: k_cwalkg -- the table from global memory, states as bytes next to their hash)
     t = make_support_table(2500, 30000, k=None, seed=200 + L, k_max=max(21, L + 4), k_lambda=10.0 if L <= 24 else float(L))
     h, o = _pair(t, L=L)
     res, ref = h.spin(24), o.spin(24)
