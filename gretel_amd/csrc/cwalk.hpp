@@ -88,6 +88,14 @@ __host__ __device__ constexpr int cw_chunk(int L, int R)
 }
 __host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)cw_chunk(L, R) * (L * cw_rows(R) * cw_cols(R) + 5) * 8; }
 
+// k_cwalkg: targets per chunk and LDS at a lag count known at run time
+__host__ __device__ inline int cwg_chunk(int L, int R)
+{
+    int c = (150 * 1024) / ((L * cw_rows(R) * cw_cols(R) + 5) * 8);
+    return c > 64 ? 64 : (c < 1 ? 1 : c);
+}
+__host__ __device__ inline size_t cwg_lds_bytes(int L, int R) { return (size_t)cwg_chunk(L, R) * (L * cw_rows(R) * cw_cols(R) + 5) * 8; }
+
 struct cw_params {
     int N, L;
     int rearm;                // spin loops: k_cemit re-arms first_hole/nodel/cm_same/narrow for the k_rw that follows
@@ -408,9 +416,10 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
 // -------------------------------------------------------------------------------------------------------------
 // k_cwalkg: k_cwalk for lag counts whose table slice no longer fits the LDS and whose state no longer fits 64 bits
 // (L > 24 over ranks, L > 21 over symbols; L <= CW_MAX_LG).  The same pools, links and chain; what differs:
-//   * the L terms of a step are read from G in global memory (L independent loads per lane, CWG_CHUNK at a time, added
-//     in lag order as everywhere) -- a step is a round trip to L2, ~2 us, where the one-wavefront k_walk_global spends
-//     that on EVERY position of the window one after the other;
+//   * the slice of G a chunk of targets needs stands in LDS target-major as in k_cwalk (round 4; rounds 2-3 read the L terms
+//     of every step from global memory: a round trip to L2 per step, 600 us per path at 25 lags), sized at run time: as many
+//     targets per chunk as 150 KB hold at this lag count (24 at 48 lags, 9 at 128); the terms are added in lag order as
+//     everywhere, CWG_CHUNK at a time;
 //   * a state is L bytes (one per pick, lag 1 first) next to its 64-bit hash; the last L picks of an entry live in a
 //     ring in LDS.
 // -------------------------------------------------------------------------------------------------------------
@@ -422,6 +431,8 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
     constexpr int LPE = cw_lanes(R);
     constexpr int PPW = R == 4 ? 16 : 8, WB = R == 4 ? 2 : 4;
     __shared__ uint8_t ring[CW_K][CW_MAX_LG];               // ring[q][(t - l) & 127] = pick of position t - l
+    extern __shared__ __align__(16) unsigned char cwg_smem[];
+    constexpr int ROWS = cw_rows(R), COLS = cw_cols(R), ENT = ROWS * COLS, NTHR = CW_K * LPE;
     dev_state *st = P.st;
     const dev_ctl c = load_ctl(st);
     if (c.stop || c.lt_stale || c.cw_unres) return;
@@ -483,57 +494,83 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
     __syncthreads();
     int word_i = 0;
     unsigned word = 0;
-    // Element of G for lag l at target t under row r:  ((t - l) * 6 + r) * L * 5 + (l - 1) * 5 + col
-    //   = t * S6 + col - 5  +  l * (5 - S6)  +  r * 5L        with S6 = 30 L -- two integer multiply-adds per term
-    // (32-bit element offsets: (N + 16) * 30 L < 2^31 for every window the band tensor itself still fits)
-    const int S6 = 6 * L * LT_ROW, KL = LT_ROW - S6, R5 = L * LT_ROW;
+    // the slice: Gs[tl][lag - 1][row][col] = G[t - lag][row][lag - 1][col] for the chunk's targets t = c0 + 1 + tl (position 0
+    // carries '_' whatever the pick says: its row 5 in every row; positions in front of it: +0.0), then the log-marginals
+    // of the targets (marginal term: in front of x1)
+    const int CH = cwg_chunk(L, R);
+    double *Gs = reinterpret_cast<double *>(cwg_smem);
+    double *Lms = Gs + (size_t)CH * L * ENT;
     const uint8_t *myring = ring[q];
-    for (int t = t0 + 1; t <= t1; t++) {
-        // lag l: source i = t - l, row = the pick made there (row 5 at position 0; positions < 0 add +0.0)
-        const int base = t * S6 + bcol - LT_ROW;
-        double acc = 0.0;
-        double lm_t = 0.0;                                          // marginal term: in front of x1
-        if (P.mt) lm_t = R == 4 ? P.rinfo[(size_t)t * RINFO + bcol] : P.minfo[(size_t)t * MINFO + bcol];
-        for (int l0 = 1; l0 <= L; l0 += CWG_CHUNK) {
-            double x[CWG_CHUNK];
-            int rows[CWG_CHUNK];
-            // (no branch around a load: a term that does not exist reads the lag-1 address and is replaced by +0.0; the picks
-            // come out of the ring first, all reads in flight together, then the table loads)
+    for (int c0 = t0; c0 < t1; c0 += CH) {
+        const int nc = t1 - c0 < CH ? t1 - c0 : CH;
+        __syncthreads();                                        // the chunk before has been walked
+        for (int u = tid; u < nc * L * ROWS; u += NTHR) {
+            const int row = u % ROWS, l1 = (u / ROWS) % L, tl = u / (ROWS * L);
+            const int i = c0 + tl - l1;
+            double v[COLS];
 #pragma unroll
-            for (int u = 0; u < CWG_CHUNK; u++) {
-                const int l = l0 + u;
-                const int le = (l <= L && t - l >= 0) ? l : 1;
-                rows[u] = (int)myring[(t - le) & (CW_MAX_LG - 1)];
+            for (int cc = 0; cc < COLS; cc++) v[cc] = 0.0;
+            if (i >= 0) {
+                const double *src = P.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * L + l1) * LT_ROW;
+#pragma unroll
+                for (int cc = 0; cc < COLS; cc++) v[cc] = src[cc];
             }
 #pragma unroll
-            for (int u = 0; u < CWG_CHUNK; u++) {
-                const int l = l0 + u;
-                const bool have = l <= L && t - l >= 0;
-                const int le = have ? l : 1;
-                int row = live ? rows[u] : 0;                       // (an idle lane group reads row 0: its ring holds nothing)
-                if (t - le <= 0) row = 5;
-                const double v = P.G[(unsigned)(base + le * KL + row * R5)];
-                x[u] = have ? v : 0.0;
+            for (int cc = 0; cc < COLS; cc++) Gs[(size_t)u * COLS + cc] = v[cc];
+        }
+        if (P.mt)
+            for (int e = tid; e < nc * LT_ROW; e += NTHR) {
+                const int tl = e / LT_ROW, bb = e - tl * LT_ROW;
+                Lms[e] = bb < R ? (R == 4 ? P.rinfo[(size_t)(c0 + 1 + tl) * RINFO + bb] : P.minfo[(size_t)(c0 + 1 + tl) * MINFO + bb]) : 0.0;
             }
+        __syncthreads();
+        for (int tl = 0; tl < nc; tl++) {
+            const int t = c0 + 1 + tl;
+            // lag l: source i = t - l, row = the pick made there
+            const double *base = Gs + (size_t)tl * L * ENT + bcol;
+            double acc = 0.0;
+            const double lm_t = P.mt ? Lms[tl * LT_ROW + bcol] : 0.0;       // marginal term: in front of x1
+            for (int l0 = 1; l0 <= L; l0 += CWG_CHUNK) {
+                double x[CWG_CHUNK];
+                int rows[CWG_CHUNK];
+                // (the picks come out of the ring first, all reads in flight together, then the table reads; a term that does
+                // not exist reads the lag-1 slot and is replaced by +0.0)
 #pragma unroll
-            for (int u = 0; u < CWG_CHUNK; u++)
-                if (l0 + u <= L) acc = (l0 + u == 1) ? (P.mt ? lm_t + x[u] : x[u]) : acc + x[u];
+                for (int u = 0; u < CWG_CHUNK; u++) {
+                    const int l = l0 + u;
+                    const int le = (l <= L && t - l >= 0) ? l : 1;
+                    rows[u] = (int)myring[(t - le) & (CW_MAX_LG - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < CWG_CHUNK; u++) {
+                    const int l = l0 + u;
+                    const bool have = l <= L && t - l >= 0;
+                    const int le = have ? l : 1;
+                    int row = live ? rows[u] : 0;                   // (an idle lane group reads row 0: its ring holds nothing)
+                    if (row >= ROWS) row = 0;
+                    const double v = base[(le - 1) * ENT + row * COLS];
+                    x[u] = have ? v : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < CWG_CHUNK; u++)
+                    if (l0 + u <= L) acc = (l0 + u == 1) ? (P.mt ? lm_t + x[u] : x[u]) : acc + x[u];
+            }
+            if (R == 5 && b >= R) acc = -INFINITY;
+            double m = vmax_f64(acc, dpp_f64<0xB1>(acc));
+            m = vmax_f64(m, dpp_f64<0x4E>(m));
+            if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));
+            const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
+            const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));
+            if (live && b == 0) ring[q][t & (CW_MAX_LG - 1)] = (uint8_t)d;      // (read again at the earliest one step later, by this lane group only)
+            const int gt = t - t0 - 1;
+            word |= d << (WB * (gt % PPW));
+            if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
+                if (live && b == 0) P.hist[((size_t)s * nw_e + word_i) * CW_K + q] = word;
+                word = 0;
+                word_i++;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (R == 5 && b >= R) acc = -INFINITY;
-        double m = vmax_f64(acc, dpp_f64<0xB1>(acc));
-        m = vmax_f64(m, dpp_f64<0x4E>(m));
-        if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));
-        const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
-        const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));
-        if (live && b == 0) ring[q][t & (CW_MAX_LG - 1)] = (uint8_t)d;      // (read again at the earliest one step later, by this lane group only)
-        const int gt = t - t0 - 1;
-        word |= d << (WB * (gt % PPW));
-        if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
-            if (live && b == 0) P.hist[((size_t)s * nw_e + word_i) * CW_K + q] = word;
-            word = 0;
-            word_i++;
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     // the exit state: the last L picks, lag 1 first (out of the ring); its hash; closure as in k_cwalk
     __syncthreads();

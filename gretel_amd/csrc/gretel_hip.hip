@@ -1601,8 +1601,15 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
         }
         if (r == 0) prof_begin(h, GH_K_SEG);                // (bench.py: the pool walker alone, first round of a path)
         if (cw_digit_mode(h)) {
-            if (!h->cw_wide) hipLaunchKernelGGL((k_cwalkg<4>), dim3(g.S), dim3(CW_K * cw_lanes(4)), 0, h->stream, P);
-            else hipLaunchKernelGGL((k_cwalkg<5>), dim3(g.S), dim3(CW_K * cw_lanes(5)), 0, h->stream, P);
+            static std::atomic<size_t> set_g[2][64];
+            const int R = h->cw_wide ? 5 : 4;
+            const size_t lds_g = cwg_lds_bytes(h->L, R);
+            if (lds_g > set_g[R - 4][h->dev & 63]) {
+                hipFuncSetAttribute(R == 4 ? (const void *)k_cwalkg<4> : (const void *)k_cwalkg<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g);
+                set_g[R - 4][h->dev & 63] = lds_g;
+            }
+            if (!h->cw_wide) hipLaunchKernelGGL((k_cwalkg<4>), dim3(g.S), dim3(CW_K * cw_lanes(4)), lds_g, h->stream, P);
+            else hipLaunchKernelGGL((k_cwalkg<5>), dim3(g.S), dim3(CW_K * cw_lanes(5)), lds_g, h->stream, P);
         } else
         switch (h->L) {
             // (the table over the symbols: 3 bits per pick, CW_MAX_L5 lags in a state)
