@@ -312,7 +312,13 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
             }
         }
     };
+    // the keys of the pool behind the segment being walked, for the closure search at its end: fetched while the walk has not
+    // begun (one lane per key) instead of one dependent global load per key behind it
+    __shared__ cw_key s_next[CW_K];
+    __shared__ int s_nn;
     for (int hop = 0; ; hop++) {
+    if (tid < CW_K) s_next[tid] = seg + 1 < g.S ? P.keys[(size_t)(seg + 1) * CW_K + tid] : 0ull;
+    if (tid == 0) s_nn = seg + 1 < g.S ? P.npool[seg + 1] : 0;      // (entries behind the count are leftovers of earlier tensors)
     fetch(t0);
     for (int c0 = t0; c0 < t1; c0 += CH) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
@@ -368,6 +374,16 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     }
     // the segment is walked.  hop 0: the entry's own walk; later hops: a walk on behalf of a pending request of pool `seg`
     int go_on = 0;
+    bool there = false;
+    {
+        // every lane of the group looks at its share of the next pool's keys (all hold the same sigma); a barrier of the chunk
+        // loop stands between the staging above and this
+        const int nn = s_nn < CW_K ? s_nn : CW_K;
+        bool mine = false;
+        for (int k = b; k < CW_K; k += LPE) mine |= k < nn && s_next[k] == sigma;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
+        there = ((bal >> shift) & ((1ull << LPE) - 1ull)) != 0ull;
+    }
     if (active && b == 0) {
         if (hop == 0) {
             P.exits[(size_t)s * CW_K + q] = sigma;
@@ -383,11 +399,6 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
         // itself, from that state, and the request carries the walk -- the chain of a NEW track is found in one launch, not
         // one segment per round.
         if (seg + 1 < g.S) {
-            const cw_key *kn = P.keys + (size_t)(seg + 1) * CW_K;
-            bool there = false;
-            const int nn = P.npool[seg + 1];              // (entries behind the count are leftovers of earlier tensors)
-            for (int k = 0; k < nn && k < CW_K; k++)
-                if (kn[k] == sigma) { there = true; break; }
             if (!there) {
                 const int slot = atomicAdd(&P.npend[seg + 1], 1);
                 if (slot < CW_K) {
