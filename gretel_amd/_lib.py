@@ -112,6 +112,7 @@ def load():
         "gh_profile_bytes": [vp, i32, P(dbl)],
         "gh_profile_overhead": [vp, i32, vp],
         "gh_debug_walk_clock": [vp, vp],
+        "gh_debug_pool_geometry": [i32, i32, i32, vp],
         "gh_coverage_sites": [i32, vp, vp, vp, i64, C.c_int32, C.c_int32, C.c_int32, vp, vp],
     }
     for name, args in sigs.items():

@@ -2684,6 +2684,20 @@ extern "C" int gh_profile_overhead(gh_t *h, int reps, double out[2])
     return GH_OK;
 }
 
+extern "C" int gh_debug_pool_geometry(int32_t n_snps, int32_t L, int32_t five, int64_t out[6])
+{
+    if (!out || n_snps < 1 || L < CW_MIN_L || L > CW_MAX_LG) return fail(GH_ERR_ARG, "pool geometry: n_snps >= 1, %d <= L <= %d", CW_MIN_L, CW_MAX_LG);
+    const int R = five ? 5 : 4;
+    const cw_geom g = cw_geometry(n_snps, L);
+    const bool packed = five ? L <= CW_MAX_L5 : L <= CW_MAX_L;
+    out[0] = g.S; out[1] = g.seglen;
+    out[2] = packed ? cw_chunk(L, R) : cwg_chunk(L, R);
+    out[3] = (int64_t)(packed ? cw_lds_bytes(L, R) : cwg_lds_bytes(L, R));
+    out[4] = packed ? 1 : 0;
+    out[5] = CW_K * cw_lanes(R);
+    return GH_OK;
+}
+
 extern "C" int gh_debug_walk_clock(gh_t *h, uint64_t out[4])
 {
     if (!h || !out) return fail(GH_ERR_ARG, "null argument");

@@ -89,6 +89,8 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
     uint4 *iti = reinterpret_cast<uint4 *>(winf + CH);
     uint32_t *wfast = reinterpret_cast<uint32_t *>(iti + 2 * CH);     // [CH / 10] 1: every target of the word has four candidates and four-candidate predecessors             // [CH] what a step of the state walk needs of its target: .x = NI | R_t << 12 | offset << 15, .y = 1.0f / NI
 
+    __shared__ int s_next_item;                                    // the next work item of (1b) to be drawn
+
     unsigned sigma[SPT];
     bool live[SPT];                                                // (threads beyond the entry states walk state 0 and store nothing)
     unsigned n_entry = 0;
@@ -181,7 +183,7 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
                 const unsigned mg = rcp15(r1) | (rcp15(r2) << 16);
                 for (unsigned q = 0; q < items; q++) iti[iinc - items + q] = make_uint4((unsigned)lane | (q << 8), rd, mg, inc - NI);
             }
-            if (lane == nc - 1) { nxo[nc] = inc; ctl[0] = nc; ctl[1] = (int)(gtot + ftot); }
+            if (lane == nc - 1) { nxo[nc] = inc; ctl[0] = nc; ctl[1] = (int)(gtot + ftot); s_next_item = 0; }
         }
         segm_lds_barrier();
         const int nc = ctl[0], nitems = ctl[1];
@@ -273,7 +275,14 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
         // scratch memory -- 176 bytes per lane, 8 us per launch, the first version of this file).  Either way the sum of a state is
         // built lag ascending -- acc = x_1; acc += x_2; ... -- like everywhere.  Lag l of chunk-local target tl comes from slot
         // tl + LC - l.
-        for (int it = wave; it < nitems; it += SEG_THREADS / 64) {
+        // (items are DRAWN, not dealt: a wavefront that is through with its item takes the next of the list -- the general ones stand
+        // first, so whoever holds one is passed by while the others work the fast ones off; dealt round-robin, a chunk with more
+        // than sixteen general items left two of them on one wavefront and the other fifteen waiting)
+        for (;;) {
+            int it = 0;
+            if (lane == 0) it = atomicAdd(&s_next_item, 1);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= nitems) break;
             const uint4 info = iti[it];
             const int tl = __builtin_amdgcn_readfirstlane((int)(info.x & 0xffu));
             const int jb = __builtin_amdgcn_readfirstlane((int)((info.x >> 8) & 0xffu));

@@ -222,6 +222,11 @@ int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
 /* diagnostic builds only (-DRWS_STAMPS_ALL): the s_memtime stamps every k_rwseg workgroup of the last launch left at its phase
  * boundaries, 16 doubles per workgroup (scratch/wg_stamps.py) -- which workgroup a launch waits for, and in which phase */
 int gh_debug_segment_stamps(gh_t *h, double *out, int n_workgroups);
+/* how the candidate-pool extension (gretel/gretel.py:143-189 for 6 <= L <= 128) would cut a window of n_snps positions at lag count
+ * L, over candidate ranks (five = 0) or over the symbols A C G T - (five = 1); no handle, no GPU: out[0] = segments, out[1] = positions
+ * per segment, out[2] = targets per LDS chunk of the walker, out[3] = bytes of dynamic LDS it is launched with, out[4] = 1 if a state
+ * is a packed 64-bit word (k_cwalk), 0 if bytes next to a hash (k_cwalkg), out[5] = threads per workgroup */
+int gh_debug_pool_geometry(int32_t n_snps, int32_t L, int32_t five, int64_t out[6]);
 /* algorithmic bytes of the last launch of each kernel */
 int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch);
 
