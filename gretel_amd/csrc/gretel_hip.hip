@@ -118,6 +118,9 @@ struct gh_handle {
     uint8_t *cm5snap;      // [N+2] candidate bits as the last k_seg saw them
     size_t fuse_lds;       // LDS of k_rw's fused prologue for this spin's state space
     bool band_zero;        // the tensor holds nothing but zeros (gh_create, gh_clear; until something is added): k_fill_own may store instead of add
+    void *tband;           // column conditionals, lane groups of 16 / 32: the band once more, TO-major (tband[bidx(W, p, d, b, a)] = band[bidx(W, p, d, a, b)])
+    bool lt_inc_seg;       // lt_inc_path was left by a reweight behind a segment-parallel walk (k_rw / k_rwseg keep the table under every conditional)
+    uint64_t band_epoch, tband_epoch;      // tband mirrors the band iff equal: everything that writes the band counts, k_rw<.., COL> keeps both
     void *seg_halo;        // k_rwseg: per segment, the band blocks of the L positions in front of it (k_emit's copy)
     size_t seg_halo_bytes;
     bool rws;              // inside a gh_spin whose paths run as k_rwseg + k_scan + k_emit (segwalk.hpp)
@@ -319,7 +322,7 @@ static void free_handle(gh_handle *h)
     if (!h) return;
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
-    hipFree(h->band); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
+    hipFree(h->band); hipFree(h->tband); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->rinfo); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
@@ -401,6 +404,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->ew_buf = nullptr;
     memset(h->fill_seen, 0, sizeof h->fill_seen);
     h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = true;      // (the allocation is zeroed below / above: gh_create)
+    h->tband = nullptr; h->band_epoch = 1; h->tband_epoch = 0; h->lt_inc_seg = false;
     h->have_orig = false;
     h->lt_inc_path = nullptr; h->d_rw_path = nullptr;
     h->prof = 0;
@@ -469,7 +473,7 @@ extern "C" int gh_clear(gh_t *h)
     memset(&h->stats, 0, sizeof h->stats);
     h->stats.L = 1;
     h->L = 1;
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = true;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = true; h->band_epoch++;
     h->have_orig = false;
     h->cw_ready = false; h->cw_off = false;
     return GH_OK;
@@ -716,7 +720,7 @@ extern "C" int gh_fill(gh_t *h, const gh_reads_t *r, int use_end_sentinels, gh_f
         prof_end(h, GH_K_FILL, bytes);
         { int rc_ = post_launch(h, "k_fill"); if (rc_) return rc_; }
     }
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; if (r->n_reads > 0) h->band_zero = false;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; if (r->n_reads > 0) h->band_zero = false; h->band_epoch++;
     h->cw_ready = false; h->cw_off = false;
     int rc = pull_fill_state(h, "gh_fill");
     if (h->stats.n_slices > 0) {                                   // util.py:333
@@ -787,7 +791,7 @@ extern "C" int gh_add_batch(gh_t *h, const uint8_t *a, const uint8_t *b, const i
             hipLaunchKernelGGL(k_add_batch<double>, dim3(nb), dim3(block), 0, h->stream, (double *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
         else
             hipLaunchKernelGGL(k_add_batch<float>, dim3(nb), dim3(block), 0, h->stream, (float *)h->band, h->N, h->W, da, db, di, dj, n, h->dstate);
-        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = false;
+        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = false; h->band_epoch++;
         int64_t s0 = h->stats.n_slices, c0 = h->stats.n_crumbs, v0 = h->stats.covered_snps;
         rc = pull_fill_state(h, "gh_add_batch");
         h->stats.n_slices = s0; h->stats.n_crumbs = c0; h->stats.covered_snps = v0;
@@ -820,7 +824,7 @@ extern "C" int gh_reweight_obs(gh_t *h, int a, int b, int i, int j, double ratio
             hipLaunchKernelGGL(k_reweight_one<float>, dim3(1), dim3(1), 0, h->stream, (float *)h->band + idx, ratio, d_rem);
         HIPCHK(hipMemcpyAsync(&rem, d_rem, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr;
+        h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_epoch++;
     }
     if (removed) *removed = rem;
     return GH_OK;
@@ -887,23 +891,31 @@ static int ensure_lt(gh_handle *h, bool baked = false, bool derived = true)
     const bool need_derived = derived && h->ht_stale;
     if (!h->dirty_lt && h->lt && h->lt_L == h->L && h->lt_baked == want_baked && !need_derived) return GH_OK;
     if ((rc = alloc_lt(h))) return rc;
-    const bool inc_ok = h->lt_inc_path && lt_incremental_ok(h) && h->lt_baked == want_baked && !need_derived;
+    // what kept the table current since the last build: k_marg<T,true> behind a serial walker (rows, conditionals A / B without the
+    // marginal term), or k_rw / k_rwseg behind a segment-parallel walk (every conditional: rows or columns; the derived tables of the
+    // depth-2 serial walker are refreshed by ROWS only, so under a column conditional or the marginal term a caller that wants those
+    // gets a full build).  Round 3 rebuilt the whole table at every look of a pool spin under C / E / the marginal term.
+    const bool col_or_mt = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E || h->cfg.marginal_term;
+    const bool inc_rule = h->lt_inc_seg ? (rw_incremental_ok(h) && (!col_or_mt || !derived)) : lt_incremental_ok(h);
+    const bool inc_ok = h->lt_inc_path && inc_rule && h->lt_baked == want_baked && !need_derived;
     const uint8_t *inc = inc_ok ? h->lt_inc_path : nullptr;
     const size_t total = inc ? (size_t)h->N * 4 : (size_t)(h->N + LT_PAD) * h->L * LT_BLK;
     const int block = 256;
     size_t nb = (total + block - 1) / block;
     if (nb > 256 * 16) nb = 256 * 16;
+    // (column conditionals: the to-major copy, while it mirrors the band, makes the column sums contiguous reads)
+    const void *tb_lt = (h->tband && h->tband_epoch == h->band_epoch) ? h->tband : nullptr;
     prof_begin(h, GH_K_LT);
     if (h->cfg.storage == GH_STORAGE_F64)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const double *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, want_baked ? 1 : 0, h->cnt, h->nvalid, h->cmask,
                            h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L),
-                           derived ? h->ht : (double *)nullptr, derived ? h->yt : (double *)nullptr, h->sm);
+                           derived ? h->ht : (double *)nullptr, derived ? h->yt : (double *)nullptr, h->sm, (const double *)tb_lt);
     else
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)nb), dim3(block), 0, h->stream, (const float *)h->band,
                            h->N, h->W, h->L, h->cfg.cond_mode, want_baked ? 1 : 0, h->cnt, h->nvalid, h->cmask,
                            h->minfo, h->lt, h->dstate, inc, (const win_desc *)nullptr, 0, walk_ranked_ok(h->wmode, h->L),
-                           derived ? h->ht : (double *)nullptr, derived ? h->yt : (double *)nullptr, h->sm);
+                           derived ? h->ht : (double *)nullptr, derived ? h->yt : (double *)nullptr, h->sm, (const float *)tb_lt);
     const int wl = h->W < h->L ? h->W : h->L;
     // algorithmic bytes: full = read the band cells within reach + write G; after a fused reweight = the two flags
     prof_end(h, GH_K_LT, inc ? 8.0
@@ -1325,8 +1337,10 @@ static int launch_rwseg(gh_handle *h, const uint8_t *d_prev, gh_path_rec *d_prev
     prof_end(h, GH_K_WALK, (double)h->N * ((1.0 + (double)h->L) * CELL * esize(h) + 28.0));
     // (what launch_reweight_marg notes behind a fused reweight: the table is current up to the rows this path's reweight wrote)
     h->lt_inc_path = d_prev;
+    h->lt_inc_seg = true;
     h->dirty_lt = true;
     h->dirty_marg = false;
+    h->band_epoch++;
     return post_launch(h, "k_rwseg/k_scan/k_emit");
 }
 
@@ -1370,12 +1384,18 @@ static int ensure_partial(gh_handle *h, int nb, int slots)
 // round), else 8; blocks per path accordingly (also the stride of the per-path partial sums of the removed mass)
 // (16: row conditionals with bands up to 32 and at most 16 lags -- the distances beyond 16 take a second round, the table
 // entries are dealt out over the group anyway, and the marginals, 7 lanes of every group, cost a wavefront half as much)
+static bool rw_col(const gh_handle *h) { return h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E; }
+// column conditionals beyond the 8-lane groups: k_rw reads its columns from a to-major copy of the band (GH_RW_TBAND=0: from the staged block)
+static bool rw_tband(const gh_handle *h)
+{
+    static const bool off = getenv("GH_RW_TBAND") && atoi(getenv("GH_RW_TBAND")) == 0;
+    return rw_col(h) && (h->W > 8 || h->L > 8) && !off;
+}
 static int rw_lanes(const gh_handle *h)
 {
     if (!(h->W > 8 || h->L > 8)) return 8;
-    const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;
     static const bool no16 = getenv("GH_RW_LP16") && atoi(getenv("GH_RW_LP16")) == 0;
-    return (!col && h->W <= 32 && h->L <= 16 && !no16) ? 16 : 32;
+    return (h->W <= 32 && h->L <= 16 && !no16 && (!rw_col(h) || rw_tband(h))) ? 16 : 32;
 }
 static int rw_blocks(const gh_handle *h, bool seg) { return (int)(((size_t)(h->N + 1) * (seg ? rw_lanes(h) : 8) + 255) / 256); }
 
@@ -1407,8 +1427,8 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         /* COL: the band block of the workgroup's positions staged in LDS when it fits (k_rw) */                                   \
         const size_t blk_b = (size_t)(256 / LP) * NSYM * h->W * NSYM * sizeof(T);                                                 \
         /* | 2: `cnt` holds the row sums of the band as it stands (k_rw takes the rows a reweight does not touch from there) */     \
-        const int stage = ((COL && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0) |  \
-                          ((!h->dirty_marg && !(getenv("GH_RW_CNT") && atoi(getenv("GH_RW_CNT")) == 0)) ? 2 : 0);                  \
+        const int stage = ((COL && !use_tb && blk_b <= 64 * 1024 && !(getenv("GH_RW_STAGE") && atoi(getenv("GH_RW_STAGE")) == 0)) ? 1 : 0) |  \
+                          ((!h->dirty_marg && !(getenv("GH_RW_CNT") && atoi(getenv("GH_RW_CNT")) == 0)) ? 2 : 0) | ((COL && use_tb) ? 4 : 0); \
         const size_t lds_b = fuse_lds + ((stage & 1) ? blk_b : 0);                                                                \
         static std::atomic<size_t> set_lds[64];                                                                                   \
         if (lds_b > set_lds[h->dev & 63]) {                                                                                       \
@@ -1417,12 +1437,24 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         }                                                                                                                         \
         hipLaunchKernelGGL((k_rw<T, LP, COL, FZ>), dim3(nb), dim3(block), lds_b, h->stream, (T *)h->band, h->N, h->W, h->cnt, h->marg, h->nvalid, \
                            h->cmask, h->minfo, h->dstate, d_path, ratio, partial, lt_rows, h->L, h->cfg.cond_mode,                \
-                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr, stage, fz, (int)fuse_lds); \
+                           (const double *)h->seg_min, d_rec, nseg_arg, h->sm, h->cfg.offer_zero, h->need_rinfo ? h->rinfo : (double *)nullptr, stage, fz, (int)fuse_lds, \
+                           (T *)(use_tb ? h->tband : nullptr));                                                                   \
     } while (0)
 #define GH_RW_LAUNCH2(T, LP) do { if (col) GH_RW_LAUNCH(T, LP, true, false); else GH_RW_LAUNCH(T, LP, false, false); } while (0)
 #define GH_RW_LAUNCHF(T) do { if (col) GH_RW_LAUNCH(T, 8, true, true); else GH_RW_LAUNCH(T, 8, false, true); } while (0)
         const bool wide = rw_lanes(h) == 32, mid = rw_lanes(h) == 16;
-        const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;      // the table entries a reweighted cell feeds: a column
+        const bool col = rw_col(h);                         // the table entries a reweighted cell feeds: a column
+        // the to-major copy: made (or made again, when something else wrote the band since) right here, kept by the kernel
+        const bool use_tb = rw_tband(h) && !(h->fuse && nseg_arg == 0);
+        if (use_tb) {
+            const size_t nel = h->n_cells * CELL;
+            if (!h->tband && hipMalloc(&h->tband, nel * esize(h)) != hipSuccess) { h->tband = nullptr; return fail(GH_ERR_NOMEM, "hipMalloc for the to-major band failed"); }
+            if (h->tband_epoch != h->band_epoch) {
+                const unsigned nbt = (unsigned)((nel + 255) / 256);
+                if (h->cfg.storage == GH_STORAGE_F64) hipLaunchKernelGGL(k_band_to_major<double>, dim3(nbt), dim3(256), 0, h->stream, (const double *)h->band, (double *)h->tband, nel, h->W);
+                else hipLaunchKernelGGL(k_band_to_major<float>, dim3(nbt), dim3(256), 0, h->stream, (const float *)h->band, (float *)h->tband, nel, h->W);
+            }
+        }
         // behind k_seg + k_scan without a k_emit (h->fuse): the kernel finds its picks itself and writes the path to d_path / d_lmsel
         fuse_params fz;
         memset(&fz, 0, sizeof fz);
@@ -1434,7 +1466,7 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
         }
         if (fz.hist) {                                      // (three-launch spins: lane groups of 8 only, gh_spin decides)
             if (h->cfg.storage == GH_STORAGE_F64) GH_RW_LAUNCHF(double); else GH_RW_LAUNCHF(float);
-        } else if (mid) { if (h->cfg.storage == GH_STORAGE_F64) GH_RW_LAUNCH(double, 16, false, false); else GH_RW_LAUNCH(float, 16, false, false); }
+        } else if (mid) { if (h->cfg.storage == GH_STORAGE_F64) GH_RW_LAUNCH2(double, 16); else GH_RW_LAUNCH2(float, 16); }
         else if (h->cfg.storage == GH_STORAGE_F64) { if (wide) GH_RW_LAUNCH2(double, 32); else GH_RW_LAUNCH2(double, 8); }
         else { if (wide) GH_RW_LAUNCH2(float, 32); else GH_RW_LAUNCH2(float, 8); }
 #undef GH_RW_LAUNCHF
@@ -1460,8 +1492,11 @@ static int launch_reweight_marg(gh_handle *h, const uint8_t *d_path, double rati
                                (lt_ok ? (double)h->N * ((double)wl * 7 * esize(h) + (double)h->L * LT_ROW * 8.0) : 0.0));
     { int rc_ = post_launch(h, "k_marg<reweight>"); if (rc_) return rc_; }
     h->lt_inc_path = lt_ok ? d_path : nullptr;
+    h->lt_inc_seg = seg;
     h->dirty_lt = true;
     h->dirty_marg = false;
+    h->band_epoch++;
+    if (seg && rw_tband(h) && !(h->fuse && nseg_arg == 0)) h->tband_epoch = h->band_epoch;      // (the kernel wrote both)
     return GH_OK;
 }
 
@@ -2437,12 +2472,12 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                 hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), ng), dim3(256), 0, st, (const double *)nullptr, N, W, L,
                                    h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                    (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm);
+                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const double *)nullptr);
             else
                 hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)(inc ? lt_nb_inc : lt_nb), ng), dim3(256), 0, st, (const float *)nullptr, N, W, L,
                                    h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
                                    (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
-                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm);
+                                   inc, gwd, s, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const float *)nullptr);
             const bool sample = g == 0 && b->prof_every > 0 && s > 0 && (s % b->prof_every) == 0;
             if (sample) { b->prof_windows = ng; pmark(0, st); }
             launch_walk_any(bwm, N, L, P, st, ng, gwd, s);
@@ -2489,7 +2524,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     for (int w = 0; w < n; w++) {
         n_out[w] = hs[w].n_done;
         hole_at[w] = hs[w].stop ? hs[w].hole_at : 0;
-        b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true;
+        b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true; b->hs[w]->band_epoch++;
         b->hs[w]->lt_inc_path = nullptr;       // the batch reweighted many paths and maintains no walker tables: rebuild in full
     }
     return GH_OK;
@@ -2554,7 +2589,7 @@ extern "C" int gh_import_band(gh_t *h, const double *in)
         hipLaunchKernelGGL(k_import<float>, dim3(nb), dim3(256), 0, h->stream, (float *)h->band, d, n, h->W);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(d);
-    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = false;
+    h->dirty_marg = h->dirty_lt = true; h->lt_inc_path = nullptr; h->band_zero = false; h->band_epoch++;
     if (e != hipSuccess) return fail(GH_ERR_HIP, "import failed: %s", hipGetErrorString(e));
     return GH_OK;
 }

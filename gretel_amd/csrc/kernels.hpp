@@ -197,14 +197,17 @@ __device__ __forceinline__ void logtab_stage(double *t)
 template <typename T>
 __device__ __forceinline__ double log_conditional(const T *__restrict__ band, int W, int cond_mode,
                                                   const double *__restrict__ cnt,
-                                                  const int32_t *__restrict__ nvalid, int a, int b, int i, int j)
+                                                  const int32_t *__restrict__ nvalid, int a, int b, int i, int j,
+                                                  const T *__restrict__ tband = nullptr)
 {
+    // (tband: the to-major copy of the band where the host keeps one -- a column sum is then a contiguous run, same addends in
+    // the same order)
     const int l = j - i;
     double obs = 0.0, sum = 0.0;
     if (l <= W) {
         obs = (double)band[bidx(W, i, l, a, b)];
         if (cond_mode == GH_COND_A || cond_mode == GH_COND_D) sum = rowsum(band, W, i, l, a);
-        else if (cond_mode == GH_COND_C || cond_mode == GH_COND_E) sum = colsum(band, W, i, l, b);
+        else if (cond_mode == GH_COND_C || cond_mode == GH_COND_E) sum = tband ? rowsum(tband, W, i, l, b) : colsum(band, W, i, l, b);
     }
     double den;
     if (cond_mode == GH_COND_A || cond_mode == GH_COND_E) den = (double)nvalid[j] + sum;
@@ -962,13 +965,13 @@ __host__ __device__ constexpr size_t walk_lds_bytes(int L, bool deep)
 template <typename T>
 __device__ __forceinline__ double lt_entry(const T *band, int N, int W, int cond_mode, int bake_lm,
                                            const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
-                                           const double *minfo, int i, int a6, int l, int b5, symmap sm)
+                                           const double *minfo, int i, int a6, int l, int b5, symmap sm, const T *tband = nullptr)
 {
     const int snp = i + l;
     if (!(i < N && snp <= N && (a6 < 5 || i == 0))) return 0.0;
     const int b = vsym(sm, b5);
     if (!((CM_CAND(cmask[snp]) >> b) & 1)) return -INFINITY;
-    double v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(sm, a6), b, i, snp);
+    double v = log_conditional(band, W, cond_mode, cnt, nvalid, fsym(sm, a6), b, i, snp, tband);
     if (bake_lm && l == 1) v = minfo[(size_t)snp * MINFO + b5] + v;
     return v;
 }
@@ -987,7 +990,7 @@ __host__ __device__ constexpr int deep_nyp(int L) { return L > 2 ? ((L - 2 + 1) 
 template <typename T>
 __device__ __forceinline__ double lt_entry_ranked(const T *band, int N, int W, int cond_mode, int bake_lm,
                                                   const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
-                                                  const double *minfo, int i, int row6, int lag, int col5, symmap sm)
+                                                  const double *minfo, int i, int row6, int lag, int col5, symmap sm, const T *tband = nullptr)
 {
     const int snp = i + lag;
     if (!(i < N && snp <= N && row6 != 4)) return 0.0;
@@ -995,7 +998,7 @@ __device__ __forceinline__ double lt_entry_ranked(const T *band, int N, int W, i
     if (a6 < 4) a6 = nth_set5(cm5_of_cmask(sm, CM_CAND(cmask[i])), a6);
     if (a6 < 0) return 0.0;
     const int b5 = nth_set5(cm5_of_cmask(sm, CM_CAND(cmask[snp])), col5);
-    return b5 >= 0 ? lt_entry(band, N, W, cond_mode, bake_lm, cnt, nvalid, cmask, minfo, i, a6, lag, b5, sm) : -INFINITY;
+    return b5 >= 0 ? lt_entry(band, N, W, cond_mode, bake_lm, cnt, nvalid, cmask, minfo, i, a6, lag, b5, sm, tband) : -INFINITY;
 }
 
 // inc_path == nullptr: rebuild every entry.  Otherwise (conditional A or B, no marginal term, and the
@@ -1008,7 +1011,7 @@ __global__ void __launch_bounds__(256)
 k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term /* = bake_lm, see above */,
      const double *cnt, const int32_t *nvalid, const uint32_t *cmask,
      const double *minfo, double *G, dev_state *st, const uint8_t *inc_path, const win_desc *wd, int spin,
-     int allow_ranked, double *Ht, double *Yt, symmap sm)
+     int allow_ranked, double *Ht, double *Yt, symmap sm, const T *tband)
 {
     if (wd) {
         const win_desc &d = wd[blockIdx.y];
@@ -1072,8 +1075,8 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term /* = b
         r /= L;
         const int a6 = (int)(r % 6);
         const int i = (int)(r / 6);
-        G[t] = ranked ? lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5, sm)
-                      : lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5, sm);
+        G[t] = ranked ? lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5, sm, tband)
+                      : lt_entry(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, a6, l, b5, sm, tband);
     }
     if (!(ranked && Ht)) return;
     // the derived tables in full, from the band (other threads are still writing G)
@@ -1084,9 +1087,9 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term /* = b
         double v = 0.0;
         if (tt >= 1 && tt - 1 < nsrc_all) {
             const int s1 = tt - 1, s2 = tt - 2;
-            v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s1, s1 == 0 ? 5 : a1, 1, b, sm);
+            v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s1, s1 == 0 ? 5 : a1, 1, b, sm, tband);
             if (tt >= 2 && L >= 2)
-                v = v + lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s2, s2 == 0 ? 5 : a2, 2, b, sm);
+                v = v + lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, s2, s2 == 0 ? 5 : a2, 2, b, sm, tband);
         }
         Ht[q] = v;
     }
@@ -1096,7 +1099,7 @@ k_lt(const T *band, int N, int W, int L, int cond_mode, int marginal_term /* = b
             const int i = (int)(q / ypos), r = (int)(q % ypos), wb = r / nyp, li = r % nyp;
             double v = 0.0;
             if (i < nsrc_all && li + 2 < L)
-                v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, i == 0 ? 5 : (wb >> 2), li + 3, wb & 3, sm);
+                v = lt_entry_ranked(band, N, W, cond_mode, marginal_term, cnt, nvalid, cmask, minfo, i, i == 0 ? 5 : (wb >> 2), li + 3, wb & 3, sm, tband);
             Yt[q] = v;
         }
     }
@@ -2053,6 +2056,19 @@ __global__ void k_reweight_one(T *p, double ratio, double *removed)
 }
 
 // the exported / imported tensor keeps the distance-major order [(N+2)][W][7][7] (cell (i, i+d) as 49 values)
+// the band once more, TO-major: tb[bidx(W, p, d, b, a)] = band[bidx(W, p, d, a, b)] (per position the symbol pair transposed) --
+// k_rw under the column conditionals reads a cell's COLUMN as one contiguous run there (gretel/gretel.py:79-98 under a
+// conditional whose denominator is a column sum)
+template <typename T>
+__global__ void __launch_bounds__(256) k_band_to_major(const T *__restrict__ band, T *__restrict__ tb, size_t n, int W)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;      // element of the copy: [p][b][d][a]
+    if (e >= n) return;
+    const size_t pe = (size_t)NSYM * W * NSYM, p = e / pe;
+    const int r = (int)(e - p * pe), a = r % NSYM, d1 = (r / NSYM) % W, b = r / (NSYM * W);
+    tb[e] = band[p * pe + ((size_t)a * W + d1) * NSYM + b];
+}
+
 template <typename T>
 __global__ void k_export(const T *__restrict__ band, double *__restrict__ out, size_t n, int W)
 {

@@ -745,11 +745,14 @@ __host__ __device__ inline size_t rw_fuse_lds_bytes(int N, int L, int R, int ppb
 
 // (row mode within 72 VGPRs = seven waves per SIMD: at C5 the kernel is a stream of dependent round trips and its
 // throughput follows the waves in flight -- 78 registers, six waves, cost 10 of 50 us)
+#ifndef RW_COL_WAVES
+#define RW_COL_WAVES 4          /* (5: 96 registers and spills, no faster; 6: 80 registers, 240 bytes of scratch per lane, 100 us at C5) */
+#endif
 template <typename T, int LP, bool COL, bool FUSED>
-__global__ void __launch_bounds__(256, (COL || FUSED) ? 4 : 7)
+__global__ void __launch_bounds__(256, FUSED ? 4 : (COL ? RW_COL_WAVES : 7))
 k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t *cmask, double *minfo, dev_state *st,
      const uint8_t *path, double min_remove, double *partial, double *G, int L, int cond_mode, const double *segmin,
-     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage, fuse_params fz, int fuse_lds)
+     gh_path_rec *rec, int nseg_arg, symmap sm, int offer_zero, double *rinfo, int stage, fuse_params fz, int fuse_lds, T *tband)
 {
     __shared__ double s_min4[4], s_sum4[4];
     __shared__ double s_logtab[256];
@@ -844,11 +847,20 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     // the row sums of cell (p, p+1) = the counts at p.  A reweight moves one element of that cell, in the row of the path's symbol:
     // every other row's sum is the one the pass before left in `cnt` (stage & 2: the host knows cnt to be current), and that
     // row is the one lane 0 reads anyway -- one 64-byte line per position instead of seven (bands of 20: 384 of ~1000 bytes read)
-    const bool cnt_ok = !COL && (stage & 2);
+    // COL with the to-major copy of the band (stage & 4; tband[bidx(W, p, d, b, a)] = band[bidx(W, p, d, a, b)]): the COLUMN a lane
+    // needs is a contiguous run there, nothing is staged, and the row sums come from cnt as well -- lane 0 then also reads the row of
+    // the path's symbol of cell (p, p+1) from the band itself (rowA), the one row whose sum moves
+    const bool tb = COL && (stage & 4);
+    const bool cnt_ok = (!COL || tb) && (stage & 2);
     T crow[NSYM];
+    T rowA[NSYM];
     double cold = 0.0;
     if (cnt_ok) {
         cold = (act && s < NSYM) ? cnt[(size_t)pp * 8 + s] : 0.0;
+        if (COL) {
+#pragma unroll
+            for (int x = 0; x < NSYM; x++) rowA[x] = (act && s == 0) ? band[bidx(W, pp, 1, a, x)] : (T)0;
+        }
     } else if (!(COL && (stage & 1))) {
 #pragma unroll
         for (int x = 0; x < NSYM; x++) crow[x] = (act && s < NSYM) ? band[bidx(W, pp, 1, s, x)] : (T)0;      // cell (p, p+1), row s
@@ -937,6 +949,10 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
         const T *lc = lp + ((size_t)(d0 <= W ? d0 : 1) - 1) * NSYM + b0;
 #pragma unroll
         for (int x = 0; x < NSYM; x++) rrow[x] = lc[(size_t)x * estride];
+    } else if (COL && tb) {
+        const T *tcol = tband + bidx(W, pp, d0 <= W ? d0 : 1, b0, 0);      // the column of symbol b0 of cell (p, p+d0): from-symbols 0..6
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) rrow[x] = need_row ? tcol[x] : (T)0;
     } else if (COL) {
 #pragma unroll
         for (int x = 0; x < NSYM; x++) rrow[x] = runp[(size_t)x * estride];
@@ -964,6 +980,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             removed += old - nw;
         }
         rowp[(size_t)esel * estride] = cur;
+        if (COL && tb) tband[bidx(W, pp, d0, b0, a)] = cur;
 #pragma unroll
         for (int x = 0; x < NSYM; x++) rrow[x] = (x == esel) ? cur : rrow[x];
         if (d0 == 1) { na = a; nb = b0; nval = cur; }
@@ -982,7 +999,7 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     if (cnt_ok) {
         // lane 0 holds the row of the path's symbol (the rewritten element in place): the same left-to-right sum in the storage type
 #pragma unroll
-        for (int x = 0; x < NSYM; x++) acc = acc + rrow[x];
+        for (int x = 0; x < NSYM; x++) acc = acc + (COL ? ((x == nb) ? nval : rowA[x]) : rrow[x]);
         const double suma = __shfl((double)acc, 0, LP);
         mine = (s == na) ? suma : cold;
     } else {
@@ -1044,6 +1061,29 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
     const double nv_i = (double)nv;
     // ---- bands wider than the lane group: the remaining distances, one by one (and, COL, their table columns) -------
     // COL: entries G[p][x][l-1][col(b)] for every from-row x that exists, from the column `colT` of cell (p, p+l)
+    // one entry of a column: from-symbol FS[q] of lag l, value of the cell's element `cval`, into column `col` of its row
+    auto col_entry = [&](int l, int q, double cval, double den, int col) __attribute__((always_inline)) {
+        const int x6 = a6_of_sym(sm, q < 4 ? q : q + 1);       // the six from-symbols a path can hold: 0 1 2 3 5 6
+        int row6 = x6;
+        if (x6 == 5) { if (p != 0) return; }                   // the '_' row exists at position 0 only
+        else if (ranked) {
+            if (!((cm5 >> x6) & 1u)) return;                   // not a candidate of p: no row
+            row6 = __popc(cm5 & ((1u << x6) - 1u));
+            if (row6 > 3) return;
+        }
+        G[(((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW + col] = gh_log10_tab((1.0 + cval) / den, s_logtab, GH_LOG_BOTH);
+    };
+    // the denominator and the column index of lag l (col < 0: no column for this symbol -- N, '_', or no candidate: a rebuild follows)
+    auto col_head = [&](const T (&colT)[NSYM], int nvt, uint32_t cmt, int b, double &den) __attribute__((always_inline)) -> int {
+        T cacc = (T)0;
+#pragma unroll
+        for (int x = 0; x < NSYM; x++) cacc = cacc + colT[x];
+        den = (cond_mode == GH_COND_C ? nv_i : (double)nvt) + (double)cacc;
+        const int b5c = a6_of_sym(sm, b);
+        const uint32_t cj5 = cm5_of_cmask(sm, cmt);
+        if (b5c >= 5 || !((cj5 >> b5c) & 1u)) return -1;
+        return ranked ? __popc(cj5 & ((1u << b5c) - 1u)) : b5c;
+    };
     auto table_col = [&](int l, const T (&colT)[NSYM], int nvt, uint32_t cmt, int b) __attribute__((always_inline)) {
         T cacc = (T)0;
 #pragma unroll
@@ -1093,20 +1133,54 @@ k_rw(T *band, int N, int W, double *cnt, double *marg, int32_t *nvalid, uint32_t
             const double old = (double)*e;
             const double nw = old - ratio * old;
             *e = (T)nw;
+            if (COL && tb) tband[bidx(W, p, d, b, a)] = (T)nw;
             removed += old - nw;
             if (COL && G && p < N && d <= L && j <= N) {
                 T colT[NSYM];
 #pragma unroll
-                for (int x = 0; x < NSYM; x++) colT[x] = band[bidx(W, p, d, x, b)];      // (all seven in flight; the element just rewritten is replaced)
+                for (int x = 0; x < NSYM; x++) colT[x] = tb ? tband[bidx(W, p, d, b, x)] : band[bidx(W, p, d, x, b)];      // (all seven in flight; the element just rewritten is replaced)
 #pragma unroll
                 for (int x = 0; x < NSYM; x++) colT[x] = (x == a) ? (T)nw : colT[x];
-                table_col(d, colT, nvalid[j], CM_CAND(cmask[j]), b);
+                if constexpr (LP == 8) table_col(d, colT, nvalid[j], CM_CAND(cmask[j]), b);
+                else {
+                    double den;
+                    const int col = col_head(colT, nvalid[j], CM_CAND(cmask[j]), b, den);
+#pragma unroll 1
+                    for (int q = 0; q < 6 && col >= 0; q++) col_entry(d, q, (double)pick7(colT, q < 4 ? q : q + 1), den, col);
+                }
             }
         }
     }
     // ---- the table entries of lag d0: the row of path[p] (same divisions, same log10 as k_lt), or the column ---------
     if (COL) {
-        if (lag_row) table_col(d0, rrow, nv_t, cm_t, b0);
+        if constexpr (LP >= 16) {
+            // as the rows below: the columns go through LDS and their 6 L entries are dealt out over the whole lane group -- six
+            // divisions and logarithms per lane held forty registers more than the kernel has at six waves per SIMD
+            __shared__ T s_cols[256 / LP][LP][NSYM];
+            __shared__ double s_cden[256 / LP][LP];
+            __shared__ int s_ccol[256 / LP][LP];
+            const int pl = tid / LP;
+            const int Lr = L < LP ? L : LP;
+            if (d0 <= Lr) {
+                double den = 1.0;
+                int col = -1;
+                if (lag_row) {
+                    col = col_head(rrow, nv_t, cm_t, b0, den);
+#pragma unroll
+                    for (int x = 0; x < NSYM; x++) s_cols[pl][s][x] = rrow[x];
+                }
+                s_cden[pl][s] = den;
+                s_ccol[pl][s] = col;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int e = s; e < Lr * 6; e += LP) {
+                const int l1 = e / 6, q = e - l1 * 6;
+                const int col = s_ccol[pl][l1];
+                if (col >= 0) col_entry(l1 + 1, q, (double)s_cols[pl][l1][q < 4 ? q : q + 1], s_cden[pl][l1], col);
+            }
+        } else if (lag_row) table_col(d0, rrow, nv_t, cm_t, b0);
     } else if (G && act && p < N && a != 4) {
         const int a6 = a6_of_sym(sm, a);
         const double ca = __shfl(mine, a, LP);
