@@ -76,3 +76,34 @@ def test_the_shortcuts_change_nothing(env, monkeypatch):
     _same(got, want)
     assert got["magnitude"].tolist() == want["magnitude"].tolist() or "GH_RW_LP16" in env      # (other workgroup shapes: another fixed summation tree)
     assert np.array_equal(h2.export_band(), band)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f64"])
+def test_the_to_major_copy_follows_every_other_writer_of_the_band(storage):
+    # conditional C over a band of 20: k_rw reads its columns from the to-major copy, which only k_rw itself keeps in step --
+    # whatever else writes the band between two spins (single observations, a single reweight, a reweight along a path through the
+    # one-call API) must make the next spin build the copy again
+    t = _table(21, 12.0, seed=515)
+    h, o = _pair(t, 11, cond_mode="C", storage=storage)
+    h.snapshot_original(); o.snapshot_original()            # (hp_original: against one and the same snapshot on both sides)
+    _same(h.spin(6), o.spin(6))
+    syms = "ACGT"
+    for k, (a, b, i) in enumerate([(0, 1, 40), (2, 2, 41), (3, 0, 700), (1, 3, 701)]):
+        for _ in range(3 + k):
+            h.add_observation(syms[a], syms[b], i, i + 1 + k)
+            o.add(a, b, i, i + 1 + k)
+    _same(h.spin(5), o.spin(5))
+    assert h.reweight_observation("A", "C", 40, 41, 0.5) == o.reweight_obs(0, 1, 40, 41, 0.5)
+    _same(h.spin(5), o.spin(5))
+    p, _ = o.generate_path()
+    got = h.generate_path()
+    assert np.array_equal(got[0], p)
+    assert h.reweight_from_path(got[0], 0.25) == pytest.approx(o.reweight_path(p, 0.25), rel=1e-12)
+    _same(h.spin(5), o.spin(5))
+    assert np.array_equal(h.export_band(), o.export_band())
+    # a copy starts without the to-major copy (and with its own snapshot of the original marginals: hp_original is not compared)
+    h2 = h.copy()
+    r2, r1 = h2.spin(4), h.spin(4)
+    assert np.array_equal(r2["paths"], r1["paths"]) and r2["hp_current"].tolist() == r1["hp_current"].tolist()
+    assert r2["ratio"].tolist() == r1["ratio"].tolist()
+    assert np.array_equal(h2.export_band(), h.export_band())
