@@ -91,7 +91,7 @@ __host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t
 // k_cwalkg: targets per chunk and LDS at a lag count known at run time
 __host__ __device__ inline int cwg_chunk(int L, int R)
 {
-    int c = (150 * 1024) / ((L * cw_rows(R) * cw_cols(R) + 5) * 8);
+    int c = (140 * 1024) / ((L * cw_rows(R) * cw_cols(R) + 5) * 8);      // (16 KB of static LDS beside it: the doubled rings of picks)
     return c > 64 ? 64 : (c < 1 ? 1 : c);
 }
 __host__ __device__ inline size_t cwg_lds_bytes(int L, int R) { return (size_t)cwg_chunk(L, R) * (L * cw_rows(R) * cw_cols(R) + 5) * 8; }
@@ -138,6 +138,7 @@ struct cw_params {
     // lag counts beyond what fits a 64-bit state (k_cwalkg): a key is then the HASH of the state, and the state itself -- one
     // byte per pick, lag 1 first -- sits next to it; equal hashes are confirmed on the bytes wherever two states are compared
     uint8_t *keys_d, *exits_d, *pend_d;       // [S][CW_K][LD], null in the packed mode
+    uint8_t *pend_d_c, *pend_exit_d, *pend_exit_d_c;      // k_cwalkg's run-on: the consumed set of the requests' bytes; the exit states a request arrives with
     int LD;                   // bytes per state (L rounded up to 4)
     int runon;                // k_cwalk: segments a walker may run on into behind its own (<= CW_RUNON)
     cw_key key0;              // key of the start state (0 in the packed mode)
@@ -435,13 +436,15 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
 //     ring in LDS.
 // -------------------------------------------------------------------------------------------------------------
 #define CW_MAX_LG 128
-#define CWG_CHUNK 32
+#define CWG_CHUNK 8           /* lags per unrolled group of a step (a group beyond L is skipped; the last one is padded) */
 template <int R>
 __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
 {
     constexpr int LPE = cw_lanes(R);
     constexpr int PPW = R == 4 ? 16 : 8, WB = R == 4 ? 2 : 4;
-    __shared__ uint8_t ring[CW_K][CW_MAX_LG];               // ring[q][(t - l) & 127] = pick of position t - l
+    // ring[q][(t - l) & 127] = pick of position t - l, kept TWICE (slot + 128 as well): the eight picks a group of lags needs
+    // then lie behind one another wherever the ring wraps, and their reads differ by a compile-time offset only
+    __shared__ __align__(16) uint8_t ring[CW_K][2 * CW_MAX_LG];
     extern __shared__ __align__(16) unsigned char cwg_smem[];
     constexpr int ROWS = cw_rows(R), COLS = cw_cols(R), ENT = ROWS * COLS, NTHR = CW_K * LPE;
     dev_state *st = P.st;
@@ -456,20 +459,25 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
         if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
         return;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->cur_hole = c.first_hole;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->cur_hole = c.first_hole;
+        if (P.round == 0) st->cw_open_at = 0;               // a new path: its chain is open until a k_cscan says otherwise (round 0's may be skipped)
+    }
     const cw_geom g = cw_geometry(P.N, P.L);
     const int s = blockIdx.x, tid = threadIdx.x, L = P.L, LD = P.LD;
     if (s >= g.S) return;
-    // (1) pending states join the pool (as k_cwalk; equal hashes are confirmed on the bytes)
+    // (1) pending states join the pool (as k_cwalk; equal hashes are confirmed on the bytes).  A request that arrives with its walk
+    // (run-on, round 4: as in k_cwalk) joins as a walked entry: exit state, its bytes and the picks are copied.
     __shared__ int s_n;
     if (tid < 64) {
         int n0 = P.npool[s];
-        const int np = P.npend[s] < CW_K ? P.npend[s] : CW_K;
+        const int np = P.npend_c[s] < CW_K ? P.npend_c[s] : CW_K;
         cw_key *keys = P.keys + (size_t)s * CW_K;
         int32_t *lh = P.last_hit + (size_t)s * CW_K;
+        const int nw_m = R == 4 ? g.NW : g.NW5;
         for (int k = 0; k < np; k++) {
-            const cw_key x = P.pend[(size_t)s * CW_K + k];
-            const uint8_t *xd = P.pend_d + ((size_t)s * CW_K + k) * LD;
+            const cw_key x = P.pend_c[(size_t)s * CW_K + k];
+            const uint8_t *xd = P.pend_d_c + ((size_t)s * CW_K + k) * LD;
             const bool mine_dup = tid < n0 && keys[tid] == x && cw_same_digits(P.keys_d + ((size_t)s * CW_K + tid) * LD, xd, L);
             if (__builtin_amdgcn_ballot_w64(mine_dup) != 0) continue;
             int slot = n0;
@@ -483,11 +491,20 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
                 if (mine >= P.stamp) continue;
                 slot = who;
             } else n0++;
-            if (tid == 0) { keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = 0; }
+            const bool ready = P.pend_ready_c && P.pend_ready_c[(size_t)s * CW_K + k] == P.stamp && P.stamp != 0;
+            if (tid == 0) {
+                keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = ready ? 1 : 0;
+                if (ready) P.exits[(size_t)s * CW_K + slot] = P.pend_exit_c[(size_t)s * CW_K + k];
+            }
             for (int l = tid; l < L; l += 64) P.keys_d[((size_t)s * CW_K + slot) * LD + l] = xd[l];
+            if (ready) {
+                const uint8_t *ed = P.pend_exit_d_c + ((size_t)s * CW_K + k) * LD;
+                for (int l = tid; l < L; l += 64) P.exits_d[((size_t)s * CW_K + slot) * LD + l] = ed[l];
+                for (int w = tid; w < nw_m; w += 64) P.hist[((size_t)s * nw_m + w) * CW_K + slot] = P.phist_c[((size_t)s * nw_m + w) * CW_K + k];
+            }
             __builtin_amdgcn_s_waitcnt(0);
         }
-        if (tid == 0) { P.npool[s] = n0; P.npend[s] = 0; s_n = n0; }
+        if (tid == 0) { P.npool[s] = n0; P.npend_c[s] = 0; s_n = n0; }
     }
     __syncthreads();
     const int n = s_n;
@@ -495,16 +512,20 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
     const int bcol = b < R ? b : R - 1;
     const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
     if (!__syncthreads_or(live ? 1 : 0)) return;
-    const int t0 = s * g.seglen;
-    const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
     const unsigned shift = (unsigned)(tid & 63 & ~(LPE - 1));
     const int nw_e = R == 4 ? g.NW : g.NW5;
     // the entry's last L picks into its ring: the pick of lag l (position t0 + 1 - l) at slot (t0 + 1 - l) & 127
+    for (int w = b; w < 2 * CW_MAX_LG / 4; w += LPE) reinterpret_cast<uint32_t *>(ring[q])[w] = 0u;      // (an idle lane group reads row 0)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (live)
-        for (int l = 1 + b; l <= L; l += LPE) ring[q][(t0 + 1 - l) & (CW_MAX_LG - 1)] = P.keys_d[((size_t)s * CW_K + q) * LD + (l - 1)];
+        for (int l = 1 + b; l <= L; l += LPE) {
+            const uint8_t d = P.keys_d[((size_t)s * CW_K + q) * LD + (l - 1)];
+            const int sl = (s * g.seglen + 1 - l) & (CW_MAX_LG - 1);
+            ring[q][sl] = d; ring[q][sl + CW_MAX_LG] = d;
+        }
     __syncthreads();
-    int word_i = 0;
-    unsigned word = 0;
     // the slice: Gs[tl][lag - 1][row][col] = G[t - lag][row][lag - 1][col] for the chunk's targets t = c0 + 1 + tl (position 0
     // carries '_' whatever the pick says: its row 5 in every row; positions in front of it: +0.0), then the log-marginals
     // of the targets (marginal term: in front of x1)
@@ -512,6 +533,14 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
     double *Gs = reinterpret_cast<double *>(cwg_smem);
     double *Lms = Gs + (size_t)CH * L * ENT;
     const uint8_t *myring = ring[q];
+    bool active = live;                                     // this lane group still walks
+    int seg = s, pslot = 0;
+    uint32_t *hdst = P.hist + (size_t)s * nw_e * CW_K + q;  // where its words of picks go (stride CW_K): the entry's own, or a pending slot's
+    for (int hop = 0; ; hop++) {
+    const int t0 = seg * g.seglen;
+    const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    int word_i = 0;
+    unsigned word = 0;
     for (int c0 = t0; c0 < t1; c0 += CH) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
         __syncthreads();                                        // the chunk before has been walked
@@ -537,34 +566,68 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
         __syncthreads();
         for (int tl = 0; tl < nc; tl++) {
             const int t = c0 + 1 + tl;
-            // lag l: source i = t - l, row = the pick made there
+            // lag l: source i = t - l, row = the pick made there.  Lag 1 first (the marginal term goes in front of it), then groups
+            // of CWG_CHUNK lags: a group that lies wholly inside the window and the lag count takes its picks from one run of the
+            // doubled ring and its terms from one run of the slice -- five instructions per lag; the group at either edge is
+            // predicated term by term (a term that does not exist reads the lag-1 slot and is replaced by +0.0)
             const double *base = Gs + (size_t)tl * L * ENT + bcol;
-            double acc = 0.0;
             const double lm_t = P.mt ? Lms[tl * LT_ROW + bcol] : 0.0;       // marginal term: in front of x1
-            for (int l0 = 1; l0 <= L; l0 += CWG_CHUNK) {
-                double x[CWG_CHUNK];
-                int rows[CWG_CHUNK];
-                // (the picks come out of the ring first, all reads in flight together, then the table reads; a term that does
-                // not exist reads the lag-1 slot and is replaced by +0.0)
+            double acc;
+            {
+                const int row1 = t - 1 <= 0 ? 0 : (int)myring[(t - 1) & (CW_MAX_LG - 1)];      // (position 0: its row 5 stands in every row)
+                const double x1 = base[row1 * COLS];
+                acc = P.mt ? lm_t + x1 : x1;
+            }
+            // NL lags l0 .. l0 + NL - 1, all inside the window: picks from one run of the doubled ring, terms from one run of the slice
+            auto group = [&](auto nl_, int l0) __attribute__((always_inline)) {
+                constexpr int NL = decltype(nl_)::value;
+                const uint8_t *rg = myring + ((t - (l0 + NL - 1)) & (CW_MAX_LG - 1));      // picks of lags l0+NL-1 .. l0, ascending positions
+                const double *bl = base + (size_t)(l0 - 1) * ENT;
+                int rows[NL];
+                double x[NL];
 #pragma unroll
-                for (int u = 0; u < CWG_CHUNK; u++) {
-                    const int l = l0 + u;
-                    const int le = (l <= L && t - l >= 0) ? l : 1;
-                    rows[u] = (int)myring[(t - le) & (CW_MAX_LG - 1)];
+                for (int u = 0; u < NL; u++) rows[u] = (int)rg[NL - 1 - u];
+#pragma unroll
+                for (int u = 0; u < NL; u++) x[u] = bl[u * ENT + rows[u] * COLS];
+#pragma unroll
+                for (int u = 0; u < NL; u++) acc = acc + x[u];
+            };
+            for (int l0 = 2; l0 <= L; l0 += CWG_CHUNK) {
+                const int nl = L - l0 + 1 < CWG_CHUNK ? L - l0 + 1 : CWG_CHUNK;
+                if (t - (l0 + nl - 1) >= 0) {
+                    static_assert(CWG_CHUNK == 8, "the switch below names the group sizes");
+                    switch (nl) {
+                        case 8: group(std::integral_constant<int, 8>{}, l0); break;
+                        case 7: group(std::integral_constant<int, 7>{}, l0); break;
+                        case 6: group(std::integral_constant<int, 6>{}, l0); break;
+                        case 5: group(std::integral_constant<int, 5>{}, l0); break;
+                        case 4: group(std::integral_constant<int, 4>{}, l0); break;
+                        case 3: group(std::integral_constant<int, 3>{}, l0); break;
+                        case 2: group(std::integral_constant<int, 2>{}, l0); break;
+                        default: group(std::integral_constant<int, 1>{}, l0); break;
+                    }
+                } else {
+                    // the first positions of the window: terms in front of it do not exist (read the lag-1 slot, replaced by +0.0)
+                    int rows[CWG_CHUNK];
+                    double x[CWG_CHUNK];
+#pragma unroll
+                    for (int u = 0; u < CWG_CHUNK; u++) {
+                        const int l = l0 + u;
+                        const int le = (l <= L && t - l >= 0) ? l : 1;
+                        rows[u] = t - le <= 0 ? 0 : (int)myring[(t - le) & (CW_MAX_LG - 1)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CWG_CHUNK; u++) {
+                        const int l = l0 + u;
+                        const bool have = l <= L && t - l >= 0;
+                        const int le = have ? l : 1;
+                        const double v = base[(le - 1) * ENT + rows[u] * COLS];
+                        x[u] = have ? v : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < CWG_CHUNK; u++)
+                        if (l0 + u <= L) acc = acc + x[u];
                 }
-#pragma unroll
-                for (int u = 0; u < CWG_CHUNK; u++) {
-                    const int l = l0 + u;
-                    const bool have = l <= L && t - l >= 0;
-                    const int le = have ? l : 1;
-                    int row = live ? rows[u] : 0;                   // (an idle lane group reads row 0: its ring holds nothing)
-                    if (row >= ROWS) row = 0;
-                    const double v = base[(le - 1) * ENT + row * COLS];
-                    x[u] = have ? v : 0.0;
-                }
-#pragma unroll
-                for (int u = 0; u < CWG_CHUNK; u++)
-                    if (l0 + u <= L) acc = (l0 + u == 1) ? (P.mt ? lm_t + x[u] : x[u]) : acc + x[u];
             }
             if (R == 5 && b >= R) acc = -INFINITY;
             double m = vmax_f64(acc, dpp_f64<0xB1>(acc));
@@ -572,53 +635,74 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
             if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));
             const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
             const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));
-            if (live && b == 0) ring[q][t & (CW_MAX_LG - 1)] = (uint8_t)d;      // (read again at the earliest one step later, by this lane group only)
+            if (active && b == 0) { ring[q][t & (CW_MAX_LG - 1)] = (uint8_t)d; ring[q][(t & (CW_MAX_LG - 1)) + CW_MAX_LG] = (uint8_t)d; }      // (read again at the earliest one step later, by this lane group only)
             const int gt = t - t0 - 1;
             word |= d << (WB * (gt % PPW));
             if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
-                if (live && b == 0) P.hist[((size_t)s * nw_e + word_i) * CW_K + q] = word;
+                if (active && b == 0) hdst[(size_t)word_i * CW_K] = word;
                 word = 0;
                 word_i++;
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
-    // the exit state: the last L picks, lag 1 first (out of the ring); its hash; closure as in k_cwalk
+    // the segment is walked.  Its exit state: the last L picks, lag 1 first (out of the ring); its hash.  hop 0: the entry's own
+    // walk; later hops: a walk on behalf of the pending request `pslot` of pool `seg` (the result goes with the request)
     __syncthreads();
     auto dg = [&](int l) -> uint8_t {                       // pick of lag l behind the segment
         const int i = t1 + 1 - l;
         return i >= 1 ? ring[q][i & (CW_MAX_LG - 1)] : (uint8_t)0;
     };
-    if (live) {
-        uint8_t *xd = P.exits_d + ((size_t)s * CW_K + q) * LD;
+    if (active) {
+        uint8_t *xd = hop == 0 ? P.exits_d + ((size_t)s * CW_K + q) * LD : P.pend_exit_d + ((size_t)seg * CW_K + pslot) * LD;
         for (int l = 1 + b; l <= L; l += LPE) xd[l - 1] = dg(l);
     }
-    if (live && b == 0) {
+    int go_on = 0;
+    if (active && b == 0) {
         unsigned long long hh = 0xcbf29ce484222325ull;      // (cw_hash_digits over the ring)
         for (int l = 1; l <= L; l++) { hh ^= dg(l); hh *= 0x100000001b3ull; }
         hh ^= hh >> 32; hh *= 0x9e3779b97f4a7c15ull; hh ^= hh >> 29;
         const cw_key sigma = hh;
-        P.exits[(size_t)s * CW_K + q] = sigma;
-        P.walked[(size_t)s * CW_K + q] = 1;
-        if (s + 1 < g.S) {
-            const cw_key *kn = P.keys + (size_t)(s + 1) * CW_K;
+        if (hop == 0) {
+            P.exits[(size_t)s * CW_K + q] = sigma;
+            P.walked[(size_t)s * CW_K + q] = 1;
+        } else {
+            const size_t pe = (size_t)seg * CW_K + (size_t)pslot;
+            P.pend_exit[pe] = sigma;
+            __builtin_amdgcn_s_waitcnt(0);                  // (the exit state's bytes were stored by this lane group above)
+            P.pend_ready[pe] = P.stamp;
+        }
+        // closure, as in k_cwalk: an exit state the next pool does not hold asks to join it -- and, run-on, is walked on from here
+        if (seg + 1 < g.S) {
+            const cw_key *kn = P.keys + (size_t)(seg + 1) * CW_K;
             bool there = false;
-            const int nn = P.npool[s + 1];
+            const int nn = P.npool[seg + 1];
             for (int k = 0; k < nn && k < CW_K && !there; k++) {
                 if (kn[k] != sigma) continue;
-                const uint8_t *kd = P.keys_d + ((size_t)(s + 1) * CW_K + k) * LD;
+                const uint8_t *kd = P.keys_d + ((size_t)(seg + 1) * CW_K + k) * LD;
                 bool same = true;
                 for (int l = 1; l <= L && same; l++) same = kd[l - 1] == dg(l);
                 there = same;
             }
             if (!there) {
-                const int slot = atomicAdd(&P.npend[s + 1], 1);
+                const int slot = atomicAdd(&P.npend[seg + 1], 1);
                 if (slot < CW_K) {
-                    P.pend[(size_t)(s + 1) * CW_K + slot] = sigma;
-                    for (int l = 1; l <= L; l++) P.pend_d[((size_t)(s + 1) * CW_K + slot) * LD + (l - 1)] = dg(l);
+                    P.pend[(size_t)(seg + 1) * CW_K + slot] = sigma;
+                    for (int l = 1; l <= L; l++) P.pend_d[((size_t)(seg + 1) * CW_K + slot) * LD + (l - 1)] = dg(l);
+                    if (P.pend_ready) {
+                        P.pend_ready[(size_t)(seg + 1) * CW_K + slot] = 0;
+                        if (hop < P.runon) go_on = 1 + slot;
+                    }
                 }
             }
         }
+    }
+    go_on = __shfl(go_on, (int)(tid & 63 & ~(LPE - 1)));      // lane b == 0 of the group decides
+    active = go_on != 0;
+    if (!__syncthreads_or(active ? 1 : 0)) break;           // nobody walks on: done
+    seg++;
+    pslot = active ? go_on - 1 : 0;
+    hdst = P.phist + (size_t)seg * nw_e * CW_K + pslot;
     }
 }
 

@@ -142,7 +142,8 @@ struct gh_handle {
     bool cw_wide;          // the conditional table is over the symbols, not over candidate ranks: k_cwalk<L, 5>
     bool cw_pool_wide;     // ... and what the pools' states are made of
     bool cw_no_rw;         // inside gh_generate_path: no reweight follows the path (k_cemit leaves the window's flags standing)
-    uint8_t *cw_keys_d, *cw_exits_d, *cw_pend_d;      // k_cwalkg: the states as bytes, [S][CW_K][cw_LD]
+    uint8_t *cw_keys_d, *cw_exits_d, *cw_pend_d;      // k_cwalkg: the states as bytes, [S][CW_K][cw_LD] (cw_pend_d: two sets, as the request lists)
+    uint8_t *cw_pend_exit_d;                          // ... and the exit states run-on requests arrive with, two sets
     int cw_LD;
     int cw_rounds;         // walk/scan rounds queued per path (adapts to how often chains stay open)
     int cw_stamp;
@@ -330,7 +331,7 @@ static void free_handle(gh_handle *h)
     hipFree(h->seg_smin); hipFree(h->seg_gmin); hipFree(h->cm5snap); hipFree(h->seg_halo);
     if (h->stage) hipHostFree(h->stage);
     hipFree(h->ew_buf);
-    hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
+    hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d); hipFree(h->cw_pend_exit_d);
     hipFree(h->cw_pend_exit); hipFree(h->cw_pend_ready); hipFree(h->cw_phist);
     hipFree(h->cw_keys); hipFree(h->cw_exits); hipFree(h->cw_hist); hipFree(h->cw_last_hit); hipFree(h->cw_npool); hipFree(h->cw_walked); hipFree(h->cw_nxt); hipFree(h->cw_true); hipFree(h->cw_pend); hipFree(h->cw_npend);
     for (int k = 0; k < GH_K_COUNT; k++)
@@ -395,7 +396,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
     h->cw_pend_exit = nullptr; h->cw_pend_ready = nullptr; h->cw_phist = nullptr;
     h->cw_walked = nullptr; h->cw_nxt = nullptr; h->cw_true = nullptr; h->cw_pend = nullptr; h->cw_npend = nullptr; h->cw_ready = false; h->cw_off = false; h->cw_wide = false; h->cw_pool_wide = false; h->cw_rounds = 2; h->cw_stamp = 0; h->cw_pp = 0; h->cw_S = 0;
-    h->cw_keys_d = nullptr; h->cw_exits_d = nullptr; h->cw_pend_d = nullptr; h->cw_LD = 0; h->cw_no_rw = false;
+    h->cw_keys_d = nullptr; h->cw_exits_d = nullptr; h->cw_pend_d = nullptr; h->cw_pend_exit_d = nullptr; h->cw_LD = 0; h->cw_no_rw = false;
     memset(h->cw_stat, 0, sizeof h->cw_stat);
     h->force_stale_at = getenv("GH_SEG_FORCE_STALE") ? atoi(getenv("GH_SEG_FORCE_STALE")) : -1;
     h->cw_round_cap = getenv("GH_CW_ROUND_CAP") ? atoi(getenv("GH_CW_ROUND_CAP")) : 0;
@@ -1575,12 +1576,15 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     const cw_geom ggr = cw_geometry(h->N, h->L);
     int runon = ggr.seglen <= 64 ? 256 / ggr.seglen : 0;      // (C5, 98 positions per segment: 168 us per path without, 175 with two segments of run-on)
     if (runon > CW_RUNON) runon = CW_RUNON;
+    // (states as bytes, beyond 32 lags: a step of k_cwalkg costs several times k_cwalk's, and a launch lasts as long as its longest
+    // walker -- 736 us per path without run-on at L = 33, 855..897 with one to three segments of it)
+    if (cw_digit_mode(h)) runon = 0;
     if (getenv("GH_CW_RUNON")) runon = atoi(getenv("GH_CW_RUNON"));
     if (runon > CW_RUNON) runon = CW_RUNON;
     const bool no_runon = runon <= 0;
     P.runon = runon;
     P.pend_c = P.pend; P.npend_c = P.npend;
-    if (!cw_digit_mode(h)) {
+    {
         // the set this launch appends to / the set it consumes (what the launch before appended to)
         const cw_geom gg = cw_geometry(h->N, h->L);
         const size_t nw = (size_t)(h->cw_wide ? gg.NW5 : gg.NW);
@@ -1592,9 +1596,14 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
             P.pend_ready = h->cw_pend_ready + a * h->cw_S * CW_K; P.pend_ready_c = h->cw_pend_ready + c * h->cw_S * CW_K;
             P.phist = h->cw_phist + a * gg.S * nw * CW_K;         P.phist_c = h->cw_phist + c * gg.S * nw * CW_K;
         }
+        if (cw_digit_mode(h)) {
+            const size_t bytes = (size_t)gg.S * CW_K * h->cw_LD;
+            P.pend_d = h->cw_pend_d + a * bytes;             P.pend_d_c = h->cw_pend_d + c * bytes;
+            P.pend_exit_d = h->cw_pend_exit_d + a * bytes;   P.pend_exit_d_c = h->cw_pend_exit_d + c * bytes;
+        }
     }
     if (cw_digit_mode(h)) {
-        P.keys_d = h->cw_keys_d; P.exits_d = h->cw_exits_d; P.pend_d = h->cw_pend_d; P.LD = h->cw_LD;
+        P.keys_d = h->cw_keys_d; P.exits_d = h->cw_exits_d; P.LD = h->cw_LD;
         unsigned long long hh = 0xcbf29ce484222325ull;      // cw_hash_digits of L zero bytes: the start state
         for (int l = 0; l < h->L; l++) { hh ^= 0u; hh *= 0x100000001b3ull; }
         hh ^= hh >> 32; hh *= 0x9e3779b97f4a7c15ull; hh ^= hh >> 29;
@@ -1620,7 +1629,7 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
     const cw_geom g = cw_geometry(h->N, h->L);
     cw_params P = cw_make_params(h, d_path, d_lmsel);
     if (h->cw_round_cap > 0 && rounds > h->cw_round_cap) rounds = h->cw_round_cap;
-    const bool skip0 = !resume && !cw_digit_mode(h) && !(getenv("GH_CW_SKIP0") && atoi(getenv("GH_CW_SKIP0")) == 0);      // (GH_CW_SKIP0=0: A/B, tests)
+    const bool skip0 = !resume && !(getenv("GH_CW_SKIP0") && atoi(getenv("GH_CW_SKIP0")) == 0);      // (GH_CW_SKIP0=0: A/B, tests)
     if (!cw_digit_mode(h) && (h->L < CW_MIN_L || h->L > CW_MAX_L)) return fail(GH_ERR_STATE, "candidate-pool walk needs %d <= L <= %d", CW_MIN_L, CW_MAX_LG);
     prof_begin(h, GH_K_WALK);
     for (int r = 0; r < rounds; r++) {
@@ -1633,6 +1642,7 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
             const cw_params Q = cw_make_params(h, d_path, d_lmsel);
             P.pend = Q.pend; P.npend = Q.npend; P.pend_exit = Q.pend_exit; P.pend_ready = Q.pend_ready; P.phist = Q.phist;
             P.pend_c = Q.pend_c; P.npend_c = Q.npend_c; P.pend_exit_c = Q.pend_exit_c; P.pend_ready_c = Q.pend_ready_c; P.phist_c = Q.phist_c;
+            P.pend_d = Q.pend_d; P.pend_d_c = Q.pend_d_c; P.pend_exit_d = Q.pend_exit_d; P.pend_exit_d_c = Q.pend_exit_d_c;
         }
         if (r == 0) prof_begin(h, GH_K_SEG);                // (bench.py: the pool walker alone, first round of a path)
         if (cw_digit_mode(h)) {
@@ -1917,17 +1927,17 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
             const int LD = (h->L + 3) & ~3;
             if (h->cw_LD != LD) {
                 hipStreamSynchronize(h->stream);
-                hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d);
-                h->cw_keys_d = h->cw_exits_d = h->cw_pend_d = nullptr;
+                hipFree(h->cw_keys_d); hipFree(h->cw_exits_d); hipFree(h->cw_pend_d); hipFree(h->cw_pend_exit_d);
+                h->cw_keys_d = h->cw_exits_d = h->cw_pend_d = h->cw_pend_exit_d = nullptr;
                 const cw_geom gg = cw_geometry(h->N, h->L);
                 const size_t bytes = (size_t)gg.S * CW_K * LD;
                 if (hipMalloc((void **)&h->cw_keys_d, bytes) != hipSuccess || hipMalloc((void **)&h->cw_exits_d, bytes) != hipSuccess ||
-                    hipMalloc((void **)&h->cw_pend_d, bytes) != hipSuccess) {
+                    hipMalloc((void **)&h->cw_pend_d, 2 * bytes) != hipSuccess || hipMalloc((void **)&h->cw_pend_exit_d, 2 * bytes) != hipSuccess) {
                     rc = fail(GH_ERR_NOMEM, "hipMalloc for the candidate pools failed");
                     h->cw_LD = 0;
                     return;
                 }
-                hipMemsetAsync(h->cw_keys_d, 0, bytes, h->stream); hipMemsetAsync(h->cw_exits_d, 0, bytes, h->stream); hipMemsetAsync(h->cw_pend_d, 0, bytes, h->stream);
+                hipMemsetAsync(h->cw_keys_d, 0, bytes, h->stream); hipMemsetAsync(h->cw_exits_d, 0, bytes, h->stream); hipMemsetAsync(h->cw_pend_d, 0, 2 * bytes, h->stream); hipMemsetAsync(h->cw_pend_exit_d, 0, 2 * bytes, h->stream);
                 h->cw_LD = LD;
                 h->cw_ready = false;
             }
