@@ -3,12 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r4'
 # Kernel trace and the PMC passes are separate runs (never combined with other trace domains); rocprofv3 is given python3
 # directly.  Back in the build container the summaries are made from gpurun_out/prof_<round>/ (where git is):
-#   cp gpurun_out/prof_r3/bench_default.json profiles/r3_bench_default.json   (... c2, c5, batch256, 2 ranks, fused)
-#   cp gpurun_out/prof_r3/kt/kt_kernel_stats.csv profiles/r3_kernel_stats_bench_c3.csv   (... kt_c5, kt_b256)
-#   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc > profiles/r3_pmc_traffic.json
-#   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc_c5 > profiles/r3_pmc_traffic_c5.json
-#   python profiles/pmc_summarize.py gpurun_out/prof_r3 pmc_b256 > profiles/r3_pmc_traffic_batch256.json
-#   python profiles/seg_isa_count.py > profiles/r3_seg_isa.json          (no GPU needed)
+#   scratch/copy_profiles.sh r4          (copies the bench lines and kernel statistics, summarises the PMC passes, recounts the ISA)
 set -u
 R=${1:-r4}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
