@@ -1,4 +1,4 @@
-"""The candidate-pool segment walk (gretel_amd/csrc/cwalk.hpp: lag counts 6..24, spins) against the C oracle and the
+"""The candidate-pool segment walk (gretel_amd/csrc/cwalk.hpp: lag counts 6..128, spins) against the C oracle and the
 serial walker: every lag count, pools kept across spins and dropped by a new fill, windows it must hand back (a
 position with five candidates), holes, a stale table in the middle of a queue, the other conditionals and f64 storage."""
 import os

@@ -1,7 +1,7 @@
 """Spins over WIDE bands -- reads of up to 49 / 101 / 201 SNPs (long reads; C5 is "long-read-style", real ones are longer) --
 at lag counts 10, 24 and 40, binary32 and binary64 storage, a row conditional (A) and a column conditional (C): the reweight
 kernels with 32 lanes per position taking several rounds over the distances (k_rw<T,32>, k_marg<T,true> at W > 32), the
-candidate pools with the table slice in LDS (L <= 24) and read from global memory (L = 40), all against the C oracle on
+candidate pools with packed states (L <= 32) and with states as bytes (L = 40), all against the C oracle on
 libm's log10, bit for bit (paths, likelihoods, ratios, the reweighted tensor).  gretel/gretel.py:79-98,102-189."""
 import numpy as np
 import pytest
