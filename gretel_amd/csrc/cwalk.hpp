@@ -1,8 +1,8 @@
 // cwalk.hpp -- segment-parallel path extension for lag counts whose state space cannot be enumerated (included by
 // gretel_hip.hip behind segwalk.hpp, which enumerates up to 5^5 states, and 4^6 when the table is ranked).
-// Ranked tables (every position has at most four candidates): 2 bits per pick, L = 6..24.  Tables over the symbols
+// Ranked tables (every position has at most four candidates): 2 bits per pick, L = 6..32.  Tables over the symbols
 // A C G T - (a five-candidate position somewhere): 3 bits per pick, L = 6..21.  Beyond (up to 128 lags): k_cwalkg, states as
-// bytes next to their hash, the table read from global memory.
+// bytes next to their hash.  Both keep the slice of the table a chunk of targets reads in LDS, target-major (round 4).
 //
 // Same decomposition -- cut the window into <= 512 segments (<= 256 beyond 13 lags), know for every segment what it does
 // to the state that enters it, chain the segments -- but a segment is only walked from a POOL of candidate entry states
@@ -426,17 +426,17 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// k_cwalkg: k_cwalk for lag counts whose table slice no longer fits the LDS and whose state no longer fits 64 bits
-// (L > 24 over ranks, L > 21 over symbols; L <= CW_MAX_LG).  The same pools, links and chain; what differs:
+// k_cwalkg: k_cwalk for lag counts whose state no longer fits 64 bits
+// (L > 32 over ranks, L > 21 over symbols; L <= CW_MAX_LG).  The same pools, links and chain; what differs:
 //   * the slice of G a chunk of targets needs stands in LDS target-major as in k_cwalk (round 4; rounds 2-3 read the L terms
 //     of every step from global memory: a round trip to L2 per step, 600 us per path at 25 lags), sized at run time: as many
-//     targets per chunk as 150 KB hold at this lag count (24 at 48 lags, 9 at 128); the terms are added in lag order as
-//     everywhere, CWG_CHUNK at a time;
+//     targets per chunk as 140 KB hold at this lag count (22 at 48 lags, 8 at 128); the terms are added in lag order as
+//     everywhere, in groups of CWG_CHUNK lags whose picks lie behind one another in a doubled ring;
 //   * a state is L bytes (one per pick, lag 1 first) next to its 64-bit hash; the last L picks of an entry live in a
 //     ring in LDS.
 // -------------------------------------------------------------------------------------------------------------
 #define CW_MAX_LG 128
-#define CWG_CHUNK 8           /* lags per unrolled group of a step (a group beyond L is skipped; the last one is padded) */
+#define CWG_CHUNK 8           /* lags per unrolled group of a step (the last group: as many as are left) */
 template <int R>
 __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
 {

@@ -1922,7 +1922,7 @@ static int spin_candidate_pools(gh_handle *h, const spin_io &io, dev_state &hs, 
     auto look_at_layout = [&](int ranked) {
         h->cw_wide = !ranked;
         if (h->cw_pool_wide != h->cw_wide) { h->cw_ready = false; h->cw_pool_wide = h->cw_wide; }
-        if (cw_digit_mode(h) && (long long)(h->N + LT_PAD) * 6 * h->L * LT_ROW >= (1LL << 31)) h->cw_off = true;      // (k_cwalkg's 32-bit element offsets)
+
         if (cw_digit_mode(h) && !h->cw_off) {
             const int LD = (h->L + 3) & ~3;
             if (h->cw_LD != LD) {

@@ -216,7 +216,7 @@ int gh_profile_overhead(gh_t *h, int reps, double out[2]);
  * queued its remaining paths again because a candidate mask moved, out[1] = the state space it enumerated (4: candidate
  * ranks of a window whose positions offer at most four; 5: all symbol histories; 6: mixed radix -- few positions offer five),
  * out[2] = the most states that enter a target as a mixed-radix number (0: not taken); 4 = candidate-pool segments
- * (L = 6..24): out[0] = re-queues of the last gh_spin, out[1] = paths this handle handed to the serial walker so far,
+ * (L = 6..128): out[0] = re-queues of the last gh_spin, out[1] = paths this handle handed to the serial walker so far,
  * out[2] = walk/scan rounds it queued so far) */
 int gh_debug_walk_clock(gh_t *h, uint64_t out[4]);
 /* diagnostic builds only (-DRWS_STAMPS_ALL): the s_memtime stamps every k_rwseg workgroup of the last launch left at its phase
