@@ -176,6 +176,15 @@ def test_c3_20_paths_under_every_switch(c3, kw):
     assert h.L == 5 and h.walk_clock()[3] == 3
 
 
+@pytest.mark.parametrize("kw", [dict(cond_mode="C"), dict(cond_mode="E", marginal_term=True, storage="f64")],
+                         ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
+def test_c5_under_the_column_conditionals(kw):
+    # config C5 (50k SNPs, band 20, L = 10): under C / E the reweight reads its columns from the to-major copy of the band
+    # (196 / 392 MB more) and keeps the table by columns; the looks of the pool spin trust that table
+    h = _spec_run(make_config("C5", seed=0), kw, 14)
+    assert 9 <= h.L <= 11 and h.walk_clock()[3] == 4
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7])
 def test_c4_windows_of_the_other_ranks(seed):
     # config C4 = eight independent C3 windows, seed = rank (bench.py): seed 0 is checked above at 100 paths; these are
