@@ -64,6 +64,7 @@ extern "C" const char *gh_last_error(void) { return g_err; }
 #include "kernels.hpp"
 #include "segwalk.hpp"
 #include "cwalk.hpp"
+#include "wpipe.hpp"
 
 // ---------------------------------------------------------------------------------------------
 // handle
@@ -2294,6 +2295,7 @@ struct gh_batch {
     double *d_partial;
     int cap_paths, nb;
     int prof_every;             // gh_batch_profile_enable
+    int pipe_windows, pipe_aborted;     // last gh_batch_spin: windows the pipeline (wpipe.hpp) carried / handed back to gh_spin
     std::vector<hipEvent_t> pev[2];     // [0] extension, [1] reweight: start/stop pairs of the last spin (group 0's stream)
     size_t pused[2];
     int prof_windows;
@@ -2339,6 +2341,7 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
     for (int g = 0; g < 3; g++) { b->gstream[g] = nullptr; b->gevent[g] = nullptr; }
     b->cap_paths = 0;
+    b->pipe_windows = b->pipe_aborted = 0;
     b->prof_every = 0; b->pused[0] = b->pused[1] = 0; b->prof_windows = 0; b->prof_bytes[0] = b->prof_bytes[1] = 0.0;
     b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_marg<.., true>
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
@@ -2349,75 +2352,127 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     return GH_OK;
 }
 
-extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out,
-                             gh_path_rec *recs, int *n_out, int *hole_at)
+// ---- the window pipeline (wpipe.hpp): one persistent workgroup per window -------------------------------------------------
+// threads per workgroup for lag count L (what the walker's register rotation leaves of 512 registers per SIMD lane); 0 = none
+static int pipe_threads(int L)
 {
-    if (!b || !paths_out || !recs || !n_out || !hole_at || max_paths < 1) return fail(GH_ERR_ARG, "bad argument");
-    HIPCHK(hipSetDevice(b->dev));
-    const int n = b->n;
+    const int env = getenv("GH_PIPE_NT") ? atoi(getenv("GH_PIPE_NT")) : 0;      // (read on every call: the tests switch)
+    if (L < 2 || L > 14) return 0;
+    if (env == 512 || env == 768 || env == 1024) return env;
+    return L <= 6 ? 1024 : (L <= 10 ? 768 : 512);
+}
+static int pipe_sweep_threads(int nt) { return nt == 1024 ? pipe_roles<1024>::NRW * 64 : (nt == 768 ? pipe_roles<768>::NRW * 64 : pipe_roles<512>::NRW * 64); }
+
+template <typename T, int LC, int NT>
+static hipError_t launch_wpipe_t(const pipe_params &P, const win_desc *d_wd, int n, size_t lds, hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_wpipe<T, LC, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_wpipe<T, LC, NT>), dim3(n), dim3(NT), lds, st, P, d_wd);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_wpipe(int L, int nt, const pipe_params &P, const win_desc *d_wd, int n, size_t lds, hipStream_t st)
+{
+#define GH_PIPE_CASE(l, t) case l: return launch_wpipe_t<T, l, t>(P, d_wd, n, lds, st);
+    if (nt == 1024) {
+        switch (L) { GH_PIPE_CASE(2, 1024) GH_PIPE_CASE(3, 1024) GH_PIPE_CASE(4, 1024) GH_PIPE_CASE(5, 1024) GH_PIPE_CASE(6, 1024) }
+    } else if (nt == 768) {
+        switch (L) { GH_PIPE_CASE(5, 768) GH_PIPE_CASE(7, 768) GH_PIPE_CASE(8, 768) GH_PIPE_CASE(9, 768) GH_PIPE_CASE(10, 768) }
+    } else if (nt == 512) {
+        switch (L) { GH_PIPE_CASE(5, 512) GH_PIPE_CASE(11, 512) GH_PIPE_CASE(12, 512) GH_PIPE_CASE(13, 512) GH_PIPE_CASE(14, 512) }
+    }
+#undef GH_PIPE_CASE
+    return hipErrorInvalidValue;
+}
+static bool pipe_instantiated(int L, int nt)
+{
+    if (nt == 1024) return L >= 2 && L <= 6;
+    if (nt == 768) return L == 5 || (L >= 7 && L <= 10);
+    if (nt == 512) return L == 5 || (L >= 11 && L <= 14);
+    return false;
+}
+
+// the window pipeline over the windows `wd` describes: marginals, snapshot and the full table for every window (what the batched
+// launches do in front of their first path), then ONE launch that carries every window through all its paths (wpipe.hpp)
+static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, int nt)
+{
+    const int n = (int)wd.size();
+    if (n == 0) return GH_OK;
+    HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
+    gh_handle *h0 = b->hs[0];
+    const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
+    const int N = b->N, W = b->W, L = b->L;
+    const int bwm = h0->wmode == WM_SEG ? WM_SPEC : h0->wmode;
+    const unsigned marg_gx = (unsigned)(((N + 1) * 8 + 255) / 256);
+    size_t lt_nb = ((size_t)(N + LT_PAD) * L * LT_BLK + 255) / 256;
+    if (lt_nb > 4096) lt_nb = 4096;
+    hipStream_t st = b->stream;
+    const win_desc *gwd = b->d_wd;
+    hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, st, (dev_state *)nullptr, gwd, 0);
+    if (f64) {
+        hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, n), dim3(256), 0, st, (double *)nullptr, N, W,
+                           (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                           (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
+                           h0->sm, h0->cfg.offer_zero, (double *)nullptr);
+        hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, st, (double *)nullptr, (const double *)nullptr, N, gwd);
+        hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)lt_nb, n), dim3(256), 0, st, (const double *)nullptr, N, W, L,
+                           h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
+                           (const uint8_t *)nullptr, gwd, 0, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const double *)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_marg<float, false>), dim3(marg_gx, n), dim3(256), 0, st, (float *)nullptr, N, W,
+                           (double *)nullptr, (double *)nullptr, (int32_t *)nullptr, (uint32_t *)nullptr, (double *)nullptr,
+                           (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
+                           h0->sm, h0->cfg.offer_zero, (double *)nullptr);
+        hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, st, (double *)nullptr, (const double *)nullptr, N, gwd);
+        hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)lt_nb, n), dim3(256), 0, st, (const float *)nullptr, N, W, L,
+                           h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                           (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
+                           (const uint8_t *)nullptr, gwd, 0, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const float *)nullptr);
+    }
+    HIPCHK(hipGetLastError());
+    const int nr = pipe_sweep_threads(nt);
+    pipe_params P;
+    P.N = N; P.W = W; P.L = L; P.C = pipe_chunk(N, L, nr); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
+    P.offer_zero = h0->cfg.offer_zero; P.prof = b->prof_every > 0 ? 1 : 0; P.min_remove = min_remove; P.sm = h0->sm;
+    const size_t lds = pipe_lds_bytes(N, L, P.C, nr);
+    b->pused[0] = b->pused[1] = 0;
+    auto pmark = [&](hipStream_t s_) {
+        if (b->pused[0] >= b->pev[0].size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            b->pev[0].push_back(e);
+        }
+        hipEventRecord(b->pev[0][b->pused[0]++], s_);
+    };
+    const bool sample = b->prof_every > 0;
+    if (sample) { b->prof_windows = n; pmark(st); }
+    const hipError_t le = f64 ? launch_wpipe<double>(L, nt, P, gwd, n, lds, st) : launch_wpipe<float>(L, nt, P, gwd, n, lds, st);
+    if (le != hipSuccess) return fail(GH_ERR_HIP, "gh_batch_spin: the pipeline launch failed (L=%d, %d threads, %zu bytes of LDS): %s", L, nt, lds, hipGetErrorString(le));
+    if (sample) pmark(st);
+    HIPCHK(hipStreamSynchronize(st));
+    {
+        // algorithmic bytes per window over the whole launch: max_paths x (extension + reweight), DESIGN.md section 3's definitions
+        const double es = f64 ? 8.0 : 4.0;
+        const int wl = W < L ? W : L;
+        const double ext = (double)N * ((1.0 + (double)L) * CELL * es + 28.0);
+        const double rw = (double)(N + 1) * ((double)W * 2.0 * es + 1.0 + CELL * es + 2 * 64 + 88 + 8) + (double)N * ((double)wl * 7 * es + (double)L * LT_ROW * 8.0);
+        b->prof_bytes[0] = (ext + rw) * max_paths;
+        b->prof_bytes[1] = 0.0;
+    }
+    return GH_OK;
+}
+
+// the batched launches of rounds 1-4 over the windows `wd` describes (a path = k_lt's flag check, one serial walker per window, the
+// fused reweight k_marg<T,true>, the removed mass); returns with every stream drained
+static int batch_run_launches(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove)
+{
+    const int n = (int)wd.size();
+    if (n == 0) return GH_OK;
     const size_t n1 = (size_t)b->N + 1;
-    int rc;
-    for (int w = 0; w < n; w++) {
-        gh_handle *h = b->hs[w];
-        if (h->L != b->hs[0]->L)
-            return fail(GH_ERR_STATE, "window %d has L=%d but window 0 has L=%d: set one L (gh_set_L) for the batch", w, h->L, b->hs[0]->L);
-        if ((rc = alloc_lt(h))) return rc;
-        if ((rc = reset_spin_state(h))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    b->L = b->hs[0]->L;
-    // (measured on C3, MI355X: 8 windows 37k haplotypes/s this way against ~16k batched; 32 windows 45k either way -- the
-    // chip is then busy with k_seg; from 48 windows on the batched serial walkers, one workgroup per window, win: 114k at 256)
-    // (read on every call: the tests switch between the two ways; -1 = always the batched kernels)
-    const int batch_cut = getenv("GH_BATCH_STREAMS_MAX") ? atoi(getenv("GH_BATCH_STREAMS_MAX")) : 47;
-    if (batch_cut >= 0 &&
-        ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || cw_ok(b->hs[0]->wmode, b->L))) {
-        // The segment-parallel extensions fill the chip poorly with ONE window (four small dependent kernels per path, most
-        // of their time launch and first-touch latency) but every window has its own stream: a few host threads each
-        // run gh_spin over their share of the windows, and the windows' kernel chains interleave on the GPU.
-        static const int nthr_env = getenv("GH_BATCH_THREADS") ? atoi(getenv("GH_BATCH_THREADS")) : 8;
-        const int nthr = nthr_env < 1 ? 1 : (nthr_env > n ? n : nthr_env);
-        std::vector<int> rcs(n, GH_OK);
-        std::vector<std::string> errs(n);
-        std::atomic<int> next(0);
-        auto work = [&]() {
-            hipSetDevice(b->dev);
-            for (;;) {
-                const int w = next.fetch_add(1);
-                if (w >= n) break;
-                rcs[w] = gh_spin(b->hs[w], max_paths, min_remove, paths_out + n1 * max_paths * w, recs + (size_t)max_paths * w,
-                                 &n_out[w], &hole_at[w]);
-                if (rcs[w]) errs[w] = gh_last_error();
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthr; t++) th.emplace_back(work);
-        work();
-        for (auto &t : th) t.join();
-        for (int w = 0; w < n; w++)
-            if (rcs[w]) return fail(rcs[w], "window %d: %s", w, errs[w].c_str());
-        return GH_OK;
-    }
-    if (max_paths > b->cap_paths) {
-        HIPCHK(hipStreamSynchronize(b->stream));
-        hipFree(b->d_paths); hipFree(b->d_recs);
-        b->d_paths = nullptr; b->d_recs = nullptr; b->cap_paths = 0;
-        HIPCHK(hipMalloc((void **)&b->d_paths, n1 * max_paths * n));
-        HIPCHK(hipMalloc((void **)&b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n));
-        b->cap_paths = max_paths;
-    }
-    std::vector<win_desc> wd(n);
-    for (int w = 0; w < n; w++) {
-        gh_handle *h = b->hs[w];
-        wd[w].band = h->band; wd[w].cnt = h->cnt; wd[w].marg = h->marg; wd[w].minfo = h->minfo;
-        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].rinfo = h->need_rinfo ? h->rinfo : nullptr; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
-        wd[w].partial = b->d_partial + (size_t)w * b->nb;
-        wd[w].paths = b->d_paths + n1 * max_paths * w;
-        wd[w].recs = b->d_recs + (size_t)max_paths * w;
-        wd[w].snap = h->have_orig ? 0 : 1;       // the first batched k_marg is followed by a batched snapshot
-        wd[w]._pad = 0;
-        h->have_orig = true;
-    }
+    (void)n1;
     HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
 
@@ -2525,9 +2580,119 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         b->prof_bytes[1] = (double)(N + 1) * ((double)W * 2.0 * es + 1.0 + CELL * es + 2 * 64 + 88 + 8) +
                            (inc_mode ? (double)N * ((double)wl * 7 * es + (double)L * LT_ROW * 8.0) : 0.0);
     }
+    return GH_OK;
+}
+
+extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out,
+                             gh_path_rec *recs, int *n_out, int *hole_at)
+{
+    if (!b || !paths_out || !recs || !n_out || !hole_at || max_paths < 1) return fail(GH_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(b->dev));
+    const int n = b->n;
+    const size_t n1 = (size_t)b->N + 1;
+    int rc;
+    for (int w = 0; w < n; w++) {
+        gh_handle *h = b->hs[w];
+        if (h->L != b->hs[0]->L)
+            return fail(GH_ERR_STATE, "window %d has L=%d but window 0 has L=%d: set one L (gh_set_L) for the batch", w, h->L, b->hs[0]->L);
+        if ((rc = alloc_lt(h))) return rc;
+        if ((rc = reset_spin_state(h))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    b->L = b->hs[0]->L;
+    // (measured on C3, MI355X: 8 windows 37k haplotypes/s this way against ~16k batched; 32 windows 45k either way -- the
+    // chip is then busy with k_seg; from 48 windows on the batched serial walkers, one workgroup per window, win: 114k at 256)
+    // (read on every call: the tests switch between the two ways; -1 = always the batched kernels)
+    const int batch_cut = getenv("GH_BATCH_STREAMS_MAX") ? atoi(getenv("GH_BATCH_STREAMS_MAX")) : 47;
+    // The window pipeline (wpipe.hpp): row conditionals without the marginal term, 2..14 lags, a path that fits the LDS beside the
+    // walker's tables; from GH_PIPE_MIN windows on (a window alone runs at one walker's pace, ~2 000 paths/s: below two dozen
+    // windows the segment-parallel spins on their own streams are faster).  GH_PIPE=0: the batched launches of rounds 1-4.
+    int pipe_nt = 0;
+    {
+        gh_handle *h0 = b->hs[0];
+        const int pipe_env = getenv("GH_PIPE") ? atoi(getenv("GH_PIPE")) : 1;
+        const int pipe_min = getenv("GH_PIPE_MIN") ? atoi(getenv("GH_PIPE_MIN")) : 24;
+        const int bwm0 = h0->wmode == WM_SEG ? WM_SPEC : h0->wmode;
+        const int nt = pipe_threads(b->L);
+        if (pipe_env && n >= pipe_min && nt && pipe_instantiated(b->L, nt) && walk_depth2_ok(bwm0, b->L) && lt_incremental_ok(h0) &&
+            pipe_chunk(b->N, b->L, pipe_sweep_threads(nt)) > 0)
+            pipe_nt = nt;
+    }
+    if (!pipe_nt && batch_cut >= 0 &&
+        ((seg_ok(b->hs[0]->wmode, b->L) && n <= batch_cut) || cw_ok(b->hs[0]->wmode, b->L))) {
+        // The segment-parallel extensions fill the chip poorly with ONE window (four small dependent kernels per path, most
+        // of their time launch and first-touch latency) but every window has its own stream: a few host threads each
+        // run gh_spin over their share of the windows, and the windows' kernel chains interleave on the GPU.
+        static const int nthr_env = getenv("GH_BATCH_THREADS") ? atoi(getenv("GH_BATCH_THREADS")) : 8;
+        const int nthr = nthr_env < 1 ? 1 : (nthr_env > n ? n : nthr_env);
+        std::vector<int> rcs(n, GH_OK);
+        std::vector<std::string> errs(n);
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            hipSetDevice(b->dev);
+            for (;;) {
+                const int w = next.fetch_add(1);
+                if (w >= n) break;
+                rcs[w] = gh_spin(b->hs[w], max_paths, min_remove, paths_out + n1 * max_paths * w, recs + (size_t)max_paths * w,
+                                 &n_out[w], &hole_at[w]);
+                if (rcs[w]) errs[w] = gh_last_error();
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; t++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        for (int w = 0; w < n; w++)
+            if (rcs[w]) return fail(rcs[w], "window %d: %s", w, errs[w].c_str());
+        return GH_OK;
+    }
+    if (max_paths > b->cap_paths) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        hipFree(b->d_paths); hipFree(b->d_recs);
+        b->d_paths = nullptr; b->d_recs = nullptr; b->cap_paths = 0;
+        HIPCHK(hipMalloc((void **)&b->d_paths, n1 * max_paths * n));
+        HIPCHK(hipMalloc((void **)&b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n));
+        b->cap_paths = max_paths;
+    }
+    std::vector<win_desc> wd(n);
+    for (int w = 0; w < n; w++) {
+        gh_handle *h = b->hs[w];
+        wd[w].band = h->band; wd[w].cnt = h->cnt; wd[w].marg = h->marg; wd[w].minfo = h->minfo;
+        wd[w].nvalid = h->nvalid; wd[w].cmask = h->cmask; wd[w].rinfo = h->need_rinfo ? h->rinfo : nullptr; wd[w].G = h->lt; wd[w].Ht = nullptr; wd[w].Yt = nullptr; wd[w].st = h->dstate;   // no walker tables in batches (kernels.hpp)
+        wd[w].partial = b->d_partial + (size_t)w * b->nb;
+        wd[w].paths = b->d_paths + n1 * max_paths * w;
+        wd[w].recs = b->d_recs + (size_t)max_paths * w;
+        wd[w].snap = h->have_orig ? 0 : 1;       // the first batched k_marg is followed by a batched snapshot
+        wd[w]._pad = 0;
+        h->have_orig = true;
+    }
     std::vector<dev_state> hs(n);
-    for (int w = 0; w < n; w++)
-        HIPCHK(hipMemcpyAsync(&hs[w], b->hs[w]->dstate, sizeof(dev_state), hipMemcpyDeviceToHost, b->stream));
+    auto fetch_states = [&]() -> int {
+        for (int w = 0; w < n; w++)
+            HIPCHK(hipMemcpyAsync(&hs[w], b->hs[w]->dstate, sizeof(dev_state), hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        return GH_OK;
+    };
+    std::vector<int> aborted;           // windows whose pipeline stopped at a moved candidate mask: gh_spin takes their remaining paths
+    b->pipe_windows = 0;
+    if (pipe_nt) {
+        if ((rc = batch_run_pipe(b, wd, max_paths, min_remove, pipe_nt))) return rc;
+        if ((rc = fetch_states())) return rc;
+        std::vector<win_desc> rest;     // not eligible when the kernel looked (a position offers five candidates, a hole): the batched launches
+        for (int w = 0; w < n; w++) {
+            if (hs[w].pipe_status == PIPE_NOT_STARTED) rest.push_back(wd[w]);
+            else if (hs[w].pipe_status == PIPE_ABORTED) aborted.push_back(w);
+            else if (hs[w].pipe_status != PIPE_DONE) return fail(GH_ERR_STATE, "gh_batch_spin: window %d left the pipeline in state %d", w, hs[w].pipe_status);
+        }
+        b->pipe_windows = n - (int)rest.size();
+        if (!rest.empty()) {
+            if ((rc = batch_run_launches(b, rest, max_paths, min_remove))) return rc;
+            if ((rc = fetch_states())) return rc;
+        }
+    } else {
+        if ((rc = batch_run_launches(b, wd, max_paths, min_remove))) return rc;
+        if ((rc = fetch_states())) return rc;
+    }
     HIPCHK(hipMemcpyAsync(paths_out, b->d_paths, n1 * max_paths * n, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(recs, b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -2537,6 +2702,27 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true; b->hs[w]->band_epoch++;
         b->hs[w]->lt_inc_path = nullptr;       // the batch reweighted many paths and maintains no walker tables: rebuild in full
     }
+    for (int w : aborted) {
+        // paths 0 .. n_done-1 are complete and reweighted; marginals and table are rebuilt from the tensor (dirty flags above)
+        const int nd = hs[w].n_done;
+        int n2 = 0, hole2 = 0;
+        if (nd < max_paths &&
+            (rc = gh_spin(b->hs[w], max_paths - nd, min_remove, paths_out + n1 * ((size_t)max_paths * w + nd), recs + (size_t)max_paths * w + nd, &n2, &hole2)))
+            return rc;
+        n_out[w] = nd + n2;
+        hole_at[w] = hole2;
+    }
+    b->pipe_aborted = (int)aborted.size();
+    return GH_OK;
+}
+
+extern "C" int gh_batch_pipe_info(gh_batch_t *b, int32_t out[4])
+{
+    if (!b || !out) return fail(GH_ERR_ARG, "bad argument");
+    const int nt = pipe_threads(b->L);
+    out[0] = b->pipe_windows; out[1] = b->pipe_aborted;
+    out[2] = b->pipe_windows ? nt : 0;
+    out[3] = b->pipe_windows ? pipe_chunk(b->N, b->L, pipe_sweep_threads(nt)) : 0;
     return GH_OK;
 }
 

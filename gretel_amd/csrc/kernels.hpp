@@ -74,6 +74,8 @@ struct dev_state {
     unsigned long long fill[6];   // slices, crumbs, covered, bad_symbol, out_of_band, -
     unsigned long long dbg[4];   // walker wave: s_memtime / s_memrealtime at start and end (diagnostics)
     unsigned long long dbg8[12]; // -DGH_STAMPS / -DSEG_STAMPS / -DRWS_STAMPS builds: cycles per segment of the code
+    int pipe_status;             // k_wpipe (wpipe.hpp): PIPE_DONE / PIPE_ABORTED / PIPE_NOT_STARTED, written by every window of a launch
+    int pipe_pad;
 };
 
 struct dev_ctl {

@@ -444,6 +444,13 @@ class HanselBatch:
         except Exception:
             pass
 
+    def pipe_info(self):
+        """The last spin(): windows the window pipeline (csrc/wpipe.hpp) carried, windows it handed back to gh_spin, its
+        threads per workgroup and positions per chunk."""
+        out = (C.c_int32 * 4)()
+        check(self._lib.gh_batch_pipe_info(self._b, out))
+        return dict(windows=out[0], handed_back=out[1], threads=out[2], chunk=out[3])
+
     def profile_enable(self, every=10):
         """HIP events around the batched extension and the batched reweight of every `every`-th path (first window group)."""
         check(self._lib.gh_batch_profile_enable(self._b, int(every)))

@@ -167,20 +167,29 @@ int gh_reweight_path(gh_t *h, const uint8_t *path, double ratio, double *removed
 int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
             int *n_out, int *hole_at);
 
-/* Batched recovery: the same spin loop over MANY windows of one shape (same n_snps, band, storage,
- * modes, device and L) with every kernel launched over all of them -- one path-extension workgroup
- * per window, so up to 256 windows walk concurrently on one MI355X.  The handles stay usable on
- * their own; fill them first.  paths_out: [n][max_paths][N+1], recs: [n][max_paths], n_out/hole_at: [n]. */
+/* Batched recovery: the spin loop of gretel/cmd.py:148-179 over MANY windows of one shape (same n_snps, band, storage,
+ * modes, device and L).  From two dozen windows on, under a row conditional (A, B, D) without the marginal term and
+ * 2..14 lags, every window is carried through ALL its paths by one persistent workgroup (gretel_amd/csrc/wpipe.hpp):
+ * the reweight of path s-1 (gretel/gretel.py:79-98) sweeps through the tensor a few chunks ahead of the walk of path s
+ * (gretel/gretel.py:143-189), one launch per batch, 256 windows at a time on one MI355X.  Otherwise (and for windows the
+ * pipeline cannot carry: a position with five candidates, a hole) every kernel of a path is launched over all windows --
+ * one path-extension workgroup per window.  The handles stay usable on their own; fill them first.
+ * paths_out: [n][max_paths][N+1], recs: [n][max_paths], n_out/hole_at: [n]. */
 typedef struct gh_batch gh_batch_t;
 int gh_batch_create(gh_t **handles, int n, gh_batch_t **out);
 int gh_batch_destroy(gh_batch_t *b);
 int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out, gh_path_rec *recs,
                   int *n_out, int *hole_at);
 /* HIP-event timing of the batched kernels (bench.py's roofline of the throughput mode): every = k > 0 brackets the batched
- * launches of every k-th path of the FIRST window group on its stream (0 = off).  gh_batch_profile_get: kernel GH_K_WALK
+ * launches of every k-th path of the FIRST window group on its stream (0 = off); the pipeline's one launch is bracketed as
+ * a whole and reported under GH_K_WALK (bytes: extension + reweight of all its paths).  gh_batch_profile_get: kernel GH_K_WALK
  * (the batched serial extension) or GH_K_REWEIGHT (the fused reweight k_marg<T,true>) of the last gh_batch_spin --
  * milliseconds summed over the sampled launches, their number, the windows one such launch covers, and the algorithmic
  * bytes per launch (per window x windows; the definitions of DESIGN.md section 3). */
+/* the last gh_batch_spin: out[0] = windows the pipeline carried, out[1] = of those, windows it handed back to gh_spin before
+ * their last path (a candidate mask moved under a reweight), out[2] = threads per pipeline workgroup, out[3] = positions per
+ * chunk of its walker tables (0, 0 when it did not run) */
+int gh_batch_pipe_info(gh_batch_t *b, int32_t out[4]);
 int gh_batch_profile_enable(gh_batch_t *b, int every);
 int gh_batch_profile_get(gh_batch_t *b, int kernel, double *total_ms, int64_t *launches, int32_t *windows, double *bytes_per_launch);
 

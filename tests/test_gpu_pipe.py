@@ -1,0 +1,181 @@
+"""The window pipeline (gretel_amd/csrc/wpipe.hpp): a batch carried through all its paths by one persistent workgroup per
+window -- the reweight of path s-1 (gretel/gretel.py:79-98) sweeping ahead of the walk of path s (gretel/gretel.py:143-189) --
+gives, bit for bit, what the C oracle's spin loop (gretel/cmd.py:148-179) gives for every window alone."""
+import numpy as np
+import pytest
+
+from gretel_amd.hansel import Hansel, HanselBatch
+from gretel_amd.synth import make_support_table
+from oracle.c_oracle import COracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _pipe_for_small_batches(monkeypatch):
+    monkeypatch.setenv("GH_PIPE_MIN", "1")
+    monkeypatch.delenv("GH_PIPE", raising=False)
+    monkeypatch.delenv("GH_PIPE_NT", raising=False)
+
+
+def _pair(seed, n, reads, k, L=None, band=None, n_haps=8, **kw):
+    t = make_support_table(n, reads, k=k, seed=seed, n_haps=n_haps, err=0.01 if n_haps > 1 else 0.0, k_max=21)
+    W = band if band is not None else t.band
+    h = Hansel(t.n_snps, band=W, **kw)
+    o = COracle(t.n_snps, W, **kw)
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    if L is not None:
+        h.L = L
+        o.L = L
+    return h, o
+
+
+def _same(r, ref, h, o):
+    assert r["n"] == ref["n"] and r["hole_at"] == ref["hole_at"], (r["n"], ref["n"], r["hole_at"], ref["hole_at"])
+    assert np.array_equal(r["paths"], ref["paths"])
+    assert r["hp_current"].tolist() == ref["hp_current"].tolist()
+    assert r["hp_original"].tolist() == ref["hp_original"].tolist()
+    assert r["ratio"].tolist() == ref["ratio"].tolist()
+    assert np.allclose(r["magnitude"], ref["magnitude"], rtol=1e-12, atol=0)
+    assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 6])
+def test_pipeline_equals_the_oracle(L):
+    wins = [_pair(100 + s, 700, 20000, 6, L=L) for s in range(4)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(12)
+    info = b.pipe_info()
+    assert info["windows"] == 4 and info["handed_back"] == 0 and info["threads"] == 1024, info
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(12), h, o)
+
+
+@pytest.mark.parametrize("L", [7, 9, 10, 11, 14])
+def test_pipeline_with_longer_memories(L):
+    wins = [_pair(200 + s, 600, 12000, None, L=L, band=21, n_haps=6) for s in range(3)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(8)
+    info = b.pipe_info()
+    assert info["windows"] == 3 and info["threads"] == (768 if L <= 10 else 512), info
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(8), h, o)
+
+
+@pytest.mark.parametrize("kw", [dict(storage="f64"), dict(cond_mode="B"), dict(cond_mode="D"), dict(cond_mode="D", storage="f64"),
+                                dict(cand_order="TGCA-"), dict(offer_zero=True)],
+                         ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
+def test_pipeline_under_the_row_conditionals(kw):
+    wins = [_pair(300 + s, 500, 15000, 5, **kw) for s in range(3)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(10)
+    # (offer_zero: every valid symbol is a candidate everywhere -> five per position, no ranked table: the batched launches)
+    assert b.pipe_info()["windows"] == (0 if kw.get("offer_zero") else 3)
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(10), h, o)
+
+
+@pytest.mark.parametrize("kw", [dict(cond_mode="C"), dict(cond_mode="E"), dict(marginal_term=True)],
+                         ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
+def test_other_specs_keep_the_batched_launches(kw):
+    wins = [_pair(320 + s, 300, 9000, 5, **kw) for s in range(3)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(6)
+    assert b.pipe_info()["windows"] == 0
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(6), h, o)
+
+
+@pytest.mark.parametrize("n", [7, 59, 60, 61, 64, 121, 1000, 2417])
+def test_window_lengths_around_the_chunk(n):
+    # chunks of 60 positions at L = 5: windows shorter than one, exactly one, one and a bit, ...
+    wins = [_pair(400 + s, n, max(60, 30 * n), min(5, n), L=min(5, n)) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(9)
+    assert b.pipe_info()["windows"] == 2
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(9), h, o)
+
+
+def test_a_window_that_empties_is_handed_back():
+    # window 1 holds a single haplotype: its first reweight moves candidate masks (counts reach zero), the pipeline stops
+    # there and gh_spin finds the hole; the others run through
+    wins = [_pair(0, 150, 5000, 4, L=4), _pair(1, 150, 1000, 4, L=4, n_haps=1), _pair(2, 150, 5000, 4, L=4)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(8)
+    info = b.pipe_info()
+    assert info["windows"] == 3 and info["handed_back"] >= 1, info
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(8), h, o)
+    assert res[1]["n"] == 1 and res[1]["hole_at"] >= 1 and res[0]["n"] == 8
+
+
+def test_deep_spins_hand_windows_back_when_masks_move():
+    # 60 paths over a small window: rare symbols run out along the way, some windows are handed back in the middle
+    wins = [_pair(500 + s, 300, 2500, 5) for s in range(6)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(60)
+    assert b.pipe_info()["windows"] == 6
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(60), h, o)
+
+
+def test_a_window_with_five_candidates_takes_the_batched_launches():
+    from spec_util import with_dels
+    wins = []
+    for s in range(3):
+        t = make_support_table(300, 9000, k=5, seed=600 + s)
+        if s == 1:
+            t = with_dels(t, 0.05, 7)
+        h = Hansel(t.n_snps, band=t.band)
+        o = COracle(t.n_snps, t.band)
+        assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+        wins.append((h, o))
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(7)
+    assert b.pipe_info()["windows"] == 2
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(7), h, o)
+
+
+def test_pipeline_and_batched_launches_agree(monkeypatch):
+    wins = [_pair(700 + s, 800, 24000, 5) for s in range(3)]
+    twins = [_pair(700 + s, 800, 24000, 5) for s in range(3)]
+    res = HanselBatch([h for h, _ in wins]).spin(20)
+    monkeypatch.setenv("GH_PIPE", "0")
+    monkeypatch.setenv("GH_BATCH_STREAMS_MAX", "-1")
+    b2 = HanselBatch([h for h, _ in twins])
+    res2 = b2.spin(20)
+    assert b2.pipe_info()["windows"] == 0
+    for r, q in zip(res, res2):
+        assert np.array_equal(r["paths"], q["paths"])
+        assert r["hp_current"].tolist() == q["hp_current"].tolist()
+        assert r["ratio"].tolist() == q["ratio"].tolist()
+    for (h, _), (h2, _) in zip(wins, twins):
+        assert np.array_equal(h.export_band(), h2.export_band())
+
+
+def test_handles_stay_usable_after_the_pipeline():
+    wins = [_pair(800 + s, 400, 12000, 5) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(5)
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(5), h, o)
+        pg, po = h.generate_path(), o.generate_path()
+        assert np.array_equal(pg[0], po[0]) and pg[1:] == po[1]
+        more, ref = h.spin(4), o.spin(4)
+        assert np.array_equal(more["paths"], ref["paths"])
+    res = b.spin(5)         # and once more through the pipeline
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(5), h, o)
+
+
+@pytest.mark.parametrize("nt", [512, 768])
+def test_other_workgroup_sizes_at_five_lags(nt, monkeypatch):
+    monkeypatch.setenv("GH_PIPE_NT", str(nt))
+    wins = [_pair(900 + s, 500, 15000, 5) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(8)
+    assert b.pipe_info()["threads"] == nt
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(8), h, o)
