@@ -90,6 +90,7 @@ struct gh_handle {
     int32_t *nvalid;
     uint32_t *cmask;
     double *rinfo;                // [(N+2)][8] log10 marginal / marginal by candidate rank (k_marg, k_rw)
+    unsigned long long *pipe_pk;  // [N+2] the window pipeline's packed candidate words (wpipe.hpp), allocated by the first batch that takes it
     bool need_rinfo;              // ... kept only where somebody reads it: with the marginal term (k_seg, k_cwalk add it in front of x1) and
                                   // for the three-launch spins (GH_FUSE at creation); nullptr goes to the kernels otherwise (C5: k_rw is bound by its stores)
     symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
@@ -325,6 +326,7 @@ static void free_handle(gh_handle *h)
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->tband); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
+    hipFree(h->pipe_pk);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->rinfo); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
@@ -381,7 +383,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memset(h->cfg.cand_order, 0, sizeof h->cfg.cand_order);
     memcpy(h->cfg.cand_order, order, 5);
     h->sm = make_symmap(order);
-    h->rinfo = nullptr; h->lt_baked = false; h->ht_stale = false;
+    h->rinfo = nullptr; h->pipe_pk = nullptr; h->lt_baked = false; h->ht_stale = false;
     h->need_rinfo = cfg->marginal_term != 0 || (getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1);
     h->dev = dev;
     h->N = cfg->n_snps;
@@ -2380,7 +2382,7 @@ static hipError_t launch_wpipe(int L, int nt, const pipe_params &P, const win_de
     } else if (nt == 768) {
         switch (L) { GH_PIPE_CASE(5, 768) GH_PIPE_CASE(7, 768) GH_PIPE_CASE(8, 768) GH_PIPE_CASE(9, 768) GH_PIPE_CASE(10, 768) }
     } else if (nt == 512) {
-        switch (L) { GH_PIPE_CASE(5, 512) GH_PIPE_CASE(11, 512) GH_PIPE_CASE(12, 512) GH_PIPE_CASE(13, 512) GH_PIPE_CASE(14, 512) }
+        switch (L) { GH_PIPE_CASE(3, 512) GH_PIPE_CASE(5, 512) GH_PIPE_CASE(11, 512) GH_PIPE_CASE(12, 512) GH_PIPE_CASE(13, 512) GH_PIPE_CASE(14, 512) }
     }
 #undef GH_PIPE_CASE
     return hipErrorInvalidValue;
@@ -2389,7 +2391,7 @@ static bool pipe_instantiated(int L, int nt)
 {
     if (nt == 1024) return L >= 2 && L <= 6;
     if (nt == 768) return L == 5 || (L >= 7 && L <= 10);
-    if (nt == 512) return L == 5 || (L >= 11 && L <= 14);
+    if (nt == 512) return L == 3 || L == 5 || (L >= 11 && L <= 14);
     return false;
 }
 
@@ -2435,9 +2437,9 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
     HIPCHK(hipGetLastError());
     const int nr = pipe_sweep_threads(nt);
     pipe_params P;
-    P.N = N; P.W = W; P.L = L; P.C = pipe_chunk(N, L, nr); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
-    P.offer_zero = h0->cfg.offer_zero; P.prof = b->prof_every > 0 ? 1 : 0; P.min_remove = min_remove; P.sm = h0->sm;
-    const size_t lds = pipe_lds_bytes(N, L, P.C, nr);
+    P.N = N; P.W = W; P.L = L; P.C = pipe_chunk(N, L, nr, f64 ? 8 : 4); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
+    P.offer_zero = h0->cfg.offer_zero; P.prof = (b->prof_every > 0 || getenv("GH_PIPE_STAMPS")) ? 1 : 0; P.min_remove = min_remove; P.sm = h0->sm;
+    const size_t lds = pipe_lds_bytes(N, L, P.C, nr, f64 ? 8 : 4);
     b->pused[0] = b->pused[1] = 0;
     auto pmark = [&](hipStream_t s_) {
         if (b->pused[0] >= b->pev[0].size()) {
@@ -2615,7 +2617,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         const int bwm0 = h0->wmode == WM_SEG ? WM_SPEC : h0->wmode;
         const int nt = pipe_threads(b->L);
         if (pipe_env && n >= pipe_min && nt && pipe_instantiated(b->L, nt) && walk_depth2_ok(bwm0, b->L) && lt_incremental_ok(h0) &&
-            pipe_chunk(b->N, b->L, pipe_sweep_threads(nt)) > 0)
+            pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), h0->cfg.storage == GH_STORAGE_F64 ? 8 : 4) > 0)
             pipe_nt = nt;
     }
     if (!pipe_nt && batch_cut >= 0 &&
@@ -2654,6 +2656,9 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         HIPCHK(hipMalloc((void **)&b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n));
         b->cap_paths = max_paths;
     }
+    if (pipe_nt)
+        for (int w = 0; w < n; w++)
+            if (!b->hs[w]->pipe_pk) HIPCHK(hipMalloc((void **)&b->hs[w]->pipe_pk, sizeof(unsigned long long) * ((size_t)b->N + 2)));
     std::vector<win_desc> wd(n);
     for (int w = 0; w < n; w++) {
         gh_handle *h = b->hs[w];
@@ -2664,6 +2669,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         wd[w].recs = b->d_recs + (size_t)max_paths * w;
         wd[w].snap = h->have_orig ? 0 : 1;       // the first batched k_marg is followed by a batched snapshot
         wd[w]._pad = 0;
+        wd[w].pk = h->pipe_pk;
         h->have_orig = true;
     }
     std::vector<dev_state> hs(n);
@@ -2685,6 +2691,24 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             else if (hs[w].pipe_status != PIPE_DONE) return fail(GH_ERR_STATE, "gh_batch_spin: window %d left the pipeline in state %d", w, hs[w].pipe_status);
         }
         b->pipe_windows = n - (int)rest.size();
+        if (getenv("GH_PIPE_STAMPS")) {         // 100 MHz ticks per path as the bookkeepers of a few windows saw them
+            for (int w = 0; w < n; w += (n > 4 ? n / 4 : 1)) {
+#ifdef PIPE_PROF
+                fprintf(stderr, "pipe window %d, Mcycles (work, own memory, barrier): sweeper %.2f %.2f %.2f  loader %.2f %.2f %.2f  bookkeeper %.2f %.2f %.2f\n", w,
+                        hs[w].dbg8[0] / 1e6, hs[w].dbg8[1] / 1e6, hs[w].dbg8[2] / 1e6, hs[w].dbg8[3] / 1e6, hs[w].dbg8[4] / 1e6, hs[w].dbg8[5] / 1e6,
+                        hs[w].dbg8[6] / 1e6, hs[w].dbg8[7] / 1e6, hs[w].dbg8[8] / 1e6);
+                fprintf(stderr, "walker: %.2f Mcycles walking, %.2f at its barriers\n", hs[w].dbg8[10] / 1e6, hs[w].dbg8[11] / 1e6);
+                fprintf(stderr, "SIMD of waves 0..15:");
+                for (int q = 0; q < 16; q++) fprintf(stderr, " %d", (int)((hs[w].dbg8[9] >> (2 * q)) & 3));
+                fprintf(stderr, "\n");
+                break;
+#else
+                fprintf(stderr, "pipe window %d, us per path:", w);
+                for (int q = 0; q < 12 && q < max_paths; q++) fprintf(stderr, " %.1f", (double)hs[w].dbg8[q] / 100.0);
+                fprintf(stderr, "\n");
+#endif
+            }
+        }
         if (!rest.empty()) {
             if ((rc = batch_run_launches(b, rest, max_paths, min_remove))) return rc;
             if ((rc = fetch_states())) return rc;
@@ -2722,7 +2746,7 @@ extern "C" int gh_batch_pipe_info(gh_batch_t *b, int32_t out[4])
     const int nt = pipe_threads(b->L);
     out[0] = b->pipe_windows; out[1] = b->pipe_aborted;
     out[2] = b->pipe_windows ? nt : 0;
-    out[3] = b->pipe_windows ? pipe_chunk(b->N, b->L, pipe_sweep_threads(nt)) : 0;
+    out[3] = b->pipe_windows ? pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), b->hs[0]->cfg.storage == GH_STORAGE_F64 ? 8 : 4) : 0;
     return GH_OK;
 }
 

@@ -113,6 +113,7 @@ struct win_desc {
     gh_path_rec *recs;     // [max_paths]
     int snap;              // batched k_snapshot: freeze this window's marginals as the original ones
     int _pad;
+    unsigned long long *pk; // [N+2] k_wpipe (wpipe.hpp): what a sweep needs of a position's candidates, packed by its prologue
 };
 
 // Band layout: band[i][a][d-1][b] -- position, FROM-symbol, distance, to-symbol.  Everything a path touches at position i

@@ -38,6 +38,11 @@
 // tests/test_gpu_pipe.py): same IEEE operations in the same order as k_marg<T,true> and the serial walker.
 #pragma once
 
+#ifdef PIPE_PROF
+#define PIPE_PROF_STAMPS 0
+#else
+#define PIPE_PROF_STAMPS 1
+#endif
 #ifndef PIPE_DEV_ROLES
 #define PIPE_DEV_ROLES 15     /* diagnostic builds: compile only some of the roles (register accounting) */
 #endif
@@ -79,17 +84,17 @@ template <> struct pipe_roles<512> {
 };
 
 // LDS of one workgroup: two table buffers of C + WALK_OV positions, the walker's words, log10's table, the sweepers' partial
-// sums, a line of control words, the path (N + 2 bytes)
+// sums and slots (pipe_group_doubles per lane group), a line of control words, the path (N + 2 bytes)
 // doubles per position of a table buffer: X1 = lag-1 terms [row][column] (16), X2 = lag-2 terms (16), Yr = lags 3..L [row][column][lag],
 // rows padded to an even number of lags as in k_walk_spec's depth-2 layout
 __host__ __device__ constexpr int pipe_pos_doubles(int L) { return 32 + 16 * deep_nyp(L); }
-__host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads)
+__host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
-    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + 64 + (((size_t)N + 2 + 15) & ~(size_t)15);
+    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + (((size_t)N + 2 + 15) & ~(size_t)15);
 }
-__host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads)
+__host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads, int esize)
 {
-    const size_t fixed = pipe_fixed_bytes(N, nr_threads);
+    const size_t fixed = pipe_fixed_bytes(N, nr_threads, esize);
     if (L < 2 || fixed + 2 * (size_t)(L + WALK_OV) * pipe_pos_doubles(L) * 8 > WALK_LDS_MAX) return 0;
     long c = (long)((WALK_LDS_MAX - fixed) / (2 * (size_t)pipe_pos_doubles(L) * 8)) - WALK_OV;
     const long cap = nr_threads / 8 - WALK_OV;
@@ -98,9 +103,9 @@ __host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads)
     c = (c / L) * L;
     return c >= L ? (int)c : 0;
 }
-__host__ __device__ constexpr size_t pipe_lds_bytes(int N, int L, int C, int nr_threads)
+__host__ __device__ constexpr size_t pipe_lds_bytes(int N, int L, int C, int nr_threads, int esize)
 {
-    return 2 * (size_t)(C + WALK_OV) * pipe_pos_doubles(L) * 8 + pipe_fixed_bytes(N, nr_threads);
+    return 2 * (size_t)(C + WALK_OV) * pipe_pos_doubles(L) * 8 + pipe_fixed_bytes(N, nr_threads, esize);
 }
 
 struct pipe_ctl {
@@ -159,7 +164,8 @@ __device__ __forceinline__ void pipe_book_consume(const double *minfo_unused, ui
 // and the walker takes H of target t as X1[t-1][a1][b] + X2[t-2][a2][b] itself: one more LDS read and one more addition per step,
 // four bodies ahead of their use; the same IEEE addition the loaders did, so bit-identical.  Everything else is spec2_walker.
 template <int LC>
-__device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *words0, int C, int nchunks, int lane)
+__device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *words0, int C, int nchunks, int lane,
+                                              unsigned long long *prof = nullptr /* diagnostic builds: [0] += cycles walking, [1] += cycles at the barriers */)
 {
     static_assert(LC >= 2, "depth-2 speculation needs two lags");
     typedef deep_layout<LC> DL;
@@ -243,163 +249,279 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
             v2 += (unsigned)LC * XB;
             vy += (unsigned)LC * YB;
         }
+#ifdef PIPE_PROF
+        const unsigned long long tw = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PIPE_PROF
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        prof[0] += tw - prof[2]; prof[1] += tb - tw; prof[2] = tb;
+#endif
     }
 }
 
-// One sweep pass: the 8-lane group `lp` reweights position p along s_path with `ratio` (gretel/gretel.py:79-98), takes the
-// marginals of p and rewrites the table row G[p][rank of path[p]] -- k_marg<T, true>'s arithmetic, operation for operation.
-template <typename T>
-__device__ __forceinline__ void pipe_sweep_pos(const pipe_params &P, const win_desc &d, const uint8_t *s_path, const double *s_logtab,
-                                               int p, int s, double ratio, double &removed, int *abort_flag)
+// What a sweep needs to know about a position and never changes while the pipeline runs (the candidate masks stand, or it stops):
+// one 64-bit word per position, made in the kernel's prologue from cmask / nvalid (win_desc::pk):
+//   bits 0..2   V(p): valid symbols seen              bits 3..5   candidates offered (<= 4 in a ranked window)
+//   bits 6..17  the symbol of the candidate of rank 0..3, 3 bits each (the order get_edge_weights_at offers them in)
+//   bits 18..38 per SYMBOL 0..6 the row of G a path through it rewrites: its rank; 5 for '_' at position 0; 7 = none
+#define PK_NVALID(w) ((int)((w) & 7u))
+#define PK_NCAND(w) ((int)(((w) >> 3) & 7u))
+#define PK_SYM(w, rb) ((int)(((w) >> (6 + 3 * (rb))) & 7u))
+#define PK_ROW6(w, sym) ((int)(((w) >> (18 + 3 * (sym))) & 7u))
+__device__ __forceinline__ unsigned long long pipe_pack(uint32_t cmw, int nvalid, int p, symmap sm)
 {
-    const int N = P.N, W = P.W, L = P.L;
+    const uint32_t cm5 = cm5_of_cmask(sm, CM_CAND(cmw));
+    int nc = __popc(cm5);
+    if (nc > 4) nc = 4;
+    unsigned long long w = (unsigned long long)(nvalid & 7) | ((unsigned long long)nc << 3);
+    for (int rb = 0; rb < 4; rb++) {
+        const int b5 = nth_set5(cm5, rb);
+        w |= (unsigned long long)(b5 >= 0 ? vsym(sm, b5) : 0) << (6 + 3 * rb);
+    }
+    for (int sym = 0; sym < NSYM; sym++) {
+        const int a6 = a6_of_sym(sm, sym);
+        int row6 = 7;
+        if (a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : 7;
+        else if (a6 == 5 && p == 0) row6 = 5;
+        w |= (unsigned long long)row6 << (18 + 3 * sym);
+    }
+    return w;
+}
+
+// seven values by NAME (a row of a cell): selects over the elements of a local array make hipcc keep the array in scratch memory and
+// select the address instead (measured: 64-176 bytes of scratch per lane and a scratch load per table entry)
+template <typename T>
+struct row7 {
+    T v0, v1, v2, v3, v4, v5, v6;
+    // (every value passes through an empty asm before it is selected: hipcc simplifies this function on its own before it inlines
+    // it, folds "select between two loads" into "load from a selected address", and the struct then has to live in scratch memory)
+    __device__ __forceinline__ T get(int k) const
+    {
+        T a0 = v0, a1 = v1, a2 = v2, a3 = v3, a4 = v4, a5 = v5, a6 = v6;
+        asm("" : "+v"(a0)); asm("" : "+v"(a1)); asm("" : "+v"(a2)); asm("" : "+v"(a3)); asm("" : "+v"(a4)); asm("" : "+v"(a5)); asm("" : "+v"(a6));
+        T r = a0;
+        r = (k == 1) ? a1 : r; r = (k == 2) ? a2 : r; r = (k == 3) ? a3 : r;
+        r = (k == 4) ? a4 : r; r = (k == 5) ? a5 : r; r = (k == 6) ? a6 : r;
+        return r;
+    }
+    __device__ __forceinline__ T sum() const { return (((((((T)0 + v0) + v1) + v2) + v3) + v4) + v5) + v6; }   // sequential, storage dtype
+    __device__ __forceinline__ void load(const T *p) { v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; v4 = p[4]; v5 = p[5]; v6 = p[6]; }
+    __device__ __forceinline__ void zero() { v0 = v1 = v2 = v3 = v4 = v5 = v6 = (T)0; }
+};
+
+// One sweep pass in two stages, an epoch apart.  The 8-lane group of position p first LOADS what the position needs -- lane s the
+// row (p, p+s+1) of the path's symbol (7 values: the cell on the path, the row sum of lag s+1's conditional, and for s = 0 the new
+// c_a(p)), the old c_s(p), the packed words of p and of the target p+s+1 -- and, one barrier later, reweights along s_path with
+// `ratio` (gretel/gretel.py:79-98), takes the marginals of p and rewrites the table row G[p][rank of path[p]]: k_marg<T, true>'s
+// arithmetic, operation for operation, but
+//   * no load between two dependent steps (bands and lag counts above 8 take their further rounds the slow way, loads in place);
+//   * only what can change is recomputed: the marginals of the CANDIDATES of p (a symbol never seen keeps m = 0, log10 m = -inf)
+//     and the table entries of candidate columns (missing ranks keep the -inf, rows behind the window the 0.0 k_lt wrote);
+//   * those entries -- a binary64 division and a log10 each, 4 per lag and one per candidate of p: 24 at five lags -- are DEALT
+//     over the eight lanes of the group through LDS slots (one lag per lane left three lanes idle for five rounds; now three
+//     rounds), and what is selected by a run-time symbol is read from the slot by address instead of through select chains over
+//     registers: the first version spent 1 300 vector instructions per lane and pass, a third of them binary64, and eight
+//     sweeper waves saturated three SIMDs.
+// A lane's LDS operations complete in order and a group sits in one wavefront: no barrier inside.
+template <typename T>
+struct sweep_regs {
+    row7<T> row;            // band[p][a][s+1][.]
+    double cnt;             // cnt[p][s]
+    unsigned long long pkp; // pk[p]
+    unsigned long long pkt; // pk[p + s + 1]
+};
+
+// doubles per lag slot (row as 8 x T, denominator, packed word of the target) and per lane group (8 slots)
+template <typename T> __host__ __device__ constexpr int pipe_slot_doubles() { return (int)(8 * sizeof(T) / 8) + 2; }
+__host__ __device__ constexpr int pipe_group_doubles(int esize) { return 8 * (esize + 2); }
+
+// (global address space spelled out: through the generic pointers of win_desc hipcc emits flat loads, which also count as LDS
+// operations; and NO branch around a load -- a load under a condition is merged with its zero default right behind the branch, and
+// the merge waits for the load: the first version of this stage prefetched nothing.  Lanes without work load a valid address.)
+#define PIPE_GLOBAL(T_) __attribute__((address_space(1))) T_
+template <typename T_> __device__ __forceinline__ PIPE_GLOBAL(T_) *pipe_gptr(T_ *p) { return (PIPE_GLOBAL(T_) *)(uintptr_t)p; }
+template <typename T_> __device__ __forceinline__ const PIPE_GLOBAL(T_) *pipe_gptr(const T_ *p) { return (const PIPE_GLOBAL(T_) *)(uintptr_t)p; }
+
+template <typename T>
+__device__ __forceinline__ void pipe_sweep_load(const pipe_params &P, const win_desc &d, const uint8_t *s_path, int p, int s, sweep_regs<T> &R)
+{
+    const int N = P.N, W = P.W;
+    const int pp = p <= N ? p : 0;                              // (a lane group without a position reads position 0 and uses nothing)
+    const int a = (int)s_path[pp];
+    const int dd = s + 1 <= W ? s + 1 : 1;                      // (beyond the band: the compute stage takes zeros)
+    const PIPE_GLOBAL(T) *rc = pipe_gptr((const T *)d.band) + bidx(W, pp, dd, a, 0);
+    R.row.v0 = rc[0]; R.row.v1 = rc[1]; R.row.v2 = rc[2]; R.row.v3 = rc[3]; R.row.v4 = rc[4]; R.row.v5 = rc[5]; R.row.v6 = rc[6];
+    R.cnt = pipe_gptr((const double *)d.cnt)[(size_t)pp * 8 + s];
+    R.pkp = pipe_gptr((const unsigned long long *)d.pk)[pp];
+    const int snp = p + s + 1;
+    R.pkt = pipe_gptr((const unsigned long long *)d.pk)[(snp <= N && s + 1 <= P.L) ? snp : N + 1];     // (pk[N + 1] = 0: no candidates, no entries)
+}
+
+// `prefetch` is called as soon as the registers of R have been consumed (the row is in its slot, the three scalars are copied):
+// the caller issues the loads of the NEXT pass into R there, and they are in flight under everything that follows.
+template <typename T, int LC, typename PF>
+__device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const win_desc &d, const uint8_t *s_path, const double *s_logtab,
+                                                   double *s_deal /* this lane group's slots */,
+                                                   int p, int s, double ratio, sweep_regs<T> &R, double &removed, int *abort_flag, PF &&prefetch)
+{
+    const int N = P.N, W = P.W;
+    constexpr int L = LC;
+    constexpr int Lr = L < 8 ? L : 8;
+    constexpr int SD = pipe_slot_doubles<T>();
     const symmap sm = P.sm;
-    T *band = (T *)d.band;
+    PIPE_GLOBAL(T) *band = pipe_gptr((T *)d.band);
+    PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.G), *g_minfo = pipe_gptr(d.minfo), *g_rinfo = pipe_gptr(d.rinfo);
     const bool act = p <= N;
     const int a = act ? (int)s_path[p] : 0;
-    int nb = -1;
-    T nval = (T)0;
+    auto mult_of = [&](int dd) __attribute__((always_inline)) {     // how often reweight_hansel_from_path visits the cell (p, p + dd): SURVEY section 8 a8
+        const int j = p + dd;
+        if (j <= N - 1) return (dd == 1) ? 2 : 1;
+        if (j == N) return (dd == 1) ? 1 : 0;
+        if (j == N + 1) return (p == N) ? 1 : 0;
+        return 0;
+    };
+    auto reweight = [&](T cur, int mult) __attribute__((always_inline)) {
+        for (int q = 0; q < mult; q++) {
+            const double old = (double)cur;
+            const double nw = old - ratio * old;
+            cur = (T)nw;
+            removed += old - nw;
+        }
+        return cur;
+    };
+    // this lane's slot: the row it loaded, as it lies in the band
+    double *slot = s_deal + s * SD;
+    T *srow = reinterpret_cast<T *>(slot);
+    typedef T rowvec __attribute__((ext_vector_type(4), aligned(16)));
+    {
+        const bool inb = s + 1 <= W;                 // beyond the band the row is zeros (the load stage fetched a valid address instead)
+        *reinterpret_cast<rowvec *>(srow) = rowvec{inb ? R.row.v0 : (T)0, inb ? R.row.v1 : (T)0, inb ? R.row.v2 : (T)0, inb ? R.row.v3 : (T)0};
+        *reinterpret_cast<rowvec *>(srow + 4) = rowvec{inb ? R.row.v4 : (T)0, inb ? R.row.v5 : (T)0, inb ? R.row.v6 : (T)0, (T)0};
+    }
+    const double cnt_old = R.cnt;
+    const unsigned long long pkp = R.pkp, pkt_in = R.pkt;
+    prefetch();
+    // the first round out of the slot: lane s owns the cell (p, p + s + 1)
+    if (act && s + 1 <= W) {
+        const int dd = s + 1, j = p + dd;
+        const int mult = mult_of(dd);
+        if (mult) {
+            const int b = (j == N + 1) ? (int)s_path[0] : (int)s_path[j];
+            const T cur = reweight(srow[b], mult);
+            band[bidx(W, p, dd, a, b)] = cur;
+            srow[b] = cur;
+        }
+    }
+    // bands wider than 8: the further cells with a load in place
     if (act) {
-        for (int dd = s + 1; dd <= W; dd += 8) {
+        for (int dd = s + 9; dd <= W; dd += 8) {
             const int j = p + dd;
-            int mult = 0;
-            if (j <= N - 1) mult = (dd == 1) ? 2 : 1;
-            else if (j == N) mult = (dd == 1) ? 1 : 0;
-            else if (j == N + 1) mult = (p == N) ? 1 : 0;
+            const int mult = mult_of(dd);
             if (mult) {
                 const int b = (j == N + 1) ? (int)s_path[0] : (int)s_path[j];
-                T *e = band + bidx(W, p, dd, a, b);
-                T cur = *e;
-                for (int q = 0; q < mult; q++) {
-                    const double old = (double)cur;
-                    const double nw = old - ratio * old;
-                    cur = (T)nw;
-                    removed += old - nw;
-                }
-                *e = cur;
-                if (dd == 1) { nb = b; nval = cur; }
+                PIPE_GLOBAL(T) *e = band + bidx(W, p, dd, a, b);
+                *e = reweight(*e, mult);
             }
         }
     }
-    nb = __shfl(nb, 0, 8);
-    nval = (T)__shfl((double)nval, 0, 8);
-    // c_s(p): the row of the path's symbol from the cell (p, p+1) just updated (sequentially, in the storage dtype); the other
-    // rows' sums are what the pass before left in cnt -- they have not changed
-    double mine = 0.0;
-    if (act && s < NSYM) {
-        if (s == a) {
-            T acc = (T)0;
-#pragma unroll
-            for (int x = 0; x < NSYM; x++) {
-                T v = band[bidx(W, p, 1, s, x)];
-                if (x == nb) v = nval;
-                acc = acc + v;
-            }
-            mine = (double)acc;
-        } else {
-            mine = d.cnt[(size_t)p * 8 + s];
-        }
-    }
-    double c[NSYM];
+    // the row as it now stands: its sum (sequentially, in the storage dtype) is the row sum of lag s+1's conditional, and on
+    // lane 0 -- the cell (p, p+1) -- the new c_a(p); the other c_s(p) are what the pass before left in cnt: they have not changed
+    const rowvec r03 = *reinterpret_cast<const rowvec *>(srow), r46 = *reinterpret_cast<const rowvec *>(srow + 4);
+    const double rowsum0 = (double)((((((((T)0 + r03.x) + r03.y) + r03.z) + r03.w) + r46.x) + r46.y) + r46.z);
+    const double ca_new = __shfl(rowsum0, 0, 8);
+    const double mine = (act && s < NSYM) ? (s == a ? ca_new : cnt_old) : 0.0;
     double tot = 0.0;
-    int nv = 0;
-    uint32_t cm = 0;
 #pragma unroll
     for (int x = 0; x < NSYM; x++) {
-        c[x] = __shfl(mine, x, 8);
-        if (c[x] > 0) {
-            tot += c[x];
-            if ((VALID_MASK >> x) & 1) { nv++; cm |= 1u << x; }
-        }
+        const double cx = __shfl(mine, x, 8);
+        if (cx > 0) tot += cx;
     }
-    const uint32_t cand = P.offer_zero ? VALID_MASK : cm;
-    const uint32_t cmw = cm | (cand << 8);
-    const uint32_t cm5 = cm5_of_cmask(sm, cand);
-    double my_m = 0.0, my_lm = 0.0;
-    if (s < NSYM) {
-        my_m = (c[s] > 0 && tot != 0.0) ? c[s] / tot : 0.0;
-        if ((VALID_MASK >> s) & 1) my_lm = gh_log10_tab(my_m, s_logtab, GH_LOG_SERIAL);
-    }
+    // this lane's share of the position's marginals: the candidate of rank rbm of p (tasks 4 Lr .. 4 Lr + 3 of the deal below)
+    const int rbm = (s - 4 * Lr) & 7;
+    const int sym_m = PK_SYM(pkp, rbm & 3);
+    const double c_m = __shfl(mine, sym_m, 8);
     if (act) {
-        if (s < NSYM) {
-            if (s == a) d.cnt[(size_t)p * 8 + s] = c[s];
-            if ((VALID_MASK >> s) & 1) {
-                const int b5 = a6_of_sym(sm, s);
-                d.minfo[(size_t)p * MINFO + b5] = my_lm;
-                d.minfo[(size_t)p * MINFO + 5 + b5] = my_m;
-                if (d.rinfo && ((cand >> s) & 1u) && __popc(cm5 & ((1u << b5) - 1u)) < 4) {
-                    const int r = __popc(cm5 & ((1u << b5) - 1u));
-                    d.rinfo[(size_t)p * RINFO + r] = my_lm;
-                    d.rinfo[(size_t)p * RINFO + 4 + r] = my_m;
+        if (s == a) g_cnt[(size_t)p * 8 + s] = mine;
+        if (s == 7) g_cnt[(size_t)p * 8 + 7] = tot;
+        // the masks stood when the pass before ended and only c_a(p) has changed since: they still stand iff it is still positive
+        if (s == 0 && ((VALID_MASK >> a) & 1) && !(ca_new > 0)) atomicOr(abort_flag, 1);
+    }
+    const int row6 = act && p < N ? PK_ROW6(pkp, a) : 7;        // the table row this position's cells feed (7: none)
+    // lag s + 1: the denominator and the target's word beside the row
+    if (s < Lr) {
+        const double nv_i = (double)PK_NVALID(pkp);
+        const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt_in) + rowsum0 : (P.cond_mode == GH_COND_D ? nv_i + rowsum0 : nv_i + ca_new);
+        slot[SD - 2] = den;
+        reinterpret_cast<unsigned long long *>(slot)[SD - 1] = row6 < 6 ? pkt_in : 0ull;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PIPE_GLOBAL(double) *rowbase = g_G + ((size_t)p * 6 + (row6 < 6 ? row6 : 0)) * L * LT_ROW;
+    for (int t = s; t < 4 * Lr + 4; t += 8) {
+        // one entry: a quotient and its log10
+        double num = 0.0, den = 1.0;
+        bool live = false;
+        PIPE_GLOBAL(double) *out = nullptr;
+        int b5m = 0;
+        const bool is_m = t >= 4 * Lr;
+        if (!is_m) {
+            const int li = t >> 2, rb = t & 3;
+            const double *sl = s_deal + li * SD;
+            const unsigned long long pkt = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
+            if (rb < PK_NCAND(pkt)) {
+                live = true;
+                num = 1.0 + (double)reinterpret_cast<const T *>(sl)[PK_SYM(pkt, rb)];
+                den = sl[SD - 2];
+                out = rowbase + (size_t)li * LT_ROW + rb;
+            }
+        } else if (act && (t - 4 * Lr) < PK_NCAND(pkp)) {
+            live = true;
+            b5m = a6_of_sym(sm, sym_m);
+            num = c_m;
+            den = tot;
+            out = g_minfo + (size_t)p * MINFO + b5m;
+        }
+        if (live) {
+            double xq = num / den;
+            if (is_m && !(c_m > 0 && tot != 0.0)) xq = 0.0;            // (k_marg: m = c > 0 && total != 0 ? c / total : 0)
+            // (k_marg takes the straight-line logarithm where the arguments are normal, the general one otherwise: same values)
+            const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+            out[0] = v;
+            if (is_m) {
+                out[5] = xq;
+                if (d.rinfo) {          // the same by candidate rank
+                    g_rinfo[(size_t)p * RINFO + (t - 4 * Lr)] = v;
+                    g_rinfo[(size_t)p * RINFO + 4 + (t - 4 * Lr)] = xq;
                 }
             }
-        } else {
-            d.cnt[(size_t)p * 8 + 7] = tot;
-            if (d.cmask[p] != cmw) atomicOr(abort_flag, 1);        // a candidate mask moved: the table is no longer the tensor's
         }
     }
-    if (act && p < N && a != SYM_N) {
-        // the table row this position's cells feed: source p, rank of path[p], lags 1..L (lane s takes lags s+1, s+9, ..)
-        const int a6 = a6_of_sym(sm, a);
-        const double nv_i = (double)nv, ca = __shfl(mine, a, 8);
-        int row6 = a6;
-        if (a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : -1;
-        for (int l = s + 1; l <= L && row6 >= 0; l += 8) {
-            double *out = d.G + (((size_t)p * 6 + row6) * L + (l - 1)) * LT_ROW;
-            const int snp = p + l;
-            if (!(snp <= N && (a6 < 5 || p == 0))) {
-#pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) out[b5] = 0.0;
-                continue;
-            }
-            double rowv[NSYM];
-            double sum = 0.0;
-            if (l <= W) {
-                const T *rc = band + bidx(W, p, l, a, 0);
-                T racc = (T)0;
-#pragma unroll
-                for (int x = 0; x < NSYM; x++) { const T v = rc[x]; rowv[x] = (double)v; racc = racc + v; }
-                sum = (double)racc;
-            } else {
-#pragma unroll
-                for (int x = 0; x < NSYM; x++) rowv[x] = 0.0;
-            }
-            const uint32_t cmj = CM_CAND(d.cmask[snp]);
-            const double den = (P.cond_mode == GH_COND_A) ? (double)d.nvalid[snp] + sum : (P.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca);
-            double xq[LT_ROW], v[LT_ROW];
-            bool odd = false;
-#pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) {
-                double rv = rowv[0];
-                const int sb = vsym(sm, b5);
-#pragma unroll
-                for (int x = 1; x < NSYM; x++) rv = (sb == x) ? rowv[x] : rv;
-                xq[b5] = (1.0 + rv) / den;
-                odd |= !gh_log10_is_normal(xq[b5]);
-            }
-#pragma unroll
-            for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_normal_tab(xq[b5], 0, s_logtab, GH_LOG_SERIAL);
-            if (odd) {
-#pragma unroll
-                for (int b5 = 0; b5 < LT_ROW; b5++) v[b5] = gh_log10_tab(xq[b5], s_logtab, GH_LOG_SERIAL);
-            }
-            // ranked table: the columns of lag l are the candidates of p+l in the order they are offered in
-            const uint32_t cj5 = cm5_of_cmask(sm, cmj);
-#pragma unroll
-            for (int rb = 0; rb < LT_ROW; rb++) {
-                const int b5 = nth_set5(cj5, rb);
-                double r = -INFINITY;
-#pragma unroll
-                for (int q = 0; q < LT_ROW; q++) r = (b5 == q) ? v[q] : r;
-                out[rb] = r;
+    if constexpr (L > 8) {
+        // lag counts above 8: the further lags one per lane, with loads in place
+        if (row6 < 6) {
+            const double nv_i = (double)PK_NVALID(pkp);
+            for (int l = s + 9; l <= L; l += 8) {
+                const int snp = p + l;
+                if (snp > N) continue;
+                row7<T> rw;
+                rw.zero();
+                if (l <= W) rw.load((const T *)d.band + bidx(W, p, l, a, 0));
+                const unsigned long long pkt = d.pk[snp];
+                const double sum = (double)rw.sum();
+                const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt) + sum : (P.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca_new);
+                PIPE_GLOBAL(double) *out = rowbase + (size_t)(l - 1) * LT_ROW;
+                for (int rb = 0; rb < PK_NCAND(pkt); rb++) {
+                    const double xq = (1.0 + (double)rw.get(PK_SYM(pkt, rb))) / den;
+                    out[rb] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+                }
             }
         }
     }
 }
 
+// (second launch bound = waves per SIMD: 512 threads at up to six lags are held to 128 registers so that TWO workgroups share a CU)
 template <typename T, int LC, int NT>
-__global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
+__global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ? 4 : (NT == 768 ? 3 : 2))) k_wpipe(pipe_params P, const win_desc *wd)
 {
     typedef pipe_roles<NT> RL;
     typedef deep_layout<LC> DL;
@@ -416,7 +538,9 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
     unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)npos * RS);
     double *const s_logtab = reinterpret_cast<double *>(words0 + 128);
     double *const s_red = s_logtab + 256;
-    pipe_ctl *const ctl = reinterpret_cast<pipe_ctl *>(s_red + NR);
+    constexpr int GD = pipe_group_doubles((int)sizeof(T));     // the sweepers' slots: doubles per lane group
+    double *const s_deal = s_red + NR;
+    pipe_ctl *const ctl = reinterpret_cast<pipe_ctl *>(s_deal + (size_t)(NR / 8) * GD);
     uint8_t *const s_path = reinterpret_cast<uint8_t *>(ctl + 1);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -434,18 +558,47 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
         }
     }
     logtab_stage(s_logtab);
+    for (int q = tid; q <= N + 1; q += NT) d.pk[q] = q <= N ? pipe_pack(d.cmask[q], d.nvalid[q], q, P.sm) : 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PIPE_PROF
+    if (blockIdx.x == 0 && tid == 0) st->dbg8[9] = 0;
+#endif
     if (tid == 0) { ctl->ratio = 0.0; ctl->abort = 0; s_path[0] = SYM_US; }
     __syncthreads();
 
+#ifdef PIPE_PROF
+    if (blockIdx.x == 0 && lane == 0) {          // which SIMD each wave sits on: HW_ID bits 5:4, two bits per wave
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        atomicOr((unsigned long long *)&st->dbg8[9], (unsigned long long)((hwid >> 4) & 3u) << (2 * wave));
+    }
+#endif
     const int nchunks = (N + C - 1) / C;
     const int npass = (N - 3 + C - 1) / C > 1 ? (N - 3 + C - 1) / C : 1;      // sweep passes that cover positions 0..N
     const int E = nchunks + 3;
 #define PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PIPE_BARRIER_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // diagnostic builds (-DPIPE_PROF): cycles a role spends at work (issue to the end of its instructions), waiting for its own
+    // memory operations, and waiting at the barrier, summed over the epochs of a launch; window 0 leaves them in st->dbg8
+#ifdef PIPE_PROF
+    unsigned long long pf_t0 = 0, pf_t1 = 0, pf_work = 0, pf_drain = 0, pf_wait = 0;
+#define PIPE_PROF_BEGIN() do { pf_t0 = __builtin_amdgcn_s_memtime(); } while (0)
+#define PIPE_PROF_MID() do { pf_t1 = __builtin_amdgcn_s_memtime(); pf_work += pf_t1 - pf_t0; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pf_t0 = __builtin_amdgcn_s_memtime(); pf_drain += pf_t0 - pf_t1; } while (0)
+#define PIPE_PROF_END() do { pf_wait += __builtin_amdgcn_s_memtime() - pf_t0; } while (0)
+#else
+#define PIPE_PROF_BEGIN()
+#define PIPE_PROF_MID()
+#define PIPE_PROF_END()
+#endif
 
     if (PIPE_DEV_ROLES & 8 ? role == PR_SWEEP : false) {
         // ---- sweepers ---------------------------------------------------------------------------------------------
         const int t = ridx * 64 + lane, lp = t >> 3, s = t & 7;
+        auto pos_of = [&](int e) {                  // the position this lane group takes in pass e (N + 1: none)
+            if (e >= npass) return N + 1;
+            if (e == 0) return lp < C + WALK_OV ? lp : N + 1;
+            return lp < C ? e * C + WALK_OV + lp : N + 1;
+        };
         for (int sp = 0; sp <= P.max_paths; sp++) {
             // sp < max_paths: beside the walk of path sp; sp == max_paths: the last path's reweight, nobody walks
             const bool last = sp == P.max_paths;
@@ -453,19 +606,29 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
             const double ratio = ctl->ratio;
             double removed = 0.0;
             const int ne = last ? npass : E;
+            // pass e takes R apart first thing (the row into its LDS slot, three scalars copied) and the loads of pass e + 1 are
+            // issued into the same registers right there: in flight under the whole computation.  (Two register sets, the next
+            // one loaded in front of the pass: hipcc parks the arriving set in other registers in the middle of the pass and
+            // waits for it there; one set loaded behind the pass: the latency stands in front of every barrier.  Both measured.)
+            sweep_regs<T> R;
+            if (do_rw) pipe_sweep_load<T>(P, d, s_path, pos_of(0), s, R);
             for (int e = 0; e < ne; e++) {
-                if (do_rw && e < npass) {
-                    const int p = e == 0 ? lp : e * C + WALK_OV + lp;
-                    const bool mine = e == 0 ? lp < C + WALK_OV : lp < C;
-                    pipe_sweep_pos<T>(P, d, s_path, s_logtab, mine ? p : N + 1, s, ratio, removed, &ctl->abort);
-                }
+                PIPE_PROF_BEGIN();
+                if (do_rw && e < npass)
+                    pipe_sweep_compute<T, LC>(P, d, s_path, s_logtab, s_deal + lp * GD, pos_of(e), s, ratio, R, removed, &ctl->abort,
+                                              [&]() __attribute__((always_inline)) { pipe_sweep_load<T>(P, d, s_path, pos_of(e + 1), s, R); });
+                PIPE_PROF_MID();
                 if (!last) PIPE_BARRIER_DRAIN();
+                PIPE_PROF_END();
             }
             s_red[t] = removed;
             PIPE_BARRIER_DRAIN();                   // tail: the bookkeeper sums s_red and closes the records
             if (last || ctl->abort != 0) break;     // (read between the tail and the barrier behind it: no sweeper is at work)
             PIPE_BARRIER();                         // (the bookkeeper's ratio stands)
         }
+#ifdef PIPE_PROF
+        if (blockIdx.x == 0 && t == 0) { st->dbg8[0] = pf_work; st->dbg8[1] = pf_drain; st->dbg8[2] = pf_wait; }
+#endif
         return;
     }
     if (PIPE_DEV_ROLES & 4 ? role == PR_LOAD : false) {
@@ -477,22 +640,26 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
         const int ntask = npos * TPP;
         typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(8)));      // G rows are 8-byte aligned
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
+        const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.G);
         auto fetch = [&](int k) {
+            // (no branch around a load: see pipe_sweep_load; tasks beyond the buffer or the table read source 0 and are dropped /
+            // zeroed when the chunk is stored)
             const int i0 = k * C;
 #pragma unroll
             for (int it = 0; it < MAXT; it++) {
                 const int q = t + it * NL;
                 const int pp = q / TPP, r = q % TPP, row = r / LC, l = r % LC;
                 const int sidx = i0 + pp;
-                R.lo[it] = ld_v2d{0.0, 0.0}; R.hi[it] = ld_v2d{0.0, 0.0};
-                if (q < ntask && sidx < nsrc_all) {
-                    const double *src = d.G + (size_t)sidx * BLK + (sidx == 0 ? 5 : row) * ROW + l * LT_ROW;
-                    R.lo[it] = *reinterpret_cast<const ld_v2d *>(src);
-                    R.hi[it] = *reinterpret_cast<const ld_v2d *>(src + 2);
-                }
+                const bool ok = q < ntask && sidx < nsrc_all;
+                const int si = ok ? sidx : 0;
+                const PIPE_GLOBAL(double) *src = gG + (size_t)si * BLK + (si == 0 ? 5 : row) * ROW + l * LT_ROW;
+                typedef PIPE_GLOBAL(ld_v2d) gv2d;
+                R.lo[it] = *reinterpret_cast<const gv2d *>(src);
+                R.hi[it] = *reinterpret_cast<const gv2d *>(src + 2);
             }
         };
         auto store = [&](int k) {
+            const int i0 = k * C;
             double *dst = g0 + (size_t)(k & 1) * npos * RS;
             double *yr = dst + (size_t)npos * 32;
 #pragma unroll
@@ -500,13 +667,15 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
                 const int q = t + it * NL;
                 const int pp = q / TPP, r = q % TPP, row = r / LC, l = r % LC;
                 if (q < ntask) {
+                    const bool z = i0 + pp >= nsrc_all;            // behind the table: zeros (the walker runs whole chunks)
+                    const double x0 = z ? 0.0 : R.lo[it].x, x1 = z ? 0.0 : R.lo[it].y, x2 = z ? 0.0 : R.hi[it].x, x3 = z ? 0.0 : R.hi[it].y;
                     if (l < 2) {
                         lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * 32 + l * 16 + row * 4);
-                        o[0] = lds_v2d{R.lo[it].x, R.lo[it].y};
-                        o[1] = lds_v2d{R.hi[it].x, R.hi[it].y};
+                        o[0] = lds_v2d{x0, x1};
+                        o[1] = lds_v2d{x2, x3};
                     } else {
                         double *o = yr + (size_t)pp * DL::YPOS + (size_t)row * 4 * DL::NYP + (l - 2);
-                        o[0] = R.lo[it].x; o[DL::NYP] = R.lo[it].y; o[2 * DL::NYP] = R.hi[it].x; o[3 * DL::NYP] = R.hi[it].y;
+                        o[0] = x0; o[DL::NYP] = x1; o[2 * DL::NYP] = x2; o[3 * DL::NYP] = x3;
                     }
                 }
             }
@@ -520,15 +689,21 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
             if (nchunks > 1) fetch(1);
             PIPE_BARRIER();                                         // epoch 2 (the loads of chunk 1 stay in flight)
             for (int k = 0; k < nchunks; k++) {                     // epoch k + 3: the walker is in chunk k
+                PIPE_PROF_BEGIN();
                 if (k + 1 < nchunks) store(k + 1);
                 if (k + 2 < nchunks) fetch(k + 2);
+                PIPE_PROF_MID();
                 PIPE_BARRIER();
+                PIPE_PROF_END();
             }
             PIPE_BARRIER();                                         // tail
             if ((aborted = ctl->abort != 0)) break;                 // (read between the tail and the barrier behind it: no sweeper is at work)
             PIPE_BARRIER();
         }
         if (!aborted) PIPE_BARRIER();                               // behind the last sweep: its partial sums
+#ifdef PIPE_PROF
+        if (blockIdx.x == 0 && t == 0) { st->dbg8[3] = pf_work; st->dbg8[4] = pf_drain; st->dbg8[5] = pf_wait; }
+#endif
         return;
     }
     if (PIPE_DEV_ROLES & 2 ? role == PR_BOOK : false) {
@@ -560,13 +735,19 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
                 pipe_book_consume(d.minfo, path_out, s_path, words0 + (c & 1) * 64, LC, c * C, C, N, lane, R, Tt, lane_min, P.sm);
             };
             for (int k = 0; k < nchunks; k += 2) {
+                PIPE_PROF_BEGIN();
                 book_prefetch(BP, k * C, C, N, lane, R0);
                 if (k >= 1) consume(k - 1, R1);
+                PIPE_PROF_MID();
                 PIPE_BARRIER();
+                PIPE_PROF_END();
                 if (k + 1 < nchunks) {
+                    PIPE_PROF_BEGIN();
                     book_prefetch(BP, (k + 1) * C, C, N, lane, R1);
                     consume(k, R0);
+                    PIPE_PROF_MID();
                     PIPE_BARRIER();
+                    PIPE_PROF_END();
                 }
             }
             if (nchunks & 1) consume(nchunks - 1, R0);
@@ -593,7 +774,7 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
                 rec->min_marginal = lane_min;
                 rec->magnitude = 0.0;
                 ctl->ratio = r;
-                if (P.prof && sp < 12) {
+                if (PIPE_PROF_STAMPS && P.prof && sp < 12) {
                     const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();
                     st->dbg8[sp] = t_now - t_prev;
                     t_prev = t_now;
@@ -606,6 +787,9 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
             const double mag = reduce_removed();
             if (lane == 0) d.recs[P.max_paths - 1].magnitude = mag;
         }
+#ifdef PIPE_PROF
+        if (blockIdx.x == 0 && lane == 0) { st->dbg8[6] = pf_work; st->dbg8[7] = pf_drain; st->dbg8[8] = pf_wait; }
+#endif
         if (lane == 0) {
             st->n_done = sp;
             st->ratio = ctl->ratio;
@@ -617,14 +801,28 @@ __global__ void __launch_bounds__(NT) k_wpipe(pipe_params P, const win_desc *wd)
     // ---- walker --------------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
     bool aborted = false;
+#ifdef PIPE_PROF
+    unsigned long long wprof[3] = {0, 0, 0};
+#endif
     for (int sp = 0; sp < P.max_paths; sp++) {
         PIPE_BARRIER(); PIPE_BARRIER(); PIPE_BARRIER();             // epochs 0..2
+#ifdef PIPE_PROF
+        wprof[2] = __builtin_amdgcn_s_memtime();
+        spec2x_walker<LC>(g0, words0, C, nchunks, lane, wprof);
+#else
         spec2x_walker<LC>(g0, words0, C, nchunks, lane);            // one barrier behind every chunk
+#endif
         PIPE_BARRIER();                                             // tail
         if ((aborted = ctl->abort != 0)) break;
         PIPE_BARRIER();
     }
     if (!aborted) PIPE_BARRIER();
+#ifdef PIPE_PROF
+    if (blockIdx.x == 0 && lane == 0) { st->dbg8[10] = wprof[0]; st->dbg8[11] = wprof[1]; }
+#endif
 #undef PIPE_BARRIER
+#undef PIPE_PROF_BEGIN
+#undef PIPE_PROF_MID
+#undef PIPE_PROF_END
 #undef PIPE_BARRIER_DRAIN
 }

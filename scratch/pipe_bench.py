@@ -1,0 +1,33 @@
+"""Throughput of the window pipeline (csrc/wpipe.hpp) on replicas of the C3 contig.  argv: windows [paths] [reps]
+env: GH_PIPE=0 -> the batched launches of rounds 1-4; GH_PIPE_NT; GH_PIPE_STAMPS=1 -> per-path times of a few windows."""
+import sys, time
+import numpy as np
+import torch
+from gretel_amd.hansel import Hansel, HanselBatch, DeviceReads
+from gretel_amd.synth import make_config
+
+nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+paths = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+cfg = sys.argv[4] if len(sys.argv) > 4 else "C3"
+t = make_config(cfg, seed=0)
+h0 = Hansel(t.n_snps, band=t.band)
+reads = DeviceReads(h0, t.rank, t.off, t.bases)
+hs = [Hansel(t.n_snps, band=t.band) for _ in range(nw)]
+hb = HanselBatch(hs)
+hb.profile_enable(10)
+for r in range(reps):
+    for h in hs:
+        h.clear()
+        h.fill_from_support(None, None, None, reads_handle=reads)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = hb.spin(paths)
+    dt = time.perf_counter() - t0
+    tot = sum(x["n"] for x in res)
+    pg = hb.profile_get()["walk"]
+    print("windows %d paths %d: %.1f ms, %.0f haplotypes/s; pipe %s; kernel %.2f ms (%d launches), %.2f TB/s on the builder's bytes"
+          % (nw, paths, dt * 1e3, tot / dt, hb.pipe_info(), pg["ms"], pg["launches"],
+             pg["bytes_per_launch"] / max(1e-9, pg["ms"] * 1e-3) / 1e12), flush=True)
+ref = res[0]
+assert all(np.array_equal(x["paths"], ref["paths"]) for x in res)
