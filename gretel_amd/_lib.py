@@ -101,6 +101,8 @@ def load():
         "gh_batch_create": [P(vp), i32, P(vp)],
         "gh_batch_destroy": [vp],
         "gh_batch_spin": [vp, i32, dbl, vp, vp, vp, vp],
+        "gh_host_alloc": [C.c_size_t, P(vp)],
+        "gh_host_free": [vp],
         "gh_batch_pipe_info": [vp, P(C.c_int32)],
         "gh_batch_profile_enable": [vp, i32],
         "gh_batch_profile_get": [vp, i32, P(dbl), P(i64), P(C.c_int32), P(dbl)],

@@ -2292,6 +2292,7 @@ struct gh_batch {
     hipStream_t gstream[3];     // window groups of the batched kernels (gh_batch_spin): created on first use
     hipEvent_t gevent[3];
     win_desc *d_wd;
+    dev_state *d_states;        // every window's dev_state, gathered by k_batch_states for one copy to the host
     uint8_t *d_paths;
     gh_path_rec *d_recs;
     double *d_partial;
@@ -2309,7 +2310,7 @@ extern "C" int gh_batch_destroy(gh_batch_t *b)
     if (!b) return GH_OK;
     hipSetDevice(b->dev);
     if (b->stream) hipStreamSynchronize(b->stream);
-    hipFree(b->d_wd); hipFree(b->d_paths); hipFree(b->d_recs); hipFree(b->d_partial);
+    hipFree(b->d_wd); hipFree(b->d_states); hipFree(b->d_paths); hipFree(b->d_recs); hipFree(b->d_partial);
     for (int g = 0; g < 3; g++) {
         if (b->gstream[g]) { hipStreamSynchronize(b->gstream[g]); hipStreamDestroy(b->gstream[g]); }
         if (b->gevent[g]) hipEventDestroy(b->gevent[g]);
@@ -2340,7 +2341,7 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     if (!b) return fail(GH_ERR_NOMEM, "host allocation failed");
     b->n = n; b->dev = h0->dev; b->N = h0->N; b->W = h0->W; b->L = 0;
     b->hs.assign(handles, handles + n);
-    b->stream = nullptr; b->d_wd = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
+    b->stream = nullptr; b->d_wd = nullptr; b->d_states = nullptr; b->d_paths = nullptr; b->d_recs = nullptr; b->d_partial = nullptr;
     for (int g = 0; g < 3; g++) { b->gstream[g] = nullptr; b->gevent[g] = nullptr; }
     b->cap_paths = 0;
     b->pipe_windows = b->pipe_aborted = 0;
@@ -2348,10 +2349,25 @@ extern "C" int gh_batch_create(gh_t **handles, int n, gh_batch_t **out)
     b->nb = (int)(((size_t)(b->N + 1) * (b->W > 8 ? b->W : 8) + 255) / 256);   // >= blocks of k_marg<.., true>
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_wd, sizeof(win_desc) * n);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_states, sizeof(dev_state) * n);
     if (e == hipSuccess) e = hipMalloc((void **)&b->d_partial, sizeof(double) * (size_t)b->nb * n);
     if (e != hipSuccess) { gh_batch_destroy(b); return fail(GH_ERR_NOMEM, "batch allocation failed: %s", hipGetErrorString(e)); }
     *out = b;
     return GH_OK;
+}
+
+// gh_batch_spin's bookkeeping over all windows in one launch each: the control words a spin starts from (k_spin_reset's), and
+// every window's state into one array the host fetches with one copy (256 small copies cost 4 ms)
+__global__ void k_batch_reset(const win_desc *wd)
+{
+    dev_state *st = wd[blockIdx.x].st;
+    if (threadIdx.x == 0) { st->stop = 0; st->hole_at = 0; st->n_done = 0; st->lt_stale = 0; st->cw_unres = 0; st->pipe_status = 0; }
+}
+__global__ void k_batch_states(const win_desc *wd, dev_state *out)
+{
+    const unsigned *src = reinterpret_cast<const unsigned *>(wd[blockIdx.x].st);
+    unsigned *dst = reinterpret_cast<unsigned *>(out + blockIdx.x);
+    for (unsigned q = threadIdx.x; q < sizeof(dev_state) / 4; q += blockDim.x) dst[q] = src[q];
 }
 
 // ---- the window pipeline (wpipe.hpp): one persistent workgroup per window -------------------------------------------------
@@ -2402,6 +2418,7 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
     const int n = (int)wd.size();
     if (n == 0) return GH_OK;
     HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(k_batch_reset, dim3(n), dim3(64), 0, b->stream, (const win_desc *)b->d_wd);
     HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
     gh_handle *h0 = b->hs[0];
     const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
@@ -2469,13 +2486,14 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
 
 // the batched launches of rounds 1-4 over the windows `wd` describes (a path = k_lt's flag check, one serial walker per window, the
 // fused reweight k_marg<T,true>, the removed mass); returns with every stream drained
-static int batch_run_launches(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove)
+static int batch_run_launches(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, bool reset = true)
 {
     const int n = (int)wd.size();
     if (n == 0) return GH_OK;
     const size_t n1 = (size_t)b->N + 1;
     (void)n1;
     HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+    if (reset) hipLaunchKernelGGL(k_batch_reset, dim3(n), dim3(64), 0, b->stream, (const win_desc *)b->d_wd);
     HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
 
     gh_handle *h0 = b->hs[0];
@@ -2590,6 +2608,10 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
 {
     if (!b || !paths_out || !recs || !n_out || !hole_at || max_paths < 1) return fail(GH_ERR_ARG, "bad argument");
     HIPCHK(hipSetDevice(b->dev));
+    const bool hprof = getenv("GH_PIPE_STAMPS") != nullptr;        // host phases of this call on stderr
+    auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tph = tnow();
+    auto phase = [&](const char *what) { if (hprof) { const double t = tnow(); fprintf(stderr, "gh_batch_spin: %-28s %8.3f ms\n", what, t - tph); tph = t; } };
     const int n = b->n;
     const size_t n1 = (size_t)b->N + 1;
     int rc;
@@ -2598,10 +2620,11 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         if (h->L != b->hs[0]->L)
             return fail(GH_ERR_STATE, "window %d has L=%d but window 0 has L=%d: set one L (gh_set_L) for the batch", w, h->L, b->hs[0]->L);
         if ((rc = alloc_lt(h))) return rc;
-        if ((rc = reset_spin_state(h))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
     }
+    // whatever the handles' own streams still carry (fills) must be done before the batch's stream touches the tensors
+    HIPCHK(hipDeviceSynchronize());
     b->L = b->hs[0]->L;
+    phase("tables allocated, device idle");
     // (measured on C3, MI355X: 8 windows 37k haplotypes/s this way against ~16k batched; 32 windows 45k either way -- the
     // chip is then busy with k_seg; from 48 windows on the batched serial walkers, one workgroup per window, win: 114k at 256)
     // (read on every call: the tests switch between the two ways; -1 = always the batched kernels)
@@ -2617,6 +2640,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         const int bwm0 = h0->wmode == WM_SEG ? WM_SPEC : h0->wmode;
         const int nt = pipe_threads(b->L);
         if (pipe_env && n >= pipe_min && nt && pipe_instantiated(b->L, nt) && walk_depth2_ok(bwm0, b->L) && lt_incremental_ok(h0) &&
+            (unsigned long long)(b->N + 2) * 49ull * (unsigned long long)b->W < (1ull << 31) &&      // (the sweep's 32-bit element offsets)
             pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), h0->cfg.storage == GH_STORAGE_F64 ? 8 : 4) > 0)
             pipe_nt = nt;
     }
@@ -2674,16 +2698,21 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     }
     std::vector<dev_state> hs(n);
     auto fetch_states = [&]() -> int {
-        for (int w = 0; w < n; w++)
-            HIPCHK(hipMemcpyAsync(&hs[w], b->hs[w]->dstate, sizeof(dev_state), hipMemcpyDeviceToHost, b->stream));
+        // (b->d_wd may describe a sub-list by now: the gather takes the full list again)
+        HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+        hipLaunchKernelGGL(k_batch_states, dim3(n), dim3(64), 0, b->stream, (const win_desc *)b->d_wd, b->d_states);
+        HIPCHK(hipMemcpyAsync(hs.data(), b->d_states, sizeof(dev_state) * n, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
         return GH_OK;
     };
     std::vector<int> aborted;           // windows whose pipeline stopped at a moved candidate mask: gh_spin takes their remaining paths
     b->pipe_windows = 0;
+    phase("descriptors");
     if (pipe_nt) {
         if ((rc = batch_run_pipe(b, wd, max_paths, min_remove, pipe_nt))) return rc;
+        phase("preamble + pipeline kernel");
         if ((rc = fetch_states())) return rc;
+        phase("states to host");
         std::vector<win_desc> rest;     // not eligible when the kernel looked (a position offers five candidates, a hole): the batched launches
         for (int w = 0; w < n; w++) {
             if (hs[w].pipe_status == PIPE_NOT_STARTED) rest.push_back(wd[w]);
@@ -2720,6 +2749,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     HIPCHK(hipMemcpyAsync(paths_out, b->d_paths, n1 * max_paths * n, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(recs, b->d_recs, sizeof(gh_path_rec) * (size_t)max_paths * n, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    phase("paths and records to host");
     for (int w = 0; w < n; w++) {
         n_out[w] = hs[w].n_done;
         hole_at[w] = hs[w].stop ? hs[w].hole_at : 0;
@@ -2737,6 +2767,20 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         hole_at[w] = hole2;
     }
     b->pipe_aborted = (int)aborted.size();
+    return GH_OK;
+}
+
+extern "C" int gh_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return fail(GH_ERR_ARG, "bad argument");
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(GH_ERR_NOMEM, "hipHostMalloc of %zu bytes failed", bytes); }
+    *out = p;
+    return GH_OK;
+}
+extern "C" int gh_host_free(void *p)
+{
+    if (p && hipHostFree(p) != hipSuccess) return fail(GH_ERR_HIP, "hipHostFree failed");
     return GH_OK;
 }
 

@@ -330,6 +330,8 @@ struct sweep_regs {
     double cnt;             // cnt[p][s]
     unsigned long long pkp; // pk[p]
     unsigned long long pkt; // pk[p + s + 1]
+    unsigned rowoff;        // element offset of that row in the band (32-bit: the host checks the tensor is smaller than 2^31 elements)
+    int a, b;               // path[p]; the to-symbol of the lane's cell: path[p + s + 1], '_' behind position N
 };
 
 // doubles per lag slot (row as 8 x T, denominator, packed word of the target) and per lane group (8 slots)
@@ -350,9 +352,13 @@ __device__ __forceinline__ void pipe_sweep_load(const pipe_params &P, const win_
     const int pp = p <= N ? p : 0;                              // (a lane group without a position reads position 0 and uses nothing)
     const int a = (int)s_path[pp];
     const int dd = s + 1 <= W ? s + 1 : 1;                      // (beyond the band: the compute stage takes zeros)
-    const PIPE_GLOBAL(T) *rc = pipe_gptr((const T *)d.band) + bidx(W, pp, dd, a, 0);
+    const int j = pp + s + 1;
+    R.a = a;
+    R.b = (int)s_path[j <= N ? j : 0];                          // (j = N + 1: the end sentinel's partner is path[0] = '_'; beyond: unused)
+    R.rowoff = (((unsigned)pp * 7u + (unsigned)a) * (unsigned)W + (unsigned)(dd - 1)) * 7u;
+    const PIPE_GLOBAL(T) *rc = pipe_gptr((const T *)d.band) + R.rowoff;
     R.row.v0 = rc[0]; R.row.v1 = rc[1]; R.row.v2 = rc[2]; R.row.v3 = rc[3]; R.row.v4 = rc[4]; R.row.v5 = rc[5]; R.row.v6 = rc[6];
-    R.cnt = pipe_gptr((const double *)d.cnt)[(size_t)pp * 8 + s];
+    R.cnt = pipe_gptr((const double *)d.cnt)[(unsigned)pp * 8u + (unsigned)s];
     R.pkp = pipe_gptr((const unsigned long long *)d.pk)[pp];
     const int snp = p + s + 1;
     R.pkt = pipe_gptr((const unsigned long long *)d.pk)[(snp <= N && s + 1 <= P.L) ? snp : N + 1];     // (pk[N + 1] = 0: no candidates, no entries)
@@ -373,7 +379,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     PIPE_GLOBAL(T) *band = pipe_gptr((T *)d.band);
     PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.G), *g_minfo = pipe_gptr(d.minfo), *g_rinfo = pipe_gptr(d.rinfo);
     const bool act = p <= N;
-    const int a = act ? (int)s_path[p] : 0;
+    const int a = R.a;
     auto mult_of = [&](int dd) __attribute__((always_inline)) {     // how often reweight_hansel_from_path visits the cell (p, p + dd): SURVEY section 8 a8
         const int j = p + dd;
         if (j <= N - 1) return (dd == 1) ? 2 : 1;
@@ -401,16 +407,16 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     }
     const double cnt_old = R.cnt;
     const unsigned long long pkp = R.pkp, pkt_in = R.pkt;
+    const unsigned rowoff = R.rowoff;
+    const int b_cell = R.b;
     prefetch();
     // the first round out of the slot: lane s owns the cell (p, p + s + 1)
     if (act && s + 1 <= W) {
-        const int dd = s + 1, j = p + dd;
-        const int mult = mult_of(dd);
+        const int mult = mult_of(s + 1);
         if (mult) {
-            const int b = (j == N + 1) ? (int)s_path[0] : (int)s_path[j];
-            const T cur = reweight(srow[b], mult);
-            band[bidx(W, p, dd, a, b)] = cur;
-            srow[b] = cur;
+            const T cur = reweight(srow[b_cell], mult);
+            band[rowoff + (unsigned)b_cell] = cur;
+            srow[b_cell] = cur;
         }
     }
     // bands wider than 8: the further cells with a load in place
@@ -438,12 +444,14 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         if (cx > 0) tot += cx;
     }
     // this lane's share of the position's marginals: the candidate of rank rbm of p (tasks 4 Lr .. 4 Lr + 3 of the deal below)
-    const int rbm = (s - 4 * Lr) & 7;
+    constexpr int NT4 = 4 * Lr;                         // table entries dealt; the marginals follow
+    const int rbm = (s - NT4) & 7;
     const int sym_m = PK_SYM(pkp, rbm & 3);
     const double c_m = __shfl(mine, sym_m, 8);
+    const unsigned p8 = (unsigned)p * 8u;
     if (act) {
-        if (s == a) g_cnt[(size_t)p * 8 + s] = mine;
-        if (s == 7) g_cnt[(size_t)p * 8 + 7] = tot;
+        if (s == a) g_cnt[p8 + (unsigned)s] = mine;
+        if (s == 7) g_cnt[p8 + 7u] = tot;
         // the masks stood when the pass before ended and only c_a(p) has changed since: they still stand iff it is still positive
         if (s == 0 && ((VALID_MASK >> a) & 1) && !(ca_new > 0)) atomicOr(abort_flag, 1);
     }
@@ -456,15 +464,22 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         reinterpret_cast<unsigned long long *>(slot)[SD - 1] = row6 < 6 ? pkt_in : 0ull;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    PIPE_GLOBAL(double) *rowbase = g_G + ((size_t)p * 6 + (row6 < 6 ? row6 : 0)) * L * LT_ROW;
-    for (int t = s; t < 4 * Lr + 4; t += 8) {
-        // one entry: a quotient and its log10
+    const unsigned rowbase = ((unsigned)p * 6u + (unsigned)(row6 < 6 ? row6 : 0)) * (unsigned)(L * LT_ROW);
+    // rounds of eight entries, a quotient and its log10 each; which rounds hold table entries, marginals or both is known at
+    // compile time
+    constexpr int NROUND = (NT4 + 4 + 7) / 8;
+#ifdef PIPE_UNROLL_ROUNDS
+#pragma unroll
+#else
+#pragma unroll 1
+#endif
+    for (int r = 0; r < NROUND; r++) {
+        const int t = s + 8 * r;
+        const bool may_tab = 8 * r < NT4, may_m = 8 * r + 7 >= NT4;     // (compile-time per round when the rounds are unrolled)
         double num = 0.0, den = 1.0;
-        bool live = false;
-        PIPE_GLOBAL(double) *out = nullptr;
-        int b5m = 0;
-        const bool is_m = t >= 4 * Lr;
-        if (!is_m) {
+        bool live = false, is_m = false;
+        unsigned oidx = 0;
+        if (may_tab && (!may_m || t < NT4)) {
             const int li = t >> 2, rb = t & 3;
             const double *sl = s_deal + li * SD;
             const unsigned long long pkt = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
@@ -472,26 +487,30 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 live = true;
                 num = 1.0 + (double)reinterpret_cast<const T *>(sl)[PK_SYM(pkt, rb)];
                 den = sl[SD - 2];
-                out = rowbase + (size_t)li * LT_ROW + rb;
+                oidx = rowbase + (unsigned)(li * LT_ROW + rb);
             }
-        } else if (act && (t - 4 * Lr) < PK_NCAND(pkp)) {
-            live = true;
-            b5m = a6_of_sym(sm, sym_m);
-            num = c_m;
-            den = tot;
-            out = g_minfo + (size_t)p * MINFO + b5m;
+        }
+        if (may_m && t >= NT4) {
+            is_m = true;
+            if (act && (t - NT4) < PK_NCAND(pkp)) {
+                live = true;
+                num = c_m;
+                den = tot;
+                oidx = (unsigned)p * (unsigned)MINFO + (unsigned)a6_of_sym(sm, sym_m);
+            }
         }
         if (live) {
             double xq = num / den;
-            if (is_m && !(c_m > 0 && tot != 0.0)) xq = 0.0;            // (k_marg: m = c > 0 && total != 0 ? c / total : 0)
+            if (may_m && is_m && !(c_m > 0 && tot != 0.0)) xq = 0.0;     // (k_marg: m = c > 0 && total != 0 ? c / total : 0)
             // (k_marg takes the straight-line logarithm where the arguments are normal, the general one otherwise: same values)
             const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+            PIPE_GLOBAL(double) *out = (may_m && is_m ? g_minfo : g_G) + oidx;
             out[0] = v;
-            if (is_m) {
+            if (may_m && is_m) {
                 out[5] = xq;
                 if (d.rinfo) {          // the same by candidate rank
-                    g_rinfo[(size_t)p * RINFO + (t - 4 * Lr)] = v;
-                    g_rinfo[(size_t)p * RINFO + 4 + (t - 4 * Lr)] = xq;
+                    g_rinfo[p8 + (unsigned)(t - NT4)] = v;
+                    g_rinfo[p8 + 4u + (unsigned)(t - NT4)] = xq;
                 }
             }
         }
@@ -509,7 +528,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const unsigned long long pkt = d.pk[snp];
                 const double sum = (double)rw.sum();
                 const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt) + sum : (P.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca_new);
-                PIPE_GLOBAL(double) *out = rowbase + (size_t)(l - 1) * LT_ROW;
+                PIPE_GLOBAL(double) *out = g_G + rowbase + (unsigned)((l - 1) * LT_ROW);
                 for (int rb = 0; rb < PK_NCAND(pkt); rb++) {
                     const double xq = (1.0 + (double)rw.get(PK_SYM(pkt, rb))) / den;
                     out[rb] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);

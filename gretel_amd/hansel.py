@@ -438,6 +438,7 @@ class HanselBatch:
 
     def __del__(self):
         try:
+            self._free_host_buffers()
             if getattr(self, "_b", None):
                 self._lib.gh_batch_destroy(self._b)
                 self._b = None
@@ -463,11 +464,35 @@ class HanselBatch:
             out[name] = dict(ms=ms.value, launches=n.value, windows=w.value, bytes_per_launch=by.value)
         return out
 
-    def spin(self, max_paths=100, min_remove=0.01):
+    def _host_buffers(self, n, max_paths, n1):
+        """Page-locked result buffers, kept from call to call (gh_host_alloc): the copies of 256 windows x 100 paths run at the
+        link's rate and no 256 MB array is faulted in per call."""
+        key = (n, max_paths, n1)
+        if getattr(self, "_hb_key", None) != key:
+            self._free_host_buffers()
+            sizes = (n * max_paths * n1, n * max_paths * 5 * 8)
+            ptrs = []
+            for sz in sizes:
+                p = C.c_void_p()
+                check(self._lib.gh_host_alloc(max(1, sz), C.byref(p)))
+                ptrs.append(p)
+            self._hb_ptrs = ptrs
+            self._hb_paths = np.frombuffer((C.c_uint8 * sizes[0]).from_address(ptrs[0].value), dtype=np.uint8).reshape(n, max_paths, n1)
+            self._hb_recs = np.frombuffer((C.c_double * (sizes[1] // 8)).from_address(ptrs[1].value), dtype=np.float64).reshape(n, max_paths, 5)
+            self._hb_key = key
+        return self._hb_paths, self._hb_recs
+
+    def _free_host_buffers(self):
+        for p in getattr(self, "_hb_ptrs", []):
+            self._lib.gh_host_free(p)
+        self._hb_ptrs, self._hb_key, self._hb_paths, self._hb_recs = [], None, None, None
+
+    def spin(self, max_paths=100, min_remove=0.01, copy=True):
+        """copy=False: the returned arrays are views of the batch's page-locked buffers, valid until the next spin() of this
+        batch (no 256 MB copy on the host); copy=True (default): every window gets its own arrays."""
         n = len(self.hansels)
         n1 = self.hansels[0].n + 1
-        paths = np.zeros((n, max_paths, n1), dtype=np.uint8)
-        recs = np.zeros((n, max_paths, 5), dtype=np.float64)
+        paths, recs = self._host_buffers(n, max_paths, n1)
         n_out = np.zeros(n, dtype=np.int32)
         hole = np.zeros(n, dtype=np.int32)
         check(self._lib.gh_batch_spin(self._b, int(max_paths), float(min_remove), _p(paths), _p(recs), _p(n_out), _p(hole)))
@@ -476,9 +501,11 @@ class HanselBatch:
             k = int(n_out[w])
             if k:
                 self.hansels[w].is_weighted = True
-            out.append(dict(n=k, hole_at=int(hole[w]), paths=paths[w, :k], hp_current=recs[w, :k, 0].copy(),
-                            hp_original=recs[w, :k, 1].copy(), ratio=recs[w, :k, 2].copy(), magnitude=recs[w, :k, 3].copy(),
-                            min_marginal=recs[w, :k, 4].copy()))
+            pw, rw = paths[w, :k], recs[w, :k]
+            if copy:
+                pw, rw = pw.copy(), rw.copy()
+            out.append(dict(n=k, hole_at=int(hole[w]), paths=pw, hp_current=rw[:, 0], hp_original=rw[:, 1], ratio=rw[:, 2],
+                            magnitude=rw[:, 3], min_marginal=rw[:, 4]))
         return out
 
 

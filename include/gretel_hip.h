@@ -26,6 +26,7 @@
 #ifndef GRETEL_HIP_H
 #define GRETEL_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -175,6 +176,12 @@ int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_pa
  * pipeline cannot carry: a position with five candidates, a hole) every kernel of a path is launched over all windows --
  * one path-extension workgroup per window.  The handles stay usable on their own; fill them first.
  * paths_out: [n][max_paths][N+1], recs: [n][max_paths], n_out/hole_at: [n]. */
+/* Page-locked host memory for result buffers (paths_out / recs of gh_spin and gh_batch_spin accept any host memory; into pinned
+ * memory the copies run at the link's rate and without a staging pass -- 256 windows x 100 paths are 256 MB).  No reference
+ * counterpart: the reference keeps its paths in Python lists (gretel/cmd.py:148-179). */
+int gh_host_alloc(size_t bytes, void **out);
+int gh_host_free(void *p);
+
 typedef struct gh_batch gh_batch_t;
 int gh_batch_create(gh_t **handles, int n, gh_batch_t **out);
 int gh_batch_destroy(gh_batch_t *b);

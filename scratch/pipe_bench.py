@@ -22,7 +22,7 @@ for r in range(reps):
         h.fill_from_support(None, None, None, reads_handle=reads)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = hb.spin(paths)
+    res = hb.spin(paths, copy=False)
     dt = time.perf_counter() - t0
     tot = sum(x["n"] for x in res)
     pg = hb.profile_get()["walk"]
