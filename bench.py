@@ -99,7 +99,8 @@ def kernel_source_sha():
     import glob
     import hashlib
     hh = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(ROOT, "gretel_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    files = sorted(glob.glob(os.path.join(ROOT, "gretel_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.inc")))
     for f in files:
         hh.update(os.path.basename(f).encode())
         hh.update(open(f, "rb").read())
@@ -309,6 +310,48 @@ def end_to_end_leg(table, paths, local):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def batch_roofline(batch, bp, paths, n_snps, band, L, es, src_sha, pmc_file):
+    """Roofline object of a batched spin.  When the window pipeline carried it (gretel_amd/csrc/wpipe.hpp: one launch, every
+    window through all its paths) the kernel is k_wpipe and the bytes are SURVEY section 8(d)'s per path -- the conditional
+    lookups of the extension N (1 + L) 196 + 28 N and the reweight's 8 N W -- times paths x windows; `builders_bytes` is the
+    wider definition of DESIGN.md section 3 (+ marginal cells, table rows, records), what gh_batch_profile_get reports."""
+    info = batch.pipe_info()
+    wk, rw = bp["walk"], bp["reweight"]
+    cell = 49.0 * es
+    if info["windows"] > 0 and wk["launches"] > 0:
+        ms = wk["ms"] / wk["launches"]
+        strict = (n_snps * ((1.0 + L) * cell + 28.0) + 2.0 * es * n_snps * band) * paths * wk["windows"]
+        traffic, note = None, "no PMC profile for the kernels of this build"
+        try:
+            pmb = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            if pmb.get("kernel_source_sha") == src_sha:
+                k = next(v for kk, v in pmb["kernels"].items() if kk.startswith("k_wpipe"))
+                traffic = k["hbm_bytes_per_launch_corrected"] * (paths * wk["windows"]) / float(pmb["paths"] * pmb["windows"])
+                note = "profiles/%s (git %s): %d windows x %d paths, scaled to this launch" % (pmc_file, pmb.get("git_head"), pmb["windows"], pmb["paths"])
+            else:
+                note = "profiles/%s was taken with kernel sources %s, this build is %s: not quoted" % (pmc_file, pmb.get("kernel_source_sha"), src_sha)
+        except Exception as exc:
+            note = "no usable PMC profile: %r" % (exc,)
+        return {"bound": "hbm", "kernel": "k_wpipe (window pipeline: walk of path s + reweight sweep of path s-1, all paths of every window in one launch)",
+                "windows_per_launch": wk["windows"], "paths_per_window": paths, "pipeline": info,
+                "avg_launch_ms_hip_events": ms, "algorithmic_bytes_per_launch": strict,
+                "achieved": strict / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": strict / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "builders_bytes_per_launch": wk["bytes_per_launch"], "builders_frac": wk["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": note, "kernel_source_sha": src_sha,
+                "note": "frac prices SURVEY section 8(d)'s bytes (extension lookups + reweight cells) per path and window against 8 TB/s; what binds "
+                        "the kernel is the vector ALU of the sweep (binary64 divisions and log10 of the table entries a path changes) "
+                        "and the walker's dependent-issue latency, DESIGN.md section 4.4"}
+    rw_ms = rw["ms"] / max(1, rw["launches"])
+    return {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)", "pipeline": info,
+            "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
+            "algorithmic_bytes_per_launch": rw["bytes_per_launch"],
+            "achieved": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9) if rw_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rw_ms > 0 else None,
+            "traffic": None, "kernel_source_sha": src_sha,
+            "note": "window groups on their own streams overlap: a bracket around one group's launch also waits for the others' kernels"}
+
+
 def bench_batch(args, cfg_name, paths, desc, rank, world, local, dev):
     """Throughput mode: B independent windows per GPU recovered by one batched launch per
     kernel.  Distinct synthetic contigs are expensive to generate on the host, so min(B, 8) seeds are
@@ -328,7 +371,7 @@ def bench_batch(args, cfg_name, paths, desc, rank, world, local, dev):
         for w, h in enumerate(hs):
             h.clear()
             h.fill_from_support(None, None, None, reads_handle=reads[w % n_tab])
-        return batch.spin(paths)
+        return batch.spin(paths, copy=False)
 
     def fence():
         if world > 1:
@@ -355,16 +398,8 @@ def bench_batch(args, cfg_name, paths, desc, rank, world, local, dev):
     if rank == 0:
         t = tables[0]
         bp = batch.profile_get()
-        rw = bp["reweight"]
-        rw_ms = rw["ms"] / max(1, rw["launches"])
         emit_line(json.dumps({
-            "roofline": {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)",
-                         "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
-                         "algorithmic_bytes_per_launch": rw["bytes_per_launch"],
-                         "achieved": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9) if rw_ms > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rw_ms > 0 else None,
-                         "traffic": None, "kernel_source_sha": kernel_source_sha(),
-                         "note": "window groups on their own streams overlap: a bracket around one group's launch also waits for the others' kernels"},
+            "roofline": batch_roofline(batch, bp, paths, t.n_snps, t.band, hs[0].L, 4.0, kernel_source_sha(), "r5_pmc_traffic_batch256.json"),
             "metric": "haplotypes/sec, batched windows (throughput mode)", "value": n_paths / dt, "unit": "haplotypes/s",
             "n_gpus": world, "steps": desc["steps"], "warmup": desc["warmup"], "ms_per_step": dt / desc["steps"] * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 counts / f64 log-likelihoods",
@@ -675,48 +710,35 @@ def main():
             except Exception as exc:       # never let the secondary leg break the contract line
                 out["throughput_mode"] = {"error": repr(exc)}
         if world == 1 and not args.no_throughput_leg and n <= 20000:
-            # secondary figure: 256 replicas of the contig in ONE batched launch per kernel (gh_batch_*: one serial
-            # path-extension workgroup per window, every CU busy) -- what `bench.py --batch 256` times with distinct windows
+            # secondary figure: 256 replicas of the contig recovered as ONE batch (gh_batch_*: the window pipeline of csrc/wpipe.hpp
+            # where it applies -- one persistent workgroup per window, one launch --, else one batched launch per kernel and path):
+            # what `bench.py --batch 256` times with distinct windows.  The first call also allocates (page-locked result buffers,
+            # the pipeline's packed words); the figure is the median of three calls behind it, each on freshly filled tensors.
             try:
                 from gretel_amd.hansel import HanselBatch
                 reps = 256
                 hs = [Hansel(n, band=table.band, device=local) for _ in range(reps)]
-                for hh in hs:
-                    hh.fill_from_support(None, None, None, reads_handle=reads)
                 hb = HanselBatch(hs)
                 hb.profile_enable(10)
-                torch.cuda.synchronize()
-                tb = time.perf_counter()
-                rb = hb.spin(paths)
-                tb = time.perf_counter() - tb
-                bp = hb.profile_get()
-                rw, wk = bp["reweight"], bp["walk"]
-                rw_ms = rw["ms"] / max(1, rw["launches"])
-                wk_ms = wk["ms"] / max(1, wk["launches"])
-                tm_traffic, tm_note = None, "no PMC profile for the batched kernels of this build"
-                try:
-                    pmb = json.load(open(os.path.join(ROOT, "profiles", "r4_pmc_traffic_batch256.json")))
-                    if pmb.get("kernel_source_sha") == src_sha:
-                        tm_traffic = next(v["hbm_bytes_per_launch_corrected"] for k, v in pmb["kernels"].items() if k.startswith("k_marg<float, true>"))
-                        tm_note = "profiles/r4_pmc_traffic_batch256.json (git %s): bytes per batched launch over all windows of a group" % pmb.get("git_head")
-                    else:
-                        tm_note = "profiles/r4_pmc_traffic_batch256.json was taken with kernel sources %s, this build is %s: not quoted" % (pmb.get("kernel_source_sha"), src_sha)
-                except Exception as exc:
-                    tm_note = "no usable PMC profile: %r" % (exc,)
-                out["throughput_mode_256"] = {"windows": reps, "value": sum(r["n"] for r in rb) / tb, "unit": "haplotypes/s",
-                                              "note": "256 replicas of the benchmark contig, one batched spin of %d paths each (fill not included, "
-                                                      "results copied back to the host included)" % paths,
-                                              "roofline": {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)",
-                                                           "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
-                                                           "algorithmic_bytes_per_launch": rw["bytes_per_launch"],
-                                                           "achieved": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9) if rw_ms > 0 else None,
-                                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                           "frac": (rw["bytes_per_launch"] / (rw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rw_ms > 0 else None,
-                                                           "traffic": tm_traffic, "traffic_source": tm_note,
-                                                           "hip_event_sampling": "every 10th path, first window group (%d launches)" % rw["launches"]},
-                                              "extension": {"kernel": "k_walk_spec (one serial walker per window)", "windows_per_launch": wk["windows"],
-                                                            "avg_launch_ms_hip_events": wk_ms, "algorithmic_bytes_per_launch": wk["bytes_per_launch"],
-                                                            "achieved_GBs": (wk["bytes_per_launch"] / (wk_ms * 1e-3) / 1e9) if wk_ms > 0 else None}}
+                tbs, rb = [], None
+                for it in range(4):
+                    for hh in hs:
+                        hh.clear()
+                        hh.fill_from_support(None, None, None, reads_handle=reads)
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter()
+                    rb = hb.spin(paths, copy=False)
+                    tbs.append(time.perf_counter() - tb)
+                first_call, tb = tbs[0], sorted(tbs[1:])[1]
+                nb = sum(r["n"] for r in rb)
+                same = all(np.array_equal(r["paths"], rb[0]["paths"]) for r in rb)
+                out["throughput_mode_256"] = {"windows": reps, "value": nb / tb, "unit": "haplotypes/s",
+                                              "first_call_value": nb / first_call, "calls_s": tbs,
+                                              "all_windows_recover_the_same_paths": bool(same),
+                                              "note": "256 replicas of the benchmark contig, one batched spin of %d paths each (fill not included; "
+                                                      "results copied back to the host -- page-locked buffers -- included); median of 3 calls "
+                                                      "behind a first one that also allocates" % paths,
+                                              "roofline": batch_roofline(hb, hb.profile_get(), paths, n, table.band, L, 4.0, src_sha, "r5_pmc_traffic_batch256.json")}
                 del hb, hs
             except Exception as exc:
                 out["throughput_mode_256"] = {"error": repr(exc)}

@@ -2726,7 +2726,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                 fprintf(stderr, "pipe window %d, Mcycles (work, own memory, barrier): sweeper %.2f %.2f %.2f  loader %.2f %.2f %.2f  bookkeeper %.2f %.2f %.2f\n", w,
                         hs[w].dbg8[0] / 1e6, hs[w].dbg8[1] / 1e6, hs[w].dbg8[2] / 1e6, hs[w].dbg8[3] / 1e6, hs[w].dbg8[4] / 1e6, hs[w].dbg8[5] / 1e6,
                         hs[w].dbg8[6] / 1e6, hs[w].dbg8[7] / 1e6, hs[w].dbg8[8] / 1e6);
-                fprintf(stderr, "walker: %.2f Mcycles walking, %.2f at its barriers\n", hs[w].dbg8[10] / 1e6, hs[w].dbg8[11] / 1e6);
+                fprintf(stderr, "walker: %.2f Mcycles walking, %.2f at its barriers; bookkeeper: %.2f per-position part, %.2f sequential sums\n", hs[w].dbg8[10] / 1e6, hs[w].dbg8[11] / 1e6, hs[w].dbg[0] / 1e6, hs[w].dbg[1] / 1e6);
                 fprintf(stderr, "SIMD of waves 0..15:");
                 for (int q = 0; q < 16; q++) fprintf(stderr, " %d", (int)((hs[w].dbg8[9] >> (2 * q)) & 3));
                 fprintf(stderr, "\n");

@@ -67,10 +67,13 @@ enum { PR_WALK = 0, PR_BOOK = 1, PR_LOAD = 2, PR_SWEEP = 3 };
 template <int NT> struct pipe_roles;
 template <> struct pipe_roles<1024> {
     static constexpr int NLW = 6, NRW = 8;
+    // SIMD class of wave w = w & 3.  Class 0: the walker and three loader waves (nothing that computes: the bookkeeper on the
+    // walker's SIMD -- a division, a log10 and 120 dependent additions per chunk -- took 13 000 cycles per chunk there and slowed
+    // the walker by 7 %); classes 1, 2: three sweepers and the bookkeeper / a loader; class 3: two sweepers, two loaders.
     //                                   w: 0         1          2          3          4         5          6          7
-    static constexpr unsigned char map[16] = {PR_WALK << 4, (PR_SWEEP << 4) | 0, (PR_SWEEP << 4) | 1, (PR_SWEEP << 4) | 2, PR_BOOK << 4, (PR_SWEEP << 4) | 3, (PR_SWEEP << 4) | 4, (PR_SWEEP << 4) | 5,
+    static constexpr unsigned char map[16] = {PR_WALK << 4, (PR_SWEEP << 4) | 0, (PR_SWEEP << 4) | 1, (PR_SWEEP << 4) | 2, (PR_LOAD << 4) | 0, (PR_SWEEP << 4) | 3, (PR_SWEEP << 4) | 4, (PR_SWEEP << 4) | 5,
     //                                      8                 9                  10                 11                12                13                14                15
-                                              (PR_LOAD << 4) | 0, (PR_SWEEP << 4) | 6, (PR_SWEEP << 4) | 7, (PR_LOAD << 4) | 5, (PR_LOAD << 4) | 1, (PR_LOAD << 4) | 2, (PR_LOAD << 4) | 3, (PR_LOAD << 4) | 4};
+                                              (PR_LOAD << 4) | 1, (PR_SWEEP << 4) | 6, (PR_SWEEP << 4) | 7, (PR_BOOK << 4), (PR_LOAD << 4) | 2, (PR_LOAD << 4) | 3, (PR_LOAD << 4) | 4, (PR_LOAD << 4) | 5};
 };
 template <> struct pipe_roles<768> {
     static constexpr int NLW = 4, NRW = 6;
@@ -90,7 +93,7 @@ template <> struct pipe_roles<512> {
 __host__ __device__ constexpr int pipe_pos_doubles(int L) { return 32 + 16 * deep_nyp(L); }
 __host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
-    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + (((size_t)N + 2 + 15) & ~(size_t)15);
+    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
 }
 __host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads, int esize)
 {
@@ -108,6 +111,35 @@ __host__ __device__ constexpr size_t pipe_lds_bytes(int N, int L, int C, int nr_
     return 2 * (size_t)(C + WALK_OV) * pipe_pos_doubles(L) * 8 + pipe_fixed_bytes(N, nr_threads, esize);
 }
 
+// What a sweep needs to know about a position and never changes while the pipeline runs (the candidate masks stand, or it stops):
+// one 64-bit word per position, made in the kernel's prologue from cmask / nvalid (win_desc::pk):
+//   bits 0..2   V(p): valid symbols seen              bits 3..5   candidates offered (<= 4 in a ranked window)
+//   bits 6..17  the symbol of the candidate of rank 0..3, 3 bits each (the order get_edge_weights_at offers them in)
+//   bits 18..38 per SYMBOL 0..6 the row of G a path through it rewrites: its rank; 5 for '_' at position 0; 7 = none
+#define PK_NVALID(w) ((int)((w) & 7u))
+#define PK_NCAND(w) ((int)(((w) >> 3) & 7u))
+#define PK_SYM(w, rb) ((int)(((w) >> (6 + 3 * (rb))) & 7u))
+#define PK_ROW6(w, sym) ((int)(((w) >> (18 + 3 * (sym))) & 7u))
+__device__ __forceinline__ unsigned long long pipe_pack(uint32_t cmw, int nvalid, int p, symmap sm)
+{
+    const uint32_t cm5 = cm5_of_cmask(sm, CM_CAND(cmw));
+    int nc = __popc(cm5);
+    if (nc > 4) nc = 4;
+    unsigned long long w = (unsigned long long)(nvalid & 7) | ((unsigned long long)nc << 3);
+    for (int rb = 0; rb < 4; rb++) {
+        const int b5 = nth_set5(cm5, rb);
+        w |= (unsigned long long)(b5 >= 0 ? vsym(sm, b5) : 0) << (6 + 3 * rb);
+    }
+    for (int sym = 0; sym < NSYM; sym++) {
+        const int a6 = a6_of_sym(sm, sym);
+        int row6 = 7;
+        if (a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : 7;
+        else if (a6 == 5 && p == 0) row6 = 5;
+        w |= (unsigned long long)row6 << (18 + 3 * sym);
+    }
+    return w;
+}
+
 struct pipe_ctl {
     double ratio;           // clamped minimum marginal of the path just walked: what the sweep of the next epochs removes
     int abort;              // a sweeper saw a candidate mask move
@@ -115,45 +147,92 @@ struct pipe_ctl {
 };
 static_assert(sizeof(pipe_ctl) == 64, "one line");
 
-// the bookkeeper's consume step (kernels.hpp: book_consume) with the symbol also stored into the LDS copy of the path
-__device__ __forceinline__ void pipe_book_consume(const double *minfo_unused, uint8_t *path_out, uint8_t *s_path, const unsigned long long *words,
-                                                  int LC, int j0, int ns, int Nw, int lane, const book_row &R, walk_totals &T,
-                                                  double &lane_min, symmap sm)
+// The bookkeeper's two steps (kernels.hpp: book_prefetch / book_consume), lane = chunk-local position.  It takes the marginal of
+// the ONE symbol the walker selected at a position from the counts itself -- m = c_s / total, log10 m: k_marg's expressions on
+// the values the sweep keeps in cnt -- instead of reading a row of minfo that the sweep would have to refresh for all four
+// candidates of every position and path (a division and a log10 each: a third of the sweep's entries; the bookkeeper's lanes
+// take one per position and chunk).  minfo is only read for the ORIGINAL log-marginals (gretel.py:186), which never change.
+struct pipe_book_row {
+    lds_v2d c[4];               // cnt[j][0..7]: c_s(j) by symbol, [7] the total
+    lds_v2d o[3];               // minfo[j][10..15]: candidate bits, log10 original marginal by compact symbol index
+    unsigned long long pk;      // pk[j]
+};
+
+__device__ __forceinline__ void pipe_book_prefetch(const win_desc &d, int j0, int ns, int Nw, int lane, pipe_book_row &R)
 {
-    (void)minfo_unused;
+    const int j = j0 + lane + 1;
+    const int jj = (lane < ns && j <= Nw) ? j : 0;              // (no branch around the loads: see pipe_sweep_load)
+    typedef __attribute__((address_space(1))) const lds_v2d gv2;
+    gv2 *cs = (gv2 *)(uintptr_t)(d.cnt + (size_t)jj * 8);
+    gv2 *os = (gv2 *)(uintptr_t)(d.minfo + (size_t)jj * MINFO + 10);
+#pragma unroll
+    for (int q = 0; q < 4; q++) R.c[q] = cs[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) R.o[q] = os[q];
+    R.pk = ((__attribute__((address_space(1))) const unsigned long long *)(uintptr_t)d.pk)[jj];
+}
+
+__device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_path, const unsigned long long *words, const double *s_logtab,
+                                                  lds_v2d *s_bk /* 64 pairs of addends */,
+                                                  int LC, int j0, int ns, int Nw, int lane, const pipe_book_row &R, walk_totals &T,
+                                                  double &lane_min, symmap sm, unsigned long long *prof = nullptr)
+{
+#ifdef PIPE_PROF
+    const unsigned long long pb0 = __builtin_amdgcn_s_memtime();
+#endif
     double lm = 0.0, lm0 = 0.0, mg = INFINITY;
     const int j = j0 + lane + 1;
     if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
-        int w = (int)((word >> (2 * (LC - 1 - lane % LC))) & 3ull);
-        w = nth_set5((uint32_t)__double_as_longlong(R.v[5].x), w);      // minfo[10]: candidate bits; rank -> compact symbol index
-        if (w < 0) w = 0;
-        const double row[16] = {R.v[0].x, R.v[0].y, R.v[1].x, R.v[1].y, R.v[2].x, R.v[2].y, R.v[3].x, R.v[3].y,
-                                R.v[4].x, R.v[4].y, R.v[5].x, R.v[5].y, R.v[6].x, R.v[6].y, R.v[7].x, R.v[7].y};
-        lm = row[0]; mg = row[5]; lm0 = row[11];
+        const int rank = (int)((word >> (2 * (LC - 1 - lane % LC))) & 3ull);
+        const int sym = PK_SYM(R.pk, rank);                     // the symbol of that rank at j (pipe_pack)
+        const int b5 = a6_of_sym(sm, sym);
+        const double cs[8] = {R.c[0].x, R.c[0].y, R.c[1].x, R.c[1].y, R.c[2].x, R.c[2].y, R.c[3].x, R.c[3].y};
+        double c = cs[0];
 #pragma unroll
-        for (int q = 1; q < 5; q++) {
-            lm = (w == q) ? row[q] : lm;
-            mg = (w == q) ? row[5 + q] : mg;
-            lm0 = (w == q) ? row[11 + q] : lm0;
-        }
-        const uint8_t sym = (uint8_t)vsym(sm, w);
-        path_out[j] = sym;
-        s_path[j] = sym;
+        for (int q = 1; q < NSYM; q++) c = (sym == q) ? cs[q] : c;
+        const double tot = cs[7];
+        mg = (c > 0 && tot != 0.0) ? c / tot : 0.0;            // k_marg: marg[p][s]
+        lm = gh_log10_tab(mg, s_logtab, GH_LOG_SERIAL);         //         minfo[p][b5]
+        const double l0[5] = {R.o[0].y, R.o[1].x, R.o[1].y, R.o[2].x, R.o[2].y};
+        lm0 = l0[0];
+#pragma unroll
+        for (int q = 1; q < 5; q++) lm0 = (b5 == q) ? l0[q] : lm0;
+        path_out[j] = (uint8_t)sym;
+        s_path[j] = (uint8_t)sym;
     }
     if (mg < lane_min) lane_min = mg;                   // gretel.py:182
+#ifdef PIPE_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long pb1 = __builtin_amdgcn_s_memtime();
+#endif
+    // the two sums strictly in position order: the addends go through LDS and come back by broadcast reads (same address in all
+    // lanes; LDS data returns in order, so the reads run ahead of the additions) -- as k_hp does; moving a register's lanes
+    // through scalar registers took four v_readlane per position
+    s_bk[lane] = lds_v2d{lm, lm0};                      // (+0.0 for unused lanes)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int s = 0;
-    for (; s + 4 <= ns; s += 4) {
+#pragma unroll 1
+    for (; s + 8 <= ns; s += 8) {
+        lds_v2d v[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            T.hp_cur += readlane_f64(lm, s + q);        // gretel.py:185
-            T.hp_orig += readlane_f64(lm0, s + q);      // gretel.py:186
+        for (int q = 0; q < 8; q++) v[q] = s_bk[s + q];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            T.hp_cur += v[q].x;                         // gretel.py:185
+            T.hp_orig += v[q].y;                        // gretel.py:186
         }
     }
     for (; s < ns; s++) {
-        T.hp_cur += readlane_f64(lm, s);
-        T.hp_orig += readlane_f64(lm0, s);
+        const lds_v2d v = s_bk[s];
+        T.hp_cur += v.x;
+        T.hp_orig += v.y;
     }
+#ifdef PIPE_PROF
+    asm volatile("" :: "v"(T.hp_cur), "v"(T.hp_orig));
+    const unsigned long long pb2 = __builtin_amdgcn_s_memtime();
+    if (prof) { prof[0] += pb1 - pb0; prof[1] += pb2 - pb1; }
+#endif
 }
 
 
@@ -260,35 +339,6 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
     }
 }
 
-// What a sweep needs to know about a position and never changes while the pipeline runs (the candidate masks stand, or it stops):
-// one 64-bit word per position, made in the kernel's prologue from cmask / nvalid (win_desc::pk):
-//   bits 0..2   V(p): valid symbols seen              bits 3..5   candidates offered (<= 4 in a ranked window)
-//   bits 6..17  the symbol of the candidate of rank 0..3, 3 bits each (the order get_edge_weights_at offers them in)
-//   bits 18..38 per SYMBOL 0..6 the row of G a path through it rewrites: its rank; 5 for '_' at position 0; 7 = none
-#define PK_NVALID(w) ((int)((w) & 7u))
-#define PK_NCAND(w) ((int)(((w) >> 3) & 7u))
-#define PK_SYM(w, rb) ((int)(((w) >> (6 + 3 * (rb))) & 7u))
-#define PK_ROW6(w, sym) ((int)(((w) >> (18 + 3 * (sym))) & 7u))
-__device__ __forceinline__ unsigned long long pipe_pack(uint32_t cmw, int nvalid, int p, symmap sm)
-{
-    const uint32_t cm5 = cm5_of_cmask(sm, CM_CAND(cmw));
-    int nc = __popc(cm5);
-    if (nc > 4) nc = 4;
-    unsigned long long w = (unsigned long long)(nvalid & 7) | ((unsigned long long)nc << 3);
-    for (int rb = 0; rb < 4; rb++) {
-        const int b5 = nth_set5(cm5, rb);
-        w |= (unsigned long long)(b5 >= 0 ? vsym(sm, b5) : 0) << (6 + 3 * rb);
-    }
-    for (int sym = 0; sym < NSYM; sym++) {
-        const int a6 = a6_of_sym(sm, sym);
-        int row6 = 7;
-        if (a6 < 5) row6 = ((cm5 >> a6) & 1u) ? __popc(cm5 & ((1u << a6) - 1u)) : 7;
-        else if (a6 == 5 && p == 0) row6 = 5;
-        w |= (unsigned long long)row6 << (18 + 3 * sym);
-    }
-    return w;
-}
-
 // seven values by NAME (a row of a cell): selects over the elements of a local array make hipcc keep the array in scratch memory and
 // select the address instead (measured: 64-176 bytes of scratch per lane and a scratch load per table entry)
 template <typename T>
@@ -377,7 +427,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     constexpr int SD = pipe_slot_doubles<T>();
     const symmap sm = P.sm;
     PIPE_GLOBAL(T) *band = pipe_gptr((T *)d.band);
-    PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.G), *g_minfo = pipe_gptr(d.minfo), *g_rinfo = pipe_gptr(d.rinfo);
+    PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.G);
     const bool act = p <= N;
     const int a = R.a;
     auto mult_of = [&](int dd) __attribute__((always_inline)) {     // how often reweight_hansel_from_path visits the cell (p, p + dd): SURVEY section 8 a8
@@ -443,11 +493,6 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         const double cx = __shfl(mine, x, 8);
         if (cx > 0) tot += cx;
     }
-    // this lane's share of the position's marginals: the candidate of rank rbm of p (tasks 4 Lr .. 4 Lr + 3 of the deal below)
-    constexpr int NT4 = 4 * Lr;                         // table entries dealt; the marginals follow
-    const int rbm = (s - NT4) & 7;
-    const int sym_m = PK_SYM(pkp, rbm & 3);
-    const double c_m = __shfl(mine, sym_m, 8);
     const unsigned p8 = (unsigned)p * 8u;
     if (act) {
         if (s == a) g_cnt[p8 + (unsigned)s] = mine;
@@ -456,8 +501,11 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         if (s == 0 && ((VALID_MASK >> a) & 1) && !(ca_new > 0)) atomicOr(abort_flag, 1);
     }
     const int row6 = act && p < N ? PK_ROW6(pkp, a) : 7;        // the table row this position's cells feed (7: none)
+    // Which lags have entries that can change: under conditionals A and D a lag beyond the band has an all-zero row and the
+    // denominator V + 0 -- constants; under B the denominator holds c_a(p), which the reweight has just changed, at every lag.
+    const int Lw = (P.cond_mode == GH_COND_B || W >= Lr) ? Lr : W;
     // lag s + 1: the denominator and the target's word beside the row
-    if (s < Lr) {
+    if (s < Lw) {
         const double nv_i = (double)PK_NVALID(pkp);
         const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt_in) + rowsum0 : (P.cond_mode == GH_COND_D ? nv_i + rowsum0 : nv_i + ca_new);
         slot[SD - 2] = den;
@@ -465,54 +513,20 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned rowbase = ((unsigned)p * 6u + (unsigned)(row6 < 6 ? row6 : 0)) * (unsigned)(L * LT_ROW);
-    // rounds of eight entries, a quotient and its log10 each; which rounds hold table entries, marginals or both is known at
-    // compile time
-    constexpr int NROUND = (NT4 + 4 + 7) / 8;
-#ifdef PIPE_UNROLL_ROUNDS
-#pragma unroll
-#else
+    // the entries, eight per round: a quotient and its log10 each (the marginals of the position are the bookkeeper's:
+    // pipe_book_consume)
+    const int NT4 = 4 * Lw;
 #pragma unroll 1
-#endif
-    for (int r = 0; r < NROUND; r++) {
-        const int t = s + 8 * r;
-        const bool may_tab = 8 * r < NT4, may_m = 8 * r + 7 >= NT4;     // (compile-time per round when the rounds are unrolled)
-        double num = 0.0, den = 1.0;
-        bool live = false, is_m = false;
-        unsigned oidx = 0;
-        if (may_tab && (!may_m || t < NT4)) {
-            const int li = t >> 2, rb = t & 3;
-            const double *sl = s_deal + li * SD;
-            const unsigned long long pkt = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
-            if (rb < PK_NCAND(pkt)) {
-                live = true;
-                num = 1.0 + (double)reinterpret_cast<const T *>(sl)[PK_SYM(pkt, rb)];
-                den = sl[SD - 2];
-                oidx = rowbase + (unsigned)(li * LT_ROW + rb);
-            }
-        }
-        if (may_m && t >= NT4) {
-            is_m = true;
-            if (act && (t - NT4) < PK_NCAND(pkp)) {
-                live = true;
-                num = c_m;
-                den = tot;
-                oidx = (unsigned)p * (unsigned)MINFO + (unsigned)a6_of_sym(sm, sym_m);
-            }
-        }
-        if (live) {
-            double xq = num / den;
-            if (may_m && is_m && !(c_m > 0 && tot != 0.0)) xq = 0.0;     // (k_marg: m = c > 0 && total != 0 ? c / total : 0)
+    for (int t = s; t < NT4; t += 8) {
+        const int li = t >> 2, rb = t & 3;
+        const double *sl = s_deal + li * SD;
+        const unsigned long long pkt = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
+        if (rb < PK_NCAND(pkt)) {
+            const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[PK_SYM(pkt, rb)];
+            const double xq = num / sl[SD - 2];
             // (k_marg takes the straight-line logarithm where the arguments are normal, the general one otherwise: same values)
-            const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
-            PIPE_GLOBAL(double) *out = (may_m && is_m ? g_minfo : g_G) + oidx;
-            out[0] = v;
-            if (may_m && is_m) {
-                out[5] = xq;
-                if (d.rinfo) {          // the same by candidate rank
-                    g_rinfo[p8 + (unsigned)(t - NT4)] = v;
-                    g_rinfo[p8 + 4u + (unsigned)(t - NT4)] = xq;
-                }
-            }
+            g_G[rowbase + (unsigned)(li * LT_ROW + rb)] =
+                gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
         }
     }
     if constexpr (L > 8) {
@@ -521,7 +535,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             const double nv_i = (double)PK_NVALID(pkp);
             for (int l = s + 9; l <= L; l += 8) {
                 const int snp = p + l;
-                if (snp > N) continue;
+                if (snp > N || (l > W && P.cond_mode != GH_COND_B)) continue;        // (behind the window / beyond the band: constants)
                 row7<T> rw;
                 rw.zero();
                 if (l <= W) rw.load((const T *)d.band + bidx(W, p, l, a, 0));
@@ -560,7 +574,8 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     constexpr int GD = pipe_group_doubles((int)sizeof(T));     // the sweepers' slots: doubles per lane group
     double *const s_deal = s_red + NR;
     pipe_ctl *const ctl = reinterpret_cast<pipe_ctl *>(s_deal + (size_t)(NR / 8) * GD);
-    uint8_t *const s_path = reinterpret_cast<uint8_t *>(ctl + 1);
+    lds_v2d *const s_bk = reinterpret_cast<lds_v2d *>(ctl + 1);      // the bookkeeper's addends: 64 x 16 bytes
+    uint8_t *const s_path = reinterpret_cast<uint8_t *>(s_bk + 64);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -727,8 +742,9 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     }
     if (PIPE_DEV_ROLES & 2 ? role == PR_BOOK : false) {
         // ---- bookkeeper -----------------------------------------------------------------------------------------------
-        walk_params BP;
-        BP.minfo = d.minfo;
+        // (a chain of dependent additions like the walker's steps: without priority every instruction of it queues behind the
+        // sweepers of its SIMD -- 14 cycles per instruction measured, 6 100 cycles per chunk for the two sums alone)
+        __builtin_amdgcn_s_setprio(2);
         unsigned long long t_prev = 0;
         if (P.prof) t_prev = __builtin_amdgcn_s_memrealtime();
         auto reduce_removed = [&]() {               // fixed order: NRW values per lane, then the wavefront's tree
@@ -741,29 +757,35 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         };
         int sp = 0;
         bool aborted = false;
+#ifdef PIPE_PROF
+        unsigned long long bprof[2] = {0, 0};
+#endif
         for (; sp < P.max_paths; sp++) {
             uint8_t *path_out = d.paths + (size_t)sp * (N + 1);
             walk_totals Tt = {0.0, 0.0, INFINITY};
             double lane_min = INFINITY;
-            book_row R0, R1;
-#pragma unroll
-            for (int q = 0; q < 8; q++) { R0.v[q] = lds_v2d{0.0, 0.0}; R1.v[q] = lds_v2d{0.0, 0.0}; }
+            pipe_book_row R0, R1;
             if (lane == 0) path_out[0] = SYM_US;
             PIPE_BARRIER(); PIPE_BARRIER(); PIPE_BARRIER();         // epochs 0..2
-            auto consume = [&](int c, const book_row &R) {
-                pipe_book_consume(d.minfo, path_out, s_path, words0 + (c & 1) * 64, LC, c * C, C, N, lane, R, Tt, lane_min, P.sm);
+            auto consume = [&](int c, const pipe_book_row &R) {
+#ifdef PIPE_PROF
+                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, Tt, lane_min, P.sm, bprof);
+#else
+                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, Tt, lane_min, P.sm);
+#endif
             };
             for (int k = 0; k < nchunks; k += 2) {
+                // (consume first: the loads it waits for were issued an epoch ago; behind a fresh prefetch hipcc waits for both)
                 PIPE_PROF_BEGIN();
-                book_prefetch(BP, k * C, C, N, lane, R0);
                 if (k >= 1) consume(k - 1, R1);
+                pipe_book_prefetch(d, k * C, C, N, lane, R0);
                 PIPE_PROF_MID();
                 PIPE_BARRIER();
                 PIPE_PROF_END();
                 if (k + 1 < nchunks) {
                     PIPE_PROF_BEGIN();
-                    book_prefetch(BP, (k + 1) * C, C, N, lane, R1);
                     consume(k, R0);
+                    pipe_book_prefetch(d, (k + 1) * C, C, N, lane, R1);
                     PIPE_PROF_MID();
                     PIPE_BARRIER();
                     PIPE_PROF_END();
@@ -807,7 +829,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
             if (lane == 0) d.recs[P.max_paths - 1].magnitude = mag;
         }
 #ifdef PIPE_PROF
-        if (blockIdx.x == 0 && lane == 0) { st->dbg8[6] = pf_work; st->dbg8[7] = pf_drain; st->dbg8[8] = pf_wait; }
+        if (blockIdx.x == 0 && lane == 0) { st->dbg8[6] = pf_work; st->dbg8[7] = pf_drain; st->dbg8[8] = pf_wait; st->dbg[0] = bprof[0]; st->dbg[1] = bprof[1]; }
 #endif
         if (lane == 0) {
             st->n_done = sp;
