@@ -91,6 +91,8 @@ struct gh_handle {
     uint32_t *cmask;
     double *rinfo;                // [(N+2)][8] log10 marginal / marginal by candidate rank (k_marg, k_rw)
     unsigned long long *pipe_pk;  // [N+2] the window pipeline's packed candidate words (wpipe.hpp), allocated by the first batch that takes it
+    double *pipe_gp;              // ... and its compact table [(N+LT_PAD)][4][L][4]
+    size_t pipe_gp_bytes;
     bool need_rinfo;              // ... kept only where somebody reads it: with the marginal term (k_seg, k_cwalk add it in front of x1) and
                                   // for the three-launch spins (GH_FUSE at creation); nullptr goes to the kernels otherwise (C5: k_rw is bound by its stores)
     symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
@@ -326,7 +328,7 @@ static void free_handle(gh_handle *h)
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->tband); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
-    hipFree(h->pipe_pk);
+    hipFree(h->pipe_pk); hipFree(h->pipe_gp);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->rinfo); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
@@ -383,7 +385,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memset(h->cfg.cand_order, 0, sizeof h->cfg.cand_order);
     memcpy(h->cfg.cand_order, order, 5);
     h->sm = make_symmap(order);
-    h->rinfo = nullptr; h->pipe_pk = nullptr; h->lt_baked = false; h->ht_stale = false;
+    h->rinfo = nullptr; h->pipe_pk = nullptr; h->pipe_gp = nullptr; h->pipe_gp_bytes = 0; h->lt_baked = false; h->ht_stale = false;
     h->need_rinfo = cfg->marginal_term != 0 || (getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1);
     h->dev = dev;
     h->N = cfg->n_snps;
@@ -2681,8 +2683,16 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         b->cap_paths = max_paths;
     }
     if (pipe_nt)
-        for (int w = 0; w < n; w++)
-            if (!b->hs[w]->pipe_pk) HIPCHK(hipMalloc((void **)&b->hs[w]->pipe_pk, sizeof(unsigned long long) * ((size_t)b->N + 2)));
+        for (int w = 0; w < n; w++) {
+            gh_handle *h = b->hs[w];
+            if (!h->pipe_pk) HIPCHK(hipMalloc((void **)&h->pipe_pk, sizeof(unsigned long long) * ((size_t)b->N + 2)));
+            const size_t need = sizeof(double) * ((size_t)b->N + LT_PAD) * 16 * (size_t)b->L;
+            if (h->pipe_gp_bytes < need) {
+                hipFree(h->pipe_gp); h->pipe_gp = nullptr; h->pipe_gp_bytes = 0;
+                HIPCHK(hipMalloc((void **)&h->pipe_gp, need));
+                h->pipe_gp_bytes = need;
+            }
+        }
     std::vector<win_desc> wd(n);
     for (int w = 0; w < n; w++) {
         gh_handle *h = b->hs[w];
@@ -2694,6 +2704,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         wd[w].snap = h->have_orig ? 0 : 1;       // the first batched k_marg is followed by a batched snapshot
         wd[w]._pad = 0;
         wd[w].pk = h->pipe_pk;
+        wd[w].gp = h->pipe_gp;
         h->have_orig = true;
     }
     std::vector<dev_state> hs(n);

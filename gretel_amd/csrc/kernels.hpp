@@ -114,6 +114,7 @@ struct win_desc {
     int snap;              // batched k_snapshot: freeze this window's marginals as the original ones
     int _pad;
     unsigned long long *pk; // [N+2] k_wpipe (wpipe.hpp): what a sweep needs of a position's candidates, packed by its prologue
+    double *gp;             // [(N+LT_PAD)][4][L][4] k_wpipe: its own compact copy of the ranked table (prologue)
 };
 
 // Band layout: band[i][a][d-1][b] -- position, FROM-symbol, distance, to-symbol.  Everything a path touches at position i

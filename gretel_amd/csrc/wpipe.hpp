@@ -427,7 +427,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     constexpr int SD = pipe_slot_doubles<T>();
     const symmap sm = P.sm;
     PIPE_GLOBAL(T) *band = pipe_gptr((T *)d.band);
-    PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.G);
+    PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.gp);      // (the pipeline's own table: k_wpipe's prologue)
     const bool act = p <= N;
     const int a = R.a;
     auto mult_of = [&](int dd) __attribute__((always_inline)) {     // how often reweight_hansel_from_path visits the cell (p, p + dd): SURVEY section 8 a8
@@ -512,7 +512,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         reinterpret_cast<unsigned long long *>(slot)[SD - 1] = row6 < 6 ? pkt_in : 0ull;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned rowbase = ((unsigned)p * 6u + (unsigned)(row6 < 6 ? row6 : 0)) * (unsigned)(L * LT_ROW);
+    const unsigned rowbase = ((unsigned)p * 4u + (unsigned)(row6 < 4 ? row6 : 0)) * (unsigned)(L * 4);     // ('_' at position 0: row 0)
     // the entries, eight per round: a quotient and its log10 each (the marginals of the position are the bookkeeper's:
     // pipe_book_consume)
     const int NT4 = 4 * Lw;
@@ -525,7 +525,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[PK_SYM(pkt, rb)];
             const double xq = num / sl[SD - 2];
             // (k_marg takes the straight-line logarithm where the arguments are normal, the general one otherwise: same values)
-            g_G[rowbase + (unsigned)(li * LT_ROW + rb)] =
+            g_G[rowbase + (unsigned)(li * 4 + rb)] =
                 gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
         }
     }
@@ -542,7 +542,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const unsigned long long pkt = d.pk[snp];
                 const double sum = (double)rw.sum();
                 const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt) + sum : (P.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca_new);
-                PIPE_GLOBAL(double) *out = g_G + rowbase + (unsigned)((l - 1) * LT_ROW);
+                PIPE_GLOBAL(double) *out = g_G + rowbase + (unsigned)((l - 1) * 4);
                 for (int rb = 0; rb < PK_NCAND(pkt); rb++) {
                     const double xq = (1.0 + (double)rw.get(PK_SYM(pkt, rb))) / den;
                     out[rb] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
@@ -593,6 +593,19 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     }
     logtab_stage(s_logtab);
     for (int q = tid; q <= N + 1; q += NT) d.pk[q] = q <= N ? pipe_pack(d.cmask[q], d.nvalid[q], q, P.sm) : 0ull;
+    // the pipeline's own copy of the conditional table: of the ranked G[source][6 rows][lag][5 columns] only what a ranked window
+    // uses -- rows and columns of the ranks 0..3, position 0's '_' row as its row 0 -- as [source][4][lag][4]: 32-byte pieces on
+    // 32-byte boundaries (a row of G is 40 bytes: every piece straddled two sectors), 640 instead of 800 of 1 200 bytes per
+    // position at five lags.  The sweeps write it, the loaders read it; G itself is rebuilt by whoever needs it next (dirty_lt).
+    for (int q = tid; q < (N + LT_PAD) * 4 * LC; q += NT) {
+        const int l = q % LC, row = (q / LC) & 3, i = q / (4 * LC);
+        const lds_v2d *src = nullptr;
+        const double *g = d.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * LC + l) * LT_ROW;
+        (void)src;
+        double *o = d.gp + (size_t)q * 4;
+        const bool keep = i != 0 || row == 0;
+        o[0] = keep ? g[0] : 0.0; o[1] = keep ? g[1] : 0.0; o[2] = keep ? g[2] : 0.0; o[3] = keep ? g[3] : 0.0;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef PIPE_PROF
     if (blockIdx.x == 0 && tid == 0) st->dbg8[9] = 0;
@@ -672,9 +685,9 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         constexpr int MAXT = (MAXPOS * TPP + NL - 1) / NL;
         const int nsrc_all = N + LT_PAD;
         const int ntask = npos * TPP;
-        typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(8)));      // G rows are 8-byte aligned
+        typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(16)));     // (32 bytes per (row, lag) of the pipeline's table)
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
-        const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.G);
+        const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.gp);
         auto fetch = [&](int k) {
             // (no branch around a load: see pipe_sweep_load; tasks beyond the buffer or the table read source 0 and are dropped /
             // zeroed when the chunk is stored)
@@ -686,7 +699,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 const int sidx = i0 + pp;
                 const bool ok = q < ntask && sidx < nsrc_all;
                 const int si = ok ? sidx : 0;
-                const PIPE_GLOBAL(double) *src = gG + (size_t)si * BLK + (si == 0 ? 5 : row) * ROW + l * LT_ROW;
+                const PIPE_GLOBAL(double) *src = gG + ((unsigned)(si * 4 + (si == 0 ? 0 : row)) * (unsigned)LC + (unsigned)l) * 4u;
                 typedef PIPE_GLOBAL(ld_v2d) gv2d;
                 R.lo[it] = *reinterpret_cast<const gv2d *>(src);
                 R.hi[it] = *reinterpret_cast<const gv2d *>(src + 2);
