@@ -900,6 +900,12 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                 for (size_t ci = 0; ci < P.cands.size(); ci++) {
                     const depth_cand &c = P.cands[ci];
                     bool drop = false;
+                    // (the running sum below is only right over ascending starts -- as is pysam's pileup, which wants a
+                    // coordinate-sorted, indexed BAM: say so instead of counting wrongly or indexing in front of the histogram)
+                    if ((int64_t)c.pos < dc_pos)
+                        return fail(-4, "records are not in coordinate order (a read at %lld behind one at %lld): the pileup's "
+                                    "depth cap (max_depth = %d, pysam's default) needs a coordinate-sorted BAM; sort it, or pass max_depth 0",
+                                    (long long)c.pos, (long long)dc_pos, (int)max_depth);
                     if ((int64_t)c.pos != dc_pos) {
                         dc_pos = c.pos;                                      // (the iterator moves here once this read is in)
                     } else {
@@ -907,6 +913,13 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                             const int64_t x = dc_exp_upto - dc_base;
                             if (x >= 0 && (size_t)x < dc_ends.size()) dc_expired += dc_ends[(size_t)x];
                             dc_exp_upto++;
+                        }
+                        // what has expired is never looked at again: the histogram stays as long as the longest read span,
+                        // not as long as the window (4 bytes per reference base of a chromosome otherwise)
+                        if (dc_exp_upto - dc_base > (int64_t)1 << 16 && dc_base >= 0) {
+                            const size_t k = std::min((size_t)(dc_exp_upto - dc_base), dc_ends.size());
+                            dc_ends.erase(dc_ends.begin(), dc_ends.begin() + (std::ptrdiff_t)k);
+                            dc_base += (int64_t)k;
                         }
                         drop = dc_accepted - dc_expired + 1 > (int64_t)max_depth;
                     }
@@ -916,6 +929,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                         continue;
                     }
                     if (dc_base < 0) { dc_base = c.pos; dc_exp_upto = c.pos; }
+                    if ((int64_t)c.end < dc_base) { dc_accepted++; dc_expired++; continue; }     // (ends in front of everything still counted: entered and expired)
                     const size_t x = (size_t)((int64_t)c.end - dc_base);
                     if (x >= dc_ends.size()) dc_ends.resize(x + 4096, 0);
                     dc_ends[x]++;

@@ -119,6 +119,7 @@ struct gh_handle {
     uint16_t *seg_maps, *seg_pmaps, *seg_gmaps;
     double *seg_min;       // [CW_MAX_SEG]
     double *seg_smin, *seg_gmin;   // minimum marginal per (segment, entry state) / per (group, entry state)
+    size_t seg_smin_bytes;
     uint8_t *cm5snap;      // [N+2] candidate bits as the last k_seg saw them
     size_t fuse_lds;       // LDS of k_rw's fused prologue for this spin's state space
     bool band_zero;        // the tensor holds nothing but zeros (gh_create, gh_clear; until something is added): k_fill_own may store instead of add
@@ -301,8 +302,8 @@ extern "C" int gh_log10_device(int device, const double *x, double *y, int64_t n
     if (n == 0) return GH_OK;
     if (device >= 0) HIPCHK(hipSetDevice(device));
     double *dx = nullptr, *dy = nullptr;
-    HIPCHK(hipMalloc(&dx, n * sizeof(double)));
-    if (hipMalloc(&dy, n * sizeof(double)) != hipSuccess) { hipFree(dx); return fail(GH_ERR_HIP, "hipMalloc"); }
+    if (hipMalloc(&dx, n * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); return fail(GH_ERR_NOMEM, "hipMalloc of %lld doubles failed", (long long)n); }
+    if (hipMalloc(&dy, n * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); hipFree(dx); return fail(GH_ERR_NOMEM, "hipMalloc of %lld doubles failed", (long long)n); }
     int rc = GH_OK;
     if (hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(GH_ERR_HIP, "hipMemcpy");
     if (rc == GH_OK) {
@@ -395,7 +396,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     h->lt = nullptr; h->ht = nullptr; h->yt = nullptr; h->lt_L = 0;
     h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
     h->seg_hist = nullptr; h->seg_maps = nullptr; h->seg_pmaps = nullptr; h->seg_gmaps = nullptr; h->seg_min = nullptr; h->lmsel1 = nullptr;
-    h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr; h->fuse = false;
+    h->seg_smin = nullptr; h->seg_gmin = nullptr; h->cm5snap = nullptr; h->fuse = false; h->seg_smin_bytes = 0;
     h->seg_halo = nullptr; h->seg_halo_bytes = 0; h->rws = false;
     h->spin_lmsel = nullptr; h->seg_L = 0; h->spin_requeues = 0; h->spin_partial_stride = 0;
     h->cw_keys = nullptr; h->cw_exits = nullptr; h->cw_hist = nullptr; h->cw_last_hit = nullptr; h->cw_npool = nullptr;
@@ -1169,6 +1170,7 @@ static int alloc_seg(gh_handle *h)
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_pmaps, maps_b + 16);        // (+ slack: 16-byte copies in k_rw)
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmaps, gmaps_b + 16);      // (+ slack: k_rw copies the group maps four bytes at a time)
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_smin, maps_b * 4);          // doubles where the maps hold 2-byte states
+    h->seg_smin_bytes = maps_b * 4;
     if (e == hipSuccess) e = hipMalloc((void **)&h->seg_gmin, gmaps_b * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&h->cm5snap, (size_t)h->N + 2);
     // (behind the segment minima: k_rwseg's flag words, one int2 per segment)
@@ -2475,11 +2477,14 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
     if (sample) pmark(st);
     HIPCHK(hipStreamSynchronize(st));
     {
-        // algorithmic bytes per window over the whole launch: max_paths x (extension + reweight), DESIGN.md section 3's definitions
+        // algorithmic bytes per window over the whole launch, the pipeline's own accounting: per position
+        // and path the walk reads its compact table (4 rows x L lags x 32 bytes) and the bookkeeper the counts, the original
+        // log-marginals and the packed word (64 + 48 + 8) and writes a path byte; the sweep reads the W rows of the path's symbol
+        // (7 elements each), the counts and two packed words, writes W cells, two counts and min(L, W) x 32 bytes of table
         const double es = f64 ? 8.0 : 4.0;
-        const int wl = W < L ? W : L;
-        const double ext = (double)N * ((1.0 + (double)L) * CELL * es + 28.0);
-        const double rw = (double)(N + 1) * ((double)W * 2.0 * es + 1.0 + CELL * es + 2 * 64 + 88 + 8) + (double)N * ((double)wl * 7 * es + (double)L * LT_ROW * 8.0);
+        const int Lw = (h0->cfg.cond_mode == GH_COND_B || W >= L) ? L : W;
+        const double ext = (double)N * (128.0 * L + 64 + 48 + 8 + 1);
+        const double rw = (double)(N + 1) * (7.0 * es * W + es * W + 64 + 16 + 16 + 32.0 * Lw + 1);
         b->prof_bytes[0] = (ext + rw) * max_paths;
         b->prof_bytes[1] = 0.0;
     }
@@ -3038,10 +3043,16 @@ extern "C" int gh_debug_segment_stamps(gh_t *h, double *out, int n_workgroups)
 {
     if (!h || !out || n_workgroups < 1) return fail(GH_ERR_ARG, "bad argument");
     if (set_dev(h)) return GH_ERR_HIP;
+#if !defined(RWS_STAMPS_ALL)
+    return fail(GH_ERR_STATE, "gh_debug_segment_stamps: this library was not built with -DRWS_STAMPS_ALL (there are no stamps to read)");
+#else
     if (!h->seg_smin) return fail(GH_ERR_STATE, "no segment-parallel walk has run on this handle");
+    if ((size_t)n_workgroups * 16 * sizeof(double) > h->seg_smin_bytes)
+        return fail(GH_ERR_ARG, "gh_debug_segment_stamps: %d workgroups asked for, the buffer holds %zu", n_workgroups, h->seg_smin_bytes / (16 * sizeof(double)));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->seg_smin, (size_t)n_workgroups * 16 * sizeof(double), hipMemcpyDeviceToHost));
     return GH_OK;
+#endif
 }
 
 extern "C" int gh_profile_bytes(gh_t *h, int kernel, double *bytes_per_launch)

@@ -87,7 +87,7 @@ __device__ __forceinline__ void seg_body_mixed(const seg_params &P, unsigned cha
     // [2 CH] work items of the Next build, everything a wavefront needs of one in a single read: .x = target | block of 64 tasks << 8,
     // .y = the target's radices, .z = reciprocal multipliers of the two youngest radices, .w = where the target's entries start
     uint4 *iti = reinterpret_cast<uint4 *>(winf + CH);
-    uint32_t *wfast = reinterpret_cast<uint32_t *>(iti + 2 * CH);     // [CH / 10] 1: every target of the word has four candidates and four-candidate predecessors             // [CH] what a step of the state walk needs of its target: .x = NI | R_t << 12 | offset << 15, .y = 1.0f / NI
+    uint32_t *wfast = reinterpret_cast<uint32_t *>(iti + 2 * CH);     // [CH / 10] 1: every target of the word has four candidates and four-candidate predecessors
 
     __shared__ int s_next_item;                                    // the next work item of (1b) to be drawn
 

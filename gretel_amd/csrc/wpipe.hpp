@@ -425,7 +425,6 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     constexpr int L = LC;
     constexpr int Lr = L < 8 ? L : 8;
     constexpr int SD = pipe_slot_doubles<T>();
-    const symmap sm = P.sm;
     PIPE_GLOBAL(T) *band = pipe_gptr((T *)d.band);
     PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.gp);      // (the pipeline's own table: k_wpipe's prologue)
     const bool act = p <= N;
@@ -560,7 +559,6 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     typedef deep_layout<LC> DL;
     constexpr int NL = RL::NLW * 64, NR = RL::NRW * 64;
     constexpr int MAXPOS = NR / 8;                      // positions per sweep pass = the most a table buffer holds (C + WALK_OV)
-    constexpr int ROW = LC * LT_ROW, BLK = 6 * ROW;
     constexpr int RS = pipe_pos_doubles(LC);
     extern __shared__ __align__(16) double smem[];
     const win_desc d = wd[blockIdx.x];
@@ -725,6 +723,8 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                         o[0] = x0; o[DL::NYP] = x1; o[2 * DL::NYP] = x2; o[3 * DL::NYP] = x3;
                     }
                 }
+                // (pacing these stores with s_sleep, as k_walk_spec's loaders do, changed nothing here: 66.7 ms per 100 paths either
+                // way at 64 windows, 70.1 with 24 units of sleep per round -- scratch/README.md)
             }
         };
         bool aborted = false;

@@ -32,6 +32,8 @@ import gzip
 import struct
 import sys
 
+import heapq
+
 import numpy as np
 
 from .hansel import Hansel, SYMBOLS, UNSYMBOLS
@@ -213,7 +215,7 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
     csum = np.concatenate([[0], np.cumsum(region)])          # csum[x] = sum(region[0:x])
     reads = {}
     order = []
-    dc_pos, dc_ends, dc_accepted = None, [], 0      # max_depth: where the pileup iterator stands, the ends of the reads that entered
+    dc_pos, dc_ends = None, []                       # max_depth: where the pileup iterator stands, the ends of the reads in its buffer (a heap)
     dbg = {}                                         # key -> (query name, [(pos, sequence)]) for --debugreads / --debugpos
     want_dbg = bool(debug_reads) or bool(debug_pos)
     for rec in records:
@@ -226,18 +228,18 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
             end = rec.pos + sum(ln for op, ln in rec.cigar if op in (0, 2, 3, 7, 8))
             end = end if end > rec.pos else rec.pos + 1
             if rec.pos < end_pos and end > start_pos - 1:         # the fetch only brings records that overlap the region
+                if dc_pos is not None and rec.pos < dc_pos:
+                    raise ValueError("records are not in coordinate order (a read at %d behind one at %d): the pileup's depth cap "
+                                     "(max_depth = %d, pysam's default) needs a coordinate-sorted BAM; sort it, or pass max_depth 0"
+                                     % (rec.pos, dc_pos, max_depth))
                 if rec.pos != dc_pos:
                     dc_pos = rec.pos                              # the first read of a position always enters
                 else:
-                    alive = dc_accepted - sum(1 for e in dc_ends if e <= rec.pos - 1)
-                    if alive + 1 > max_depth:
+                    while dc_ends and dc_ends[0] <= rec.pos - 1:  # a min-heap of the ends: what has expired leaves for good
+                        heapq.heappop(dc_ends)
+                    if len(dc_ends) + 1 > max_depth:
                         continue
-                dc_ends.append(end)
-                dc_accepted += 1
-                if len(dc_ends) > 4 * max_depth + 64:             # (forget the expired ones now and then)
-                    keep = [e for e in dc_ends if e > rec.pos - 1]
-                    dc_accepted -= len(dc_ends) - len(keep)
-                    dc_ends = keep
+                heapq.heappush(dc_ends, end)
         if rec.l_seq == 0:
             continue
         one_or_two = 0

@@ -23,7 +23,25 @@
  *              x86-64 server since 2013): r = fma(z, 1/c, -1) and the fused
  *              multiply-adds exactly where that build has them (read off the
  *              instruction sequence of Ubuntu GLIBC 2.35-0ubuntu3.11's libm.so.6);
- *   table:     include/gh_logtab.inc, glibc's __log_data.tab (tools/gen_logtab.py).
+ *   table:     include/gh_logtab.inc (tools/gen_logtab.py).
+ *
+ * Provenance and licence.  The table-driven log() restated here -- its decomposition x = 2^k z, the 128 subintervals of
+ * [0x1.6p-1, 0x1.6p0), the two polynomials and their coefficients, and the table { 1/c, log c } -- is Szabolcs Nagy's
+ * double-precision log of the Arm Optimized Routines (math/log.c, math/log_data.c, LOG_TABLE_BITS = 7, LOG_POLY_ORDER = 6,
+ * LOG_POLY1_ORDER = 12), which glibc 2.28 imported unchanged as sysdeps/ieee754/dbl-64/e_log.c / e_log_data.c:
+ *
+ *     Copyright (c) 2018, Arm Limited.
+ *     SPDX-License-Identifier: MIT OR Apache-2.0 WITH LLVM-exception
+ *
+ * This header is an independent restatement of that published algorithm (no source text of either project is reproduced);
+ * the constants are the algorithm's numerical data.  The table's construction is checkable without either source and
+ * tools/gen_logtab.py --verify (tests/test_detlog.py) checks it with exact arithmetic: every c lies within 2^29 ulp of its
+ * subinterval's centre (Arm's search range for 1/c) and every log c IS round(2^43 ln(1/invc)) / 2^43 -- the second column
+ * follows from the first.  The first build of this header read the table out of a distribution's libm binary; the committed
+ * values are the same 256 doubles, now carried with their origin, and `gen_logtab.py --from-libm` remains only as a
+ * cross-check that the running libm still holds them.  The wrapper log10 (split of the exponent, ivln10, log10_2hi/lo) is
+ * fdlibm's e_log10.c as glibc ships it (Copyright (C) 1993 by Sun Microsystems, Inc.; "Permission to use, copy, modify, and
+ * distribute this software is freely granted, provided that this notice is preserved").
  *
  * Every operation below is an IEEE-754 binary64 +, -, *, or an EXPLICIT fma;
  * compile with -ffp-contract=off so the compiler adds none of its own.  gcc on

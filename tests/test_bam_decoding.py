@@ -212,3 +212,39 @@ def test_max_depth_native_equals_python_on_a_deep_pileup(tmp_path):
         b = util.support_table_from_bam(bam, "c", 45, 300, util.process_vcf(vcf, "c", 45, 300), decoder="python", max_depth=cap)
         for x, y in zip(a, b):
             assert np.array_equal(x, y), cap
+
+
+def test_the_depth_cap_refuses_an_unsorted_bam(tmp_path):
+    # the cap's running sum (and pysam's pileup) needs ascending starts: both decoders say so instead of counting wrongly;
+    # without the cap (max_depth=0) the decoders take records in any order, as before
+    seq = "ACGTACGTAC" * 6
+    reads = [("a", 0, 0, 150, 60, "60M", seq), ("b", 0, 0, 10, 60, "60M", seq), ("c", 0, 0, 10, 60, "60M", seq)]
+    bam = str(tmp_path / "unsorted.bam")
+    vcf = str(tmp_path / "u.vcf.gz")
+    bamio.write_bam(bam, [("c", 400)], reads, index=False)
+    bamio.write_vcf_gz(vcf, "c", [20, 30, 40, 50, 60])
+    v = util.process_vcf(vcf, "c", 1, 400)
+    for dec in ("native", "python"):
+        with pytest.raises(Exception) as ei:
+            util.support_table_from_bam(bam, "c", 1, 400, v, decoder=dec)
+        assert "coordinate" in str(ei.value), (dec, str(ei.value))
+        assert len(_rows(util.support_table_from_bam(bam, "c", 1, 400, v, decoder=dec, max_depth=0))) == 2
+
+
+def test_the_depth_histogram_stays_short_over_a_long_window(tmp_path):
+    # reads spread over 300 kb with a crowd at the far end: the cap is applied there as at the start (the native decoder's
+    # histogram of ends is rebased as it goes instead of growing with the window)
+    seq = "ACGTACGTAC" * 5
+    reads = [("s%d" % i, 0, 0, 100 + 997 * i, 60, "50M", seq) for i in range(300)]
+    reads += [("t%d" % i, 0, 0, 299_000 + (i // 4), 60, "50M", seq) for i in range(40)]
+    reads.sort(key=lambda r: r[3])
+    bam = str(tmp_path / "long.bam")
+    vcf = str(tmp_path / "long.vcf.gz")
+    bamio.write_bam(bam, [("c", 300_100)], reads)
+    bamio.write_vcf_gz(vcf, "c", [299_010, 299_020, 299_030])
+    v = util.process_vcf(vcf, "c", 1, 300_100)
+    a = util.support_table_from_bam(bam, "c", 1, 300_100, v, decoder="native", max_depth=6)
+    b = util.support_table_from_bam(bam, "c", 1, 300_100, v, decoder="python", max_depth=6)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert 0 < len(a[0]) < 40
