@@ -127,9 +127,9 @@ def small_window(n, L, R):
 def issue_model_seg(n, L, ranked, clock_ghz, measured_ms, rw_bytes=None):
     """k_seg is bound by vector-ALU issue (binary64 adds / compares / selects for every state of every position, then one
     table lookup per state and position), not by HBM.  Floor = the instructions of its two inner loops as compiled
-    (profiles/seg_isa_count.py -> profiles/r4_seg_isa.json) x trips per SIMD x issue cost / clock, for the ONE workgroup a CU
+    (profiles/seg_isa_count.py -> profiles/r5_seg_isa.json) x trips per SIMD x issue cost / clock, for the ONE workgroup a CU
     runs (all segments run at once: <= 256 workgroups on 256 CUs, 16 waves = 4 per SIMD)."""
-    isa = json.load(open(os.path.join(ROOT, "profiles", "r4_seg_isa.json")))
+    isa = json.load(open(os.path.join(ROOT, "profiles", "r5_seg_isa.json")))
     sec = isa.get("rwseg", {}).get("L") if rw_bytes is not None else None      # (the same two loops as compiled inside k_rwseg)
     ent = (sec or isa["L"]).get(str(L), {}).get("R4" if ranked else "R5")
     if not ent or "next_table_loop" not in ent or "state_walk_loop" not in ent or not ranked:
@@ -159,16 +159,16 @@ def issue_model_seg(n, L, ranked, clock_ghz, measured_ms, rw_bytes=None):
             "instructions_per_position_and_state": nj * ent["next_table_loop"]["instructions"] / g["NS"] + ent["state_walk_loop"]["instructions"] / dpw / spt,
             "issue_cycles_per_simd": cyc, "clock_ghz": clock_ghz, "floor_us": floor_us,
             "measured_us": measured_ms * 1e3, "frac": floor_us / (measured_ms * 1e3) if measured_ms > 0 else None,
-            "isa_profile": {"file": "profiles/r4_seg_isa.json", "git_head": isa.get("git_head"), "cost_cycles": isa["cost_cycles_per_wave_instruction"]},
+            "isa_profile": {"file": "profiles/r5_seg_isa.json", "git_head": isa.get("git_head"), "cost_cycles": isa["cost_cycles_per_wave_instruction"]},
             "note": "floor = compute phases only (Next tables + state walk); the kernel also stages its table slice (~1.5 us) and pays "
                     "launch + teardown (~3.4 us), see DESIGN.md section 4.1", **extra}
 
 
 def issue_model_pools(n, L, clock_ghz, measured_ms):
     """k_cwalk: one wavefront walks 16 pool entries through its segment, a chain of dependent steps: instructions per step
-    (profiles/r4_seg_isa.json, 'cwalk') x steps per segment x cycles per instruction of a wave that shares its SIMD with at
+    (profiles/r5_seg_isa.json, 'cwalk') x steps per segment x cycles per instruction of a wave that shares its SIMD with at
     most one other (5 alone, 2.5 with a partner: cwalk.hpp)."""
-    isa = json.load(open(os.path.join(ROOT, "profiles", "r4_seg_isa.json")))
+    isa = json.load(open(os.path.join(ROOT, "profiles", "r5_seg_isa.json")))
     ent = isa.get("cwalk", {}).get("L", {}).get(str(L))
     if not ent:
         return None
@@ -180,7 +180,7 @@ def issue_model_pools(n, L, clock_ghz, measured_ms):
             "instructions_per_step": ent["instructions_per_step"], "steps_per_segment": seglen, "cycles_per_instruction": cpi,
             "clock_ghz": clock_ghz, "floor_us": floor_us, "measured_us": measured_ms * 1e3,
             "frac": floor_us / (measured_ms * 1e3) if measured_ms > 0 else None,
-            "isa_profile": {"file": "profiles/r4_seg_isa.json", "git_head": isa.get("git_head")},
+            "isa_profile": {"file": "profiles/r5_seg_isa.json", "git_head": isa.get("git_head")},
             "note": "measured = the first k_cwalk launch of a path (every pool entry is walked; later rounds walk only what is new)"}
 
 
@@ -300,8 +300,13 @@ def end_to_end_leg(table, paths, local):
                        haplotypes=int(res["n"]), haplotypes_per_s=res["n"] / wall)
             if best is None or cur["wall_s"] < best["wall_s"]:
                 best = cur
-            del h
-        best.update(bam_bytes=os.path.getsize(bam), reads=int(len(rank)), decoder=st,
+            n_reads_decoded = int(len(rank))
+            # (the pass's buffers are released HERE, outside the next pass's clock: handing 40 MB of the previous table back to
+            # the system -- munmap -- used to be counted as a third of the next decode)
+            del h, rank, off, bases, res
+            import gc
+            gc.collect()
+        best.update(bam_bytes=os.path.getsize(bam), reads=n_reads_decoded, decoder=st,
                     files_written_s_untimed=t_write,
                     note="BAM (+ .bai) and bgzipped VCF of the same contig -> gretel_amd.util.process_vcf + native BAM decode "
                          "(include/gretel_io.h) + upload + GPU fill + %d spins; best of 2 passes" % paths)
@@ -572,7 +577,7 @@ def main():
         traffic, traffic_note = None, "no PMC profile for this config"
         src_sha = kernel_source_sha()
         try:
-            pmf = "r4_pmc_traffic_c5.json" if cfg_name == "C5" else "r4_pmc_traffic.json"
+            pmf = "r5_pmc_traffic_c5.json" if cfg_name == "C5" else "r5_pmc_traffic.json"
             pmj = json.load(open(os.path.join(ROOT, "profiles", pmf)))
             if cfg_name in ("C3", "C5") and spec_kw == dict(cond_mode="A", marginal_term=False, storage="f32"):
                 if pmj.get("kernel_source_sha") != src_sha:
@@ -586,7 +591,7 @@ def main():
             traffic, traffic_note = None, "no usable PMC profile: %r" % (exc,)
         from gretel_amd._lib import device_clock_khz
         clock_ghz = device_clock_khz(local) / 1e6
-        # what actually binds the dominant kernel: instruction issue, priced from the ISA (profiles/r4_seg_isa.json)
+        # what actually binds the dominant kernel: instruction issue, priced from the ISA (profiles/r5_seg_isa.json)
         issue_model = None
         try:
             if segwalk and (seg["launches"] or fused_rw):

@@ -129,7 +129,7 @@ static int n_threads()
     static const int n = [] {
         int t = getenv("GIO_THREADS") ? atoi(getenv("GIO_THREADS")) : (int)std::thread::hardware_concurrency();
         if (t < 1) t = 1;
-        if (t > 16) t = 16;
+        if (t > 16) t = 16;      // (measured on a 256-core host, C3 file: 8 threads 50 ms, 16 38 ms, 32 39 ms, 64 50 ms -- the serial parts bind)
         return t;
     }();
     return n;

@@ -144,16 +144,24 @@ class ResultExchange:
     gathered (None elsewhere).  Two slots: a slot is handed out again only when its previous submission has been collected, so
     no buffer is rewritten while a copy or the collective may still read it.  Every rank submits once per step, in step order:
     the collectives match across ranks.  Wire format per window: paths u8[max_paths][N+1], gh_path_rec f64[max_paths][5],
-    f64[2] = (n, hole_at)."""
+    f64[2] = (n, hole_at).
+
+    Rules the class enforces or states: (1) buffers() REFUSES to hand out a slot whose previous submission has not been
+    collected (a forgotten collect() used to lose a step's records silently); (2) the worker thread issues its gather on the
+    default process group: the caller must not run another collective while submissions are outstanding -- drain() first, as
+    bench.py does in front of its barrier -- or pass `group=` (torch.distributed.new_group) to give the exchange its own;
+    (3) a submission that does not complete within `timeout_s` (a peer whose worker raised never enters the collective)
+    raises instead of blocking forever."""
 
     NREC = 5
 
-    def __init__(self, n_snps, max_paths, device, world, rank, force=False, slots=2):
+    def __init__(self, n_snps, max_paths, device, world, rank, force=False, slots=2, group=None, timeout_s=120.0):
         import queue as queue_mod
         import threading
         import torch
         self.n1, self.max_paths, self.device, self.world, self.rank = n_snps + 1, max_paths, device, world, rank
         self.active = world > 1 or force
+        self.group, self.timeout_s = group, timeout_s
         self.cuda = device.type == "cuda"
         self.nb_p = max_paths * self.n1
         self.off_r = (self.nb_p + 7) & ~7
@@ -193,8 +201,9 @@ class ResultExchange:
     def buffers(self):
         """(paths, recs) views of the slot the next submit() sends: hand them to Hansel.spin(out_paths=, out_recs=)."""
         sl = self.slots[self.next_slot]
-        while any(q[0] == self.next_slot for q in self.queue):      # its last submission is still out: finish the oldest first
-            self._finish(self.queue.pop(0), keep=False)
+        if any(q[0] == self.next_slot for q in self.queue):
+            raise RuntimeError("ResultExchange: slot %d still holds a submission that was never collected -- call collect() (or "
+                               "drain()) once per submit(); handing the slot out again would lose that step's records" % self.next_slot)
         p, r, _ = self._views(sl["np"])
         return p, r
 
@@ -224,13 +233,13 @@ class ResultExchange:
                 if self.cuda:
                     with torch.cuda.stream(self.side):
                         sl["dev"].copy_(sl["host"], non_blocking=True)
-                        dist.gather(sl["dev"], recv, dst=0)
+                        dist.gather(sl["dev"], recv, dst=0, group=self.group)
                         if self.rank == 0:
                             sl["recv_host"].copy_(sl["recv_dev"], non_blocking=True)
                         sl["event"].record(self.side)
                     sl["event"].synchronize()
                 else:
-                    dist.gather(sl["dev"], recv, dst=0)
+                    dist.gather(sl["dev"], recv, dst=0, group=self.group)
             except BaseException as exc:           # (handed to the thread that collects)
                 sl["error"] = exc
             sl["done"].set()
@@ -246,7 +255,9 @@ class ResultExchange:
         si, n, hole = q
         sl = self.slots[si]
         if self.active:
-            sl["done"].wait()
+            if not sl["done"].wait(self.timeout_s):
+                raise TimeoutError("ResultExchange: a gather did not complete within %.0f s (a peer that failed never enters the "
+                                   "collective)" % self.timeout_s)
             if sl.get("error") is not None:
                 exc, sl["error"] = sl["error"], None
                 raise exc

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profiles of one round, to be run on the GPU box from the repo root:
-#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r4'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash profiles/collect.sh r5'      (COMMIT FIRST: the summaries record whether the tree was dirty)
 # Kernel trace and the PMC passes are separate runs (never combined with other trace domains); rocprofv3 is given python3
 # directly.  Back in the build container the summaries are made from gpurun_out/prof_<round>/ (where git is):
-#   scratch/copy_profiles.sh r4          (copies the bench lines and kernel statistics, summarises the PMC passes, recounts the ISA)
+#   scratch/copy_profiles.sh r5          (copies the bench lines and kernel statistics, summarises the PMC passes, recounts the ISA)
 set -u
-R=${1:-r4}
+R=${1:-r5}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
@@ -20,6 +20,17 @@ python3 scratch/l_sweep.py > $out/l_sweep.txt 2>&1
 # the fills alone (HIP events), and the sparse-deletion window (mixed radix) beside the plain one and the five-symbol radix
 for c in C2 C3 C5; do python3 scratch/fill_time.py $c 2>&1 | tail -2; done > $out/fill_times.txt
 (python3 scratch/mixed_try.py 0.01; GH_MIXED=0 python3 scratch/mixed_try.py 0.01; python3 scratch/mixed_try.py 0) > $out/mixed_radix.txt 2>&1
+# the window pipeline (csrc/wpipe.hpp): windows per GPU, the batched launches of rounds 1-4 beside it, two workgroups per CU, and
+# the per-role cycle accounting of the diagnostic build (scratch/lib_pipe_prof.so: -DPIPE_PROF, built in the container)
+export PYTHONPATH=$GRAFT_REPO_ROOT
+(for w in 32 64 128 256 512; do python3 scratch/pipe_bench.py $w 100 2 2>&1 | grep -v amdgpu.ids | tail -1; done
+ echo "--- GH_PIPE=0 (batched launches)"; GH_PIPE=0 python3 scratch/pipe_bench.py 256 100 2 2>&1 | grep -v amdgpu.ids | tail -1
+ echo "--- GH_PIPE_NT=512 (two workgroups per CU), 512 windows"; GH_PIPE_NT=512 python3 scratch/pipe_bench.py 512 100 2 2>&1 | grep -v amdgpu.ids | tail -1
+ echo "--- C2 (1k SNPs, L = 3), 256 windows"; python3 scratch/pipe_bench.py 256 100 2 C2 2>&1 | grep -v amdgpu.ids | tail -1) > $out/pipe_windows.txt 2>&1
+if [ -f scratch/lib_pipe_prof.so ]; then
+  (GH_LIB=$GRAFT_REPO_ROOT/scratch/lib_pipe_prof.so GH_PIPE_STAMPS=1 python3 scratch/pipe_bench.py 256 21 1 2>&1 | grep -v "amdgpu.ids\|gh_batch_spin" | tail -4
+   GH_LIB=$GRAFT_REPO_ROOT/scratch/lib_pipe_prof.so GH_PIPE_STAMPS=1 python3 scratch/pipe_bench.py 64 21 1 2>&1 | grep -v "amdgpu.ids\|gh_batch_spin" | tail -4) > $out/pipe_roles.txt 2>&1
+fi
 Q0="--no-cpu-baseline --no-throughput-leg --no-e2e --no-spec-matrix --steps 30 --warmup 3"
 for a in "" "--force-dist" "--force-dist --blocking-gather" "" "--force-dist" "--force-dist --blocking-gather"; do
   python3 bench.py $Q0 $a 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s %.0f hap/s %.4f ms/step' % (sys.argv[1], d['value'], d['ms_per_step']))" "[$a]"

@@ -40,7 +40,13 @@ def main(root, prefix="pmc"):
     import subprocess
     try:
         line = [l for l in open("%s/%s_FETCH_SIZE.json" % (root, prefix)) if l.startswith("{")][-1]
-        out["kernel_source_sha"] = json.loads(line)["roofline"]["kernel_source_sha"]
+        doc = json.loads(line)
+        out["kernel_source_sha"] = doc["roofline"]["kernel_source_sha"]
+        # batched runs (bench.py --batch B --paths P): what one launch of the window pipeline covered -- bench.py scales its
+        # traffic figure to the launch it times
+        cfg = doc.get("config", {})
+        if "windows_per_gpu" in cfg:
+            out["windows"], out["paths"] = cfg["windows_per_gpu"], cfg["paths"]
     except Exception:
         out["kernel_source_sha"] = None
     here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -4,6 +4,7 @@ import numpy as np
 from gretel_amd import bamio, util
 from gretel_amd.synth import make_config
 d = sys.argv[1] if len(sys.argv) > 1 else "/tmp/e2e"
+os.makedirs(d, exist_ok=True)
 bam, vcf = os.path.join(d, "s.bam"), os.path.join(d, "s.vcf.gz")
 t = make_config("C3", seed=0)
 if not os.path.exists(bam):

@@ -32,3 +32,24 @@ def test_variable_k_config():
     assert ks.min() >= 2 and ks.max() <= 21
     assert (t.rank + ks <= 2000).all()
     assert set(CONFIGS) == {"C2", "C3", "C5"}
+
+
+def test_result_exchange_refuses_to_drop_an_uncollected_step():
+    # two staging slots: the third buffers() without a collect() in between would hand out a slot whose records nobody has
+    # looked at -- the class used to finish and DROP that submission silently
+    import torch
+    from gretel_amd.dist import ResultExchange
+    ex = ResultExchange(n_snps=10, max_paths=3, device=torch.device("cpu"), world=1, rank=0)
+    for step in range(2):
+        pv, rv = ex.buffers()
+        pv[:] = step
+        ex.submit(1, 0)
+    import pytest
+    with pytest.raises(RuntimeError, match="never collected"):
+        ex.buffers()
+    got = ex.collect()
+    assert got[0]["n"] == 1 and int(got[0]["paths"][0, 0]) == 0
+    pv, rv = ex.buffers()           # the collected slot is free again
+    ex.submit(2, 0)
+    assert ex.collect()[0]["paths"][0, 0] == 1 and ex.collect()[0]["n"] == 2 and ex.collect() is None
+    ex.close()
