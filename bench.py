@@ -803,6 +803,37 @@ def main():
                 del hw, rw
             except Exception as exc:
                 out["wide_window_sparse"] = {"error": repr(exc)}
+        if world == 1:
+            # co-headline: the same step under the spec the PUBLISHED method describes (reference README.md:79-94 -> Nicholls et al.
+            # 2021: naive Bayes, the marginal of the candidate times the conditionals of the earlier variants GIVEN the candidate) --
+            # conditional E (or C: the "unique variants" term at the target or at the source, gretel.py:10) + marginal term, f32.
+            # `value` runs the frozen default (A, no marginal term), which is a reconstruction.
+            try:
+                pub = {}
+                for cm_ in ("E", "C"):
+                    hx = Hansel(n, band=table.band, device=local, storage="f32", cond_mode=cm_, marginal_term=True)
+
+                    def pstep():
+                        hx.clear()
+                        hx.fill_from_support(None, None, None, reads_handle=reads)
+                        return hx.spin(paths)
+                    pstep(); pstep()
+                    torch.cuda.synchronize(); hx.sync()
+                    ts_, nx = [], 0
+                    for _ in range(7):
+                        tx = time.perf_counter()
+                        nx = pstep()["n"]
+                        ts_.append(time.perf_counter() - tx)
+                    ts_.sort()
+                    pub[cm_] = nx / ts_[len(ts_) // 2]
+                    del hx
+                out["value_published_spec"] = {"value": min(pub.values()), "unit": "haplotypes/s", "by_conditional": pub,
+                                               "over_value": min(pub.values()) / out["value"],
+                                               "spec": "cond_mode E / C + marginal_term, f32 (the slower of the two is quoted)",
+                                               "note": "the benchmark step (clear + fill + %d spins), 2 warm-up steps, median of 7 steps timed one by one; "
+                                                       "which of the specs hanselx 0.0.92 implements is unpinned (DESIGN.md section 0)" % paths}
+            except Exception as exc:
+                out["value_published_spec"] = {"error": repr(exc)}
         if world == 1 and not args.no_spec_matrix:
             # the switches of the Hansel arithmetic the reference leaves to hanselx: the same step
             # (clear + fill + `paths` spins) under every conditional x marginal term x storage.  Every spec runs the same
