@@ -15,6 +15,7 @@ rng = np.random.default_rng(seed0)
 t_end = time.time() + budget
 n_cases = 0
 n_batch = 0
+n_pipe = 0
 variants = {}
 while time.time() < t_end:
     n = int(rng.choice([4000, 7777, 12000, 20011])) if big else int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
@@ -49,7 +50,7 @@ while time.time() < t_end:
         L = 5
     paths = int(rng.integers(1, 9))
     desc = dict(n=n, reads=reads, k=k, k_max=kmx, k_lambda=lam, sparse_dels=sparse, n_haps=n_haps, err=err, storage=storage, mode=mode, mt=mt, L=L, paths=paths, **sw)
-    if k is not None and rng.random() < 0.12:
+    if k is not None and rng.random() < float(os.environ.get("FUZZ_BATCH_P", "0.12")):
         # batched launch over 3 windows of one shape (same N, band, switches, L)
         ts = [t] + [make_support_table(n, reads, k=k, n_haps=int(rng.integers(1, 9)), err=err, seed=int(rng.integers(0, 1 << 30)))
                     for _ in range(2)]
@@ -61,17 +62,31 @@ while time.time() < t_end:
                 assert hh.fill_from_support(x.rank, x.off, x.bases) == oo.fill(x)
                 hh.L = L if L is not None else 3; oo.L = hh.L
                 hs.append(hh); os_.append(oo)
-            # either way of running a batch: windows on their own streams, or kernels launched over all windows
-            if rng.random() < 0.5:
+            # the ways of running a batch: the window pipeline (csrc/wpipe.hpp: one persistent workgroup per window; it takes what
+            # it can -- row conditionals, 2..14 lags, ranked windows -- and leaves the rest to the others), windows on their own
+            # streams, or kernels launched over all windows
+            way = rng.random()
+            os.environ.pop("GH_PIPE_NT", None)
+            if way < 0.5:
+                os.environ["GH_PIPE_MIN"] = "1"
+                if rng.random() < 0.3:
+                    os.environ["GH_PIPE_NT"] = str(rng.choice([512, 768, 1024]))
+            else:
+                os.environ["GH_PIPE_MIN"] = "1000000"
+            if way < 0.75:
                 os.environ["GH_BATCH_STREAMS_MAX"] = "-1"
             else:
                 os.environ.pop("GH_BATCH_STREAMS_MAX", None)
-            for res, oo in zip(HanselBatch(hs).spin(paths), os_):
-                ref = oo.spin(paths)
+            deep = int(rng.integers(10, 60)) if rng.random() < 0.3 else paths       # deep spins: masks move, windows are handed back
+            hb = HanselBatch(hs)
+            for res, oo, hh in zip(hb.spin(deep), os_, hs):
+                ref = oo.spin(deep)
                 if not (res["n"] == ref["n"] and res["hole_at"] == ref["hole_at"] and np.array_equal(res["paths"], ref["paths"])
-                        and res["hp_current"].tolist() == ref["hp_current"].tolist()):
-                    print("MISMATCH batch", desc, flush=True)
+                        and res["hp_current"].tolist() == ref["hp_current"].tolist() and res["hp_original"].tolist() == ref["hp_original"].tolist()
+                        and res["ratio"].tolist() == ref["ratio"].tolist() and np.array_equal(hh.export_band(), oo.export_band())):
+                    print("MISMATCH batch", desc, dict(way=way, deep=deep, pipe=hb.pipe_info(), nt=os.environ.get("GH_PIPE_NT")), flush=True)
                     sys.exit(1)
+            n_pipe += 1 if hb.pipe_info()["windows"] else 0
             n_batch += 1
             continue
     # the serial walkers instead of the segment-parallel / pool extension now and then (GH_WALK is read when a handle is created)
@@ -151,4 +166,4 @@ while time.time() < t_end:
         print("ERROR", repr(e), desc, flush=True)
         sys.exit(1)
     n_cases += 1
-print("fuzz ok: %d cases + %d batched triples, walker variants %s" % (n_cases, n_batch, variants))
+print("fuzz ok: %d cases + %d batched triples (%d through the window pipeline), walker variants %s" % (n_cases, n_batch, n_pipe, variants))
