@@ -2379,7 +2379,10 @@ __global__ void k_batch_states(const win_desc *wd, dev_state *out)
 static int pipe_threads(int L)
 {
     const int env = getenv("GH_PIPE_NT") ? atoi(getenv("GH_PIPE_NT")) : 0;      // (read on every call: the tests switch)
-    if (L < 2 || L > 14) return 0;
+    // (beyond ten lags the 512-thread form walks chunks of 11..14 positions and loses to the candidate pools on their own streams:
+    // 20-25k against 31k haplotypes/s at 128 windows, scratch/pipe_lsweep.py; GH_PIPE_MAX_L=14 takes it all the same -- the tests)
+    const int max_l = getenv("GH_PIPE_MAX_L") ? atoi(getenv("GH_PIPE_MAX_L")) : 10;
+    if (L < 2 || L > 14 || L > max_l) return 0;
     if (env == 512 || env == 768 || env == 1024) return env;
     return L <= 6 ? 1024 : (L <= 10 ? 768 : 512);
 }

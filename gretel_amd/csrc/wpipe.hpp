@@ -382,6 +382,8 @@ struct sweep_regs {
     unsigned long long pkt; // pk[p + s + 1]
     unsigned rowoff;        // element offset of that row in the band (32-bit: the host checks the tensor is smaller than 2^31 elements)
     int a, b;               // path[p]; the to-symbol of the lane's cell: path[p + s + 1], '_' behind position N
+    T xe[3];                // bands wider than 8: the elements of the lane's further cells (p, p + s + 1 + 8 r), r = 1..3, on the path
+    unsigned xoff[3];       // ... and where they lie (0xffffffff: no such cell)
 };
 
 // doubles per lag slot (row as 8 x T, denominator, packed word of the target) and per lane group (8 slots)
@@ -410,6 +412,16 @@ __device__ __forceinline__ void pipe_sweep_load(const pipe_params &P, const win_
     R.row.v0 = rc[0]; R.row.v1 = rc[1]; R.row.v2 = rc[2]; R.row.v3 = rc[3]; R.row.v4 = rc[4]; R.row.v5 = rc[5]; R.row.v6 = rc[6];
     R.cnt = pipe_gptr((const double *)d.cnt)[(unsigned)pp * 8u + (unsigned)s];
     R.pkp = pipe_gptr((const unsigned long long *)d.pk)[pp];
+    // bands up to 32: the path's element of each further cell of this lane (one value, not the row: no lag beyond the eighth
+    // takes its row from here).  No branch around the loads: a cell that does not exist reads the first one's address.
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int dx = s + 9 + 8 * r, jx = pp + dx;
+        const bool ex = W > 8 && dx <= W && p <= N && jx <= N + 1;
+        const int bx = (int)s_path[(ex && jx <= N) ? jx : 0];
+        R.xoff[r] = ex ? (((unsigned)pp * 7u + (unsigned)a) * (unsigned)W + (unsigned)(dx - 1)) * 7u + (unsigned)bx : 0xffffffffu;
+        R.xe[r] = pipe_gptr((const T *)d.band)[ex ? R.xoff[r] : R.rowoff];
+    }
     const int snp = p + s + 1;
     R.pkt = pipe_gptr((const unsigned long long *)d.pk)[(snp <= N && s + 1 <= P.L) ? snp : N + 1];     // (pk[N + 1] = 0: no candidates, no entries)
 }
@@ -458,6 +470,8 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     const unsigned long long pkp = R.pkp, pkt_in = R.pkt;
     const unsigned rowoff = R.rowoff;
     const int b_cell = R.b;
+    const T xe0 = R.xe[0], xe1 = R.xe[1], xe2 = R.xe[2];
+    const unsigned xo0 = R.xoff[0], xo1 = R.xoff[1], xo2 = R.xoff[2];
     prefetch();
     // the first round out of the slot: lane s owns the cell (p, p + s + 1)
     if (act && s + 1 <= W) {
@@ -468,9 +482,19 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             srow[b_cell] = cur;
         }
     }
-    // bands wider than 8: the further cells with a load in place
-    if (act) {
-        for (int dd = s + 9; dd <= W; dd += 8) {
+    // bands wider than 8: the lane's further cells, their elements prefetched with the row (up to a band of 32), beyond that
+    // with a load in place
+    if (act && W > 8) {
+        auto further = [&](T e, unsigned off, int dd) __attribute__((always_inline)) {
+            if (off != 0xffffffffu) {
+                const int mult = mult_of(dd);
+                if (mult) band[off] = reweight(e, mult);
+            }
+        };
+        further(xe0, xo0, s + 9);
+        further(xe1, xo1, s + 17);
+        further(xe2, xo2, s + 25);
+        for (int dd = s + 33; dd <= W; dd += 8) {
             const int j = p + dd;
             const int mult = mult_of(dd);
             if (mult) {

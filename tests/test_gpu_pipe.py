@@ -18,8 +18,8 @@ def _pipe_for_small_batches(monkeypatch):
     monkeypatch.delenv("GH_PIPE_NT", raising=False)
 
 
-def _pair(seed, n, reads, k, L=None, band=None, n_haps=8, **kw):
-    t = make_support_table(n, reads, k=k, seed=seed, n_haps=n_haps, err=0.01 if n_haps > 1 else 0.0, k_max=21)
+def _pair(seed, n, reads, k, L=None, band=None, n_haps=8, k_max=21, **kw):
+    t = make_support_table(n, reads, k=k, seed=seed, n_haps=n_haps, err=0.01 if n_haps > 1 else 0.0, k_max=k_max)
     W = band if band is not None else t.band
     h = Hansel(t.n_snps, band=W, **kw)
     o = COracle(t.n_snps, W, **kw)
@@ -52,7 +52,8 @@ def test_pipeline_equals_the_oracle(L):
 
 
 @pytest.mark.parametrize("L", [7, 9, 10, 11, 14])
-def test_pipeline_with_longer_memories(L):
+def test_pipeline_with_longer_memories(L, monkeypatch):
+    monkeypatch.setenv("GH_PIPE_MAX_L", "14")           # (by default the pipeline stops at ten lags: beyond, the pools are faster)
     wins = [_pair(200 + s, 600, 12000, None, L=L, band=21, n_haps=6) for s in range(3)]
     b = HanselBatch([h for h, _ in wins])
     res = b.spin(8)
@@ -84,6 +85,26 @@ def test_other_specs_keep_the_batched_launches(kw):
     assert b.pipe_info()["windows"] == 0
     for (h, o), r in zip(wins, res):
         _same(r, o.spin(6), h, o)
+
+
+def test_beyond_ten_lags_the_pools_take_the_batch():
+    wins = [_pair(260 + s, 400, 9000, None, L=12, band=21, n_haps=6) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(5)
+    assert b.pipe_info()["windows"] == 0
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(5), h, o)
+
+
+@pytest.mark.parametrize("band", [9, 16, 17, 25, 32, 33, 40])
+def test_wide_bands(band):
+    # the sweep prefetches the path's element of a lane's further cells up to a band of 32 and loads in place beyond
+    wins = [_pair(270 + s, 500, 10000, None, L=5, band=band, n_haps=6, k_max=min(band + 1, 34)) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(8)
+    assert b.pipe_info()["windows"] == 2
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(8), h, o)
 
 
 @pytest.mark.parametrize("n", [7, 59, 60, 61, 64, 121, 1000, 2417])
