@@ -93,6 +93,7 @@ struct gh_handle {
     unsigned long long *pipe_pk;  // [N+2] the window pipeline's packed candidate words (wpipe.hpp), allocated by the first batch that takes it
     double *pipe_gp;              // ... and its compact table [(N+LT_PAD)][4][L][4]
     size_t pipe_gp_bytes;
+    double *pipe_lm;              // ... and, with the marginal term, the candidates' log-marginals by rank [N+2][4]
     bool need_rinfo;              // ... kept only where somebody reads it: with the marginal term (k_seg, k_cwalk add it in front of x1) and
                                   // for the three-launch spins (GH_FUSE at creation); nullptr goes to the kernels otherwise (C5: k_rw is bound by its stores)
     symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
@@ -329,7 +330,7 @@ static void free_handle(gh_handle *h)
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->tband); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
-    hipFree(h->pipe_pk); hipFree(h->pipe_gp);
+    hipFree(h->pipe_pk); hipFree(h->pipe_gp); hipFree(h->pipe_lm);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->rinfo); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
@@ -386,7 +387,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memset(h->cfg.cand_order, 0, sizeof h->cfg.cand_order);
     memcpy(h->cfg.cand_order, order, 5);
     h->sm = make_symmap(order);
-    h->rinfo = nullptr; h->pipe_pk = nullptr; h->pipe_gp = nullptr; h->pipe_gp_bytes = 0; h->lt_baked = false; h->ht_stale = false;
+    h->rinfo = nullptr; h->pipe_pk = nullptr; h->pipe_gp = nullptr; h->pipe_gp_bytes = 0; h->pipe_lm = nullptr; h->lt_baked = false; h->ht_stale = false;
     h->need_rinfo = cfg->marginal_term != 0 || (getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1);
     h->dev = dev;
     h->N = cfg->n_snps;
@@ -2386,6 +2387,16 @@ static int pipe_threads(int L)
     if (env == 512 || env == 768 || env == 1024) return env;
     return L <= 6 ? 1024 : (L <= 10 ? 768 : 512);
 }
+// which specs the pipeline carries: every conditional -- the row conditionals A, B, D and, on the to-major copy of the band, the
+// column conditionals C, E --, with or without the marginal term (the walker adds it in front of the lag-1 term from the
+// log-marginals the sweep keeps by rank).  GH_PIPE_COL=0 / GH_PIPE_MT=0 leave those to the batched launches (A/B measurements).
+static bool pipe_spec_ok(const gh_handle *h)
+{
+    const bool col = h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E;
+    const bool no_mt = getenv("GH_PIPE_MT") && atoi(getenv("GH_PIPE_MT")) == 0;
+    const bool no_col = getenv("GH_PIPE_COL") && atoi(getenv("GH_PIPE_COL")) == 0;
+    return !h->lt_full && !(col && no_col) && !(h->cfg.marginal_term && no_mt);
+}
 static int pipe_sweep_threads(int nt) { return nt == 1024 ? pipe_roles<1024>::NRW * 64 : (nt == 768 ? pipe_roles<768>::NRW * 64 : pipe_roles<512>::NRW * 64); }
 
 template <typename T, int LC, int NT>
@@ -2443,8 +2454,9 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
                            (dev_state *)nullptr, gwd, (const uint8_t *)nullptr, 0.0, 0, (double *)nullptr, 0, (double *)nullptr, 0, 0, (const double *)nullptr, (gh_path_rec *)nullptr,
                            h0->sm, h0->cfg.offer_zero, (double *)nullptr);
         hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, st, (double *)nullptr, (const double *)nullptr, N, gwd);
+        // (the table WITHOUT the marginal term baked into its lag-1 entries: the pipeline's walker adds it itself)
         hipLaunchKernelGGL(k_lt<double>, dim3((unsigned)lt_nb, n), dim3(256), 0, st, (const double *)nullptr, N, W, L,
-                           h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                           h0->cfg.cond_mode, 0, (const double *)nullptr, (const int32_t *)nullptr,
                            (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
                            (const uint8_t *)nullptr, gwd, 0, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const double *)nullptr);
     } else {
@@ -2454,16 +2466,17 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
                            h0->sm, h0->cfg.offer_zero, (double *)nullptr);
         hipLaunchKernelGGL(k_snapshot, dim3(marg_gx, n), dim3(256), 0, st, (double *)nullptr, (const double *)nullptr, N, gwd);
         hipLaunchKernelGGL(k_lt<float>, dim3((unsigned)lt_nb, n), dim3(256), 0, st, (const float *)nullptr, N, W, L,
-                           h0->cfg.cond_mode, h0->cfg.marginal_term, (const double *)nullptr, (const int32_t *)nullptr,
+                           h0->cfg.cond_mode, 0, (const double *)nullptr, (const int32_t *)nullptr,
                            (const uint32_t *)nullptr, (const double *)nullptr, (double *)nullptr, (dev_state *)nullptr,
                            (const uint8_t *)nullptr, gwd, 0, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const float *)nullptr);
     }
     HIPCHK(hipGetLastError());
     const int nr = pipe_sweep_threads(nt);
     pipe_params P;
-    P.N = N; P.W = W; P.L = L; P.C = pipe_chunk(N, L, nr, f64 ? 8 : 4); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
+    P.N = N; P.W = W; P.L = L; P.mt = h0->cfg.marginal_term ? 1 : 0; P.col = (h0->cfg.cond_mode == GH_COND_C || h0->cfg.cond_mode == GH_COND_E) ? 1 : 0;
+    P.C = pipe_chunk(N, L, nr, f64 ? 8 : 4, P.mt); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
     P.offer_zero = h0->cfg.offer_zero; P.prof = (b->prof_every > 0 || getenv("GH_PIPE_STAMPS")) ? 1 : 0; P.min_remove = min_remove; P.sm = h0->sm;
-    const size_t lds = pipe_lds_bytes(N, L, P.C, nr, f64 ? 8 : 4);
+    const size_t lds = pipe_lds_bytes(N, L, P.C, nr, f64 ? 8 : 4, P.mt);
     b->pused[0] = b->pused[1] = 0;
     auto pmark = [&](hipStream_t s_) {
         if (b->pused[0] >= b->pev[0].size()) {
@@ -2649,9 +2662,9 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         const int pipe_min = getenv("GH_PIPE_MIN") ? atoi(getenv("GH_PIPE_MIN")) : 24;
         const int bwm0 = h0->wmode == WM_SEG ? WM_SPEC : h0->wmode;
         const int nt = pipe_threads(b->L);
-        if (pipe_env && n >= pipe_min && nt && pipe_instantiated(b->L, nt) && walk_depth2_ok(bwm0, b->L) && lt_incremental_ok(h0) &&
+        if (pipe_env && n >= pipe_min && nt && pipe_instantiated(b->L, nt) && walk_depth2_ok(bwm0, b->L) && pipe_spec_ok(h0) &&
             (unsigned long long)(b->N + 2) * 49ull * (unsigned long long)b->W < (1ull << 31) &&      // (the sweep's 32-bit element offsets)
-            pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), h0->cfg.storage == GH_STORAGE_F64 ? 8 : 4) > 0)
+            pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), h0->cfg.storage == GH_STORAGE_F64 ? 8 : 4, h0->cfg.marginal_term) > 0)
             pipe_nt = nt;
     }
     if (!pipe_nt && batch_cut >= 0 &&
@@ -2700,6 +2713,18 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                 HIPCHK(hipMalloc((void **)&h->pipe_gp, need));
                 h->pipe_gp_bytes = need;
             }
+            if (h->cfg.marginal_term && !h->pipe_lm) HIPCHK(hipMalloc((void **)&h->pipe_lm, sizeof(double) * 4 * ((size_t)b->N + 2)));
+            if (h->cfg.cond_mode == GH_COND_C || h->cfg.cond_mode == GH_COND_E) {
+                // the to-major copy of the band, in step with it (the pipeline's sweep then keeps both, element by element)
+                const size_t nel = h->n_cells * CELL;
+                if (!h->tband && hipMalloc(&h->tband, nel * esize(h)) != hipSuccess) { h->tband = nullptr; return fail(GH_ERR_NOMEM, "hipMalloc for the to-major band failed"); }
+                if (h->tband_epoch != h->band_epoch) {
+                    const unsigned nbt = (unsigned)((nel + 255) / 256);
+                    if (h->cfg.storage == GH_STORAGE_F64) hipLaunchKernelGGL(k_band_to_major<double>, dim3(nbt), dim3(256), 0, b->stream, (const double *)h->band, (double *)h->tband, nel, h->W);
+                    else hipLaunchKernelGGL(k_band_to_major<float>, dim3(nbt), dim3(256), 0, b->stream, (const float *)h->band, (float *)h->tband, nel, h->W);
+                    h->tband_epoch = h->band_epoch;
+                }
+            }
         }
     std::vector<win_desc> wd(n);
     for (int w = 0; w < n; w++) {
@@ -2713,6 +2738,8 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         wd[w]._pad = 0;
         wd[w].pk = h->pipe_pk;
         wd[w].gp = h->pipe_gp;
+        wd[w].lmr = h->pipe_lm;
+        wd[w].tband = h->tband;
         h->have_orig = true;
     }
     std::vector<dev_state> hs(n);
@@ -2772,7 +2799,11 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     for (int w = 0; w < n; w++) {
         n_out[w] = hs[w].n_done;
         hole_at[w] = hs[w].stop ? hs[w].hole_at : 0;
+        const bool kept = b->hs[w]->tband && b->hs[w]->tband_epoch == b->hs[w]->band_epoch && pipe_nt &&
+                          (hs[w].pipe_status == PIPE_DONE || hs[w].pipe_status == PIPE_ABORTED) &&
+                          (b->hs[w]->cfg.cond_mode == GH_COND_C || b->hs[w]->cfg.cond_mode == GH_COND_E);
         b->hs[w]->dirty_marg = b->hs[w]->dirty_lt = true; b->hs[w]->band_epoch++;
+        if (kept) b->hs[w]->tband_epoch = b->hs[w]->band_epoch;       // (the pipeline's sweep wrote both)
         b->hs[w]->lt_inc_path = nullptr;       // the batch reweighted many paths and maintains no walker tables: rebuild in full
     }
     for (int w : aborted) {
@@ -2809,7 +2840,7 @@ extern "C" int gh_batch_pipe_info(gh_batch_t *b, int32_t out[4])
     const int nt = pipe_threads(b->L);
     out[0] = b->pipe_windows; out[1] = b->pipe_aborted;
     out[2] = b->pipe_windows ? nt : 0;
-    out[3] = b->pipe_windows ? pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), b->hs[0]->cfg.storage == GH_STORAGE_F64 ? 8 : 4) : 0;
+    out[3] = b->pipe_windows ? pipe_chunk(b->N, b->L, pipe_sweep_threads(nt), b->hs[0]->cfg.storage == GH_STORAGE_F64 ? 8 : 4, b->hs[0]->cfg.marginal_term) : 0;
     return GH_OK;
 }
 

@@ -115,6 +115,8 @@ struct win_desc {
     int _pad;
     unsigned long long *pk; // [N+2] k_wpipe (wpipe.hpp): what a sweep needs of a position's candidates, packed by its prologue
     double *gp;             // [(N+LT_PAD)][4][L][4] k_wpipe: its own compact copy of the ranked table (prologue)
+    double *lmr;            // [N+2][4] k_wpipe with the marginal term: log10 marginal of a position's candidates by rank
+    void *tband;            // k_wpipe under the column conditionals: the to-major copy of the band (kept in step)
 };
 
 // Band layout: band[i][a][d-1][b] -- position, FROM-symbol, distance, to-symbol.  Everything a path touches at position i

@@ -54,9 +54,11 @@ struct pipe_params {
     int N, W, L;
     int C;                  // positions per chunk: multiple of L, <= NR/8 - 4
     int max_paths;
-    int cond_mode;          // A, B or D (row conditionals; no marginal term)
+    int cond_mode;          // GH_COND_*: A, B, D rewrite a ROW of the table per position and lag, C and E a COLUMN (col = 1)
     int offer_zero;
     int prof;               // 1: the bookkeeper leaves s_memrealtime stamps per path in st->dbg8
+    int mt;                 // marginal term: the walker adds log10 marginal of the candidate in front of the lag-1 term
+    int col;                // column conditionals (C, E): the sweep works on the to-major copy of the band as well
     double min_remove;
     symmap sm;
 };
@@ -90,25 +92,25 @@ template <> struct pipe_roles<512> {
 // sums and slots (pipe_group_doubles per lane group), a line of control words, the path (N + 2 bytes)
 // doubles per position of a table buffer: X1 = lag-1 terms [row][column] (16), X2 = lag-2 terms (16), Yr = lags 3..L [row][column][lag],
 // rows padded to an even number of lags as in k_walk_spec's depth-2 layout
-__host__ __device__ constexpr int pipe_pos_doubles(int L) { return 32 + 16 * deep_nyp(L); }
+__host__ __device__ constexpr int pipe_pos_doubles(int L, int mt = 0) { return 32 + (mt ? 4 : 0) + 16 * deep_nyp(L); }
 __host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
     return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
 }
-__host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads, int esize)
+__host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads, int esize, int mt = 0)
 {
     const size_t fixed = pipe_fixed_bytes(N, nr_threads, esize);
-    if (L < 2 || fixed + 2 * (size_t)(L + WALK_OV) * pipe_pos_doubles(L) * 8 > WALK_LDS_MAX) return 0;
-    long c = (long)((WALK_LDS_MAX - fixed) / (2 * (size_t)pipe_pos_doubles(L) * 8)) - WALK_OV;
+    if (L < 2 || fixed + 2 * (size_t)(L + WALK_OV) * pipe_pos_doubles(L, mt) * 8 > WALK_LDS_MAX) return 0;
+    long c = (long)((WALK_LDS_MAX - fixed) / (2 * (size_t)pipe_pos_doubles(L, mt) * 8)) - WALK_OV;
     const long cap = nr_threads / 8 - WALK_OV;
     if (c > cap) c = cap;
     if (c > 60) c = 60;
     c = (c / L) * L;
     return c >= L ? (int)c : 0;
 }
-__host__ __device__ constexpr size_t pipe_lds_bytes(int N, int L, int C, int nr_threads, int esize)
+__host__ __device__ constexpr size_t pipe_lds_bytes(int N, int L, int C, int nr_threads, int esize, int mt = 0)
 {
-    return 2 * (size_t)(C + WALK_OV) * pipe_pos_doubles(L) * 8 + pipe_fixed_bytes(N, nr_threads, esize);
+    return 2 * (size_t)(C + WALK_OV) * pipe_pos_doubles(L, mt) * 8 + pipe_fixed_bytes(N, nr_threads, esize);
 }
 
 // What a sweep needs to know about a position and never changes while the pipeline runs (the candidate masks stand, or it stops):
@@ -242,15 +244,17 @@ __device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_
 //   Yr[i][w][b][l - 3] = G[i][w][lag l][b], l = 3..L          (position 0: its '_' row in every row slot)
 // and the walker takes H of target t as X1[t-1][a1][b] + X2[t-2][a2][b] itself: one more LDS read and one more addition per step,
 // four bodies ahead of their use; the same IEEE addition the loaders did, so bit-identical.  Everything else is spec2_walker.
-template <int LC>
+// MT (the marginal term): a position's record also holds LM[b] = log10 marginal of the candidate of rank b of the TARGET the
+// source's lag-1 terms belong to, and the walker starts the sum with it: (LM + x1) + x2 -- the reference's (0.0 + lm) + x1, then x2.
+template <int LC, bool MT>
 __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *words0, int C, int nchunks, int lane,
                                               unsigned long long *prof = nullptr /* diagnostic builds: [0] += cycles walking, [1] += cycles at the barriers */)
 {
     static_assert(LC >= 2, "depth-2 speculation needs two lags");
     typedef deep_layout<LC> DL;
     constexpr int NY = DL::NY;
-    constexpr unsigned XB = 32 * 8, YB = DL::YPOS * 8, YWB = 4 * DL::NYP * 8;
-    constexpr int RS = pipe_pos_doubles(LC);
+    constexpr unsigned XB = (MT ? 36 : 32) * 8, YB = DL::YPOS * 8, YWB = 4 * DL::NYP * 8;
+    constexpr int RS = pipe_pos_doubles(LC, MT ? 1 : 0);
     const int b = lane & 3;
     double Y[LC][LC];
 #pragma unroll
@@ -267,9 +271,17 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
     asm("" : "+v"(x10), "+v"(x20), "+v"(y0));
 
     // state entering body 0: target 1 has the single term x1 of source 0 (not 0.0 + x1), targets 2 and 3 both terms
-    unsigned long long B = group_argmax<true>(*(lds_cdouble *)(x10));
-    double accP = *(lds_cdouble *)(x10 + XB) + *(lds_cdouble *)(x20);
-    double H12 = *(lds_cdouble *)(x10 + 2 * XB) + *(lds_cdouble *)(x20 + XB);
+    unsigned lm0 = (unsigned)(uintptr_t)g0 + 256u + (unsigned)b * 8u;
+    asm("" : "+v"(lm0));
+    auto h_of = [&](unsigned a1, unsigned a2, unsigned al) __attribute__((always_inline)) {     // x1 (+ LM in front) + x2
+        if constexpr (MT) return (*(lds_cdouble *)al + *(lds_cdouble *)a1) + *(lds_cdouble *)a2;
+        else return *(lds_cdouble *)a1 + *(lds_cdouble *)a2;
+    };
+    unsigned long long B;
+    if constexpr (MT) B = group_argmax<true>(*(lds_cdouble *)(lm0) + *(lds_cdouble *)(x10));
+    else B = group_argmax<true>(*(lds_cdouble *)(x10));
+    double accP = h_of(x10 + XB, x20, lm0 + XB);
+    double H12 = h_of(x10 + 2 * XB, x20 + XB, lm0 + 2 * XB);
 #pragma unroll
     for (int l = 2; l < LC; l++) Y[0][l] = *(lds_cdouble *)(y0 + (unsigned)(l - 2) * 8u);
     unsigned hist = 0, sh = 0;
@@ -278,6 +290,7 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
 
     for (int k = 0; k < nchunks; k++) {
         unsigned v1 = x10 + (unsigned)(k & 1) * bufB, v2 = x20 + (unsigned)(k & 1) * bufB, vy = y0 + (unsigned)(k & 1) * bufB;
+        unsigned vl = lm0 + (unsigned)(k & 1) * bufB;
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
         constexpr int UG = LC <= 8 ? 2 : 1;
@@ -309,7 +322,7 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
                     }
                     if constexpr (NY & 1) Y[(u + 1) % LC][LC - 1] = *(lds_cdouble *)(rb + (unsigned)(NY - 1) * 8u);
                 }
-                H12 = *(lds_cdouble *)(v1 + (unsigned)(gg * LC + u + 3) * XB) + *(lds_cdouble *)(v2 + (unsigned)(gg * LC + u + 2) * XB);
+                H12 = h_of(v1 + (unsigned)(gg * LC + u + 3) * XB, v2 + (unsigned)(gg * LC + u + 2) * XB, vl + (unsigned)(gg * LC + u + 3) * XB);
             }
             wk[g] = (unsigned long long)hist;
         };
@@ -320,12 +333,14 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
             if constexpr (UG > 1) group(g + 1, std::integral_constant<int, 1>{});
             v1 += (unsigned)(UG * LC) * XB;
             v2 += (unsigned)(UG * LC) * XB;
+            vl += (unsigned)(UG * LC) * XB;
             vy += (unsigned)(UG * LC) * YB;
         }
         for (; g < ngroups; g++) {
             group(g, std::integral_constant<int, 0>{});
             v1 += (unsigned)LC * XB;
             v2 += (unsigned)LC * XB;
+            vl += (unsigned)LC * XB;
             vy += (unsigned)LC * YB;
         }
 #ifdef PIPE_PROF
@@ -384,6 +399,10 @@ struct sweep_regs {
     int a, b;               // path[p]; the to-symbol of the lane's cell: path[p + s + 1], '_' behind position N
     T xe[3];                // bands wider than 8: the elements of the lane's further cells (p, p + s + 1 + 8 r), r = 1..3, on the path
     unsigned xoff[3];       // ... and where they lie (0xffffffff: no such cell)
+    // column conditionals (C, E): `row` holds the COLUMN of the lane's cell through the path's to-symbol -- tband[p][b][s+1][.], the
+    // to-major copy -- because the reweighted element changes its column's sum and with it the entries of ALL rows in that column;
+    row7<T> xrow;           // ... and the row of the path's symbol in the cell (p, p+1), for c_a(p)
+    unsigned coloff;        // element offset of that column in tband
 };
 
 // doubles per lag slot (row as 8 x T, denominator, packed word of the target) and per lane group (8 slots)
@@ -408,8 +427,14 @@ __device__ __forceinline__ void pipe_sweep_load(const pipe_params &P, const win_
     R.a = a;
     R.b = (int)s_path[j <= N ? j : 0];                          // (j = N + 1: the end sentinel's partner is path[0] = '_'; beyond: unused)
     R.rowoff = (((unsigned)pp * 7u + (unsigned)a) * (unsigned)W + (unsigned)(dd - 1)) * 7u;
-    const PIPE_GLOBAL(T) *rc = pipe_gptr((const T *)d.band) + R.rowoff;
+    R.coloff = (((unsigned)pp * 7u + (unsigned)(j <= N ? R.b : SYM_US)) * (unsigned)W + (unsigned)(dd - 1)) * 7u;
+    const PIPE_GLOBAL(T) *rc = P.col ? pipe_gptr((const T *)d.tband) + R.coloff : pipe_gptr((const T *)d.band) + R.rowoff;
     R.row.v0 = rc[0]; R.row.v1 = rc[1]; R.row.v2 = rc[2]; R.row.v3 = rc[3]; R.row.v4 = rc[4]; R.row.v5 = rc[5]; R.row.v6 = rc[6];
+    {
+        // (column conditionals; the row conditionals read the same seven values once more and use none of them)
+        const PIPE_GLOBAL(T) *xr = pipe_gptr((const T *)d.band) + ((unsigned)pp * 7u + (unsigned)a) * (unsigned)W * 7u;
+        R.xrow.v0 = xr[0]; R.xrow.v1 = xr[1]; R.xrow.v2 = xr[2]; R.xrow.v3 = xr[3]; R.xrow.v4 = xr[4]; R.xrow.v5 = xr[5]; R.xrow.v6 = xr[6];
+    }
     R.cnt = pipe_gptr((const double *)d.cnt)[(unsigned)pp * 8u + (unsigned)s];
     R.pkp = pipe_gptr((const unsigned long long *)d.pk)[pp];
     // bands up to 32: the path's element of each further cell of this lane (one value, not the row: no lag beyond the eighth
@@ -468,18 +493,27 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     }
     const double cnt_old = R.cnt;
     const unsigned long long pkp = R.pkp, pkt_in = R.pkt;
-    const unsigned rowoff = R.rowoff;
+    const unsigned rowoff = R.rowoff, coloff = R.coloff;
     const int b_cell = R.b;
+    const row7<T> xrow = R.xrow;
+    PIPE_GLOBAL(T) *tband = pipe_gptr((T *)d.tband);
+    const bool COL = P.col != 0;
     const T xe0 = R.xe[0], xe1 = R.xe[1], xe2 = R.xe[2];
     const unsigned xo0 = R.xoff[0], xo1 = R.xoff[1], xo2 = R.xoff[2];
     prefetch();
     // the first round out of the slot: lane s owns the cell (p, p + s + 1)
+    // (the slot holds the row of the path's symbol -- the element on the path is [b] -- or, under a column conditional, the column
+    // of the path's to-symbol -- the element is [a]; the tensor's element is the same one either way, and the to-major copy follows)
+    T cur0 = (T)0;
     if (act && s + 1 <= W) {
         const int mult = mult_of(s + 1);
         if (mult) {
-            const T cur = reweight(srow[b_cell], mult);
+            const int k_el = COL ? a : b_cell;
+            const T cur = reweight(srow[k_el], mult);
             band[rowoff + (unsigned)b_cell] = cur;
-            srow[b_cell] = cur;
+            if (COL) tband[coloff + (unsigned)a] = cur;
+            srow[k_el] = cur;
+            cur0 = cur;
         }
     }
     // bands wider than 8: the lane's further cells, their elements prefetched with the row (up to a band of 32), beyond that
@@ -488,7 +522,14 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         auto further = [&](T e, unsigned off, int dd) __attribute__((always_inline)) {
             if (off != 0xffffffffu) {
                 const int mult = mult_of(dd);
-                if (mult) band[off] = reweight(e, mult);
+                if (mult) {
+                    const T cur = reweight(e, mult);
+                    band[off] = cur;
+                    if (COL) {          // (off = ((p 7 + a) W + dd - 1) 7 + b: the to-symbol back out of it)
+                        const unsigned base = (((unsigned)p * 7u + (unsigned)a) * (unsigned)W + (unsigned)(dd - 1)) * 7u;
+                        tband[(((unsigned)p * 7u + (off - base)) * (unsigned)W + (unsigned)(dd - 1)) * 7u + (unsigned)a] = cur;
+                    }
+                }
             }
         };
         further(xe0, xo0, s + 9);
@@ -500,15 +541,26 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             if (mult) {
                 const int b = (j == N + 1) ? (int)s_path[0] : (int)s_path[j];
                 PIPE_GLOBAL(T) *e = band + bidx(W, p, dd, a, b);
-                *e = reweight(*e, mult);
+                const T cur = reweight(*e, mult);
+                *e = cur;
+                if (COL) tband[bidx(W, p, dd, b, a)] = cur;
             }
         }
     }
-    // the row as it now stands: its sum (sequentially, in the storage dtype) is the row sum of lag s+1's conditional, and on
-    // lane 0 -- the cell (p, p+1) -- the new c_a(p); the other c_s(p) are what the pass before left in cnt: they have not changed
+    // the slot as it now stands: its sum (sequentially, in the storage dtype) is the row (column) sum of lag s+1's conditional.
+    // The new c_a(p) is the sum of the row of the path's symbol in the cell (p, p+1): lane 0's slot under a row conditional, the
+    // extra row with lane 0's new element in place under a column conditional; the other c_s(p) are what the pass before left in
+    // cnt: they have not changed
     const rowvec r03 = *reinterpret_cast<const rowvec *>(srow), r46 = *reinterpret_cast<const rowvec *>(srow + 4);
     const double rowsum0 = (double)((((((((T)0 + r03.x) + r03.y) + r03.z) + r03.w) + r46.x) + r46.y) + r46.z);
-    const double ca_new = __shfl(rowsum0, 0, 8);
+    double ca_src = rowsum0;
+    if (COL) {
+        const int bq = b_cell;
+        const T e0 = bq == 0 ? cur0 : xrow.v0, e1 = bq == 1 ? cur0 : xrow.v1, e2 = bq == 2 ? cur0 : xrow.v2, e3 = bq == 3 ? cur0 : xrow.v3,
+                e4 = bq == 4 ? cur0 : xrow.v4, e5 = bq == 5 ? cur0 : xrow.v5, e6 = bq == 6 ? cur0 : xrow.v6;
+        ca_src = (double)((((((((T)0 + e0) + e1) + e2) + e3) + e4) + e5) + e6);
+    }
+    const double ca_new = __shfl(ca_src, 0, 8);
     const double mine = (act && s < NSYM) ? (s == a ? ca_new : cnt_old) : 0.0;
     double tot = 0.0;
 #pragma unroll
@@ -527,35 +579,68 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     // Which lags have entries that can change: under conditionals A and D a lag beyond the band has an all-zero row and the
     // denominator V + 0 -- constants; under B the denominator holds c_a(p), which the reweight has just changed, at every lag.
     const int Lw = (P.cond_mode == GH_COND_B || W >= Lr) ? Lr : W;
-    // lag s + 1: the denominator and the target's word beside the row
+    // lag s + 1: the denominator and the target's word beside the row (column)
+    const double nv_i = (double)PK_NVALID(pkp);
     if (s < Lw) {
-        const double nv_i = (double)PK_NVALID(pkp);
-        const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt_in) + rowsum0 : (P.cond_mode == GH_COND_D ? nv_i + rowsum0 : nv_i + ca_new);
+        double den;
+        unsigned long long word;
+        if (!COL) {
+            den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt_in) + rowsum0 : (P.cond_mode == GH_COND_D ? nv_i + rowsum0 : nv_i + ca_new);
+            word = row6 < 6 ? pkt_in : 0ull;
+        } else {
+            // C: V(p) + column sum, E: V(target) + column sum; the entries this cell feeds sit in the column of the path's
+            // to-symbol -- its rank among the target's candidates -- of every row of the source (pkt_in = 0: no target)
+            den = (P.cond_mode == GH_COND_C ? nv_i : (double)PK_NVALID(pkt_in)) + rowsum0;
+            const int rbs = PK_ROW6(pkt_in, b_cell);
+            word = (act && p < N && pkt_in != 0ull && rbs < 4) ? (unsigned long long)(8 + rbs) : 0ull;      // (bit 3: live)
+        }
         slot[SD - 2] = den;
-        reinterpret_cast<unsigned long long *>(slot)[SD - 1] = row6 < 6 ? pkt_in : 0ull;
+        reinterpret_cast<unsigned long long *>(slot)[SD - 1] = word;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned rowbase = ((unsigned)p * 4u + (unsigned)(row6 < 4 ? row6 : 0)) * (unsigned)(L * 4);     // ('_' at position 0: row 0)
     // the entries, eight per round: a quotient and its log10 each (the marginals of the position are the bookkeeper's:
-    // pipe_book_consume)
+    // pipe_book_consume).  Row conditionals: entry (lag, column rb of the path's row); column conditionals: entry (lag, row ra,
+    // the column of the path's to-symbol).
     const int NT4 = 4 * Lw;
+    const int nrows = p == 0 ? 1 : PK_NCAND(pkp);              // (column conditionals: position 0 has its '_' row only)
 #pragma unroll 1
     for (int t = s; t < NT4; t += 8) {
         const int li = t >> 2, rb = t & 3;
         const double *sl = s_deal + li * SD;
-        const unsigned long long pkt = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
-        if (rb < PK_NCAND(pkt)) {
-            const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[PK_SYM(pkt, rb)];
+        const unsigned long long word = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
+        bool live;
+        int k_el;
+        unsigned oidx;
+        if (!COL) {
+            live = rb < PK_NCAND(word);
+            k_el = PK_SYM(word, rb);
+            oidx = rowbase + (unsigned)(li * 4 + rb);
+        } else {
+            live = (word & 8ull) != 0 && rb < nrows;
+            k_el = p == 0 ? SYM_US : PK_SYM(pkp, rb);
+            oidx = (((unsigned)p * 4u + (unsigned)rb) * (unsigned)L + (unsigned)li) * 4u + (unsigned)(word & 3ull);
+        }
+        if (live) {
+            const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[k_el];
             const double xq = num / sl[SD - 2];
             // (k_marg takes the straight-line logarithm where the arguments are normal, the general one otherwise: same values)
-            g_G[rowbase + (unsigned)(li * 4 + rb)] =
-                gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+            g_G[oidx] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+        }
+    }
+    if (P.mt) {
+        // the marginal term: the walker of the next path adds log10 marginal of the CANDIDATE in front of its lag-1 term, so the
+        // log-marginals of all candidates of p are due again after every reweight (lmr, by rank): lanes 0..3, one each
+        const int sym_m = PK_SYM(pkp, s & 3);
+        const double c_m = __shfl(mine, sym_m, 8);
+        if (act && s < PK_NCAND(pkp)) {
+            const double m = (c_m > 0 && tot != 0.0) ? c_m / tot : 0.0;            // k_marg: marg[p][s], minfo[p][b5]
+            pipe_gptr(d.lmr)[(unsigned)p * 4u + (unsigned)s] = gh_log10_tab(m, s_logtab, GH_LOG_SERIAL);
         }
     }
     if constexpr (L > 8) {
         // lag counts above 8: the further lags one per lane, with loads in place
-        if (row6 < 6) {
-            const double nv_i = (double)PK_NVALID(pkp);
+        if (!COL && row6 < 6) {
             for (int l = s + 9; l <= L; l += 8) {
                 const int snp = p + l;
                 if (snp > N || (l > W && P.cond_mode != GH_COND_B)) continue;        // (behind the window / beyond the band: constants)
@@ -572,6 +657,24 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 }
             }
         }
+        if (COL && act && p < N) {
+            for (int l = s + 9; l <= L; l += 8) {
+                const int snp = p + l;
+                if (snp > N || l > W) continue;                     // (behind the window / beyond the band: constants)
+                const int b = (int)s_path[snp];
+                const unsigned long long pkt = d.pk[snp];
+                const int rbs = PK_ROW6(pkt, b);
+                if (rbs >= 4) continue;
+                row7<T> cw;
+                cw.load((const T *)d.tband + bidx(W, p, l, b, 0));  // (the column as this lane's reweight of the cell left it)
+                const double den = (P.cond_mode == GH_COND_C ? nv_i : (double)PK_NVALID(pkt)) + (double)cw.sum();
+                for (int ra = 0; ra < nrows; ra++) {
+                    const double xq = (1.0 + (double)cw.get(p == 0 ? SYM_US : PK_SYM(pkp, ra))) / den;
+                    g_G[(((unsigned)p * 4u + (unsigned)ra) * (unsigned)L + (unsigned)(l - 1)) * 4u + (unsigned)rbs] =
+                        gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+                }
+            }
+        }
     }
 }
 
@@ -583,7 +686,8 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     typedef deep_layout<LC> DL;
     constexpr int NL = RL::NLW * 64, NR = RL::NRW * 64;
     constexpr int MAXPOS = NR / 8;                      // positions per sweep pass = the most a table buffer holds (C + WALK_OV)
-    constexpr int RS = pipe_pos_doubles(LC);
+    const int XD = P.mt ? 36 : 32;                       // doubles of a position's x1 / x2 (/ LM) record
+    const int RS = XD + DL::YPOS;
     extern __shared__ __align__(16) double smem[];
     const win_desc d = wd[blockIdx.x];
     dev_state *st = d.st;
@@ -614,7 +718,15 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         }
     }
     logtab_stage(s_logtab);
-    for (int q = tid; q <= N + 1; q += NT) d.pk[q] = q <= N ? pipe_pack(d.cmask[q], d.nvalid[q], q, P.sm) : 0ull;
+    for (int q = tid; q <= N + 1; q += NT) {
+        const unsigned long long w = q <= N ? pipe_pack(d.cmask[q], d.nvalid[q], q, P.sm) : 0ull;
+        d.pk[q] = w;
+        if (P.mt) {             // log10 marginal of the candidates of q by RANK (k_marg left them by compact symbol index in minfo)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                d.lmr[(size_t)q * 4 + r] = (q <= N && r < PK_NCAND(w)) ? d.minfo[(size_t)q * MINFO + a6_of_sym(P.sm, PK_SYM(w, r))] : 0.0;
+        }
+    }
     // the pipeline's own copy of the conditional table: of the ranked G[source][6 rows][lag][5 columns] only what a ranked window
     // uses -- rows and columns of the ranks 0..3, position 0's '_' row as its row 0 -- as [source][4][lag][4]: 32-byte pieces on
     // 32-byte boundaries (a row of G is 40 bytes: every piece straddled two sectors), 640 instead of 800 of 1 200 bytes per
@@ -703,10 +815,13 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     if (PIPE_DEV_ROLES & 4 ? role == PR_LOAD : false) {
         // ---- loaders: the raw terms of chunk k from G, 32 bytes (columns 0..3 of one lag of one row) per task --------------
         const int t = ridx * 64 + lane;
-        constexpr int TPP = 4 * LC;                                  // tasks per position: (row, lag)
-        constexpr int MAXT = (MAXPOS * TPP + NL - 1) / NL;
+        // tasks per position: (row, lag), and with the marginal term one more: the log10 marginals of the candidates of the
+        // position's lag-1 TARGET by rank (lmr, kept by the sweep), which the walker adds in front of x1
+        const int TPP = 4 * LC + (P.mt ? 1 : 0);
+        constexpr int MAXT = (MAXPOS * (4 * LC + 1) + NL - 1) / NL;
         const int nsrc_all = N + LT_PAD;
         const int ntask = npos * TPP;
+        const PIPE_GLOBAL(double) *gLM = pipe_gptr((const double *)d.lmr);
         typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(16)));     // (32 bytes per (row, lag) of the pipeline's table)
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
         const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.gp);
@@ -722,6 +837,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 const bool ok = q < ntask && sidx < nsrc_all;
                 const int si = ok ? sidx : 0;
                 const PIPE_GLOBAL(double) *src = gG + ((unsigned)(si * 4 + (si == 0 ? 0 : row)) * (unsigned)LC + (unsigned)l) * 4u;
+                if (r == 4 * LC) src = gLM + (unsigned)(si + 1 <= N ? si + 1 : N + 1) * 4u;      // (marginal term only)
                 typedef PIPE_GLOBAL(ld_v2d) gv2d;
                 R.lo[it] = *reinterpret_cast<const gv2d *>(src);
                 R.hi[it] = *reinterpret_cast<const gv2d *>(src + 2);
@@ -730,7 +846,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         auto store = [&](int k) {
             const int i0 = k * C;
             double *dst = g0 + (size_t)(k & 1) * npos * RS;
-            double *yr = dst + (size_t)npos * 32;
+            double *yr = dst + (size_t)npos * XD;
 #pragma unroll
             for (int it = 0; it < MAXT; it++) {
                 const int q = t + it * NL;
@@ -738,8 +854,12 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 if (q < ntask) {
                     const bool z = i0 + pp >= nsrc_all;            // behind the table: zeros (the walker runs whole chunks)
                     const double x0 = z ? 0.0 : R.lo[it].x, x1 = z ? 0.0 : R.lo[it].y, x2 = z ? 0.0 : R.hi[it].x, x3 = z ? 0.0 : R.hi[it].y;
-                    if (l < 2) {
-                        lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * 32 + l * 16 + row * 4);
+                    if (r == 4 * LC) {
+                        lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + 32);
+                        o[0] = lds_v2d{x0, x1};
+                        o[1] = lds_v2d{x2, x3};
+                    } else if (l < 2) {
+                        lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + l * 16 + row * 4);
                         o[0] = lds_v2d{x0, x1};
                         o[1] = lds_v2d{x2, x3};
                     } else {
@@ -886,9 +1006,11 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         PIPE_BARRIER(); PIPE_BARRIER(); PIPE_BARRIER();             // epochs 0..2
 #ifdef PIPE_PROF
         wprof[2] = __builtin_amdgcn_s_memtime();
-        spec2x_walker<LC>(g0, words0, C, nchunks, lane, wprof);
+        if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane, wprof);
+        else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane, wprof);
 #else
-        spec2x_walker<LC>(g0, words0, C, nchunks, lane);            // one barrier behind every chunk
+        if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane);      // one barrier behind every chunk
+        else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane);
 #endif
         PIPE_BARRIER();                                             // tail
         if ((aborted = ctl->abort != 0)) break;

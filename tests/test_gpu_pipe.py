@@ -64,7 +64,8 @@ def test_pipeline_with_longer_memories(L, monkeypatch):
 
 
 @pytest.mark.parametrize("kw", [dict(storage="f64"), dict(cond_mode="B"), dict(cond_mode="D"), dict(cond_mode="D", storage="f64"),
-                                dict(cand_order="TGCA-"), dict(offer_zero=True)],
+                                dict(cand_order="TGCA-"), dict(offer_zero=True), dict(marginal_term=True),
+                                dict(cond_mode="B", marginal_term=True, storage="f64"), dict(cond_mode="D", marginal_term=True, cand_order="-TGCA")],
                          ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
 def test_pipeline_under_the_row_conditionals(kw):
     wins = [_pair(300 + s, 500, 15000, 5, **kw) for s in range(3)]
@@ -76,15 +77,53 @@ def test_pipeline_under_the_row_conditionals(kw):
         _same(r, o.spin(10), h, o)
 
 
-@pytest.mark.parametrize("kw", [dict(cond_mode="C"), dict(cond_mode="E"), dict(marginal_term=True)],
+@pytest.mark.parametrize("kw", [dict(cond_mode="C"), dict(cond_mode="E"), dict(cond_mode="E", marginal_term=True),
+                                dict(cond_mode="C", marginal_term=True, storage="f64"), dict(cond_mode="E", storage="f64", cand_order="G-TAC")],
                          ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
-def test_other_specs_keep_the_batched_launches(kw):
-    wins = [_pair(320 + s, 300, 9000, 5, **kw) for s in range(3)]
+def test_pipeline_under_the_column_conditionals(kw):
+    # C / E: a reweighted cell changes the sum of its COLUMN and with it the entries of every row in that column; the sweep works
+    # on the to-major copy of the band and keeps it in step (E + marginal term: the published method's form)
+    wins = [_pair(320 + s, 500, 15000, 5, **kw) for s in range(3)]
     b = HanselBatch([h for h, _ in wins])
-    res = b.spin(6)
-    assert b.pipe_info()["windows"] == 0
+    res = b.spin(25)
+    assert b.pipe_info()["windows"] == 3
     for (h, o), r in zip(wins, res):
-        _same(r, o.spin(6), h, o)
+        _same(r, o.spin(25), h, o)
+        more, ref = h.spin(4), o.spin(4)            # the handle goes on (the to-major copy was kept in step or is rebuilt)
+        assert np.array_equal(more["paths"], ref["paths"]) and np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [2, 4, 7, 9, 10])
+@pytest.mark.parametrize("cm", ["C", "E"])
+def test_column_conditionals_across_lag_counts_and_bands(L, cm):
+    wins = [_pair(340 + s, 600, 14000, None, L=L, band=21, n_haps=6, cond_mode=cm, marginal_term=bool(L & 1)) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(12)
+    assert b.pipe_info()["windows"] == 2
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(12), h, o)
+
+
+def test_the_switches_that_leave_specs_to_the_batched_launches(monkeypatch):
+    monkeypatch.setenv("GH_PIPE_COL", "0")
+    monkeypatch.setenv("GH_PIPE_MT", "0")
+    for kw in (dict(cond_mode="C"), dict(marginal_term=True)):
+        wins = [_pair(360 + s, 300, 9000, 5, **kw) for s in range(2)]
+        b = HanselBatch([h for h, _ in wins])
+        res = b.spin(6)
+        assert b.pipe_info()["windows"] == 0
+        for (h, o), r in zip(wins, res):
+            _same(r, o.spin(6), h, o)
+
+
+@pytest.mark.parametrize("L", [2, 3, 6, 8, 10])
+def test_marginal_term_across_lag_counts(L):
+    wins = [_pair(230 + s, 600, 15000, None, L=L, band=21, n_haps=6, marginal_term=True) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(25)
+    assert b.pipe_info()["windows"] == 2
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(25), h, o)
 
 
 def test_beyond_ten_lags_the_pools_take_the_batch():
