@@ -69,13 +69,13 @@ enum { PR_WALK = 0, PR_BOOK = 1, PR_LOAD = 2, PR_SWEEP = 3 };
 template <int NT> struct pipe_roles;
 template <> struct pipe_roles<1024> {
     static constexpr int NLW = 6, NRW = 8;
-    // SIMD class of wave w = w & 3.  Class 0: the walker and three loader waves (nothing that computes: the bookkeeper on the
-    // walker's SIMD -- a division, a log10 and 120 dependent additions per chunk -- took 13 000 cycles per chunk there and slowed
-    // the walker by 7 %); classes 1, 2: three sweepers and the bookkeeper / a loader; class 3: two sweepers, two loaders.
+    // SIMD class of wave w = w & 3.  Class 0: the walker, the bookkeeper (issue priority 2 below the walker's 3; with its sums
+    // through LDS and its marginal per lane it is light enough to sit here: beside two sweepers it cost the default spec 1.5 % and
+    // the column conditionals 10-20 %, same-call A/B) and two loader waves; classes 1, 2: three sweepers and a loader; class 3:
+    // two sweepers, two loaders.
     //                                   w: 0         1          2          3          4         5          6          7
-    static constexpr unsigned char map[16] = {PR_WALK << 4, (PR_SWEEP << 4) | 0, (PR_SWEEP << 4) | 1, (PR_SWEEP << 4) | 2, (PR_LOAD << 4) | 0, (PR_SWEEP << 4) | 3, (PR_SWEEP << 4) | 4, (PR_SWEEP << 4) | 5,
-    //                                      8                 9                  10                 11                12                13                14                15
-                                              (PR_LOAD << 4) | 1, (PR_SWEEP << 4) | 6, (PR_SWEEP << 4) | 7, (PR_BOOK << 4), (PR_LOAD << 4) | 2, (PR_LOAD << 4) | 3, (PR_LOAD << 4) | 4, (PR_LOAD << 4) | 5};
+    static constexpr unsigned char map[16] = {PR_WALK << 4, (PR_SWEEP << 4) | 0, (PR_SWEEP << 4) | 1, (PR_SWEEP << 4) | 2, (PR_BOOK << 4), (PR_SWEEP << 4) | 3, (PR_SWEEP << 4) | 4, (PR_SWEEP << 4) | 5,
+                                              (PR_LOAD << 4) | 1, (PR_SWEEP << 4) | 6, (PR_SWEEP << 4) | 7, (PR_LOAD << 4) | 0, (PR_LOAD << 4) | 2, (PR_LOAD << 4) | 3, (PR_LOAD << 4) | 4, (PR_LOAD << 4) | 5};
 };
 template <> struct pipe_roles<768> {
     static constexpr int NLW = 4, NRW = 6;
@@ -619,7 +619,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         } else {
             live = (word & 8ull) != 0 && rb < nrows;
             k_el = p == 0 ? SYM_US : PK_SYM(pkp, rb);
-            oidx = (((unsigned)p * 4u + (unsigned)rb) * (unsigned)L + (unsigned)li) * 4u + (unsigned)(word & 3ull);
+            oidx = (((unsigned)p * 4u + (unsigned)(word & 3ull)) * (unsigned)L + (unsigned)li) * 4u + (unsigned)rb;       // (transposed copy)
         }
         if (live) {
             const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[k_el];
@@ -670,7 +670,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const double den = (P.cond_mode == GH_COND_C ? nv_i : (double)PK_NVALID(pkt)) + (double)cw.sum();
                 for (int ra = 0; ra < nrows; ra++) {
                     const double xq = (1.0 + (double)cw.get(p == 0 ? SYM_US : PK_SYM(pkp, ra))) / den;
-                    g_G[(((unsigned)p * 4u + (unsigned)ra) * (unsigned)L + (unsigned)(l - 1)) * 4u + (unsigned)rbs] =
+                    g_G[(((unsigned)p * 4u + (unsigned)rbs) * (unsigned)L + (unsigned)(l - 1)) * 4u + (unsigned)ra] =
                         gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
                 }
             }
@@ -731,14 +731,22 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     // uses -- rows and columns of the ranks 0..3, position 0's '_' row as its row 0 -- as [source][4][lag][4]: 32-byte pieces on
     // 32-byte boundaries (a row of G is 40 bytes: every piece straddled two sectors), 640 instead of 800 of 1 200 bytes per
     // position at five lags.  The sweeps write it, the loaders read it; G itself is rebuilt by whoever needs it next (dirty_lt).
+    // Under a column conditional the copy is TRANSPOSED, [source][column][lag][row]: what a reweighted cell changes -- the entries
+    // of every row in one column -- is then one 32-byte piece per lag as well (four pieces in four rows otherwise: 169k against
+    // 267k haplotypes/s for E against A before), and the loaders transpose back while they stage.
     for (int q = tid; q < (N + LT_PAD) * 4 * LC; q += NT) {
         const int l = q % LC, row = (q / LC) & 3, i = q / (4 * LC);
-        const lds_v2d *src = nullptr;
-        const double *g = d.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * LC + l) * LT_ROW;
-        (void)src;
         double *o = d.gp + (size_t)q * 4;
-        const bool keep = i != 0 || row == 0;
-        o[0] = keep ? g[0] : 0.0; o[1] = keep ? g[1] : 0.0; o[2] = keep ? g[2] : 0.0; o[3] = keep ? g[3] : 0.0;
+        if (!P.col) {
+            const double *g = d.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * LC + l) * LT_ROW;
+            const bool keep = i != 0 || row == 0;
+            o[0] = keep ? g[0] : 0.0; o[1] = keep ? g[1] : 0.0; o[2] = keep ? g[2] : 0.0; o[3] = keep ? g[3] : 0.0;
+        } else {
+            // (`row` of this piece is a COLUMN c: o[r] = the entry of row r -- position 0: its '_' row as row 0, nothing else)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                o[r] = (i != 0 || r == 0) ? d.G[(((size_t)i * 6 + (i == 0 ? 5 : r)) * LC + l) * LT_ROW + row] : 0.0;
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef PIPE_PROF
@@ -836,7 +844,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 const int sidx = i0 + pp;
                 const bool ok = q < ntask && sidx < nsrc_all;
                 const int si = ok ? sidx : 0;
-                const PIPE_GLOBAL(double) *src = gG + ((unsigned)(si * 4 + (si == 0 ? 0 : row)) * (unsigned)LC + (unsigned)l) * 4u;
+                const PIPE_GLOBAL(double) *src = gG + ((unsigned)(si * 4 + ((si == 0 && !P.col) ? 0 : row)) * (unsigned)LC + (unsigned)l) * 4u;
                 if (r == 4 * LC) src = gLM + (unsigned)(si + 1 <= N ? si + 1 : N + 1) * 4u;      // (marginal term only)
                 typedef PIPE_GLOBAL(ld_v2d) gv2d;
                 R.lo[it] = *reinterpret_cast<const gv2d *>(src);
@@ -858,13 +866,26 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                         lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + 32);
                         o[0] = lds_v2d{x0, x1};
                         o[1] = lds_v2d{x2, x3};
-                    } else if (l < 2) {
-                        lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + l * 16 + row * 4);
-                        o[0] = lds_v2d{x0, x1};
-                        o[1] = lds_v2d{x2, x3};
+                    } else if (!P.col) {
+                        if (l < 2) {
+                            lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + l * 16 + row * 4);
+                            o[0] = lds_v2d{x0, x1};
+                            o[1] = lds_v2d{x2, x3};
+                        } else {
+                            double *o = yr + (size_t)pp * DL::YPOS + (size_t)row * 4 * DL::NYP + (l - 2);
+                            o[0] = x0; o[DL::NYP] = x1; o[2 * DL::NYP] = x2; o[3 * DL::NYP] = x3;
+                        }
                     } else {
-                        double *o = yr + (size_t)pp * DL::YPOS + (size_t)row * 4 * DL::NYP + (l - 2);
-                        o[0] = x0; o[DL::NYP] = x1; o[2 * DL::NYP] = x2; o[3 * DL::NYP] = x3;
+                        // transposed copy: the piece holds rows 0..3 of COLUMN `row`; position 0's '_' row stands in every row slot
+                        const bool p0 = i0 + pp == 0;
+                        const double r1 = p0 ? x0 : x1, r2 = p0 ? x0 : x2, r3 = p0 ? x0 : x3;
+                        if (l < 2) {
+                            double *o = dst + (size_t)pp * XD + l * 16 + row;
+                            o[0] = x0; o[4] = r1; o[8] = r2; o[12] = r3;
+                        } else {
+                            double *o = yr + (size_t)pp * DL::YPOS + (size_t)row * DL::NYP + (l - 2);
+                            o[0] = x0; o[4 * DL::NYP] = r1; o[8 * DL::NYP] = r2; o[12 * DL::NYP] = r3;
+                        }
                     }
                 }
                 // (pacing these stores with s_sleep, as k_walk_spec's loaders do, changed nothing here: 66.7 ms per 100 paths either

@@ -169,8 +169,8 @@ int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths_out, gh_pa
             int *n_out, int *hole_at);
 
 /* Batched recovery: the spin loop of gretel/cmd.py:148-179 over MANY windows of one shape (same n_snps, band, storage,
- * modes, device and L).  From two dozen windows on, under a row conditional (A, B, D) without the marginal term and
- * 2..14 lags, every window is carried through ALL its paths by one persistent workgroup (gretel_amd/csrc/wpipe.hpp):
+ * modes, device and L).  From two dozen windows on and at 2..10 lags -- under every conditional, with or without the marginal
+ * term -- every window is carried through ALL its paths by one persistent workgroup (gretel_amd/csrc/wpipe.hpp):
  * the reweight of path s-1 (gretel/gretel.py:79-98) sweeps through the tensor a few chunks ahead of the walk of path s
  * (gretel/gretel.py:143-189), one launch per batch, 256 windows at a time on one MI355X.  Otherwise (and for windows the
  * pipeline cannot carry: a position with five candidates, a hole) every kernel of a path is launched over all windows --

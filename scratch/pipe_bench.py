@@ -1,6 +1,7 @@
-"""Throughput of the window pipeline (csrc/wpipe.hpp) on replicas of the C3 contig.  argv: windows [paths] [reps]
-env: GH_PIPE=0 -> the batched launches of rounds 1-4; GH_PIPE_NT; GH_PIPE_STAMPS=1 -> per-path times of a few windows."""
-import sys, time
+"""Throughput of the window pipeline (csrc/wpipe.hpp) on replicas of a config's contig.  argv: windows [paths] [reps] [config]
+env: GH_PIPE=0 -> the batched launches of rounds 1-4; GH_PIPE_NT; GH_PIPE_STAMPS=1 -> per-path times of a few windows;
+PB_COND (A..E), PB_MT (0/1), PB_STORAGE (f32/f64): the spec."""
+import os, sys, time
 import numpy as np
 import torch
 from gretel_amd.hansel import Hansel, HanselBatch, DeviceReads
@@ -10,10 +11,13 @@ nw = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 paths = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 cfg = sys.argv[4] if len(sys.argv) > 4 else "C3"
+spec = dict(cond_mode=os.environ.get("PB_COND", "A"), marginal_term=bool(int(os.environ.get("PB_MT", "0"))),
+            storage=os.environ.get("PB_STORAGE", "f32"))
+tag = "%s%s %s" % (spec["cond_mode"], "+mt" if spec["marginal_term"] else "", spec["storage"])
 t = make_config(cfg, seed=0)
-h0 = Hansel(t.n_snps, band=t.band)
+h0 = Hansel(t.n_snps, band=t.band, **spec)
 reads = DeviceReads(h0, t.rank, t.off, t.bases)
-hs = [Hansel(t.n_snps, band=t.band) for _ in range(nw)]
+hs = [Hansel(t.n_snps, band=t.band, **spec) for _ in range(nw)]
 hb = HanselBatch(hs)
 hb.profile_enable(10)
 for r in range(reps):
@@ -26,8 +30,8 @@ for r in range(reps):
     dt = time.perf_counter() - t0
     tot = sum(x["n"] for x in res)
     pg = hb.profile_get()["walk"]
-    print("windows %d paths %d: %.1f ms, %.0f haplotypes/s; pipe %s; kernel %.2f ms (%d launches), %.2f TB/s on the builder's bytes"
-          % (nw, paths, dt * 1e3, tot / dt, hb.pipe_info(), pg["ms"], pg["launches"],
+    print("%s windows %d paths %d: %.1f ms, %.0f haplotypes/s; pipe %s; kernel %.2f ms (%d launches), %.2f TB/s on the pipeline's own bytes"
+          % (tag, nw, paths, dt * 1e3, tot / dt, hb.pipe_info(), pg["ms"], pg["launches"],
              pg["bytes_per_launch"] / max(1e-9, pg["ms"] * 1e-3) / 1e12), flush=True)
 ref = res[0]
 assert all(np.array_equal(x["paths"], ref["paths"]) for x in res)
