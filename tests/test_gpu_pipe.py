@@ -126,6 +126,20 @@ def test_marginal_term_across_lag_counts(L):
         _same(r, o.spin(25), h, o)
 
 
+@pytest.mark.parametrize("paths", [1, 2, 3])
+def test_very_short_spins(paths):
+    # one path: a walk and the last sweep, nothing beside each other; two: one sweep beside a walk
+    wins = [_pair(250 + s, 300, 9000, 5) for s in range(2)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(paths)
+    assert b.pipe_info()["windows"] == 2
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(paths), h, o)
+    res = b.spin(paths)             # and again on the reweighted tensors, other lag count: the compact table is rebuilt
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(paths), h, o)
+
+
 def test_beyond_ten_lags_the_pools_take_the_batch():
     wins = [_pair(260 + s, 400, 9000, None, L=12, band=21, n_haps=6) for s in range(2)]
     b = HanselBatch([h for h, _ in wins])
