@@ -7,7 +7,7 @@ mkdir -p $out
 export PYTHONPATH=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o pmc -- python3 $GRAFT_REPO_ROOT/scratch/pipe_bench.py $W $P 1 > $out/$c.log 2> $out/$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/$c -o pmc -- python3 $GRAFT_REPO_ROOT/scratch/pipe_bench.py $W $P 1 C3 > $out/$c.log 2> $out/$c.err
 done
 python3 - <<PY
 import csv, glob, collections
