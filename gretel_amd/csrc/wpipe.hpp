@@ -95,7 +95,7 @@ template <> struct pipe_roles<512> {
 __host__ __device__ constexpr int pipe_pos_doubles(int L, int mt = 0) { return 32 + (mt ? 4 : 0) + 16 * deep_nyp(L); }
 __host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
-    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
+    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 128 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
 }
 __host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads, int esize, int mt = 0)
 {
@@ -146,8 +146,9 @@ struct pipe_ctl {
     double ratio;           // clamped minimum marginal of the path just walked: what the sweep of the next epochs removes
     int abort;              // a sweeper saw a candidate mask move
     int _pad[13];
+    double lt_beyond[8];    // the table entry of a lag beyond the band by V: log10((1 + 0) / (V + 0)) as k_lt takes it
 };
-static_assert(sizeof(pipe_ctl) == 64, "one line");
+static_assert(sizeof(pipe_ctl) == 128, "two lines");
 
 // The bookkeeper's two steps (kernels.hpp: book_prefetch / book_consume), lane = chunk-local position.  It takes the marginal of
 // the ONE symbol the walker selected at a position from the counts itself -- m = c_s / total, log10 m: k_marg's expressions on
@@ -174,9 +175,45 @@ __device__ __forceinline__ void pipe_book_prefetch(const win_desc &d, int j0, in
     R.pk = ((__attribute__((address_space(1))) const unsigned long long *)(uintptr_t)d.pk)[jj];
 }
 
+// The two sums of a path (gretel.py:185-186) strictly in position order, one chunk's addends per call, by broadcast reads (same
+// address in all lanes) -- as k_hp does; moving a register's lanes through scalar registers took four v_readlane per position.
+// Lane 0 adds up the first sum, lane 1 the second (the other lanes one of the two, unused): ONE addition per position, and all 64
+// slots of the chunk -- slots behind the chunk's last position hold +0.0, which leaves a sum that starts at +0.0 as it is.
+// PIPE_SUM_DEPTH reads in flight, waited for one by one (LDS data returns in order).  Before: a batch of eight read, awaited, added
+// -- every batch waited out an LDS round trip, 2 900 cycles per chunk, a third of the bookkeeper's time and on some boxes what
+// the workgroup waited for; now 2 400 beside the walker (1 600 on a SIMD without it: the chain of dependent additions itself).  Left to hipcc, 26 reads went out at once into 52
+// registers, every s_waitcnt it writes is lgkmcnt(0), and an addition outside the asm statement is moved away from its wait.
+// (Tried: the last loader wavefront adding up one epoch behind the bookkeeper -- it became the slowest wavefront instead.)
+#ifndef PIPE_SUM_DEPTH
+#define PIPE_SUM_DEPTH 16
+#endif
+template <int J>
+__device__ __forceinline__ void pipe_sum_step(unsigned addr, double &acc, double (&r)[PIPE_SUM_DEPTH])
+{
+    constexpr int D = PIPE_SUM_DEPTH;
+    if constexpr (J < 64) {
+        if constexpr (J >= D) {
+            constexpr int I = J - D;                            // wait for read I, add it, put read J into its register
+            asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_add_f64 %0, %0, %1" : "+v"(acc) : "v"(r[I % D]), "n"(D - 1));      // gretel.py:185 (lane 0), :186 (lane 1)
+        }
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[J % D]) : "v"(addr), "n"(16 * J));
+        pipe_sum_step<J + 1>(addr, acc, r);
+    } else if constexpr (J < 64 + D) {
+        constexpr int I = J - D;
+        asm volatile("s_waitcnt lgkmcnt(%2)\n\tv_add_f64 %0, %0, %1" : "+v"(acc) : "v"(r[I % D]), "n"(63 - I));
+        pipe_sum_step<J + 1>(addr, acc, r);
+    }
+}
+__device__ __forceinline__ void pipe_sum_chunk(const lds_v2d *s_bk, int lane, double &acc)
+{
+    const unsigned addr = (unsigned)(uintptr_t)s_bk + (unsigned)(lane & 1) * 8u;
+    double r[PIPE_SUM_DEPTH];
+    pipe_sum_step<0>(addr, acc, r);
+}
+
 __device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_path, const unsigned long long *words, const double *s_logtab,
                                                   lds_v2d *s_bk /* 64 pairs of addends */,
-                                                  int LC, int j0, int ns, int Nw, int lane, const pipe_book_row &R, walk_totals &T,
+                                                  int LC, int j0, int ns, int Nw, int lane, const pipe_book_row &R, double &hp_acc /* lane 0: hp_current, lane 1: hp_original */,
                                                   double &lane_min, symmap sm, unsigned long long *prof = nullptr)
 {
 #ifdef PIPE_PROF
@@ -208,35 +245,16 @@ __device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long pb1 = __builtin_amdgcn_s_memtime();
 #endif
-    // the two sums strictly in position order: the addends go through LDS and come back by broadcast reads (same address in all
-    // lanes; LDS data returns in order, so the reads run ahead of the additions) -- as k_hp does; moving a register's lanes
-    // through scalar registers took four v_readlane per position
+    // the two sums strictly in position order: the addends go through LDS and come back by broadcast reads
     s_bk[lane] = lds_v2d{lm, lm0};                      // (+0.0 for unused lanes)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    int s = 0;
-#pragma unroll 1
-    for (; s + 8 <= ns; s += 8) {
-        lds_v2d v[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) v[q] = s_bk[s + q];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            T.hp_cur += v[q].x;                         // gretel.py:185
-            T.hp_orig += v[q].y;                        // gretel.py:186
-        }
-    }
-    for (; s < ns; s++) {
-        const lds_v2d v = s_bk[s];
-        T.hp_cur += v.x;
-        T.hp_orig += v.y;
-    }
+    pipe_sum_chunk(s_bk, lane, hp_acc);
 #ifdef PIPE_PROF
-    asm volatile("" :: "v"(T.hp_cur), "v"(T.hp_orig));
+    asm volatile("" :: "v"(hp_acc));
     const unsigned long long pb2 = __builtin_amdgcn_s_memtime();
     if (prof) { prof[0] += pb1 - pb0; prof[1] += pb2 - pb1; }
 #endif
 }
-
 
 // spec2_walker (kernels.hpp) over the RAW lag-1 / lag-2 terms: the batched loaders of rounds 1-4 expanded H = x1 + x2 for all 16
 // hypotheses (64 doubles per target, every term fetched four times, 66 VGPRs of prefetch per loader lane); here a buffer holds
@@ -753,6 +771,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     if (blockIdx.x == 0 && tid == 0) st->dbg8[9] = 0;
 #endif
     if (tid == 0) { ctl->ratio = 0.0; ctl->abort = 0; s_path[0] = SYM_US; }
+    if (tid < 8) ctl->lt_beyond[tid] = gh_log10((1.0 + 0.0) / ((double)tid + 0.0));
     __syncthreads();
 
 #ifdef PIPE_PROF
@@ -833,22 +852,58 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(16)));     // (32 bytes per (row, lag) of the pipeline's table)
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
         const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.gp);
+        const PIPE_GLOBAL(double) *gPK = pipe_gptr((const double *)(const void *)d.pk);      // (a made entry's two packed words ride in lo.x / hi.x)
+        // Lags beyond the band are not read but MADE (conditionals other than B): their rows of the tensor are zeros, so an entry
+        // is log10((1 + 0) / (V + 0)) for a candidate column of an existing row, -inf for a missing column, 0.0 for a missing row or
+        // behind the window -- k_lt's values, from the packed words of source and target (8 bytes per position of HBM traffic where
+        // the table has 128 per lag: at C3, band 4 and five lags, a fifth of what the loaders read)
+        // (measured, 256 windows x 100 paths: + 1..3 % on boxes where the kernel takes 90 ms, - 1.7 % where it takes 75 -- the loaders'
+        // arithmetic against their bytes; kept for the traffic)
+        const bool synth_on = P.cond_mode != GH_COND_B && P.W < LC;
+        // A lane's tasks are the same in every chunk: one word each, taken apart where it is used.  (Left to itself hipcc keeps every
+        // address of every branch of every task in a register across the path loop and spills them.)
+        unsigned desc[MAXT];
+#pragma unroll
+        for (int it = 0; it < MAXT; it++) {
+            const int q = t + it * NL;
+            const int pp = q / TPP, r = q % TPP;
+            desc[it] = (unsigned)pp | (unsigned)r << 12 | (q < ntask ? 1u << 20 : 0u);
+        }
+        struct task_of {
+            int pp, r, row, l; bool live;
+            __device__ __forceinline__ explicit task_of(unsigned w) {
+                asm volatile("" : "+v"(w));
+                pp = w & 0xfff; r = (w >> 12) & 0xff; live = (w >> 20) != 0;
+                row = r / LC; l = r - row * LC;
+            }
+        };
         auto fetch = [&](int k) {
             // (no branch around a load: see pipe_sweep_load; tasks beyond the buffer or the table read source 0 and are dropped /
             // zeroed when the chunk is stored)
             const int i0 = k * C;
 #pragma unroll
             for (int it = 0; it < MAXT; it++) {
-                const int q = t + it * NL;
-                const int pp = q / TPP, r = q % TPP, row = r / LC, l = r % LC;
+                const task_of q_(desc[it]);
+                const int pp = q_.pp, r = q_.r, row = q_.row, l = q_.l;
                 const int sidx = i0 + pp;
-                const bool ok = q < ntask && sidx < nsrc_all;
+                const bool ok = q_.live && sidx < nsrc_all;
                 const int si = ok ? sidx : 0;
                 const PIPE_GLOBAL(double) *src = gG + ((unsigned)(si * 4 + ((si == 0 && !P.col) ? 0 : row)) * (unsigned)LC + (unsigned)l) * 4u;
                 if (r == 4 * LC) src = gLM + (unsigned)(si + 1 <= N ? si + 1 : N + 1) * 4u;      // (marginal term only)
-                typedef PIPE_GLOBAL(ld_v2d) gv2d;
-                R.lo[it] = *reinterpret_cast<const gv2d *>(src);
-                R.hi[it] = *reinterpret_cast<const gv2d *>(src + 2);
+                const bool syn = synth_on && r < 4 * LC && l >= P.W;
+                const int tg = si + l + 1;
+                const PIPE_GLOBAL(double) *src2 = src + 2;
+                if (syn) {                                            // made, not read: the packed words of source and target instead
+                    src = gPK + (si <= N ? si : N + 1);
+                    src2 = gPK + (tg <= N ? tg : N + 1);
+                }
+                typedef PIPE_GLOBAL(double) gd8 __attribute__((aligned(8)));
+                typedef double ld_v2d8 __attribute__((ext_vector_type(2), aligned(8)));
+                typedef PIPE_GLOBAL(ld_v2d8) gv2d;
+                (void)sizeof(gd8);
+                const ld_v2d8 a_ = *reinterpret_cast<const gv2d *>(src), b_ = *reinterpret_cast<const gv2d *>(src2);
+                R.lo[it] = ld_v2d{a_.x, a_.y};
+                R.hi[it] = ld_v2d{b_.x, b_.y};
             }
         };
         auto store = [&](int k) {
@@ -857,11 +912,21 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
             double *yr = dst + (size_t)npos * XD;
 #pragma unroll
             for (int it = 0; it < MAXT; it++) {
-                const int q = t + it * NL;
-                const int pp = q / TPP, r = q % TPP, row = r / LC, l = r % LC;
-                if (q < ntask) {
+                const task_of q_(desc[it]);
+                const int pp = q_.pp, r = q_.r, row = q_.row, l = q_.l;
+                if (q_.live) {
                     const bool z = i0 + pp >= nsrc_all;            // behind the table: zeros (the walker runs whole chunks)
-                    const double x0 = z ? 0.0 : R.lo[it].x, x1 = z ? 0.0 : R.lo[it].y, x2 = z ? 0.0 : R.hi[it].x, x3 = z ? 0.0 : R.hi[it].y;
+                    double x0 = z ? 0.0 : R.lo[it].x, x1 = z ? 0.0 : R.lo[it].y, x2 = z ? 0.0 : R.hi[it].x, x3 = z ? 0.0 : R.hi[it].y;
+                    if (synth_on && r < 4 * LC && l >= P.W) {
+                        const int sa = i0 + pp, tg = sa + l + 1;
+                        const unsigned pka = (unsigned)__double_as_longlong(R.lo[it].x), pkb = (unsigned)__double_as_longlong(R.hi[it].x);
+                        const bool dead = sa >= N || tg > N;
+                        const double lt = ctl->lt_beyond[(P.cond_mode == GH_COND_A || P.cond_mode == GH_COND_E) ? PK_NVALID(pkb) : PK_NVALID(pka)];
+                        const int nrow = sa == 0 ? 4 : PK_NCAND(pka), ncol = PK_NCAND(pkb);      // (position 0: its '_' row in every slot)
+                        auto val = [&](int rr, int cc) __attribute__((always_inline)) { return (dead || rr >= nrow) ? 0.0 : (cc < ncol ? lt : -INFINITY); };
+                        if (!P.col) { x0 = val(row, 0); x1 = val(row, 1); x2 = val(row, 2); x3 = val(row, 3); }
+                        else { x0 = val(0, row); x1 = val(1, row); x2 = val(2, row); x3 = val(3, row); }
+                    }
                     if (r == 4 * LC) {
                         lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + 32);
                         o[0] = lds_v2d{x0, x1};
@@ -940,16 +1005,15 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
 #endif
         for (; sp < P.max_paths; sp++) {
             uint8_t *path_out = d.paths + (size_t)sp * (N + 1);
-            walk_totals Tt = {0.0, 0.0, INFINITY};
-            double lane_min = INFINITY;
+            double lane_min = INFINITY, hp_acc = 0.0;
             pipe_book_row R0, R1;
             if (lane == 0) path_out[0] = SYM_US;
             PIPE_BARRIER(); PIPE_BARRIER(); PIPE_BARRIER();         // epochs 0..2
             auto consume = [&](int c, const pipe_book_row &R) {
 #ifdef PIPE_PROF
-                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, Tt, lane_min, P.sm, bprof);
+                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, hp_acc, lane_min, P.sm, bprof);
 #else
-                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, Tt, lane_min, P.sm);
+                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, hp_acc, lane_min, P.sm);
 #endif
             };
             for (int k = 0; k < nchunks; k += 2) {
@@ -987,8 +1051,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 double r = lane_min;
                 if (r < P.min_remove) r = P.min_remove;             // cmd.py:157-160
                 gh_path_rec *rec = d.recs + sp;
-                rec->hp_current = Tt.hp_cur;
-                rec->hp_original = Tt.hp_orig;
+                rec->hp_current = hp_acc;
                 rec->ratio = r;
                 rec->min_marginal = lane_min;
                 rec->magnitude = 0.0;
@@ -999,6 +1062,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                     t_prev = t_now;
                 }
             }
+            if (lane == 1) d.recs[sp].hp_original = hp_acc;
             PIPE_BARRIER();
         }
         if (!aborted) {
