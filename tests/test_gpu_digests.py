@@ -51,15 +51,83 @@ def test_full_depth_against_the_oracles_digests(name):
     assert [int(x) for x in st] == want["fill_stats"] and h.L == want["L"]
     res = h.spin(case["paths"])
     got = mk.digest_result(res, h.export_band())
-    assert got["n"] == want["n"] == case["paths"] and got["hole_at"] == want["hole_at"]
+    assert got["n"] == case["paths"]
+    _compare(got, want, name)
+
+def _compare(got, want, what):
+    assert got["n"] == want["n"] and got["hole_at"] == want["hole_at"], what
     bad = [q for q in range(got["n"]) if got["path_sha"][q] != want["path_sha"][q]]
-    assert not bad, "recovered SNP sequences differ from the oracle's, first at path %d of %d" % (bad[0], got["n"])
+    assert not bad, "%s: recovered SNP sequences differ from the oracle's, first at path %d of %d" % (what, bad[0], got["n"])
     for key in ("hp_current", "hp_original", "ratio"):
         bad = [q for q in range(got["n"]) if got[key][q] != want[key][q]]
-        assert not bad, "%s differs, first at path %d: %s vs %s" % (key, bad[0], got[key][bad[0]], want[key][bad[0]])
+        assert not bad, "%s: %s differs, first at path %d: %s vs %s" % (what, key, bad[0], got[key][bad[0]], want[key][bad[0]])
     mg = np.array([float.fromhex(x) for x in got["magnitude"]]), np.array([float.fromhex(x) for x in want["magnitude"]])
-    assert np.allclose(mg[0], mg[1], rtol=1e-10, atol=0)
-    assert got["band_sha"] == want["band_sha"], "the reweighted tensor behind the last path differs"
+    assert np.allclose(mg[0], mg[1], rtol=1e-10, atol=0), what
+    assert got["band_sha"] == want["band_sha"], "%s: the reweighted tensor behind the last path differs" % what
+
+
+def test_the_window_pipeline_at_full_depth_c4s_eight_windows_in_one_batch(monkeypatch):
+    """Throughput mode (gretel_amd/csrc/wpipe.hpp) against the same digests: the eight 10k-SNP windows of C4 as ONE batch, 100
+    paths each, every window carried through all its paths by its persistent workgroup."""
+    from gretel_amd.hansel import Hansel, HanselBatch
+    monkeypatch.setenv("GH_PIPE_MIN", "1")
+    names = ["C3/seed%d/default/100" % s for s in range(8)]
+    hs = []
+    for nm in names:
+        case = DIGESTS[nm]["case"]
+        t = mk.make_table(case)
+        h = Hansel(t.n_snps, band=t.band, **case["spec"])
+        st = h.fill_from_support(t.rank, t.off, t.bases)
+        assert [int(x) for x in st] == DIGESTS[nm]["fill_stats"]
+        hs.append(h)
+        del t
+    b = HanselBatch(hs)
+    res = b.spin(100)
+    info = b.pipe_info()
+    assert info["windows"] == 8 and info["handed_back"] == 0, info
+    for nm, h, r in zip(names, hs, res):
+        _compare(mk.digest_result(r, h.export_band()), DIGESTS[nm], nm + " through the pipeline")
+
+
+@pytest.mark.parametrize("storage", ["f32", "f64"])
+def test_the_window_pipeline_at_full_depth_under_every_spec(storage, monkeypatch):
+    """C3 seed 0 x 100 paths under the specs of bench.py's spec_matrix, each as a batch of one window through the pipeline."""
+    from gretel_amd.hansel import Hansel, HanselBatch
+    monkeypatch.setenv("GH_PIPE_MIN", "1")
+    names = sorted(k for k in DIGESTS if k.startswith("C3/seed0/cond_mode=") and k.endswith("storage=%s/100" % storage))
+    if storage == "f32":
+        names.append("C3/seed0/default/100")
+    assert len(names) == 10
+    t = mk.make_table(DIGESTS[names[0]]["case"])
+    for nm in names:
+        case = DIGESTS[nm]["case"]
+        h = Hansel(t.n_snps, band=t.band, **case["spec"])
+        h.fill_from_support(t.rank, t.off, t.bases)
+        b = HanselBatch([h])
+        r = b.spin(100)[0]
+        assert b.pipe_info()["windows"] == 1, (nm, b.pipe_info())
+        _compare(mk.digest_result(r, h.export_band()), DIGESTS[nm], nm + " through the pipeline")
+        del b, h
+
+
+@pytest.mark.parametrize("name", ["C5/seed0/default/1000", "C5/seed0/cond_mode=C/100", "C5/seed0/cond_mode=E-marginal_term=True-storage=f64/100"])
+def test_the_window_pipeline_at_full_depth_c5(name, monkeypatch):
+    """C5 (50k SNPs, L = 11, the deep spin of 1 000 paths) as a batch of one window through the pipeline -- which by default
+    leaves lag counts beyond ten to the candidate pools (GH_PIPE_MAX_L): a second, independent HIP flow against the same digest."""
+    from gretel_amd.hansel import Hansel, HanselBatch
+    monkeypatch.setenv("GH_PIPE_MIN", "1")
+    monkeypatch.setenv("GH_PIPE_MAX_L", "14")
+    want = DIGESTS[name]
+    case = want["case"]
+    t = _table(case)
+    h = Hansel(t.n_snps, band=t.band, **case["spec"])
+    h.fill_from_support(t.rank, t.off, t.bases)
+    assert h.L == want["L"] == 11
+    b = HanselBatch([h])
+    r = b.spin(case["paths"])[0]
+    info = b.pipe_info()
+    assert info["windows"] == 1 and info["handed_back"] == 0 and info["threads"] == 512, info
+    _compare(mk.digest_result(r, h.export_band()), want, name + " through the pipeline")
 
 
 def test_the_digest_file_covers_what_it_says():
