@@ -344,9 +344,13 @@ def batch_roofline(batch, bp, paths, n_snps, band, L, es, src_sha, pmc_file):
                 "frac": strict / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "builders_bytes_per_launch": wk["bytes_per_launch"], "builders_frac": wk["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": note, "kernel_source_sha": src_sha,
-                "note": "frac prices SURVEY section 8(d)'s bytes (extension lookups + reweight cells) per path and window against 8 TB/s; what binds "
-                        "the kernel is the vector ALU of the sweep (binary64 divisions and log10 of the table entries a path changes) "
-                        "and the walker's dependent-issue latency, DESIGN.md section 4.4"}
+                "traffic_over_algorithmic": (traffic / strict) if traffic else None,
+                "traffic_rate": (traffic / (ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_rate_frac_of_peak": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "note": "frac prices SURVEY section 8(d)'s bytes (extension lookups + reweight cells) per path and window against 8 TB/s; "
+                        "traffic_rate is what the counters saw (profiles/, scaled to this launch) over this launch's duration: with one workgroup "
+                        "per CU the kernel moves 4.4-5.4 TB/s of actual traffic depending on the box, and the walker's chain of dependent "
+                        "steps (150 cycles per position) is the other bound, a few per cent behind: DESIGN.md section 4.4"}
     rw_ms = rw["ms"] / max(1, rw["launches"])
     return {"bound": "hbm", "kernel": "k_marg<float, true> (batched fused reweight + marginals + table rows)", "pipeline": info,
             "windows_per_launch": rw["windows"], "avg_launch_ms_hip_events": rw_ms,
