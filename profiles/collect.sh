@@ -4,11 +4,21 @@
 # Kernel trace and the PMC passes are separate runs (never combined with other trace domains); rocprofv3 is given python3
 # directly.  Back in the build container the summaries are made from gpurun_out/prof_<round>/ (where git is):
 #   scratch/copy_profiles.sh r5          (copies the bench lines and kernel statistics, summarises the PMC passes, recounts the ISA)
+# then commit and: gpurun ... 'bash profiles/collect.sh r5 lines'; scratch/copy_profiles.sh r5 lines    (the bench lines with `traffic`)
 set -u
 R=${1:-r5}
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
+if [ "${2:-}" = "lines" ]; then
+  # second call, once scratch/copy_profiles.sh has put the counter summaries of THIS build into profiles/ (committed): the bench
+  # lines again, which then quote `roofline.traffic` from them (the first call's lines cannot: the summaries did not exist yet)
+  python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+  python3 bench.py --config C2 > $out/bench_c2.json 2> $out/bench_c2.err
+  python3 bench.py --config C5 --steps 2 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err
+  python3 bench.py --batch 256 --steps 1 --warmup 1 > $out/bench_batch256.json 2> $out/bench_batch256.err
+  exit 0
+fi
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --config C2 > $out/bench_c2.json 2> $out/bench_c2.err
 python3 bench.py --config C5 --steps 2 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err

@@ -1,6 +1,10 @@
 #!/bin/bash
 # copies what profiles/collect.sh left under gpurun_out/prof_<round>/ into profiles/<round>_* (run in the build container, from the repo root)
 R=${1:-r5}; D=gpurun_out/prof_$R
+if [ "${2:-}" = "lines" ]; then
+  for f in bench_default bench_c2 bench_c5 bench_batch256; do cp $D/$f.json profiles/${R}_$f.json; done
+  exit 0
+fi
 for f in bench_default bench_c2 bench_c5 bench_batch256 bench_three_launches bench_four_launches bench_under_rocprof bench_2ranks_one_gpu_gloo; do cp $D/$f.json profiles/${R}_$f.json; done
 cp $D/kt/kt_kernel_stats.csv profiles/${R}_kernel_stats_bench_c3.csv
 cp $D/kt_c5/kt_kernel_stats.csv profiles/${R}_kernel_stats_bench_c5.csv
