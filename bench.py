@@ -329,7 +329,9 @@ def batch_roofline(batch, bp, paths, n_snps, band, L, es, src_sha, pmc_file):
         traffic, note = None, "no PMC profile for the kernels of this build"
         try:
             pmb = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            if pmb.get("kernel_source_sha") == src_sha:
+            if (n_snps, L) != (10000, 5):
+                note = "profiles/%s is the C3 window's (10k SNPs, five lags): not quoted for this one" % pmc_file
+            elif pmb.get("kernel_source_sha") == src_sha:
                 k = next(v for kk, v in pmb["kernels"].items() if kk.startswith("k_wpipe"))
                 traffic = k["hbm_bytes_per_launch_corrected"] * (paths * wk["windows"]) / float(pmb["paths"] * pmb["windows"])
                 note = "profiles/%s (git %s): %d windows x %d paths, scaled to this launch" % (pmc_file, pmb.get("git_head"), pmb["windows"], pmb["paths"])
