@@ -91,7 +91,7 @@ struct gh_handle {
     uint32_t *cmask;
     double *rinfo;                // [(N+2)][8] log10 marginal / marginal by candidate rank (k_marg, k_rw)
     unsigned long long *pipe_pk;  // [N+2] the window pipeline's packed candidate words (wpipe.hpp), allocated by the first batch that takes it
-    double *pipe_gp;              // ... and its compact table [(N+LT_PAD)][4][L][4]
+    double *pipe_gp;              // ... and its compact table, (N+LT_PAD) sources of L x 128 bytes (wpipe.hpp: pipe_gp_piece)
     size_t pipe_gp_bytes;
     double *pipe_lm;              // ... and, with the marginal term, the candidates' log-marginals by rank [N+2][4]
     bool need_rinfo;              // ... kept only where somebody reads it: with the marginal term (k_seg, k_cwalk add it in front of x1) and

@@ -114,7 +114,7 @@ struct win_desc {
     int snap;              // batched k_snapshot: freeze this window's marginals as the original ones
     int _pad;
     unsigned long long *pk; // [N+2] k_wpipe (wpipe.hpp): what a sweep needs of a position's candidates, packed by its prologue
-    double *gp;             // [(N+LT_PAD)][4][L][4] k_wpipe: its own compact copy of the ranked table (prologue)
+    double *gp;             // (N+LT_PAD) sources x L x 128 bytes (pipe_gp_piece) k_wpipe: its own compact copy of the ranked table (prologue)
     double *lmr;            // [N+2][4] k_wpipe with the marginal term: log10 marginal of a position's candidates by rank
     void *tband;            // k_wpipe under the column conditionals: the to-major copy of the band (kept in step)
 };

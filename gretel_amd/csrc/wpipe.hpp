@@ -93,6 +93,19 @@ template <> struct pipe_roles<512> {
 // doubles per position of a table buffer: X1 = lag-1 terms [row][column] (16), X2 = lag-2 terms (16), Yr = lags 3..L [row][column][lag],
 // rows padded to an even number of lags as in k_walk_spec's depth-2 layout
 __host__ __device__ constexpr int pipe_pos_doubles(int L, int mt = 0) { return 32 + (mt ? 4 : 0) + 16 * deep_nyp(L); }
+// The pipeline's own table gp: 32-byte pieces -- the four columns of one row at one lag (column conditionals: the four rows of one
+// column).  Inside a source (L x 128 bytes, always whole 64-byte lines) a row's lags lie together, [row][lag][4], up to the last EVEN
+// lag count: a row is then whole lines (128 bytes at four or five lags), and the piece of an odd last lag sits behind the rows,
+// [row][4].  What this is for: the sweep rewrites one row per position and path, and the memory system charges for partial-line
+// writes, not for bytes (see the loaders' comment on the far lags) -- with five lags a row was 160 bytes, two lines and a half; at C3 (band 4: the fifth lag is
+// never rewritten) it now is two whole lines: 92 -> 81 ms per 100 paths x 256 windows, same call.  (The position's line of cnt written
+// whole instead of its two values that change: no difference -- one line either way.  What counts is the number of LINES written.)
+// Offset in doubles:
+__host__ __device__ constexpr unsigned pipe_gp_piece(unsigned src, unsigned rc, unsigned lag0, unsigned L)
+{
+    const unsigned Le = L & ~1u;
+    return src * (L * 16u) + (lag0 < Le ? (rc * Le + lag0) * 4u : (4u * Le + rc) * 4u);
+}
 __host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
     return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
@@ -587,8 +600,8 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     }
     const unsigned p8 = (unsigned)p * 8u;
     if (act) {
-        if (s == a) g_cnt[p8 + (unsigned)s] = mine;
-        if (s == 7) g_cnt[p8 + 7u] = tot;
+        // (the position's whole line -- the seven counts as they stand and the total --, not just the two values that changed)
+        g_cnt[p8 + (unsigned)s] = s == 7 ? tot : mine;
         // the masks stood when the pass before ended and only c_a(p) has changed since: they still stand iff it is still positive
         if (s == 0 && ((VALID_MASK >> a) & 1) && !(ca_new > 0)) atomicOr(abort_flag, 1);
     }
@@ -615,7 +628,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         reinterpret_cast<unsigned long long *>(slot)[SD - 1] = word;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned rowbase = ((unsigned)p * 4u + (unsigned)(row6 < 4 ? row6 : 0)) * (unsigned)(L * 4);     // ('_' at position 0: row 0)
+    const unsigned row4 = (unsigned)(row6 < 4 ? row6 : 0);                                                  // ('_' at position 0: row 0)
     // the entries, eight per round: a quotient and its log10 each (the marginals of the position are the bookkeeper's:
     // pipe_book_consume).  Row conditionals: entry (lag, column rb of the path's row); column conditionals: entry (lag, row ra,
     // the column of the path's to-symbol).
@@ -632,11 +645,11 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
         if (!COL) {
             live = rb < PK_NCAND(word);
             k_el = PK_SYM(word, rb);
-            oidx = rowbase + (unsigned)(li * 4 + rb);
+            oidx = pipe_gp_piece((unsigned)p, row4, (unsigned)li, (unsigned)L) + (unsigned)rb;
         } else {
             live = (word & 8ull) != 0 && rb < nrows;
             k_el = p == 0 ? SYM_US : PK_SYM(pkp, rb);
-            oidx = (((unsigned)p * 4u + (unsigned)(word & 3ull)) * (unsigned)L + (unsigned)li) * 4u + (unsigned)rb;       // (transposed copy)
+            oidx = pipe_gp_piece((unsigned)p, (unsigned)(word & 3ull), (unsigned)li, (unsigned)L) + (unsigned)rb;       // (transposed copy)
         }
         if (live) {
             const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[k_el];
@@ -667,7 +680,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const unsigned long long pkt = d.pk[snp];
                 const double sum = (double)rw.sum();
                 const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt) + sum : (P.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca_new);
-                PIPE_GLOBAL(double) *out = g_G + rowbase + (unsigned)((l - 1) * 4);
+                PIPE_GLOBAL(double) *out = g_G + pipe_gp_piece((unsigned)p, row4, (unsigned)(l - 1), (unsigned)L);
                 for (int rb = 0; rb < PK_NCAND(pkt); rb++) {
                     const double xq = (1.0 + (double)rw.get(PK_SYM(pkt, rb))) / den;
                     out[rb] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
@@ -687,7 +700,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const double den = (P.cond_mode == GH_COND_C ? nv_i : (double)PK_NVALID(pkt)) + (double)cw.sum();
                 for (int ra = 0; ra < nrows; ra++) {
                     const double xq = (1.0 + (double)cw.get(p == 0 ? SYM_US : PK_SYM(pkp, ra))) / den;
-                    g_G[(((unsigned)p * 4u + (unsigned)rbs) * (unsigned)L + (unsigned)(l - 1)) * 4u + (unsigned)ra] =
+                    g_G[pipe_gp_piece((unsigned)p, (unsigned)rbs, (unsigned)(l - 1), (unsigned)L) + (unsigned)ra] =
                         gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
                 }
             }
@@ -753,7 +766,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     // 267k haplotypes/s for E against A before), and the loaders transpose back while they stage.
     for (int q = tid; q < (N + LT_PAD) * 4 * LC; q += NT) {
         const int l = q % LC, row = (q / LC) & 3, i = q / (4 * LC);
-        double *o = d.gp + (size_t)q * 4;
+        double *o = d.gp + pipe_gp_piece((unsigned)i, (unsigned)row, (unsigned)l, (unsigned)LC);
         if (!P.col) {
             const double *g = d.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * LC + l) * LT_ROW;
             const bool keep = i != 0 || row == 0;
@@ -854,7 +867,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         // log10(1 / V), -inf or 0.0.  With the table as it lies, a row's five lags in 160 contiguous bytes, the skipped piece shares its
         // 64-byte line with the next row's first and the counters show the same bytes fetched; with the table lag-major inside a source
         // the fetch falls by 10 % and the kernel takes 19 % LONGER, 109 against 92 ms -- the sweeps' stores then are five 32-byte pieces
-        // 128 bytes apart instead of one run of 160.  What binds is the number of partial-line writes, not the bytes.)
+        // 128 bytes apart instead of one run of 160.  What binds is the number of lines written, not the bytes: pipe_gp_piece.)
         // A lane's tasks are the same in every chunk: one word each, taken apart where it is used.  (Left to itself hipcc keeps every
         // address of every branch of every task in a register across the path loop and spills them.)
         unsigned desc[MAXT];
@@ -883,7 +896,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 const int sidx = i0 + pp;
                 const bool ok = q_.live && sidx < nsrc_all;
                 const int si = ok ? sidx : 0;
-                const PIPE_GLOBAL(double) *src = gG + ((unsigned)(si * 4 + ((si == 0 && !P.col) ? 0 : row)) * (unsigned)LC + (unsigned)l) * 4u;
+                const PIPE_GLOBAL(double) *src = gG + pipe_gp_piece((unsigned)si, (unsigned)((si == 0 && !P.col) ? 0 : row), (unsigned)l, (unsigned)LC);
                 if (r == 4 * LC) src = gLM + (unsigned)(si + 1 <= N ? si + 1 : N + 1) * 4u;      // (marginal term only)
                 typedef PIPE_GLOBAL(ld_v2d) gv2d;
                 R.lo[it] = *reinterpret_cast<const gv2d *>(src);
