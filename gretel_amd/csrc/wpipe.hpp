@@ -59,6 +59,7 @@ struct pipe_params {
     int prof;               // 1: the bookkeeper leaves s_memrealtime stamps per path in st->dbg8
     int mt;                 // marginal term: the walker adds log10 marginal of the candidate in front of the lag-1 term
     int col;                // column conditionals (C, E): the sweep works on the to-major copy of the band as well
+    int synth;              // the loaders make the table entries of lags beyond the band instead of reading them (see there)
     double min_remove;
     symmap sm;
 };
@@ -108,7 +109,7 @@ __host__ __device__ constexpr unsigned pipe_gp_piece(unsigned src, unsigned rc, 
 }
 __host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
-    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 64 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
+    return (size_t)2 * 64 * 8 + 256 * 8 + (size_t)nr_threads * 8 + (size_t)(nr_threads / 8) * 8 * (esize + 2) * 8 + 128 + 1024 + (((size_t)N + 2 + 15) & ~(size_t)15);
 }
 __host__ __device__ constexpr int pipe_chunk(int N, int L, int nr_threads, int esize, int mt = 0)
 {
@@ -159,8 +160,9 @@ struct pipe_ctl {
     double ratio;           // clamped minimum marginal of the path just walked: what the sweep of the next epochs removes
     int abort;              // a sweeper saw a candidate mask move
     int _pad[13];
+    double lt_beyond[8];    // the table entry of a lag beyond the band by V: log10((1 + 0) / (V + 0)) as k_lt takes it
 };
-static_assert(sizeof(pipe_ctl) == 64, "one line");
+static_assert(sizeof(pipe_ctl) == 128, "two lines");
 
 // The bookkeeper's two steps (kernels.hpp: book_prefetch / book_consume), lane = chunk-local position.  It takes the marginal of
 // the ONE symbol the walker selected at a position from the counts itself -- m = c_s / total, log10 m: k_marg's expressions on
@@ -783,6 +785,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     if (blockIdx.x == 0 && tid == 0) st->dbg8[9] = 0;
 #endif
     if (tid == 0) { ctl->ratio = 0.0; ctl->abort = 0; s_path[0] = SYM_US; }
+    if (tid < 8) ctl->lt_beyond[tid] = gh_log10((1.0 + 0.0) / ((double)tid + 0.0));
     __syncthreads();
 
 #ifdef PIPE_PROF
@@ -863,11 +866,19 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(16)));     // (32 bytes per (row, lag) of the pipeline's table)
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
         const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.gp);
-        // (Tried: lags beyond the band MADE from the packed words instead of read -- their rows of the tensor are zeros, so an entry is
-        // log10(1 / V), -inf or 0.0.  With the table as it lies, a row's five lags in 160 contiguous bytes, the skipped piece shares its
-        // 64-byte line with the next row's first and the counters show the same bytes fetched; with the table lag-major inside a source
-        // the fetch falls by 10 % and the kernel takes 19 % LONGER, 109 against 92 ms -- the sweeps' stores then are five 32-byte pieces
-        // 128 bytes apart instead of one run of 160.  What binds is the number of lines written, not the bytes: pipe_gp_piece.)
+        const PIPE_GLOBAL(double) *gPK = pipe_gptr((const double *)(const void *)d.pk);      // (a made entry's two packed words ride in lo.x / hi.x)
+        // Lags beyond the band are not read but MADE (conditionals other than B): their rows of the tensor are zeros, so an entry
+        // is log10((1 + 0) / (V + 0)) for a candidate column of an existing row, -inf for a missing column, 0.0 for a missing row or
+        // behind the window -- k_lt's values, from the packed words of source and target.  This only saves anything where the pieces
+        // not read are whole lines: with a row's lags contiguous (160 bytes at five lags, the first layout) the counters showed the
+        // same bytes fetched; with the table lag-major inside a source the fetch fell by 10 % and the kernel took 19 % LONGER (the
+        // sweep then wrote five half lines per position instead of one run); with pipe_gp_piece's layout the odd last lag of the four
+        // rows is two whole lines behind the rows -- at C3 (band 4, five lags) two of a source's ten.
+        // Measured with that layout (256 windows x 100 paths, same calls, boxes on which the walker's pace nearly binds): fetch
+        // - 11 %; E + marginal term 114.5 -> 109.3 ms; A 71.3 -> 72.3 ms (the loaders' arithmetic on the walker's SIMD).  So: on by
+        // default under the column conditionals, whose sweeps move twice the bytes, off under the row conditionals; GH_PIPE_SYNTH=0 / 1
+        // says otherwise.
+        const bool synth_on = P.synth != 0 && P.cond_mode != GH_COND_B && P.W < LC;
         // A lane's tasks are the same in every chunk: one word each, taken apart where it is used.  (Left to itself hipcc keeps every
         // address of every branch of every task in a register across the path loop and spills them.)
         unsigned desc[MAXT];
@@ -898,9 +909,18 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 const int si = ok ? sidx : 0;
                 const PIPE_GLOBAL(double) *src = gG + pipe_gp_piece((unsigned)si, (unsigned)((si == 0 && !P.col) ? 0 : row), (unsigned)l, (unsigned)LC);
                 if (r == 4 * LC) src = gLM + (unsigned)(si + 1 <= N ? si + 1 : N + 1) * 4u;      // (marginal term only)
-                typedef PIPE_GLOBAL(ld_v2d) gv2d;
-                R.lo[it] = *reinterpret_cast<const gv2d *>(src);
-                R.hi[it] = *reinterpret_cast<const gv2d *>(src + 2);
+                const bool syn = synth_on && r < 4 * LC && l >= P.W;
+                const int tg = si + l + 1;
+                const PIPE_GLOBAL(double) *src2 = src + 2;
+                if (syn) {                                            // made, not read: the packed words of source and target instead
+                    src = gPK + (si <= N ? si : N + 1);
+                    src2 = gPK + (tg <= N ? tg : N + 1);
+                }
+                typedef double ld_v2d8 __attribute__((ext_vector_type(2), aligned(8)));
+                typedef PIPE_GLOBAL(ld_v2d8) gv2d;
+                const ld_v2d8 a_ = *reinterpret_cast<const gv2d *>(src), b_ = *reinterpret_cast<const gv2d *>(src2);
+                R.lo[it] = ld_v2d{a_.x, a_.y};
+                R.hi[it] = ld_v2d{b_.x, b_.y};
             }
         };
         auto store = [&](int k) {
@@ -914,6 +934,16 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 if (q_.live) {
                     const bool z = i0 + pp >= nsrc_all;            // behind the table: zeros (the walker runs whole chunks)
                     double x0 = z ? 0.0 : R.lo[it].x, x1 = z ? 0.0 : R.lo[it].y, x2 = z ? 0.0 : R.hi[it].x, x3 = z ? 0.0 : R.hi[it].y;
+                    if (synth_on && r < 4 * LC && l >= P.W) {
+                        const int sa = i0 + pp, tg = sa + l + 1;
+                        const unsigned pka = (unsigned)__double_as_longlong(R.lo[it].x), pkb = (unsigned)__double_as_longlong(R.hi[it].x);
+                        const bool dead = sa >= N || tg > N;
+                        const double lt = ctl->lt_beyond[(P.cond_mode == GH_COND_A || P.cond_mode == GH_COND_E) ? PK_NVALID(pkb) : PK_NVALID(pka)];
+                        const int nrow = sa == 0 ? 4 : PK_NCAND(pka), ncol = PK_NCAND(pkb);      // (position 0: its '_' row in every slot)
+                        auto val = [&](int rr, int cc) __attribute__((always_inline)) { return (dead || rr >= nrow) ? 0.0 : (cc < ncol ? lt : -INFINITY); };
+                        if (!P.col) { x0 = val(row, 0); x1 = val(row, 1); x2 = val(row, 2); x3 = val(row, 3); }
+                        else { x0 = val(0, row); x1 = val(1, row); x2 = val(2, row); x3 = val(3, row); }
+                    }
                     if (r == 4 * LC) {
                         lds_v2d *o = reinterpret_cast<lds_v2d *>(dst + (size_t)pp * XD + 32);
                         o[0] = lds_v2d{x0, x1};

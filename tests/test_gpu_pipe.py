@@ -253,3 +253,19 @@ def test_other_workgroup_sizes_at_five_lags(nt, monkeypatch):
     assert b.pipe_info()["threads"] == nt
     for (h, o), r in zip(wins, res):
         _same(r, o.spin(8), h, o)
+
+
+@pytest.mark.parametrize("synth", ["0", "1"])
+@pytest.mark.parametrize("kw", [dict(), dict(cond_mode="D", marginal_term=True), dict(cond_mode="E", marginal_term=True), dict(cond_mode="C", storage="f64")],
+                         ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())) or "default")
+@pytest.mark.parametrize("L,band", [(5, 4), (5, 2), (6, 3), (3, 2), (8, 5)])
+def test_far_lags_made_by_the_loaders_or_read(L, band, kw, synth, monkeypatch):
+    """Lags beyond the band: their table entries are constants of V and the candidate counts, which the loaders either read from
+    the pipeline's table or make from the packed position words (GH_PIPE_SYNTH; default: made under the column conditionals)."""
+    monkeypatch.setenv("GH_PIPE_SYNTH", synth)
+    wins = [_pair(900 + s, 337, 9000, band + 1, L=L, band=band, k_max=band + 1, **kw) for s in range(3)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(9)
+    assert b.pipe_info()["windows"] == 3, b.pipe_info()
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(9), h, o)
