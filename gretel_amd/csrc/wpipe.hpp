@@ -102,10 +102,18 @@ __host__ __device__ constexpr int pipe_pos_doubles(int L, int mt = 0) { return 3
 // never rewritten) it now is two whole lines: 92 -> 81 ms per 100 paths x 256 windows, same call.  (The position's line of cnt written
 // whole instead of its two values that change: no difference -- one line either way.  What counts is the number of LINES written.)
 // Offset in doubles:
+// (-DPIPE_GP_ROWMAJOR / -DPIPE_GP_LAGMAJOR: the two layouts this one was measured against -- a row's lags contiguous; lag-major inside
+// a source -- for profiles/r5_table_layout.txt; diagnostic builds only)
 __host__ __device__ constexpr unsigned pipe_gp_piece(unsigned src, unsigned rc, unsigned lag0, unsigned L)
 {
+#if defined(PIPE_GP_ROWMAJOR)
+    return ((src * 4u + rc) * L + lag0) * 4u;
+#elif defined(PIPE_GP_LAGMAJOR)
+    return ((src * L + lag0) * 4u + rc) * 4u;
+#else
     const unsigned Le = L & ~1u;
     return src * (L * 16u) + (lag0 < Le ? (rc * Le + lag0) * 4u : (4u * Le + rc) * 4u);
+#endif
 }
 __host__ __device__ constexpr size_t pipe_fixed_bytes(int N, int nr_threads, int esize)
 {
