@@ -2475,7 +2475,7 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
     pipe_params P;
     P.N = N; P.W = W; P.L = L; P.mt = h0->cfg.marginal_term ? 1 : 0; P.col = (h0->cfg.cond_mode == GH_COND_C || h0->cfg.cond_mode == GH_COND_E) ? 1 : 0;
     P.C = pipe_chunk(N, L, nr, f64 ? 8 : 4, P.mt); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
-    P.synth = getenv("GH_PIPE_SYNTH") ? (atoi(getenv("GH_PIPE_SYNTH")) != 0) : P.col;      // (wpipe.hpp, the loaders: what it gains and costs)
+    P.synth = getenv("GH_PIPE_SYNTH") ? (atoi(getenv("GH_PIPE_SYNTH")) != 0) : 1;          // (wpipe.hpp, the loaders: what it gains and costs)
     P.offer_zero = h0->cfg.offer_zero; P.prof = (b->prof_every > 0 || getenv("GH_PIPE_STAMPS")) ? 1 : 0; P.min_remove = min_remove; P.sm = h0->sm;
     const size_t lds = pipe_lds_bytes(N, L, P.C, nr, f64 ? 8 : 4, P.mt);
     b->pused[0] = b->pused[1] = 0;

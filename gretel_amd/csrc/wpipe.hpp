@@ -882,10 +882,10 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         // same bytes fetched; with the table lag-major inside a source the fetch fell by 10 % and the kernel took 19 % LONGER (the
         // sweep then wrote five half lines per position instead of one run); with pipe_gp_piece's layout the odd last lag of the four
         // rows is two whole lines behind the rows -- at C3 (band 4, five lags) two of a source's ten.
-        // Measured with that layout (256 windows x 100 paths, same calls, boxes on which the walker's pace nearly binds): fetch
-        // - 11 %; E + marginal term 114.5 -> 109.3 ms; A 71.3 -> 72.3 ms (the loaders' arithmetic on the walker's SIMD).  So: on by
-        // default under the column conditionals, whose sweeps move twice the bytes, off under the row conditionals; GH_PIPE_SYNTH=0 / 1
-        // says otherwise.
+        // Measured with that layout (profiles/r5_table_layout.txt, 256 windows x 100 paths, same call): fetch - 11 %; on a box where the
+        // memory system binds A 86.7 -> 75.3 ms and E + marginal term 154.1 -> 146.9; on boxes where the walker's pace nearly binds
+        // E + marginal term 114.5 -> 109.3 ms and A 71.3 -> 72.3 (the loaders' arithmetic shares the walker's SIMD).  On by default;
+        // GH_PIPE_SYNTH=0 reads every lag.
         const bool synth_on = P.synth != 0 && P.cond_mode != GH_COND_B && P.W < LC;
         // A lane's tasks are the same in every chunk: one word each, taken apart where it is used.  (Left to itself hipcc keeps every
         // address of every branch of every task in a register across the path loop and spills them.)

@@ -261,7 +261,7 @@ def test_other_workgroup_sizes_at_five_lags(nt, monkeypatch):
 @pytest.mark.parametrize("L,band", [(5, 4), (5, 2), (6, 3), (3, 2), (8, 5)])
 def test_far_lags_made_by_the_loaders_or_read(L, band, kw, synth, monkeypatch):
     """Lags beyond the band: their table entries are constants of V and the candidate counts, which the loaders either read from
-    the pipeline's table or make from the packed position words (GH_PIPE_SYNTH; default: made under the column conditionals)."""
+    the pipeline's table or make from the packed position words (GH_PIPE_SYNTH=0; default: made)."""
     monkeypatch.setenv("GH_PIPE_SYNTH", synth)
     wins = [_pair(900 + s, 337, 9000, band + 1, L=L, band=band, k_max=band + 1, **kw) for s in range(3)]
     b = HanselBatch([h for h, _ in wins])
