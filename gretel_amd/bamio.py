@@ -313,8 +313,16 @@ def io_lib():
         L.gio_last_stats.argtypes = [C.POINTER(gio_stats)]
         L.gio_last_stats.restype = None
         L.gio_count_coverage.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.gio_release_buffers.argtypes = []
+        L.gio_release_buffers.restype = None
         _io = L
     return _io
+
+
+def native_release_buffers():
+    """The decoder keeps its large working buffers from call to call (include/gretel_io.h: gio_release_buffers, GIO_KEEP_MB); this
+    hands them back to the system."""
+    io_lib().gio_release_buffers()
 
 
 def native_ref_len(bam_path, contig):

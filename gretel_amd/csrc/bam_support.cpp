@@ -22,13 +22,16 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <string_view>
@@ -135,17 +138,168 @@ static int n_threads()
     return n;
 }
 
+// The decoder's parallel regions -- inflate, frame + records, the key table's two passes, the table's two -- run on a pool of
+// threads that is started once and kept: a C3-sized file goes through fourteen regions of up to sixteen threads, and creating and
+// joining 200 threads was 3 ms of its 27.  run(n, fn) calls fn(0) .. fn(n - 1), each once, on up to n threads of which the caller is
+// one, and returns when all have run; one region at a time (callers queue); the first exception of a task is rethrown in the caller.
+// The pool is never destroyed (its threads are detached and sleep between regions).  After a fork the child has no workers: the
+// caller then runs every task itself.
+class worker_pool {
+public:
+    static worker_pool &get() { static worker_pool *p = new worker_pool(); return *p; }
+    template <typename F> void run(int n, F &&fn)
+    {
+        if (n <= 0) return;
+        if (n == 1) { fn(0); return; }
+        std::lock_guard<std::mutex> region(run_mu_);
+        std::function<void(int)> f = [&fn](int t) { fn(t); };
+        job j;
+        j.fn = &f;
+        j.n = n;
+        j.left.store(n);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            const int want = std::min(n - 1, n_threads() - 1);
+            while (started_ < want) {
+                try { std::thread([this] { loop(); }).detach(); } catch (...) { break; }
+                started_++;
+            }
+            cur_ = &j;
+            epoch_++;
+        }
+        cv_.notify_all();
+        work_on(j);
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cur_ = nullptr;                                   // nobody picks it up from here on
+            done_cv_.wait(lk, [&] { return j.left.load() == 0 && j.active == 0; });
+        }
+        if (j.err) std::rethrow_exception(j.err);
+    }
+
+private:
+    struct job {
+        std::function<void(int)> *fn = nullptr;
+        int n = 0;
+        std::atomic<int> next{0}, left{0};
+        int active = 0;                                       // workers inside work_on (under mu_)
+        std::exception_ptr err;
+        std::mutex err_mu;
+    };
+    void work_on(job &j)
+    {
+        for (;;) {
+            const int t = j.next.fetch_add(1);
+            if (t >= j.n) break;
+            try { (*j.fn)(t); }
+            catch (...) {
+                std::lock_guard<std::mutex> g(j.err_mu);
+                if (!j.err) j.err = std::current_exception();
+            }
+            j.left.fetch_sub(1);
+        }
+    }
+    void loop()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            job *j = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                j = cur_;
+                if (j) j->active++;
+            }
+            if (!j) continue;
+            work_on(*j);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                j->active--;
+            }
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex run_mu_, mu_;
+    std::condition_variable cv_, done_cv_;
+    job *cur_ = nullptr;
+    unsigned long epoch_ = 0;
+    int started_ = 0;
+};
+
 // Large arrays on transparent huge pages: a million-read table touches ~200 MB of fresh memory, and at 4 KB a page the
 // faults cost more than the decoding (madvise is a hint: where THP is off nothing changes).
+// ... and they are KEPT from one decode to the next (up to GIO_KEEP_MB, default 1024; 0: nothing is kept): handing 130 MB back to
+// the system when a decode ends costs 8 ms of unmapping on the caller's clock (on a thread of its own it holds the address-space
+// lock against the upload that follows, measured), and the next decode then faults the same pages in again -- a third of the time
+// a C3-sized file takes from call to return, for a process that decodes window after window.  gio_release_buffers() frees what is
+// kept.  Blocks are handed out again as they are (nobody here relies on fresh pages being zero: the key table, which does, maps its own).
+struct big_cache {
+    struct blk { void *p; size_t bytes; };
+    std::mutex mu;
+    std::vector<blk> free_blocks;
+    size_t kept = 0;
+    static big_cache &get() { static big_cache *c = new big_cache(); return *c; }
+    static size_t limit()
+    {
+        static const size_t l = [] {
+            const char *e = getenv("GIO_KEEP_MB");
+            const long mb = e ? atol(e) : 1024;
+            return (size_t)(mb < 0 ? 0 : mb) << 20;
+        }();
+        return l;
+    }
+    void *take(size_t bytes)                            // the smallest kept block that holds `bytes` without wasting three quarters of itself
+    {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < free_blocks.size(); i++)
+            if (free_blocks[i].bytes >= bytes && free_blocks[i].bytes <= 4 * bytes && (best == (size_t)-1 || free_blocks[i].bytes < free_blocks[best].bytes)) best = i;
+        if (best == (size_t)-1) return nullptr;
+        void *p = free_blocks[best].p;
+        kept -= free_blocks[best].bytes;
+        free_blocks[best] = free_blocks.back();
+        free_blocks.pop_back();
+        return p;
+    }
+    bool give(void *p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (kept + bytes > limit()) return false;
+        try { free_blocks.push_back(blk{p, bytes}); } catch (...) { return false; }
+        kept += bytes;
+        return true;
+    }
+    void release_all()
+    {
+        std::vector<blk> v;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            v.swap(free_blocks);
+            kept = 0;
+        }
+        for (auto &b : v) free(b.p);
+    }
+};
+static const size_t BIG_BYTES = (size_t)4 << 20;
+static size_t big_round(size_t bytes) { const size_t al = (size_t)2 << 20; return (bytes + al - 1) / al * al; }
 static void *big_alloc(size_t bytes)
 {
-    if (bytes >= ((size_t)4 << 20)) {
-        const size_t al = (size_t)2 << 20, sz = (bytes + al - 1) / al * al;
+    if (bytes >= BIG_BYTES) {
+        const size_t al = (size_t)2 << 20, sz = big_round(bytes);
+        if (void *q = big_cache::get().take(sz)) return q;
         void *p = aligned_alloc(al, sz);
         if (p) madvise(p, sz, MADV_HUGEPAGE);
         return p;
     }
     return malloc(bytes);
+}
+// (bytes: what big_alloc was asked for)
+static void big_free(void *p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes >= BIG_BYTES && big_cache::get().give(p, big_round(bytes))) return;
+    free(p);
 }
 template <typename T> struct big_allocator {
     typedef T value_type;
@@ -157,7 +311,7 @@ template <typename T> struct big_allocator {
         if (!p) throw std::bad_alloc();
         return (T *)p;
     }
-    void deallocate(T *p, size_t) { free(p); }
+    void deallocate(T *p, size_t n) { big_free(p, n * sizeof(T)); }
     template <typename U> bool operator==(const big_allocator<U> &) const { return true; }
     template <typename U> bool operator!=(const big_allocator<U> &) const { return false; }
 };
@@ -180,7 +334,7 @@ public:
     rawbuf() = default;
     rawbuf(const rawbuf &) = delete;
     rawbuf &operator=(const rawbuf &) = delete;
-    ~rawbuf() { free(p_); }
+    ~rawbuf() { big_free(p_, cap_); }
     size_t size() const { return n_; }
     uint8_t *data() { return p_; }
     const uint8_t *data() const { return p_; }
@@ -194,7 +348,7 @@ public:
             uint8_t *q = (uint8_t *)big_alloc(c);
             if (!q) return false;
             if (n_) memcpy(q, p_, n_);
-            free(p_);
+            big_free(p_, cap_);
             p_ = q;
             cap_ = c;
         }
@@ -319,11 +473,7 @@ private:
         };
         const int nt = (int)std::min<size_t>((size_t)n_threads(), blocks.size() / 8 + 1);
         if (nt <= 1) work();
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++) th.emplace_back(work);
-            for (auto &t : th) t.join();
-        }
+        else worker_pool::get().run(nt, [&](int) { work(); });
         if (bad.load()) return fail(-3, "inflate failed in %s", path_.c_str());
         g_stats.blocks += (int64_t)blocks.size();
         cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (ptrdiff_t)o);
@@ -451,6 +601,8 @@ static int gio_ref_len_impl(const char *bam_path, const char *contig, int64_t *l
     return fail(-5, "contig %s not in %s", contig, bam_path);
 }
 
+extern "C" void gio_release_buffers(void) { big_cache::get().release_all(); }
+
 extern "C" void gio_table_free(gio_table *t)
 {
     if (!t) return;
@@ -571,7 +723,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     struct rinfo_vec {
         rinfo *p = nullptr;
         size_t n = 0, cap = 0;
-        ~rinfo_vec() { free(p); }
+        ~rinfo_vec() { big_free(p, cap * sizeof(rinfo)); }
         size_t size() const { return n; }
         size_t capacity() const { return cap; }
         rinfo *data() { return p; }
@@ -582,7 +734,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             rinfo *q = (rinfo *)big_alloc(c * sizeof(rinfo));
             if (!q) return false;
             if (n) memcpy(q, p, n * sizeof(rinfo));
-            free(p);
+            big_free(p, cap * sizeof(rinfo));
             p = q;
             cap = c;
             return true;
@@ -846,9 +998,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         };
         if (nt <= 1) work(0);
         else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; t++) th.emplace_back(work, t);
-            for (auto &t : th) t.join();
+            worker_pool::get().run(nt, work);
         }
         // every chain must end where the next one began (then, by induction from the true start 0, every start was true)
         bool chained = true;
@@ -1018,10 +1168,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             }
         };
         auto run = [&](int n, auto &&fn) {
-            if (n <= 1) { if (n == 1) fn(0); return; }
-            std::vector<std::thread> th;
-            for (int t = 0; t < n; t++) th.emplace_back([&fn, t] { fn(t); });
-            for (auto &t : th) t.join();
+            worker_pool::get().run(n, fn);
         };
         auto K0 = now();
         run(n_valid, fill);
@@ -1063,10 +1210,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     const int nt_out = (int)std::min<int64_t>((int64_t)n_threads(), n_rec / 65536 + 1);
     std::vector<int64_t> rows_in((size_t)nt_out + 1, 0), chars_in((size_t)nt_out + 1, 0);
     auto run_out = [&](auto &&fn) {
-        if (nt_out <= 1) { fn(0); return; }
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt_out; t++) th.emplace_back([&fn, t] { fn(t); });
-        for (auto &t : th) t.join();
+        worker_pool::get().run(nt_out, fn);
     };
     run_out([&](int t) {
         int64_t r = 0, c = 0;

@@ -248,3 +248,24 @@ def test_the_depth_histogram_stays_short_over_a_long_window(tmp_path):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert 0 < len(a[0]) < 40
+
+
+def test_the_decoders_kept_buffers_change_nothing(tmp_path, monkeypatch):
+    """libgretel_io.so keeps its large working buffers between calls (include/gretel_io.h: gio_release_buffers, GIO_KEEP_MB): the same
+    table with fresh buffers, with reused ones (handed out as the decode before left them) and after they were released."""
+    from gretel_amd import bamio, util
+    from gretel_amd.synth import make_support_table
+    monkeypatch.setenv("GIO_PART_RECORDS", "512")
+    t = make_support_table(2000, 120000, k=6, seed=11, n_haps=5, err=0.01)          # (large enough for blocks beyond 4 MB to be kept)
+    bam, vcf = str(tmp_path / "k.bam"), str(tmp_path / "k.vcf.gz")
+    contig, start, end = bamio.synth_to_files(t, bam, vcf)
+    v = util.process_vcf(vcf, contig, start, end)
+    bamio.native_release_buffers()
+    first = [np.array(a) for a in util.support_table_from_bam(bam, contig, start, end, v)]
+    for round_ in range(3):
+        again = util.support_table_from_bam(bam, contig, start, end, v)
+        assert all(np.array_equal(a, b) for a, b in zip(first, again)), round_
+        del again
+        if round_ == 1:
+            bamio.native_release_buffers()
+    assert np.array_equal(first[0], t.rank) and np.array_equal(first[1], t.off) and np.array_equal(first[2], t.bases)
