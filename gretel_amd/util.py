@@ -57,6 +57,13 @@ def process_vcf(vcf_path, contig_name, start_pos, end_pos):
         data = fp.read()                                      # (whole file at once: line iteration over gzip is the slow part)
     key = contig_name.encode() + b"\t"
     klen = len(key)
+    positions = _vcf_positions(data, key)
+    if positions is not None:
+        # (the loop below over 10 000 records is 3 of the 3.7 ms this function took; here: the same records, the same order)
+        keep = positions[(positions >= start_pos) & (positions <= end_pos)]
+        region[keep] = 1
+        lst = keep.tolist()
+        return {"N": len(lst), "snp_fwd": dict(zip(lst, range(len(lst)))), "snp_rev": dict(enumerate(lst)), "region": region}
     for line in data.split(b"\n"):
         if not line.startswith(key):                          # header lines, other contigs
             continue
@@ -70,6 +77,43 @@ def process_vcf(vcf_path, contig_name, start_pos, end_pos):
         snp_forward[pos] = i
         i += 1
     return {"N": n_snps, "snp_fwd": snp_forward, "snp_rev": snp_reverse, "region": region}
+
+
+def _vcf_positions(data, key):
+    """POS of every record whose line starts with `key` (contig + tab), in file order, as an int64 array -- or None when a line
+    does not look as expected (no digits behind the contig, more than 18 of them, the file's last line cut short): the caller's
+    line-by-line loop then decides, with int()'s own errors.  A repeated position is kept here as the loop keeps it."""
+    if not data:
+        return None
+    arr = np.frombuffer(data, dtype=np.uint8)
+    nl = np.flatnonzero(arr == 10)
+    starts = np.concatenate([[0], nl + 1])
+    starts = starts[starts + len(key) < len(arr)]                 # (a line too short to hold the key and a digit is no record)
+    if len(starts) == 0:
+        return np.zeros(0, dtype=np.int64)
+    kb = np.frombuffer(key, dtype=np.uint8)
+    hit = np.ones(len(starts), dtype=bool)
+    for j in range(len(kb)):
+        hit &= arr[starts + j] == kb[j]
+    starts = starts[hit]
+    if len(starts) == 0:
+        return np.zeros(0, dtype=np.int64)
+    width = 19
+    idx = starts[:, None] + len(key) + np.arange(width)[None, :]
+    chunk = arr[np.minimum(idx, len(arr) - 1)]
+    chunk = np.where(idx < len(arr), chunk, 0)
+    isdig = (chunk >= 48) & (chunk <= 57)
+    ndig = np.where(isdig.all(axis=1), width, np.argmin(isdig, axis=1))
+    if (ndig == 0).any() or (ndig >= width).any():
+        return None
+    term = chunk[np.arange(len(starts)), ndig]                    # what ends the number: a tab, or the line / the file
+    if not np.isin(term, (9, 10, 0)).all():
+        return None                                               # (e.g. "12x": int() would raise -- let it)
+    val = np.zeros(len(starts), dtype=np.int64)
+    for j in range(int(ndig.max())):
+        live = j < ndig
+        val = np.where(live, val * 10 + (chunk[:, j].astype(np.int64) - 48), val)
+    return val
 
 
 def _is_gzip(path):

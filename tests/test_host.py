@@ -53,3 +53,37 @@ def test_result_exchange_refuses_to_drop_an_uncollected_step():
     ex.submit(2, 0)
     assert ex.collect()[0]["paths"][0, 0] == 1 and ex.collect()[0]["n"] == 2 and ex.collect() is None
     ex.close()
+
+
+def test_process_vcf_fast_path_is_the_loop(tmp_path, monkeypatch):
+    """gretel/util.py:354-414: the vectorised scan of the POS column gives what the line-by-line loop gives -- header lines, other
+    contigs, a contig whose name starts with ours, repeated positions, a last line without a newline, CRLF -- and steps aside
+    (the loop then raises what int() raises) when a POS field is not a number."""
+    import gzip
+    import numpy as np
+    import pytest
+    from gretel_amd import util
+    body = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT", "ctg\t5\t.\tA\tC", "ctg2\t6\t.\tA\tC", "other\t7\t.\tA\tC",
+            "ctg\t12\t.\tG\tT", "ctg\t12\t.\tG\tA", "ctg\t300\t.\tG\tA", "ctg\t41"]
+
+    def both(text, name, lo, hi, gz=False):
+        f = tmp_path / ("v.vcf.gz" if gz else "v.vcf")
+        (gzip.open if gz else open)(f, "wb").write(text)
+        fast = util.process_vcf(str(f), name, lo, hi)
+        monkeypatch.setattr(util, "_vcf_positions", lambda d, k: None)
+        slow = util.process_vcf(str(f), name, lo, hi)
+        monkeypatch.undo()
+        assert fast["N"] == slow["N"] and fast["snp_fwd"] == slow["snp_fwd"] and fast["snp_rev"] == slow["snp_rev"]
+        assert np.array_equal(fast["region"], slow["region"]) and fast["region"].dtype == slow["region"].dtype
+        return fast
+
+    v = both("\n".join(body).encode(), "ctg", 1, 100, gz=True)
+    assert v["N"] == 4 and v["snp_rev"] == {0: 5, 1: 12, 2: 12, 3: 41} and v["snp_fwd"][12] == 2
+    assert both("\n".join(body).encode() + b"\n", "ctg", 6, 300)["N"] == 4
+    assert both("\r\n".join(body[:-1]).encode(), "ctg2", 1, 10)["N"] == 1
+    assert both(b"", "ctg", 1, 10)["N"] == 0 and both(b"#only a header\n", "ctg", 1, 10)["N"] == 0
+    f = tmp_path / "bad.vcf"
+    f.write_bytes(b"ctg\t12x\t.\n")
+    assert util._vcf_positions(f.read_bytes(), b"ctg\t") is None
+    with pytest.raises(ValueError):
+        util.process_vcf(str(f), "ctg", 1, 100)
