@@ -87,3 +87,36 @@ def test_process_vcf_fast_path_is_the_loop(tmp_path, monkeypatch):
     assert util._vcf_positions(f.read_bytes(), b"ctg\t") is None
     with pytest.raises(ValueError):
         util.process_vcf(str(f), "ctg", 1, 100)
+
+
+def test_the_builds_hash_covers_kernel_sources_only():
+    """bench.kernel_source_sha names the build a profile belongs to (profiles/*.json quote it, bench.py only quotes the counters'
+    traffic when it matches): every kernel source and C-ABI header of the GPU library, not the host-side BAM decoder's header."""
+    import glob
+    import hashlib
+    import os
+    import bench
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    files = sorted(glob.glob(os.path.join(root, "gretel_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "include", "*.h")) +
+                   glob.glob(os.path.join(root, "include", "*.inc")))
+    names = [os.path.basename(f) for f in files]
+    for must in ("wpipe.hpp", "kernels.hpp", "segwalk.hpp", "segmix.hpp", "cwalk.hpp", "seg_geom.hpp", "gretel_hip.hip", "gretel_hip.h", "gh_detlog.h", "gh_logtab.inc"):
+        assert must in names, must
+    hh = hashlib.sha256()
+    for f in files:
+        if os.path.basename(f) == "gretel_io.h":
+            continue
+        hh.update(os.path.basename(f).encode())
+        hh.update(open(f, "rb").read())
+    assert bench.kernel_source_sha() == hh.hexdigest()[:16]
+    # the committed counter summaries of this round belong to this build (scratch/copy_profiles.sh after profiles/collect.sh)
+    import json
+    import pytest
+    stale = []
+    for name in ("r5_pmc_traffic.json", "r5_pmc_traffic_c5.json", "r5_pmc_traffic_batch256.json"):
+        doc = json.load(open(os.path.join(root, "profiles", name)))
+        assert doc["git_dirty"] is False, name
+        if doc["kernel_source_sha"] != bench.kernel_source_sha():
+            stale.append(name)
+    if stale:       # (while kernels are being worked on this is the normal state: bench.py then leaves `traffic` null and says why)
+        pytest.skip("the counter summaries %s are of another build: run profiles/collect.sh before quoting them" % ", ".join(stale))
