@@ -335,7 +335,15 @@ def batch_roofline(batch, bp, paths, n_snps, band, L, es, src_sha, pmc_file):
             elif pmb.get("kernel_source_sha") == src_sha:
                 k = next(v for kk, v in pmb["kernels"].items() if kk.startswith("k_wpipe"))
                 traffic = k["hbm_bytes_per_launch_corrected"] * (paths * wk["windows"]) / float(pmb["paths"] * pmb["windows"])
-                note = "profiles/%s (git %s): %d windows x %d paths, scaled to this launch" % (pmc_file, pmb.get("git_head"), pmb["windows"], pmb["paths"])
+                if (pmb["paths"], pmb["windows"]) == (paths, wk["windows"]):
+                    note = "profiles/%s (git %s): the counters of a launch of this very shape, %d windows x %d paths" % (
+                        pmc_file, pmb.get("git_head"), pmb["windows"], pmb["paths"])
+                else:
+                    # (k_wpipe's prologue -- G repacked into gp, pk / lmr packed: ~18 MB per window -- is paid once per launch, not
+                    # per path: scaled linearly from a launch with fewer paths it is counted too often)
+                    note = ("profiles/%s (git %s): %d windows x %d paths, scaled linearly to this launch -- the per-launch prologue (table "
+                            "repack, ~18 MB per window) is scaled with the paths: overstated by a few per cent when the profile has fewer paths"
+                            % (pmc_file, pmb.get("git_head"), pmb["windows"], pmb["paths"]))
             else:
                 note = "profiles/%s was taken with kernel sources %s, this build is %s: not quoted" % (pmc_file, pmb.get("kernel_source_sha"), src_sha)
         except Exception as exc:

@@ -236,6 +236,12 @@ def main(argv=None):
     else:
         paths = recover(hansel, vcf_h["N"], args.paths)
     write_outputs(paths, hansel, vcf_h, args)
+    try:                        # the decoder's kept working buffers (include/gretel_io.h: GIO_KEEP_MB): a run has one decode
+        from . import bamio
+        if getattr(bamio, "_io", None) is not None:
+            bamio.native_release_buffers()
+    except Exception:
+        pass
     return 0
 
 

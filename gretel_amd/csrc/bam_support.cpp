@@ -36,6 +36,7 @@
 #include <string>
 #include <string_view>
 #include <thread>
+#include <pthread.h>
 #include <unordered_map>
 #include <vector>
 
@@ -146,7 +147,19 @@ static int n_threads()
 // caller then runs every task itself.
 class worker_pool {
 public:
-    static worker_pool &get() { static worker_pool *p = new worker_pool(); return *p; }
+    // (a forked child gets a NEW pool: none of the parent's worker threads exists there, and a mutex that another thread of the
+    // parent held at the moment of the fork would stay locked for good -- the next decode in the child would never return, ADVICE r5.
+    // The old object is leaked in the child, locked mutexes and all; workers are started again on demand.)
+    static worker_pool *&slot() { static worker_pool *p = nullptr; return p; }
+    static worker_pool &get()
+    {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            slot() = new worker_pool();
+            pthread_atfork(nullptr, nullptr, [] { slot() = new worker_pool(); });
+        });
+        return *slot();
+    }
     template <typename F> void run(int n, F &&fn)
     {
         if (n <= 0) return;
@@ -229,7 +242,7 @@ private:
 
 // Large arrays on transparent huge pages: a million-read table touches ~200 MB of fresh memory, and at 4 KB a page the
 // faults cost more than the decoding (madvise is a hint: where THP is off nothing changes).
-// ... and they are KEPT from one decode to the next (up to GIO_KEEP_MB, default 1024; 0: nothing is kept): handing 130 MB back to
+// ... and they are KEPT from one decode to the next (up to GIO_KEEP_MB, default 512; 0: nothing is kept): handing 130 MB back to
 // the system when a decode ends costs 8 ms of unmapping on the caller's clock (on a thread of its own it holds the address-space
 // lock against the upload that follows, measured), and the next decode then faults the same pages in again -- a third of the time
 // a C3-sized file takes from call to return, for a process that decodes window after window.  gio_release_buffers() frees what is
@@ -239,12 +252,23 @@ struct big_cache {
     std::mutex mu;
     std::vector<blk> free_blocks;
     size_t kept = 0;
-    static big_cache &get() { static big_cache *c = new big_cache(); return *c; }
+    // (as the pool: a forked child starts with an empty cache of its own -- the parent's kept blocks stay mapped in the child and are
+    // simply not used there; its mutex may have been held at the fork)
+    static big_cache *&slot() { static big_cache *c = nullptr; return c; }
+    static big_cache &get()
+    {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            slot() = new big_cache();
+            pthread_atfork(nullptr, nullptr, [] { slot() = new big_cache(); });
+        });
+        return *slot();
+    }
     static size_t limit()
     {
         static const size_t l = [] {
             const char *e = getenv("GIO_KEEP_MB");
-            const long mb = e ? atol(e) : 1024;
+            const long mb = e ? atol(e) : 512;          // (a C3-sized file keeps ~260 MB: its inflated window and the reads' arrays)
             return (size_t)(mb < 0 ? 0 : mb) << 20;
         }();
         return l;

@@ -1710,6 +1710,11 @@ static int ensure_spin_buffers(gh_handle *h, int max_paths)
 {
     const size_t n1 = (size_t)h->N + 1;
     if (max_paths > h->spin_cap) {
+        // (a handle is sized for the reference's default spin -- 100 paths, gretel/cmd.py:148 -- the first time it spins, however
+        // few paths that first call asks for: growing later costs three frees, three allocations and the pinned staging buffer
+        // over again, 0.7 ms on the caller's clock -- a fifth of a C3 spin -- unless the window is so long that the floor is real memory)
+        const int floor_paths = 128;
+        if (max_paths < floor_paths && n1 * 9 * (size_t)floor_paths <= ((size_t)256 << 20)) max_paths = floor_paths;
         HIPCHK(hipStreamSynchronize(h->stream));
         hipFree(h->spin_paths); hipFree(h->spin_recs);
         h->spin_paths = nullptr; h->spin_recs = nullptr; h->spin_cap = 0;
@@ -1872,7 +1877,9 @@ static int state_and_results_to_stage(gh_handle *h, dev_state *hs, const uint8_t
     if (need > h->stage_cap) {
         if (h->stage) hipHostFree(h->stage);
         h->stage = nullptr; h->stage_cap = 0;
-        const size_t cap = need + need / 2 + 4096;
+        // (pinned memory is the dearest allocation of a spin: sized once for what the device buffers hold -- ensure_spin_buffers)
+        const size_t lc = (size_t)(launched > h->spin_cap ? launched : h->spin_cap);
+        const size_t cap = (n1 + sizeof(gh_path_rec)) * lc + sizeof(dev_state) + 64 + 4096;
         if (hipHostMalloc((void **)&h->stage, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h->stage = nullptr; return 1; }
         h->stage_cap = cap;
     }
@@ -2196,7 +2203,7 @@ extern "C" int gh_spin(gh_t *h, int max_paths, double min_remove, uint8_t *paths
     int nb = rw_blocks(h, seg || cw_ok(h->wmode, h->L));       // (the widest reweight kernel this spin may launch)
     if (h->rws && rws_S > nb) nb = rws_S;                       // ... k_rwseg leaves one partial sum per segment
     h->spin_partial_stride = nb;
-    if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths);       // L only changes through gh_set_L / gh_fill, never inside a spin
+    if (rc == GH_OK) rc = ensure_partial(h, nb, max_paths > h->spin_cap ? max_paths : h->spin_cap);       // L only changes through gh_set_L / gh_fill, never inside a spin
     // (k_rwseg: every slot is summed over the whole stride: what a kernel with fewer workgroups leaves untouched must read 0)
     if (rc == GH_OK) rc = reset_spin_state(h, h->rws ? h->partial : nullptr, h->rws ? (size_t)nb * max_paths : 0);
     // Segment-parallel walks with a conditional table that the fused reweight keeps current (conditional A/B, no marginal
@@ -2627,6 +2634,43 @@ static int batch_run_launches(gh_batch *b, const std::vector<win_desc> &wd, int 
     return GH_OK;
 }
 
+// gh_spin over some windows of a batch from a few host threads, every window on its own stream (the windows' kernel chains
+// interleave on the GPU).  A job is (window, paths it already has): the spin writes the window's remaining paths behind them.
+static int batch_spin_on_streams(gh_batch *b, const std::vector<std::pair<int, int>> &jobs, int max_paths, double min_remove,
+                                 uint8_t *paths_out, gh_path_rec *recs, int *n_out, int *hole_at)
+{
+    const int nj = (int)jobs.size();
+    if (nj == 0) return GH_OK;
+    const size_t n1 = (size_t)b->N + 1;
+    static const int nthr_env = getenv("GH_BATCH_THREADS") ? atoi(getenv("GH_BATCH_THREADS")) : 8;
+    const int nthr = nthr_env < 1 ? 1 : (nthr_env > nj ? nj : nthr_env);
+    std::vector<int> rcs(nj, GH_OK);
+    std::vector<std::string> errs(nj);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        hipSetDevice(b->dev);
+        for (;;) {
+            const int q = next.fetch_add(1);
+            if (q >= nj) break;
+            const int w = jobs[q].first, nd = jobs[q].second;
+            int n2 = 0, hole2 = 0;
+            if (nd < max_paths) {
+                rcs[q] = gh_spin(b->hs[w], max_paths - nd, min_remove, paths_out + n1 * ((size_t)max_paths * w + nd), recs + (size_t)max_paths * w + nd, &n2, &hole2);
+                if (rcs[q]) errs[q] = gh_last_error();
+            }
+            n_out[w] = nd + n2;
+            hole_at[w] = hole2;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthr; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    for (int q = 0; q < nj; q++)
+        if (rcs[q]) return fail(rcs[q], "window %d: %s", jobs[q].first, errs[q].c_str());
+    return GH_OK;
+}
+
 extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, uint8_t *paths_out,
                              gh_path_rec *recs, int *n_out, int *hole_at)
 {
@@ -2645,8 +2689,10 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             return fail(GH_ERR_STATE, "window %d has L=%d but window 0 has L=%d: set one L (gh_set_L) for the batch", w, h->L, b->hs[0]->L);
         if ((rc = alloc_lt(h))) return rc;
     }
-    // whatever the handles' own streams still carry (fills) must be done before the batch's stream touches the tensors
-    HIPCHK(hipDeviceSynchronize());
+    // whatever the handles' own streams still carry (fills) must be done before the batch's stream touches the tensors -- those
+    // streams, not the device: a device-wide wait also waits for whatever else the process runs (ResultExchange's gather on its
+    // side stream in a multi-rank run)
+    for (int w = 0; w < n; w++) HIPCHK(hipStreamSynchronize(b->hs[w]->stream));
     b->L = b->hs[0]->L;
     phase("tables allocated, device idle");
     // (measured on C3, MI355X: 8 windows 37k haplotypes/s this way against ~16k batched; 32 windows 45k either way -- the
@@ -2673,28 +2719,9 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         // The segment-parallel extensions fill the chip poorly with ONE window (four small dependent kernels per path, most
         // of their time launch and first-touch latency) but every window has its own stream: a few host threads each
         // run gh_spin over their share of the windows, and the windows' kernel chains interleave on the GPU.
-        static const int nthr_env = getenv("GH_BATCH_THREADS") ? atoi(getenv("GH_BATCH_THREADS")) : 8;
-        const int nthr = nthr_env < 1 ? 1 : (nthr_env > n ? n : nthr_env);
-        std::vector<int> rcs(n, GH_OK);
-        std::vector<std::string> errs(n);
-        std::atomic<int> next(0);
-        auto work = [&]() {
-            hipSetDevice(b->dev);
-            for (;;) {
-                const int w = next.fetch_add(1);
-                if (w >= n) break;
-                rcs[w] = gh_spin(b->hs[w], max_paths, min_remove, paths_out + n1 * max_paths * w, recs + (size_t)max_paths * w,
-                                 &n_out[w], &hole_at[w]);
-                if (rcs[w]) errs[w] = gh_last_error();
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthr; t++) th.emplace_back(work);
-        work();
-        for (auto &t : th) t.join();
-        for (int w = 0; w < n; w++)
-            if (rcs[w]) return fail(rcs[w], "window %d: %s", w, errs[w].c_str());
-        return GH_OK;
+        std::vector<std::pair<int, int>> jobs;
+        for (int w = 0; w < n; w++) jobs.emplace_back(w, 0);
+        return batch_spin_on_streams(b, jobs, max_paths, min_remove, paths_out, recs, n_out, hole_at);
     }
     if (max_paths > b->cap_paths) {
         HIPCHK(hipStreamSynchronize(b->stream));
@@ -2753,6 +2780,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         return GH_OK;
     };
     std::vector<int> aborted;           // windows whose pipeline stopped at a moved candidate mask: gh_spin takes their remaining paths
+    std::vector<std::pair<int, int>> later;     // (window, paths done): windows gh_spin finishes on their own streams behind the batch's copy
     b->pipe_windows = 0;
     phase("descriptors");
     if (pipe_nt) {
@@ -2785,6 +2813,15 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
 #endif
             }
         }
+        // What the pipeline left untouched.  A FEW such windows (a deletion column in one window of a batch of narrow ones) go the
+        // single window's way, each on its own stream from a few host threads -- the segment-parallel / candidate-pool spins (mixed
+        // radix at five lags): 25-37k haplotypes/s where the batched serial walkers, one wavefront per window, give 16k for eight
+        // windows; from four dozen on the batched launches over all of them.
+        if (!rest.empty() && batch_cut >= 0 && (int)rest.size() <= batch_cut && (seg_ok(b->hs[0]->wmode, b->L) || cw_ok(b->hs[0]->wmode, b->L))) {
+            for (int w = 0; w < n; w++)
+                if (hs[w].pipe_status == PIPE_NOT_STARTED) later.emplace_back(w, 0);
+            rest.clear();
+        }
         if (!rest.empty()) {
             if ((rc = batch_run_launches(b, rest, max_paths, min_remove))) return rc;
             if ((rc = fetch_states())) return rc;
@@ -2807,16 +2844,11 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         if (kept) b->hs[w]->tband_epoch = b->hs[w]->band_epoch;       // (the pipeline's sweep wrote both)
         b->hs[w]->lt_inc_path = nullptr;       // the batch reweighted many paths and maintains no walker tables: rebuild in full
     }
-    for (int w : aborted) {
-        // paths 0 .. n_done-1 are complete and reweighted; marginals and table are rebuilt from the tensor (dirty flags above)
-        const int nd = hs[w].n_done;
-        int n2 = 0, hole2 = 0;
-        if (nd < max_paths &&
-            (rc = gh_spin(b->hs[w], max_paths - nd, min_remove, paths_out + n1 * ((size_t)max_paths * w + nd), recs + (size_t)max_paths * w + nd, &n2, &hole2)))
-            return rc;
-        n_out[w] = nd + n2;
-        hole_at[w] = hole2;
-    }
+    // aborted windows: paths 0 .. n_done-1 are complete and reweighted; marginals and table are rebuilt from the tensor (dirty flags
+    // above).  In a deep spin many windows stop once counts reach zero: they, and the few the pipeline did not take, are finished
+    // side by side (one after the other on the calling thread they were the tail of the batch)
+    for (int w : aborted) later.emplace_back(w, hs[w].n_done);
+    if ((rc = batch_spin_on_streams(b, later, max_paths, min_remove, paths_out, recs, n_out, hole_at))) return rc;
     b->pipe_aborted = (int)aborted.size();
     return GH_OK;
 }

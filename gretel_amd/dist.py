@@ -151,7 +151,8 @@ class ResultExchange:
     default process group: the caller must not run another collective while submissions are outstanding -- drain() first, as
     bench.py does in front of its barrier -- or pass `group=` (torch.distributed.new_group) to give the exchange its own;
     (3) a submission that does not complete within `timeout_s` (a peer whose worker raised never enters the collective)
-    raises instead of blocking forever."""
+    raises instead of blocking forever -- the submission stays queued (its slot is not handed out again), the exchange refuses
+    further use, and close() returns without waiting for the stuck worker."""
 
     NREC = 5
 
@@ -186,6 +187,7 @@ class ResultExchange:
         self.side = torch.cuda.Stream(device=device) if (self.cuda and self.active) else None
         self.next_slot = 0
         self.queue = []                 # submitted, not yet collected: (slot index, n, hole_at)
+        self.broken = False             # a gather timed out: a slot may be stuck inside the collective for good
         self._thread = None
         if self.active:
             self._jobs = queue_mod.Queue()
@@ -201,6 +203,8 @@ class ResultExchange:
     def buffers(self):
         """(paths, recs) views of the slot the next submit() sends: hand them to Hansel.spin(out_paths=, out_recs=)."""
         sl = self.slots[self.next_slot]
+        if self.broken:
+            raise RuntimeError("ResultExchange: an earlier gather timed out; the exchange is closed to further use")
         if any(q[0] == self.next_slot for q in self.queue):
             raise RuntimeError("ResultExchange: slot %d still holds a submission that was never collected -- call collect() (or "
                                "drain()) once per submit(); handing the slot out again would lose that step's records" % self.next_slot)
@@ -208,6 +212,8 @@ class ResultExchange:
         return p, r
 
     def submit(self, n, hole_at):
+        if self.broken:
+            raise RuntimeError("ResultExchange: an earlier gather timed out; the exchange is closed to further use")
         si = self.next_slot
         sl = self.slots[si]
         self.next_slot = (si + 1) % len(self.slots)
@@ -246,21 +252,33 @@ class ResultExchange:
 
     def close(self):
         if self.active and self._thread is not None:
-            self.drain()
-            self._jobs.put(None)
-            self._thread.join()
-            self._thread = None
+            try:
+                if not self.broken:
+                    self.drain()
+            finally:
+                self._jobs.put(None)
+                # (a worker stuck inside a collective that a failed peer never entered cannot be joined: the thread is a daemon,
+                # the timeout has already been reported once -- do not block the caller's cleanup on it a second time)
+                self._thread.join(None if not self.broken else 1.0)
+                self._thread = None
 
     def _finish(self, q, keep=True):
         si, n, hole = q
         sl = self.slots[si]
         if self.active:
+            if self.broken:
+                raise RuntimeError("ResultExchange: an earlier gather timed out; the exchange is closed to further use")
             if not sl["done"].wait(self.timeout_s):
+                # the submission STAYS in the queue (its slot may still be inside the collective: buffers() must not hand it out)
+                # and the exchange is closed to further use: buffers() / submit() / collect() raise, close() does not wait
+                self.broken = True
                 raise TimeoutError("ResultExchange: a gather did not complete within %.0f s (a peer that failed never enters the "
                                    "collective)" % self.timeout_s)
             if sl.get("error") is not None:
                 exc, sl["error"] = sl["error"], None
+                self.queue.remove(q)
                 raise exc
+        self.queue.remove(q)
         if not keep or (self.active and self.rank != 0):
             return None
         if not self.active:
@@ -280,10 +298,10 @@ class ResultExchange:
         ranks other than 0, and when nothing is outstanding."""
         if not self.queue:
             return None
-        return self._finish(self.queue.pop(0))
+        return self._finish(self.queue[0])          # (popped by _finish once its gather is known to have completed)
 
     def drain(self):
         last = None
         while self.queue:
-            last = self._finish(self.queue.pop(0))
+            last = self._finish(self.queue[0])
         return last

@@ -419,6 +419,32 @@ class Hansel:
             check(self._lib.gh_sync(self._h))
 
 
+class _PinnedBlock:
+    """One gh_host_alloc block; freed (gh_host_free) when the last numpy array made over it has gone."""
+
+    def __init__(self, lib, nbytes):
+        self._lib = lib
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib.gh_host_alloc(self.nbytes, C.byref(p)))
+        self._p = p
+
+    def array(self, dtype, count):
+        dtype = np.dtype(dtype)
+        assert count * dtype.itemsize <= self.nbytes
+        raw = (C.c_uint8 * max(1, count * dtype.itemsize)).from_address(self._p.value)
+        raw._gh_owner = self            # numpy keeps `raw` as the array's base, `raw` keeps the block
+        return np.frombuffer(raw, dtype=dtype, count=count)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_p", None):
+                self._lib.gh_host_free(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
 class HanselBatch:
     """Many windows of one shape recovered together (gh_batch_*): every kernel of the spin loop
     (gretel/cmd.py:148-179) is launched over all windows at once, one path-extension workgroup per
@@ -466,30 +492,27 @@ class HanselBatch:
 
     def _host_buffers(self, n, max_paths, n1):
         """Page-locked result buffers, kept from call to call (gh_host_alloc): the copies of 256 windows x 100 paths run at the
-        link's rate and no 256 MB array is faulted in per call."""
+        link's rate and no 256 MB array is faulted in per call.  Every block is owned by a _PinnedBlock that the arrays made over
+        it keep alive: a view handed out by spin(copy=False) stays valid memory for as long as anything refers to it, also when
+        the batch has moved on to buffers of another shape or is gone (they used to point at freed pinned memory)."""
         key = (n, max_paths, n1)
         if getattr(self, "_hb_key", None) != key:
             self._free_host_buffers()
             sizes = (n * max_paths * n1, n * max_paths * 5 * 8)
-            ptrs = []
-            for sz in sizes:
-                p = C.c_void_p()
-                check(self._lib.gh_host_alloc(max(1, sz), C.byref(p)))
-                ptrs.append(p)
-            self._hb_ptrs = ptrs
-            self._hb_paths = np.frombuffer((C.c_uint8 * sizes[0]).from_address(ptrs[0].value), dtype=np.uint8).reshape(n, max_paths, n1)
-            self._hb_recs = np.frombuffer((C.c_double * (sizes[1] // 8)).from_address(ptrs[1].value), dtype=np.float64).reshape(n, max_paths, 5)
+            blocks = [_PinnedBlock(self._lib, max(1, sz)) for sz in sizes]
+            self._hb_paths = blocks[0].array(np.uint8, sizes[0]).reshape(n, max_paths, n1)
+            self._hb_recs = blocks[1].array(np.float64, sizes[1] // 8).reshape(n, max_paths, 5)
             self._hb_key = key
         return self._hb_paths, self._hb_recs
 
     def _free_host_buffers(self):
-        for p in getattr(self, "_hb_ptrs", []):
-            self._lib.gh_host_free(p)
-        self._hb_ptrs, self._hb_key, self._hb_paths, self._hb_recs = [], None, None, None
+        # (the blocks free themselves when the last array over them is gone)
+        self._hb_key, self._hb_paths, self._hb_recs = None, None, None
 
     def spin(self, max_paths=100, min_remove=0.01, copy=True):
-        """copy=False: the returned arrays are views of the batch's page-locked buffers, valid until the next spin() of this
-        batch (no 256 MB copy on the host); copy=True (default): every window gets its own arrays."""
+        """copy=False: the returned arrays are views of the batch's page-locked buffers (no 256 MB copy on the host); their
+        CONTENTS stand until the next spin() of this batch overwrites them, the memory itself for as long as a view refers to it.
+        copy=True (default): every window gets its own arrays."""
         n = len(self.hansels)
         n1 = self.hansels[0].n + 1
         paths, recs = self._host_buffers(n, max_paths, n1)

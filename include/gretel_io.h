@@ -78,7 +78,7 @@ int gio_support_table_from_bam_depth(const char *bam_path, const char *contig, i
 void gio_table_free(gio_table *t);
 /* The decoder keeps its large working buffers (the inflated window, the reads' entries, keys and characters: about 130 bytes per
  * read) from one call to the next instead of unmapping them before it returns and faulting them in again -- a third of a decode's
- * time.  GIO_KEEP_MB in the environment bounds what is kept (default 1024, 0: nothing); this frees it. */
+ * time.  GIO_KEEP_MB in the environment bounds what is kept (default 512, 0: nothing); this frees it. */
 void gio_release_buffers(void);
 
 /* pysam's bam.count_coverage(contig, start0, stop, quality_threshold=0, read_callback='nofilter') as

@@ -59,7 +59,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_c2 -o kt -- pyth
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 $Q > $out/pmc_$c.json 2> $out/pmc_$c.err
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_c5_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --config C5 --paths 100 --steps 1 --warmup 0 $Q > $out/pmc_c5_$c.json 2> $out/pmc_c5_$c.err
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_b256_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --batch 256 --paths 20 --steps 1 --warmup 0 > $out/pmc_b256_$c.json 2> $out/pmc_b256_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_b256_$c -o pmc -- python3 $GRAFT_REPO_ROOT/bench.py --batch 256 --paths 100 --steps 1 --warmup 0 > $out/pmc_b256_$c.json 2> $out/pmc_b256_$c.err
 done
 # what travels back is capped at 64 MiB: the per-dispatch traces are not needed for the summaries (kernel statistics, counter sums)
 find $out -name "*_kernel_trace.csv" -delete

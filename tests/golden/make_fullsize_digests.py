@@ -16,6 +16,13 @@ Cases:
     C3 seeds 0..7 x 100 (C4's eight windows)
     C3 seed 0 x 100 under the 20 specs of bench.py's spec_matrix ({A..E} x marginal term x {f32, f64})
     the wide_window_sparse window of bench.py (deletions at 1 % of the positions) x 100
+Round 6 (VERDICT r5 "offline-closable gaps": no digest covered deletions or L >= 6 outside C5):
+    the lag-sweep window (10k SNPs, reads of ~10 SNPs, band 25) with deletions at 1 % of the positions at L = 3, 4, 6, 7, 8, 11,
+      16, 22 x 100 (five-symbol enumeration, candidate pools over the symbols A C G T -: k_cwalk<L, 5>, k_cwalkg<5>), at L = 6, 8
+      also under E + marginal term
+    the same window with 5 % of the BASES read as deletions (nearly every position offers five candidates) at L = 4, 6, 8, 12 x 50
+    C3 with 5 % of the bases read as deletions (bench.py's wide_window: 5^5 states per target) x 100, also under E + marginal term
+    the lag-sweep window without deletions at L = 33, 40, 48 x 50 (k_cwalkg: states as bytes)
 
 Run from the repo root:   python tests/golden/make_fullsize_digests.py [--jobs 6] [--only NAME_SUBSTRING]
 Writes tests/golden/fullsize_digests.json (one entry per case, keyed by name).  Inputs come from the seeded generator
@@ -60,17 +67,39 @@ def cases():
         out.append(("C3/seed0/%s/100" % spec_name(kw), dict(config="C3", seed=0, paths=100, spec=kw, table=None)))
     out.append(("C3/seed0/sparse_deletions/default/100",
                 dict(config="C3", seed=0, paths=100, spec={}, table="sparse_deletions")))
+    # round 6: deletions beyond L = 5, dense deletions, byte states.  `L` overrides what the fill gives (util.py:333), as
+    # scratch/l_sweep.py does: the same window at every lag count
+    pub = dict(cond_mode="E", marginal_term=True)       # the published method's form (README.md:79-94)
+    for L in (3, 4, 6, 7, 8, 11, 16, 22):
+        out.append(("sweep/seed5/sparse_deletions/L=%d/100" % L, dict(config="sweep", seed=5, paths=100, spec={}, table="sparse_deletions", L=L)))
+    for L in (6, 8):
+        out.append(("sweep/seed5/sparse_deletions/L=%d/%s/100" % (L, spec_name(pub)),
+                    dict(config="sweep", seed=5, paths=100, spec=pub, table="sparse_deletions", L=L)))
+    for L in (4, 6, 8, 12):
+        out.append(("sweep/seed5/dense_deletions/L=%d/50" % L, dict(config="sweep", seed=5, paths=50, spec={}, table="dense_deletions", L=L)))
+    out.append(("C3/seed0/dense_deletions/default/100", dict(config="C3", seed=0, paths=100, spec={}, table="dense_deletions")))
+    out.append(("C3/seed0/dense_deletions/%s/100" % spec_name(pub), dict(config="C3", seed=0, paths=100, spec=pub, table="dense_deletions")))
+    for L in (33, 40, 48):
+        out.append(("sweep/seed5/none/L=%d/50" % L, dict(config="sweep", seed=5, paths=50, spec={}, table=None, L=L)))
     return out
 
 
 def make_table(case):
     """The input of a case; tests/test_gpu_digests.py calls this very function."""
-    from gretel_amd.synth import make_config, sprinkle_deletions
-    t = make_config(case["config"], seed=case["seed"])
+    from gretel_amd.synth import make_config, make_support_table, sprinkle_deletions
+    if case["config"] == "sweep":                       # scratch/l_sweep.py's window: long-read-style reads, band 25
+        t = make_support_table(10000, 150000, k=None, seed=case["seed"], n_haps=8, err=0.0, k_max=26)
+    else:
+        t = make_config(case["config"], seed=case["seed"])
     if case.get("table") == "sparse_deletions":         # bench.py's wide_window_sparse window
         t = copy.copy(t)
         t.bases = t.bases.copy()
         sprinkle_deletions(t, 0.01, seed=4321)
+    elif case.get("table") == "dense_deletions":        # bench.py's wide_window: 5 % of the BASES read as '-'
+        t = copy.copy(t)
+        bw = t.bases.copy()
+        bw[np.random.default_rng(12345).random(len(bw)) < 0.05] = ord('-')
+        t.bases = bw
     elif case.get("table"):
         raise ValueError(case["table"])
     return t
@@ -97,6 +126,8 @@ def run_case(item):
     t = make_table(case)
     o = COracle(t.n_snps, t.band, **case["spec"])
     stats = o.fill(t)
+    if case.get("L"):
+        o.L = case["L"]
     res = o.spin(case["paths"])
     d = digest_result(res, o.export_band())
     d.update(case=case, fill_stats=[int(x) for x in stats], L=int(o.L), n_snps=int(t.n_snps), band=int(t.band),
@@ -116,7 +147,7 @@ def main():
             out = json.load(f)["cases"]
     import multiprocessing as mp
     # longest first (C5 x 1000 is five minutes of one core)
-    todo.sort(key=lambda c: -(c[1]["paths"] * (25 if c[1]["config"] == "C5" else 1)))
+    todo.sort(key=lambda c: -(c[1]["paths"] * (25 if c[1]["config"] == "C5" else 1) * max(1, c[1].get("L", 5) // 5)))
     with mp.get_context("spawn").Pool(args.jobs) as pool:
         for name, d in pool.imap_unordered(run_case, todo):
             out[name] = d

@@ -269,3 +269,52 @@ def test_the_decoders_kept_buffers_change_nothing(tmp_path, monkeypatch):
         if round_ == 1:
             bamio.native_release_buffers()
     assert np.array_equal(first[0], t.rank) and np.array_equal(first[1], t.off) and np.array_equal(first[2], t.bases)
+
+
+def test_a_forked_child_decodes_with_a_pool_of_its_own(tmp_path):
+    """the decoder's thread pool and buffer cache are process-wide singletons guarded by mutexes.  A child forked while the
+    parent has decoded (its workers exist, its cache holds blocks) gets fresh ones (pthread_atfork): its decode returns, with the
+    parent's answer -- it used to depend on no thread holding a pool mutex at the moment of the fork."""
+    import os
+    import threading
+    from gretel_amd import bamio, util
+    from gretel_amd.synth import make_support_table
+    t = make_support_table(1500, 60000, k=6, seed=3, n_haps=5, err=0.01)
+    bam, vcf = str(tmp_path / "f.bam"), str(tmp_path / "f.vcf.gz")
+    contig, start, end = bamio.synth_to_files(t, bam, vcf)
+    v = util.process_vcf(vcf, contig, start, end)
+    want = [np.array(a) for a in util.support_table_from_bam(bam, contig, start, end, v)]
+    # a thread of the parent keeps decoding (and so keeps taking the pool's mutexes) while the children are forked
+    stop = threading.Event()
+
+    def churn():
+        while not stop.is_set():
+            util.support_table_from_bam(bam, contig, start, end, v)
+
+    th = threading.Thread(target=churn, daemon=True)
+    th.start()
+    try:
+        for attempt in range(4):
+            r, w = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                code = 3
+                try:
+                    os.close(r)
+                    got = util.support_table_from_bam(bam, contig, start, end, v)
+                    code = 0 if all(np.array_equal(a, b) for a, b in zip(want, got)) else 2
+                    os.write(w, b"k")
+                finally:
+                    os._exit(code)
+            os.close(w)
+            import select
+            ready, _, _ = select.select([r], [], [], 60.0)
+            if not ready:
+                os.kill(pid, 9)
+            _, status = os.waitpid(pid, 0)
+            os.close(r)
+            assert ready, "the forked child's decode never returned"
+            assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    finally:
+        stop.set()
+        th.join(30.0)

@@ -1,7 +1,8 @@
 """Full-depth parity against committed digests (tests/golden/fullsize_digests.json, written by the C oracle on libm in the
 build container: tests/golden/make_fullsize_digests.py).  Every case goes through the HIP path (C ABI) at its full depth --
 C5 x 1000 paths, C5 x 100 under C and E + marginal term + f64, C3 seeds 0..7 x 100 (C4's windows), C3 x 100 under the 20
-specs of bench.py's spec_matrix, the sparse-deletion window x 100 -- and is compared path by path: the sha256 of the path
+specs of bench.py's spec_matrix, the sparse-deletion window x 100; round 6: deletion columns at L = 3..22, dense deletions at
+L = 4..12, states as bytes at L = 33, 40, 48 -- and is compared path by path: the sha256 of the path
 bytes, hp_current / hp_original / ratio bit for bit, the removed mass to 1e-10 relative, and the sha256 of the reweighted
 tensor behind the last path.  The oracle is not needed on the GPU box for these (reference: gretel/gretel.py:79-98,143-189,
 gretel/cmd.py:148-179)."""
@@ -48,6 +49,9 @@ def test_full_depth_against_the_oracles_digests(name):
     assert (t.n_snps, t.band) == (want["n_snps"], want["band"])
     h = Hansel(t.n_snps, band=t.band, **case["spec"])
     st = h.fill_from_support(t.rank, t.off, t.bases)
+    if case.get("L"):
+        assert [int(x) for x in st] == want["fill_stats"]
+        h.L = case["L"]             # (the lag count of the case, not the fill's: gretel/util.py:333 gives one per window)
     assert [int(x) for x in st] == want["fill_stats"] and h.L == want["L"]
     res = h.spin(case["paths"])
     got = mk.digest_result(res, h.export_band())
@@ -130,10 +134,35 @@ def test_the_window_pipeline_at_full_depth_c5(name, monkeypatch):
     _compare(mk.digest_result(r, h.export_band()), want, name + " through the pipeline")
 
 
+@pytest.mark.parametrize("name", ["C3/seed0/sparse_deletions/default/100", "C3/seed0/dense_deletions/default/100",
+                                  "sweep/seed5/sparse_deletions/L=4/100", "sweep/seed5/sparse_deletions/L=6/100",
+                                  "sweep/seed5/sparse_deletions/L=8/cond_mode=E-marginal_term=True/100", "sweep/seed5/dense_deletions/L=8/50"])
+def test_batched_recovery_of_windows_with_deletions_at_full_depth(name, monkeypatch):
+    """Windows with five-candidate positions as a batch of one (gh_batch_spin): whatever flow the batch gives them -- the
+    pipeline where it carries them, the batched launches over the five-symbol table where it does not -- against the digest."""
+    from gretel_amd.hansel import Hansel, HanselBatch
+    monkeypatch.setenv("GH_PIPE_MIN", "1")
+    want = DIGESTS[name]
+    case = want["case"]
+    t = _table(case)
+    h = Hansel(t.n_snps, band=t.band, **case["spec"])
+    h.fill_from_support(t.rank, t.off, t.bases)
+    if case.get("L"):
+        h.L = case["L"]
+    b = HanselBatch([h])
+    r = b.spin(case["paths"])[0]
+    _compare(mk.digest_result(r, h.export_band()), want, name + " as a batch")
+
+
 def test_the_digest_file_covers_what_it_says():
     names = set(DIGESTS)
     assert "C5/seed0/default/1000" in names and DIGESTS["C5/seed0/default/1000"]["n"] == 1000
     assert all("C3/seed%d/default/100" % s in names for s in range(8))
     assert sum(1 for k in names if k.startswith("C3/seed0/cond_mode=")) == 19      # + the default spec = spec_matrix's 20
     assert "C3/seed0/sparse_deletions/default/100" in names
+    # round 6: deletions beyond five lags, dense deletions, states as bytes
+    assert all("sweep/seed5/sparse_deletions/L=%d/100" % L in names for L in (3, 4, 6, 7, 8, 11, 16, 22))
+    assert all("sweep/seed5/dense_deletions/L=%d/50" % L in names for L in (4, 6, 8, 12))
+    assert all("sweep/seed5/none/L=%d/50" % L in names for L in (33, 40, 48))
+    assert {"C3/seed0/dense_deletions/default/100", "C3/seed0/dense_deletions/cond_mode=E-marginal_term=True/100"} <= names
     assert {c[0] for c in mk.cases()} == names

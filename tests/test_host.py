@@ -120,3 +120,71 @@ def test_the_builds_hash_covers_kernel_sources_only():
             stale.append(name)
     if stale:       # (while kernels are being worked on this is the normal state: bench.py then leaves `traffic` null and says why)
         pytest.skip("the counter summaries %s are of another build: run profiles/collect.sh before quoting them" % ", ".join(stale))
+
+
+def test_result_exchange_after_a_timeout_is_closed_and_close_returns():
+    """a gather that never completes (a peer that failed never enters the collective) -- collect() raises, the slot is
+    NOT handed out again while the worker may still be inside the collective, and close() in a `finally` does not hang."""
+    import threading
+    import time
+    import pytest
+    import torch
+    from gretel_amd.dist import ResultExchange
+    ex = ResultExchange(n_snps=10, max_paths=3, device=torch.device("cpu"), world=1, rank=0, force=False)
+    # a stuck worker by hand (no process group needed): the exchange believes it is active and its worker never signals
+    ex.active, ex.timeout_s = True, 0.2
+    import queue as queue_mod
+    ex._jobs = queue_mod.Queue()
+    release = threading.Event()
+    ex._thread = threading.Thread(target=lambda: release.wait(30.0), daemon=True)
+    ex._thread.start()
+    ex.buffers()
+    ex.submit(1, 0)
+    with pytest.raises(TimeoutError):
+        ex.collect()
+    assert ex.broken and len(ex.queue) == 1            # still tracked: its slot is not free
+    for call in (ex.buffers, ex.collect, lambda: ex.submit(1, 0)):
+        with pytest.raises(RuntimeError, match="timed out"):
+            call()
+    t0 = time.time()
+    ex.close()                                          # (the worker is still blocked)
+    assert time.time() - t0 < 5.0
+    release.set()
+
+
+def test_pinned_block_lives_as_long_as_its_views():
+    """HanselBatch.spin(copy=False) hands out views of page-locked memory; the block must outlive the batch for as long
+    as a view refers to it (it used to be freed with the batch or on a change of shape: use after free)."""
+    import ctypes as C
+    import gc
+    from gretel_amd.hansel import _PinnedBlock
+
+    class FakeLib:
+        def __init__(self):
+            self.live = {}
+            self.libc = C.CDLL(None)
+            self.libc.malloc.restype = C.c_void_p
+            self.libc.free.argtypes = [C.c_void_p]
+
+        def gh_host_alloc(self, n, out):
+            p = self.libc.malloc(C.c_size_t(n))
+            C.cast(out, C.POINTER(C.c_void_p))[0] = p
+            self.live[p] = n
+            return 0
+
+        def gh_host_free(self, p):
+            self.live.pop(p.value)
+            self.libc.free(p)
+            return 0
+
+    lib = FakeLib()
+    blk = _PinnedBlock(lib, 64)
+    a = blk.array(np.uint8, 64).reshape(4, 16)
+    view = a[1, :4]
+    a[:] = 7
+    del blk, a
+    gc.collect()
+    assert len(lib.live) == 1 and int(view.sum()) == 28    # the view keeps the block
+    del view
+    gc.collect()
+    assert not lib.live
