@@ -94,6 +94,8 @@ struct gh_handle {
     double *pipe_gp;              // ... and its compact table, (N+LT_PAD) sources of L x 128 bytes (wpipe.hpp: pipe_gp_piece)
     size_t pipe_gp_bytes;
     double *pipe_lm;              // ... and, with the marginal term, the candidates' log-marginals by rank [N+2][4]
+    double *pipe_gw;              // ... and, for a window with a few five-candidate positions, their side table + the chunk directory (wpipe.hpp)
+    size_t pipe_gw_bytes;
     bool need_rinfo;              // ... kept only where somebody reads it: with the marginal term (k_seg, k_cwalk add it in front of x1) and
                                   // for the three-launch spins (GH_FUSE at creation); nullptr goes to the kernels otherwise (C5: k_rw is bound by its stores)
     symmap sm;                    // compact index <-> symbol (gh_config.cand_order)
@@ -330,7 +332,7 @@ static void free_handle(gh_handle *h)
     hipSetDevice(h->dev);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->band); hipFree(h->tband); hipFree(h->cnt); hipFree(h->marg); hipFree(h->minfo);
-    hipFree(h->pipe_pk); hipFree(h->pipe_gp); hipFree(h->pipe_lm);
+    hipFree(h->pipe_pk); hipFree(h->pipe_gp); hipFree(h->pipe_lm); hipFree(h->pipe_gw);
     hipFree(h->nvalid); hipFree(h->cmask); hipFree(h->rinfo); hipFree(h->lt); hipFree(h->ht); hipFree(h->yt); hipFree(h->dstate); hipFree(h->partial);
     hipFree(h->spin_paths); hipFree(h->spin_recs);
     hipFree(h->d_path); hipFree(h->d_rw_path); hipFree(h->d_rec);
@@ -387,7 +389,7 @@ extern "C" int gh_create(const gh_config *cfg, gh_t **out)
     memset(h->cfg.cand_order, 0, sizeof h->cfg.cand_order);
     memcpy(h->cfg.cand_order, order, 5);
     h->sm = make_symmap(order);
-    h->rinfo = nullptr; h->pipe_pk = nullptr; h->pipe_gp = nullptr; h->pipe_gp_bytes = 0; h->pipe_lm = nullptr; h->lt_baked = false; h->ht_stale = false;
+    h->rinfo = nullptr; h->pipe_pk = nullptr; h->pipe_gp = nullptr; h->pipe_gp_bytes = 0; h->pipe_lm = nullptr; h->pipe_gw = nullptr; h->pipe_gw_bytes = 0; h->lt_baked = false; h->ht_stale = false;
     h->need_rinfo = cfg->marginal_term != 0 || (getenv("GH_FUSE") && atoi(getenv("GH_FUSE")) >= 1);
     h->dev = dev;
     h->N = cfg->n_snps;
@@ -2428,6 +2430,29 @@ static hipError_t launch_wpipe(int L, int nt, const pipe_params &P, const win_de
 #undef GH_PIPE_CASE
     return hipErrorInvalidValue;
 }
+// ... and for windows with a few five-candidate positions (k_wpipe<.., WIDE = true>, wpipe.hpp): the default thread counts only
+template <typename T, int LC, int NT>
+static hipError_t launch_wpipe_w_t(const pipe_params &P, const win_desc *d_wd, int n, size_t lds, hipStream_t st)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)k_wpipe<T, LC, NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_wpipe<T, LC, NT, true>), dim3(n), dim3(NT), lds, st, P, d_wd);
+    return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_wpipe_w(int L, int nt, const pipe_params &P, const win_desc *d_wd, int n, size_t lds, hipStream_t st)
+{
+#define GH_PIPE_CASE(l, t) case l: return launch_wpipe_w_t<T, l, t>(P, d_wd, n, lds, st);
+    if (nt == 1024) {
+        switch (L) { GH_PIPE_CASE(2, 1024) GH_PIPE_CASE(3, 1024) GH_PIPE_CASE(4, 1024) GH_PIPE_CASE(5, 1024) GH_PIPE_CASE(6, 1024) }
+    } else if (nt == 768) {
+        switch (L) { GH_PIPE_CASE(7, 768) GH_PIPE_CASE(8, 768) GH_PIPE_CASE(9, 768) GH_PIPE_CASE(10, 768) }
+    }
+#undef GH_PIPE_CASE
+    return hipErrorInvalidValue;
+}
+static bool pipe_wide_instantiated(int L, int nt) { return (nt == 1024 && L >= 2 && L <= 6) || (nt == 768 && L >= 7 && L <= 10); }
+
 static bool pipe_instantiated(int L, int nt)
 {
     if (nt == 1024) return L >= 2 && L <= 6;
@@ -2634,6 +2659,30 @@ static int batch_run_launches(gh_batch *b, const std::vector<win_desc> &wd, int 
     return GH_OK;
 }
 
+// the windows the narrow pipeline left untouched because a position offers five candidates: the WIDE pipeline (wpipe.hpp) over them --
+// marginals, snapshot and table stand (batch_run_pipe's preamble ran over every window); a window it cannot take either (too many such
+// positions) keeps PIPE_NOT_STARTED
+static int batch_run_pipe_wide(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, int nt)
+{
+    const int n = (int)wd.size();
+    if (n == 0) return GH_OK;
+    gh_handle *h0 = b->hs[0];
+    const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
+    const int N = b->N, W = b->W, L = b->L;
+    HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+    const int nr = pipe_sweep_threads(nt);
+    pipe_params P;
+    P.N = N; P.W = W; P.L = L; P.mt = h0->cfg.marginal_term ? 1 : 0; P.col = (h0->cfg.cond_mode == GH_COND_C || h0->cfg.cond_mode == GH_COND_E) ? 1 : 0;
+    P.C = pipe_chunk_w(N, L, nr, f64 ? 8 : 4, P.mt); P.max_paths = max_paths; P.cond_mode = h0->cfg.cond_mode;
+    P.synth = getenv("GH_PIPE_SYNTH") ? (atoi(getenv("GH_PIPE_SYNTH")) != 0) : 1;
+    P.offer_zero = h0->cfg.offer_zero; P.prof = 0; P.min_remove = min_remove; P.sm = h0->sm;
+    const size_t lds = pipe_lds_bytes_w(N, L, P.C, nr, f64 ? 8 : 4, P.mt);
+    const hipError_t le = f64 ? launch_wpipe_w<double>(L, nt, P, b->d_wd, n, lds, b->stream) : launch_wpipe_w<float>(L, nt, P, b->d_wd, n, lds, b->stream);
+    if (le != hipSuccess) return fail(GH_ERR_HIP, "gh_batch_spin: the wide pipeline launch failed (L=%d, %d threads, %zu bytes of LDS): %s", L, nt, lds, hipGetErrorString(le));
+    HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
+    return GH_OK;
+}
+
 // gh_spin over some windows of a batch from a few host threads, every window on its own stream (the windows' kernel chains
 // interleave on the GPU).  A job is (window, paths it already has): the spin writes the window's remaining paths behind them.
 static int batch_spin_on_streams(gh_batch *b, const std::vector<std::pair<int, int>> &jobs, int max_paths, double min_remove,
@@ -2768,6 +2817,8 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         wd[w].gp = h->pipe_gp;
         wd[w].lmr = h->pipe_lm;
         wd[w].tband = h->tband;
+        wd[w].gw = h->pipe_gw;
+        wd[w].wdir = h->pipe_gw ? reinterpret_cast<int *>(h->pipe_gw + (size_t)PIPE_WMAX * pipe_wrec_doubles(b->L)) : nullptr;
         h->have_orig = true;
     }
     std::vector<dev_state> hs(n);
@@ -2813,7 +2864,42 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
 #endif
             }
         }
-        // What the pipeline left untouched.  A FEW such windows (a deletion column in one window of a batch of narrow ones) go the
+        // What the narrow pipeline left untouched: windows in which a position offers five candidates.  The WIDE pipeline takes those
+        // whose five-candidate positions are few (GH_PIPE_WIDE=0: not)
+        {
+            gh_handle *h0 = b->hs[0];
+            const bool wide_on = !(getenv("GH_PIPE_WIDE") && atoi(getenv("GH_PIPE_WIDE")) == 0);
+            if (!rest.empty() && wide_on && pipe_wide_instantiated(b->L, pipe_nt) && !h0->cfg.offer_zero && b->N < 65536 &&
+                pipe_chunk_w(b->N, b->L, pipe_sweep_threads(pipe_nt), h0->cfg.storage == GH_STORAGE_F64 ? 8 : 4, h0->cfg.marginal_term) > 0) {
+                std::vector<win_desc> wrest;
+                const size_t need = pipe_gw_bytes(b->N, b->L);
+                for (int w = 0; w < n; w++) {
+                    if (hs[w].pipe_status != PIPE_NOT_STARTED || hs[w].stop || hs[w].ranked != 0 || hs[w].first_hole <= b->N) continue;
+                    gh_handle *h = b->hs[w];
+                    if (h->pipe_gw_bytes < need) {
+                        hipFree(h->pipe_gw); h->pipe_gw = nullptr; h->pipe_gw_bytes = 0;
+                        HIPCHK(hipMalloc((void **)&h->pipe_gw, need));
+                        h->pipe_gw_bytes = need;
+                    }
+                    wd[w].gw = h->pipe_gw;
+                    wd[w].wdir = reinterpret_cast<int *>(h->pipe_gw + (size_t)PIPE_WMAX * pipe_wrec_doubles(b->L));
+                    wrest.push_back(wd[w]);
+                }
+                if (!wrest.empty()) {
+                    if ((rc = batch_run_pipe_wide(b, wrest, max_paths, min_remove, pipe_nt))) return rc;
+                    phase("wide pipeline kernel");
+                    if ((rc = fetch_states())) return rc;
+                    rest.clear();
+                    for (int w = 0; w < n; w++) {
+                        if (hs[w].pipe_status == PIPE_NOT_STARTED) rest.push_back(wd[w]);
+                        else if (hs[w].pipe_status == PIPE_ABORTED) { if (std::find(aborted.begin(), aborted.end(), w) == aborted.end()) aborted.push_back(w); }
+                        else if (hs[w].pipe_status != PIPE_DONE) return fail(GH_ERR_STATE, "gh_batch_spin: window %d left the wide pipeline in state %d", w, hs[w].pipe_status);
+                    }
+                    b->pipe_windows = n - (int)rest.size();
+                }
+            }
+        }
+        // A FEW such windows (a deletion column in one window of a batch of narrow ones) go the
         // single window's way, each on its own stream from a few host threads -- the segment-parallel / candidate-pool spins (mixed
         // radix at five lags): 25-37k haplotypes/s where the batched serial walkers, one wavefront per window, give 16k for eight
         // windows; from four dozen on the batched launches over all of them.

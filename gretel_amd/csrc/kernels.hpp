@@ -117,6 +117,8 @@ struct win_desc {
     double *gp;             // (N+LT_PAD) sources x L x 128 bytes (pipe_gp_piece) k_wpipe: its own compact copy of the ranked table (prologue)
     double *lmr;            // [N+2][4] k_wpipe with the marginal term: log10 marginal of a position's candidates by rank
     void *tband;            // k_wpipe under the column conditionals: the to-major copy of the band (kept in step)
+    double *gw;             // k_wpipe<.., WIDE>: the side table of the window's five-candidate positions (wpipe.hpp: PIPE_WMAX records)
+    int *wdir;              // ... and, per chunk, the records the chunk can see: first | count << 16
 };
 
 // Band layout: band[i][a][d-1][b] -- position, FROM-symbol, distance, to-symbol.  Everything a path touches at position i

@@ -89,6 +89,11 @@ template <> struct pipe_roles<512> {
                                               0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// windows with a few five-candidate positions (WIDE launches, see below): the side table's geometry
+#define PIPE_WREC 8             /* records per LDS buffer: wide positions among the L + C positions a chunk can see */
+#define PIPE_WMAX 4096          /* wide positions per window (the side table's size) */
+__host__ __device__ constexpr int pipe_wrec_doubles(int L) { return 16 * L + 8; }
+__host__ __device__ constexpr size_t pipe_gw_bytes(int N, int L) { return (size_t)PIPE_WMAX * pipe_wrec_doubles(L) * 8 + ((size_t)N / (L > 0 ? L : 1) + 4) * 4 + 64; }
 // LDS of one workgroup: two table buffers of C + WALK_OV positions, the walker's words, log10's table, the sweepers' partial
 // sums and slots (pipe_group_doubles per lane group), a line of control words, the path (N + 2 bytes)
 // doubles per position of a table buffer: X1 = lag-1 terms [row][column] (16), X2 = lag-2 terms (16), Yr = lags 3..L [row][column][lag],
@@ -134,22 +139,64 @@ __host__ __device__ constexpr size_t pipe_lds_bytes(int N, int L, int C, int nr_
 {
     return 2 * (size_t)(C + WALK_OV) * pipe_pos_doubles(L, mt) * 8 + pipe_fixed_bytes(N, nr_threads, esize);
 }
+// WIDE launches: a buffer holds L more sources in front of the chunk, and behind the two buffers stand the two record areas
+// (PIPE_WREC records each) and, per buffer, one byte per position of the buffer: its record's slot (0xff: not wide)
+#define PIPE_WSLOT_BYTES 128
+__host__ __device__ constexpr size_t pipe_wide_extra_bytes(int L) { return 2 * ((size_t)PIPE_WREC * pipe_wrec_doubles(L) * 8 + PIPE_WSLOT_BYTES); }
+__host__ __device__ constexpr int pipe_chunk_w(int N, int L, int nr_threads, int esize, int mt = 0)
+{
+    const size_t fixed = pipe_fixed_bytes(N, nr_threads, esize) + pipe_wide_extra_bytes(L);
+    if (L < 2 || fixed + 2 * (size_t)(2 * L + WALK_OV) * pipe_pos_doubles(L, mt) * 8 > WALK_LDS_MAX) return 0;
+    long c = (long)((WALK_LDS_MAX - fixed) / (2 * (size_t)pipe_pos_doubles(L, mt) * 8)) - WALK_OV - L;
+    const long cap = nr_threads / 8 - WALK_OV - L;
+    if (c > cap) c = cap;
+    if (c > 60) c = 60;
+    if (c > PIPE_WSLOT_BYTES - WALK_OV - L) c = PIPE_WSLOT_BYTES - WALK_OV - L;
+    c = (c / L) * L;
+    return c >= L ? (int)c : 0;
+}
+__host__ __device__ constexpr size_t pipe_lds_bytes_w(int N, int L, int C, int nr_threads, int esize, int mt = 0)
+{
+    return 2 * (size_t)(C + L + WALK_OV) * pipe_pos_doubles(L, mt) * 8 + pipe_fixed_bytes(N, nr_threads, esize) + pipe_wide_extra_bytes(L);
+}
 
 // What a sweep needs to know about a position and never changes while the pipeline runs (the candidate masks stand, or it stops):
 // one 64-bit word per position, made in the kernel's prologue from cmask / nvalid (win_desc::pk):
 //   bits 0..2   V(p): valid symbols seen              bits 3..5   candidates offered (<= 4 in a ranked window)
 //   bits 6..17  the symbol of the candidate of rank 0..3, 3 bits each (the order get_edge_weights_at offers them in)
 //   bits 18..38 per SYMBOL 0..6 the row of G a path through it rewrites: its rank; 5 for '_' at position 0; 7 = none
+//   WIDE windows (below: a few positions offer five candidates):
+//   bits 39..41 the symbol of the candidate of rank 4          bits 42..57 1 + the position's index among the window's wide positions (0: not wide)
 #define PK_NVALID(w) ((int)((w) & 7u))
 #define PK_NCAND(w) ((int)(((w) >> 3) & 7u))
 #define PK_SYM(w, rb) ((int)(((w) >> (6 + 3 * (rb))) & 7u))
 #define PK_ROW6(w, sym) ((int)(((w) >> (18 + 3 * (sym))) & 7u))
+#define PK_SYM4(w) ((int)(((w) >> 39) & 7u))
+#define PK_WIDX(w) ((int)(((w) >> 42) & 0xffffu) - 1)
+// ---- windows with a FEW five-candidate positions (round 6: k_wpipe<.., WIDE = true>) ----------------------------------------
+// A deletion column here and there (gretel/util.py:178-190: '-' is an ordinary symbol) used to send the whole window to the batched
+// launches of rounds 1-4.  The pipeline's tables stay what they are -- ranks 0..3 of every position, 4 x 4 entries per (source,
+// lag) -- and what a fifth candidate adds lives in a SIDE table, one record per wide position w:
+//     S[l][c]   the row of w's candidate of rank 4 as a SOURCE: lag l + 1, column c = 0..4                      (l = 0..L-1)
+//     T[l][r]   the column of w's candidate of rank 4 as a TARGET: lag l + 1, row r = 0..4 of source w - l - 1
+//     LM4       log10 marginal of that candidate (marginal term)
+// (entry (row 4, column 4) of two wide positions l + 1 apart stands in both records).  The sweepers keep the records current like the
+// table (the entries a reweighted cell feeds, a division and a log10 each), the loaders bring the records of the wide positions a chunk
+// can see into LDS beside the chunk's tables (at most PIPE_WREC per chunk; records are numbered in position order, so they are one
+// contiguous run), and the walker is an exact stepper over five lanes (no speculation: pipe_wide_walker) that takes an entry from the
+// table or from a record by the ranks involved.  Buffers of a WIDE launch hold L more sources in FRONT of the chunk: the stepper
+// reads the rows of the last L picks from the buffer (the narrow walker carries them in registers).
+template <bool WIDE = false>
 __device__ __forceinline__ unsigned long long pipe_pack(uint32_t cmw, int nvalid, int p, symmap sm)
 {
     const uint32_t cm5 = cm5_of_cmask(sm, CM_CAND(cmw));
     int nc = __popc(cm5);
-    if (nc > 4) nc = 4;
+    if (!WIDE && nc > 4) nc = 4;
     unsigned long long w = (unsigned long long)(nvalid & 7) | ((unsigned long long)nc << 3);
+    if (WIDE) {
+        const int b4 = nth_set5(cm5, 4);
+        w |= (unsigned long long)(b4 >= 0 ? vsym(sm, b4) : 0) << 39;
+    }
     for (int rb = 0; rb < 4; rb++) {
         const int b5 = nth_set5(cm5, rb);
         w |= (unsigned long long)(b5 >= 0 ? vsym(sm, b5) : 0) << (6 + 3 * rb);
@@ -233,6 +280,7 @@ __device__ __forceinline__ void pipe_sum_chunk(const lds_v2d *s_bk, int lane, do
     pipe_sum_step<0>(addr, acc, r);
 }
 
+template <bool WIDE = false>
 __device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_path, const unsigned long long *words, const double *s_logtab,
                                                   lds_v2d *s_bk /* 64 pairs of addends */,
                                                   int LC, int j0, int ns, int Nw, int lane, const pipe_book_row &R, double &hp_acc /* lane 0: hp_current, lane 1: hp_original */,
@@ -245,8 +293,9 @@ __device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_
     const int j = j0 + lane + 1;
     if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
-        const int rank = (int)((word >> (2 * (LC - 1 - lane % LC))) & 3ull);
-        const int sym = PK_SYM(R.pk, rank);                     // the symbol of that rank at j (pipe_pack)
+        // (WIDE: the exact stepper leaves three bits per pick -- a rank may be 4)
+        const int rank = WIDE ? (int)((word >> (3 * (LC - 1 - lane % LC))) & 7ull) : (int)((word >> (2 * (LC - 1 - lane % LC))) & 3ull);
+        const int sym = (WIDE && rank == 4) ? PK_SYM4(R.pk) : PK_SYM(R.pk, rank);      // the symbol of that rank at j (pipe_pack)
         const int b5 = a6_of_sym(sm, sym);
         const double cs[8] = {R.c[0].x, R.c[0].y, R.c[1].x, R.c[1].y, R.c[2].x, R.c[2].y, R.c[3].x, R.c[3].y};
         double c = cs[0];
@@ -394,6 +443,84 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
     }
 }
 
+// The walker of a WIDE launch (windows in which a few positions offer five candidates): an exact stepper, no speculation.  Lane
+// b = 0..4 of every group of eight holds candidate b of the target (all eight groups compute the same: the pick comes out of group 0);
+// the term of lag l is the entry (row = the pick made l positions ago, column b) of source t - l, read from the chunk's tables where
+// both ranks are below 4, from the S record of the source where its pick was its fifth candidate, from the T record of the target for
+// lane 4 -- same lag-ascending IEEE additions as everywhere ((lm + x1) + x2 + ...; lags in front of the window are not added:
+// gretel/gretel.py:155, the reference's own loop bound), first-wins arg-max over the lanes (gretel.py:166-174).  Buffer position
+// bi holds source k C - L + bi: target k C + q sits at bi = q + L, its sources at q + L - l.
+template <int LC, bool MT>
+__device__ __forceinline__ void pipe_wide_walker(const double *g0, unsigned long long *words0, const double *wide0, const uint8_t *wslot0,
+                                                 int C, int nchunks, int N, int lane)
+{
+    typedef deep_layout<LC> DL;
+    constexpr int XD = MT ? 36 : 32, YPOS = DL::YPOS, NYP = DL::NYP, RS = XD + YPOS;
+    constexpr int RECD = pipe_wrec_doubles(LC);
+    static_assert(3 * LC < 64, "a group's picks, three bits each, in one word");
+    const int npos = C + LC + WALK_OV;
+    const int b = lane & 7, b3 = lane & 3;
+    const int bc = b < 5 ? b : 4;
+    unsigned long long h3 = 0;                              // the picks so far, three bits each, the latest lowest (uniform)
+    for (int k = 0; k < nchunks; k++) {
+        const double *X = g0 + (size_t)(k & 1) * npos * RS;
+        const double *Yr = X + (size_t)npos * XD;
+        const double *WA = wide0 + (size_t)(k & 1) * PIPE_WREC * RECD;
+        const uint8_t *WS = wslot0 + (k & 1) * PIPE_WSLOT_BYTES;
+        unsigned long long *wk = words0 + (k & 1) * 64;
+        const int ngroups = C / LC;
+        for (int g = 0; g < ngroups; g++) {
+#pragma unroll
+            for (int u = 0; u < LC; u++) {
+                const int q = g * LC + u + 1;               // chunk-local target 1 .. C
+                const int t = k * C + q;
+                unsigned pick = 0;
+                if (t <= N) {
+                    const unsigned slot_t = (unsigned)__builtin_amdgcn_readfirstlane((int)WS[q + LC]);
+                    const bool wide_t = slot_t != 0xffu;
+                    const unsigned st_c = wide_t ? slot_t : 0u;
+                    double x[LC];
+#pragma unroll
+                    for (int l = 1; l <= LC; l++) {
+                        x[l - 1] = 0.0;
+                        if (l <= t) {
+                            const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)((h3 >> (3 * (l - 1))) & 7ull));
+                            const int bi = q + LC - l;
+                            const double *addr;
+                            if (b >= 4) addr = WA + st_c * RECD + 8 * LC + (l - 1) * 8 + r;                  // (column 4: the target's record)
+                            else if (r == 4u) {
+                                const unsigned ss = (unsigned)WS[bi];                                          // (row 4: the source's record)
+                                addr = WA + (ss != 0xffu ? ss : 0u) * RECD + (l - 1) * 8 + bc;
+                            } else if (l <= 2) addr = X + (size_t)bi * XD + (l - 1) * 16 + r * 4 + b3;
+                            else addr = Yr + (size_t)bi * YPOS + (r * 4 + b3) * NYP + (l - 3);
+                            x[l - 1] = *addr;
+                        }
+                    }
+                    double acc = x[0];
+                    if constexpr (MT) {
+                        // the marginal term in front of the first addition: (0.0 + lm) + x1 -- it rides with the lag-1 source's record,
+                        // the fifth candidate's in the target's record
+                        const double lm = b >= 4 ? WA[st_c * RECD + 16 * LC] : X[(size_t)(q + LC - 1) * XD + 32 + b3];
+                        acc = lm + acc;
+                    }
+#pragma unroll
+                    for (int l = 2; l <= LC; l++) acc = (l <= t) ? acc + x[l - 1] : acc;
+                    if (b > 4 || (b == 4 && !wide_t)) acc = -INFINITY;
+                    double m = acc;
+                    m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
+                    m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
+                    m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
+                    const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+                    pick = (unsigned)__builtin_ctz((unsigned)win & 0xffu) & 7u;      // first wins (gretel.py:166-174)
+                }
+                h3 = (h3 << 3) | (unsigned long long)pick;
+            }
+            wk[g] = h3 & ((1ull << (3 * LC)) - 1ull);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
 // seven values by NAME (a row of a cell): selects over the elements of a local array make hipcc keep the array in scratch memory and
 // select the address instead (measured: 64-176 bytes of scratch per lane and a scratch load per table entry)
 template <typename T>
@@ -493,7 +620,7 @@ __device__ __forceinline__ void pipe_sweep_load(const pipe_params &P, const win_
 
 // `prefetch` is called as soon as the registers of R have been consumed (the row is in its slot, the three scalars are copied):
 // the caller issues the loads of the NEXT pass into R there, and they are in flight under everything that follows.
-template <typename T, int LC, typename PF>
+template <typename T, int LC, bool WIDE, typename PF>
 __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const win_desc &d, const uint8_t *s_path, const double *s_logtab,
                                                    double *s_deal /* this lane group's slots */,
                                                    int p, int s, double ratio, sweep_regs<T> &R, double &removed, int *abort_flag, PF &&prefetch)
@@ -504,6 +631,8 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     constexpr int SD = pipe_slot_doubles<T>();
     PIPE_GLOBAL(T) *band = pipe_gptr((T *)d.band);
     PIPE_GLOBAL(double) *g_cnt = pipe_gptr(d.cnt), *g_G = pipe_gptr(d.gp);      // (the pipeline's own table: k_wpipe's prologue)
+    PIPE_GLOBAL(double) *g_W = pipe_gptr(d.gw);                                 // (WIDE: the side table of the five-candidate positions)
+    constexpr unsigned RECD = (unsigned)pipe_wrec_doubles(LC);
     const bool act = p <= N;
     const int a = R.a;
     auto mult_of = [&](int dd) __attribute__((always_inline)) {     // how often reweight_hansel_from_path visits the cell (p, p + dd): SURVEY section 8 a8
@@ -632,7 +761,8 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             // to-symbol -- its rank among the target's candidates -- of every row of the source (pkt_in = 0: no target)
             den = (P.cond_mode == GH_COND_C ? nv_i : (double)PK_NVALID(pkt_in)) + rowsum0;
             const int rbs = PK_ROW6(pkt_in, b_cell);
-            word = (act && p < N && pkt_in != 0ull && rbs < 4) ? (unsigned long long)(8 + rbs) : 0ull;      // (bit 3: live)
+            word = (act && p < N && pkt_in != 0ull && rbs < (WIDE ? 5 : 4)) ? (unsigned long long)(8 + rbs) : 0ull;      // (bit 3: live)
+            if constexpr (WIDE) word |= ((pkt_in >> 42) & 0xffffull) << 8;      // (the target's record, should the column be its fifth)
         }
         slot[SD - 2] = den;
         reinterpret_cast<unsigned long long *>(slot)[SD - 1] = word;
@@ -642,40 +772,69 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     // the entries, eight per round: a quotient and its log10 each (the marginals of the position are the bookkeeper's:
     // pipe_book_consume).  Row conditionals: entry (lag, column rb of the path's row); column conditionals: entry (lag, row ra,
     // the column of the path's to-symbol).
-    const int NT4 = 4 * Lw;
+    constexpr int EPL = WIDE ? 5 : 4;                          // entries per lag: WIDE also the fifth column (row conditionals) / the fifth row (column conditionals)
+    const int NT4 = EPL * Lw;
     const int nrows = p == 0 ? 1 : PK_NCAND(pkp);              // (column conditionals: position 0 has its '_' row only)
+    // WIDE: where an entry goes.  Row conditionals: entry (row of the path's symbol at p, lag li + 1, column rb of the target whose word
+    // stands in the slot) -- the table where both ranks are below 4; the S record of p where the path's symbol is p's fifth candidate;
+    // the T record of the target for its fifth column (and, where both are fifth, both records).  Column conditionals: entry (row rb of
+    // p, lag, the column cb of the path's to-symbol at the target) likewise.
+    const unsigned rowT = (unsigned)(row6 <= 4 ? row6 : 0);    // (the '_' row of position 0 stands in row slot 0)
+    auto row_dst = [&](unsigned li, unsigned rb, unsigned long long tword, PIPE_GLOBAL(double) *&dst, PIPE_GLOBAL(double) *&dst2) __attribute__((always_inline)) {
+        dst2 = nullptr;
+        if (!WIDE || (rb < 4u && row6 != 4)) dst = g_G + pipe_gp_piece((unsigned)p, row4, li, (unsigned)L) + rb;
+        else if (rb < 4u) dst = g_W + (unsigned)PK_WIDX(pkp) * RECD + li * 8u + rb;
+        else {
+            dst = g_W + (unsigned)PK_WIDX(tword) * RECD + 8u * (unsigned)L + li * 8u + rowT;
+            if (row6 == 4) dst2 = g_W + (unsigned)PK_WIDX(pkp) * RECD + li * 8u + 4u;
+        }
+    };
+    auto col_dst = [&](unsigned li, unsigned rb, unsigned cb, unsigned widx_t, PIPE_GLOBAL(double) *&dst, PIPE_GLOBAL(double) *&dst2) __attribute__((always_inline)) {
+        dst2 = nullptr;
+        if (!WIDE || (cb < 4u && rb < 4u)) dst = g_G + pipe_gp_piece((unsigned)p, cb, li, (unsigned)L) + rb;       // (transposed copy)
+        else if (cb < 4u) dst = g_W + (unsigned)PK_WIDX(pkp) * RECD + li * 8u + cb;
+        else {
+            dst = g_W + widx_t * RECD + 8u * (unsigned)L + li * 8u + rb;
+            if (rb == 4u) dst2 = g_W + (unsigned)PK_WIDX(pkp) * RECD + li * 8u + 4u;
+        }
+    };
 #pragma unroll 1
     for (int t = s; t < NT4; t += 8) {
-        const int li = t >> 2, rb = t & 3;
+        const int li = WIDE ? t / 5 : t >> 2, rb = WIDE ? t - 5 * (t / 5) : t & 3;
         const double *sl = s_deal + li * SD;
         const unsigned long long word = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
         bool live;
         int k_el;
-        unsigned oidx;
+        PIPE_GLOBAL(double) *dst, *dst2;
         if (!COL) {
             live = rb < PK_NCAND(word);
-            k_el = PK_SYM(word, rb);
-            oidx = pipe_gp_piece((unsigned)p, row4, (unsigned)li, (unsigned)L) + (unsigned)rb;
+            k_el = (WIDE && rb == 4) ? PK_SYM4(word) : PK_SYM(word, rb);
+            row_dst((unsigned)li, (unsigned)rb, word, dst, dst2);
         } else {
             live = (word & 8ull) != 0 && rb < nrows;
-            k_el = p == 0 ? SYM_US : PK_SYM(pkp, rb);
-            oidx = pipe_gp_piece((unsigned)p, (unsigned)(word & 3ull), (unsigned)li, (unsigned)L) + (unsigned)rb;       // (transposed copy)
+            k_el = p == 0 ? SYM_US : ((WIDE && rb == 4) ? PK_SYM4(pkp) : PK_SYM(pkp, rb));
+            col_dst((unsigned)li, (unsigned)rb, (unsigned)(word & 7ull), (unsigned)((word >> 8) & 0xffffull) - 1u, dst, dst2);
         }
         if (live) {
             const double num = 1.0 + (double)reinterpret_cast<const T *>(sl)[k_el];
             const double xq = num / sl[SD - 2];
             // (k_marg takes the straight-line logarithm where the arguments are normal, the general one otherwise: same values)
-            g_G[oidx] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+            const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+            *dst = v;
+            if constexpr (WIDE) { if (dst2) *dst2 = v; }
         }
     }
     if (P.mt) {
         // the marginal term: the walker of the next path adds log10 marginal of the CANDIDATE in front of its lag-1 term, so the
-        // log-marginals of all candidates of p are due again after every reweight (lmr, by rank): lanes 0..3, one each
-        const int sym_m = PK_SYM(pkp, s & 3);
+        // log-marginals of all candidates of p are due again after every reweight (lmr, by rank): lanes 0..3, one each (WIDE: lane 4
+        // the fifth candidate's, into the position's record)
+        const int sym_m = (WIDE && s == 4) ? PK_SYM4(pkp) : PK_SYM(pkp, s & 3);
         const double c_m = __shfl(mine, sym_m, 8);
         if (act && s < PK_NCAND(pkp)) {
             const double m = (c_m > 0 && tot != 0.0) ? c_m / tot : 0.0;            // k_marg: marg[p][s], minfo[p][b5]
-            pipe_gptr(d.lmr)[(unsigned)p * 4u + (unsigned)s] = gh_log10_tab(m, s_logtab, GH_LOG_SERIAL);
+            const double lmv = gh_log10_tab(m, s_logtab, GH_LOG_SERIAL);
+            if (!WIDE || s < 4) pipe_gptr(d.lmr)[(unsigned)p * 4u + (unsigned)s] = lmv;
+            else g_W[(unsigned)PK_WIDX(pkp) * RECD + 16u * (unsigned)L] = lmv;
         }
     }
     if constexpr (L > 8) {
@@ -690,10 +849,13 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const unsigned long long pkt = d.pk[snp];
                 const double sum = (double)rw.sum();
                 const double den = (P.cond_mode == GH_COND_A) ? (double)PK_NVALID(pkt) + sum : (P.cond_mode == GH_COND_D ? nv_i + sum : nv_i + ca_new);
-                PIPE_GLOBAL(double) *out = g_G + pipe_gp_piece((unsigned)p, row4, (unsigned)(l - 1), (unsigned)L);
                 for (int rb = 0; rb < PK_NCAND(pkt); rb++) {
-                    const double xq = (1.0 + (double)rw.get(PK_SYM(pkt, rb))) / den;
-                    out[rb] = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+                    const double xq = (1.0 + (double)rw.get((WIDE && rb == 4) ? PK_SYM4(pkt) : PK_SYM(pkt, rb))) / den;
+                    const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+                    PIPE_GLOBAL(double) *dst, *dst2;
+                    row_dst((unsigned)(l - 1), (unsigned)rb, pkt, dst, dst2);
+                    *dst = v;
+                    if constexpr (WIDE) { if (dst2) *dst2 = v; }
                 }
             }
         }
@@ -704,14 +866,17 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
                 const int b = (int)s_path[snp];
                 const unsigned long long pkt = d.pk[snp];
                 const int rbs = PK_ROW6(pkt, b);
-                if (rbs >= 4) continue;
+                if (rbs >= (WIDE ? 5 : 4)) continue;
                 row7<T> cw;
                 cw.load((const T *)d.tband + bidx(W, p, l, b, 0));  // (the column as this lane's reweight of the cell left it)
                 const double den = (P.cond_mode == GH_COND_C ? nv_i : (double)PK_NVALID(pkt)) + (double)cw.sum();
                 for (int ra = 0; ra < nrows; ra++) {
-                    const double xq = (1.0 + (double)cw.get(p == 0 ? SYM_US : PK_SYM(pkp, ra))) / den;
-                    g_G[pipe_gp_piece((unsigned)p, (unsigned)rbs, (unsigned)(l - 1), (unsigned)L) + (unsigned)ra] =
-                        gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+                    const double xq = (1.0 + (double)cw.get(p == 0 ? SYM_US : ((WIDE && ra == 4) ? PK_SYM4(pkp) : PK_SYM(pkp, ra)))) / den;
+                    const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
+                    PIPE_GLOBAL(double) *dst, *dst2;
+                    col_dst((unsigned)(l - 1), (unsigned)ra, (unsigned)rbs, (unsigned)PK_WIDX(pkt), dst, dst2);
+                    *dst = v;
+                    if constexpr (WIDE) { if (dst2) *dst2 = v; }
                 }
             }
         }
@@ -719,7 +884,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
 }
 
 // (second launch bound = waves per SIMD: 512 threads at up to six lags are held to 128 registers so that TWO workgroups share a CU)
-template <typename T, int LC, int NT>
+template <typename T, int LC, int NT, bool WIDE = false>
 __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ? 4 : (NT == 768 ? 3 : 2))) k_wpipe(pipe_params P, const win_desc *wd)
 {
     typedef pipe_roles<NT> RL;
@@ -732,9 +897,13 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     const win_desc d = wd[blockIdx.x];
     dev_state *st = d.st;
     const int N = P.N, C = P.C;
-    const int npos = C + WALK_OV;
+    const int npos = C + WALK_OV + (WIDE ? LC : 0);     // (WIDE: L more sources in front of the chunk -- pipe_wide_walker)
     double *const g0 = smem;
-    unsigned long long *const words0 = reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)npos * RS);
+    constexpr int RECD = pipe_wrec_doubles(LC);
+    double *const wide0 = smem + 2 * (size_t)npos * RS;                                    // WIDE: [2][PIPE_WREC][RECD] the chunk's records
+    uint8_t *const wslot0 = reinterpret_cast<uint8_t *>(wide0 + 2 * (size_t)PIPE_WREC * RECD);   // WIDE: [2][PIPE_WSLOT_BYTES] buffer position -> slot
+    unsigned long long *const words0 = WIDE ? reinterpret_cast<unsigned long long *>(wslot0 + 2 * PIPE_WSLOT_BYTES)
+                                            : reinterpret_cast<unsigned long long *>(smem + 2 * (size_t)npos * RS);
     double *const s_logtab = reinterpret_cast<double *>(words0 + 128);
     double *const s_red = s_logtab + 256;
     constexpr int GD = pipe_group_doubles((int)sizeof(T));     // the sweepers' slots: doubles per lane group
@@ -751,20 +920,70 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     // eligible?  (uniform: the control line as the kernels before this one left it)
     {
         const dev_ctl c0 = load_ctl(st);
-        const bool ok = !c0.stop && c0.ranked != 0 && c0.first_hole > N && c0.narrow != 0;
+        // (WIDE: the windows the narrow launch left -- a table over the symbols, i.e. a position with five candidates somewhere)
+        const bool ok = WIDE ? (!c0.stop && c0.ranked == 0 && c0.first_hole > N && N < 65536)
+                             : (!c0.stop && c0.ranked != 0 && c0.first_hole > N && c0.narrow != 0);
         if (!ok) {
             if (tid == 0) st->pipe_status = PIPE_NOT_STARTED;
             return;
         }
     }
     logtab_stage(s_logtab);
+    const int nchunks = (N + C - 1) / C;
+    int *const s_cnt = reinterpret_cast<int *>(g0);                                        // WIDE prologue: [nchunks + 2] (the buffers are not in use yet)
+    uint16_t *const s_wpos = reinterpret_cast<uint16_t *>(s_cnt + nchunks + 2);            // WIDE prologue: [PIPE_WMAX] position of every record
+    // (no static LDS in this kernel: it would move the dynamic region off its 16-byte alignment)
+    volatile int *const s_badp = &ctl->_pad[0];
+    if constexpr (WIDE) {
+        for (int q = tid; q <= nchunks; q += NT) s_cnt[q] = 0;
+        if (tid == 0) *s_badp = 0;
+        __syncthreads();
+    }
     for (int q = tid; q <= N + 1; q += NT) {
-        const unsigned long long w = q <= N ? pipe_pack(d.cmask[q], d.nvalid[q], q, P.sm) : 0ull;
+        const unsigned long long w = q <= N ? pipe_pack<WIDE>(d.cmask[q], d.nvalid[q], q, P.sm) : 0ull;
         d.pk[q] = w;
+        if constexpr (WIDE) { if (q >= 1 && q <= N && PK_NCAND(w) == 5) atomicAdd(&s_cnt[(q - 1) / C], 1); }
         if (P.mt) {             // log10 marginal of the candidates of q by RANK (k_marg left them by compact symbol index in minfo)
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 d.lmr[(size_t)q * 4 + r] = (q <= N && r < PK_NCAND(w)) ? d.minfo[(size_t)q * MINFO + a6_of_sym(P.sm, PK_SYM(w, r))] : 0.0;
+        }
+    }
+    if constexpr (WIDE) {
+        // the records: numbered in POSITION order (a chunk's records are then one contiguous run of the side table), at most
+        // PIPE_WMAX per window and PIPE_WREC among the L + C positions a chunk can see -- else the window is left to the launches
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int k = 0; k < nchunks; k++) { const int c = s_cnt[k]; s_cnt[k] = acc; acc += c; }
+            s_cnt[nchunks] = acc;
+            if (acc > PIPE_WMAX) *s_badp = 1;
+        }
+        __syncthreads();
+        if (!*s_badp) {
+            for (int k = tid; k < nchunks; k += NT) {
+                int idx = s_cnt[k], nprev = 0, nown = 0;
+                for (int p = k * C + 1 - LC; p <= k * C; p++)
+                    if (p >= 1 && PK_NCAND(d.pk[p]) == 5) nprev++;
+                const int pe = k * C + C < N ? k * C + C : N;
+                for (int p = k * C + 1; p <= pe; p++) {
+                    const unsigned long long w = d.pk[p];
+                    if (PK_NCAND(w) == 5) {
+                        d.pk[p] = w | ((unsigned long long)(idx + 1) << 42);
+                        s_wpos[idx] = (uint16_t)p;
+                        idx++; nown++;
+                    }
+                }
+                if (nprev + nown > PIPE_WREC) *s_badp = 1;
+                d.wdir[k] = (s_cnt[k] - nprev) | ((nprev + nown) << 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (*s_badp) {
+            if (tid == 0) st->pipe_status = PIPE_NOT_STARTED;
+            return;
         }
     }
     // the pipeline's own copy of the conditional table: of the ranked G[source][6 rows][lag][5 columns] only what a ranked window
@@ -774,7 +993,43 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     // Under a column conditional the copy is TRANSPOSED, [source][column][lag][row]: what a reweighted cell changes -- the entries
     // of every row in one column -- is then one 32-byte piece per lag as well (four pieces in four rows otherwise: 169k against
     // 267k haplotypes/s for E against A before), and the loaders transpose back while they stage.
-    for (int q = tid; q < (N + LT_PAD) * 4 * LC; q += NT) {
+    // WIDE: G is laid out over the SYMBOLS (k_lt: a position offers five candidates); entry (rank r of source i, lag l + 1, rank c of
+    // the target) through the packed words -- what k_lt's ranked layout holds for the same window: a rank the source does not have is a
+    // row of zeros, a rank the target does not have -inf, behind the window zeros; position 0 has its '_' row only (row slot 0)
+    auto tab5 = [&](int i, int r, int l, int c) __attribute__((always_inline)) -> double {
+        const int snp = i + l + 1;
+        if (i < 0 || !(i < N && snp <= N)) return 0.0;
+        const unsigned long long wi = d.pk[i], wt = d.pk[snp];
+        int a6 = 5;
+        if (i != 0) {
+            if (r >= PK_NCAND(wi)) return 0.0;
+            a6 = a6_of_sym(P.sm, r == 4 ? PK_SYM4(wi) : PK_SYM(wi, r));
+        } else if (r != 0) return 0.0;
+        if (c >= PK_NCAND(wt)) return -INFINITY;
+        const int b5 = a6_of_sym(P.sm, c == 4 ? PK_SYM4(wt) : PK_SYM(wt, c));
+        return d.G[(((size_t)i * 6 + a6) * LC + l) * LT_ROW + b5];
+    };
+    if constexpr (WIDE) {
+        for (int q = tid; q < (N + LT_PAD) * 4 * LC; q += NT) {
+            const int l = q % LC, row = (q / LC) & 3, i = q / (4 * LC);
+            double *o = d.gp + pipe_gp_piece((unsigned)i, (unsigned)row, (unsigned)l, (unsigned)LC);
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = !P.col ? tab5(i, row, l, e) : tab5(i, e, l, row);      // (column conditionals: the transposed copy)
+        }
+        // the records: S = the row of the fifth candidate as a source, T = its column as a target, LM4 = its log10 marginal
+        const int nwide = s_cnt[nchunks];
+        for (int q = tid; q < nwide * LC * 10; q += NT) {
+            const int e = q % 5, part = (q / 5) & 1, l = (q / 10) % LC, wi = q / (10 * LC);
+            const int w = (int)s_wpos[wi];
+            d.gw[(size_t)wi * RECD + (part ? 8 * LC : 0) + l * 8 + e] = part ? tab5(w - l - 1, (w - l - 1) == 0 ? 0 : e, l, 4) : tab5(w, 4, l, e);
+        }
+        if (P.mt)
+            for (int wi = tid; wi < nwide; wi += NT) {
+                const int w = (int)s_wpos[wi];
+                d.gw[(size_t)wi * RECD + 16 * LC] = d.minfo[(size_t)w * MINFO + a6_of_sym(P.sm, PK_SYM4(d.pk[w]))];
+            }
+    }
+    for (int q = tid; q < (WIDE ? 0 : (N + LT_PAD) * 4 * LC); q += NT) {
         const int l = q % LC, row = (q / LC) & 3, i = q / (4 * LC);
         double *o = d.gp + pipe_gp_piece((unsigned)i, (unsigned)row, (unsigned)l, (unsigned)LC);
         if (!P.col) {
@@ -803,7 +1058,6 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         atomicOr((unsigned long long *)&st->dbg8[9], (unsigned long long)((hwid >> 4) & 3u) << (2 * wave));
     }
 #endif
-    const int nchunks = (N + C - 1) / C;
     const int npass = (N - 3 + C - 1) / C > 1 ? (N - 3 + C - 1) / C : 1;      // sweep passes that cover positions 0..N
     const int E = nchunks + 3;
 #define PIPE_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -845,7 +1099,7 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
             for (int e = 0; e < ne; e++) {
                 PIPE_PROF_BEGIN();
                 if (do_rw && e < npass)
-                    pipe_sweep_compute<T, LC>(P, d, s_path, s_logtab, s_deal + lp * GD, pos_of(e), s, ratio, R, removed, &ctl->abort,
+                    pipe_sweep_compute<T, LC, WIDE>(P, d, s_path, s_logtab, s_deal + lp * GD, pos_of(e), s, ratio, R, removed, &ctl->abort,
                                               [&]() __attribute__((always_inline)) { pipe_sweep_load<T>(P, d, s_path, pos_of(e + 1), s, R); });
                 PIPE_PROF_MID();
                 if (!last) PIPE_BARRIER_DRAIN();
@@ -907,13 +1161,13 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         auto fetch = [&](int k) {
             // (no branch around a load: see pipe_sweep_load; tasks beyond the buffer or the table read source 0 and are dropped /
             // zeroed when the chunk is stored)
-            const int i0 = k * C;
+            const int i0 = k * C - (WIDE ? LC : 0);               // (WIDE: the buffer begins L sources in front of the chunk)
 #pragma unroll
             for (int it = 0; it < MAXT; it++) {
                 const task_of q_(desc[it]);
                 const int pp = q_.pp, r = q_.r, row = q_.row, l = q_.l;
                 const int sidx = i0 + pp;
-                const bool ok = q_.live && sidx < nsrc_all;
+                const bool ok = q_.live && sidx >= 0 && sidx < nsrc_all;
                 const int si = ok ? sidx : 0;
                 const PIPE_GLOBAL(double) *src = gG + pipe_gp_piece((unsigned)si, (unsigned)((si == 0 && !P.col) ? 0 : row), (unsigned)l, (unsigned)LC);
                 if (r == 4 * LC) src = gLM + (unsigned)(si + 1 <= N ? si + 1 : N + 1) * 4u;      // (marginal term only)
@@ -932,20 +1186,36 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
             }
         };
         auto store = [&](int k) {
-            const int i0 = k * C;
+            const int i0 = k * C - (WIDE ? LC : 0);
             double *dst = g0 + (size_t)(k & 1) * npos * RS;
             double *yr = dst + (size_t)npos * XD;
+            if constexpr (WIDE) {
+                // the records of the wide positions this chunk can see (one contiguous run of the side table: they are numbered in
+                // position order), and for every position of the buffer the slot its record stands in (0xff: none here)
+                const unsigned wd_ = (unsigned)pipe_gptr((const int *)d.wdir)[k];
+                const int first = (int)(wd_ & 0xffffu), cnt = (int)(wd_ >> 16);
+                double *WA = wide0 + (size_t)(k & 1) * PIPE_WREC * RECD;
+                const PIPE_GLOBAL(double) *gW = pipe_gptr((const double *)d.gw) + (size_t)first * RECD;
+                for (int e = t; e < cnt * RECD; e += NL) WA[e] = gW[e];
+                uint8_t *WS = wslot0 + (k & 1) * PIPE_WSLOT_BYTES;
+                for (int pp = t; pp < npos; pp += NL) {
+                    const int pq = i0 + pp;
+                    const unsigned long long w = pipe_gptr((const unsigned long long *)d.pk)[(pq >= 1 && pq <= N) ? pq : N + 1];
+                    const int wi = PK_WIDX(w) - first;
+                    WS[pp] = (PK_WIDX(w) >= 0 && wi >= 0 && wi < cnt) ? (uint8_t)wi : (uint8_t)0xff;
+                }
+            }
 #pragma unroll
             for (int it = 0; it < MAXT; it++) {
                 const task_of q_(desc[it]);
                 const int pp = q_.pp, r = q_.r, row = q_.row, l = q_.l;
                 if (q_.live) {
-                    const bool z = i0 + pp >= nsrc_all;            // behind the table: zeros (the walker runs whole chunks)
+                    const bool z = i0 + pp >= nsrc_all || i0 + pp < 0;     // behind (in front of) the table: zeros (the walker runs whole chunks)
                     double x0 = z ? 0.0 : R.lo[it].x, x1 = z ? 0.0 : R.lo[it].y, x2 = z ? 0.0 : R.hi[it].x, x3 = z ? 0.0 : R.hi[it].y;
                     if (synth_on && r < 4 * LC && l >= P.W) {
                         const int sa = i0 + pp, tg = sa + l + 1;
                         const unsigned pka = (unsigned)__double_as_longlong(R.lo[it].x), pkb = (unsigned)__double_as_longlong(R.hi[it].x);
-                        const bool dead = sa >= N || tg > N;
+                        const bool dead = sa >= N || tg > N || sa < 0;
                         const double lt = ctl->lt_beyond[(P.cond_mode == GH_COND_A || P.cond_mode == GH_COND_E) ? PK_NVALID(pkb) : PK_NVALID(pka)];
                         const int nrow = sa == 0 ? 4 : PK_NCAND(pka), ncol = PK_NCAND(pkb);      // (position 0: its '_' row in every slot)
                         auto val = [&](int rr, int cc) __attribute__((always_inline)) { return (dead || rr >= nrow) ? 0.0 : (cc < ncol ? lt : -INFINITY); };
@@ -1036,9 +1306,9 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
             PIPE_BARRIER(); PIPE_BARRIER(); PIPE_BARRIER();         // epochs 0..2
             auto consume = [&](int c, const pipe_book_row &R) {
 #ifdef PIPE_PROF
-                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, hp_acc, lane_min, P.sm, bprof);
+                pipe_book_consume<WIDE>(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, hp_acc, lane_min, P.sm, bprof);
 #else
-                pipe_book_consume(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, hp_acc, lane_min, P.sm);
+                pipe_book_consume<WIDE>(path_out, s_path, words0 + (c & 1) * 64, s_logtab, s_bk, LC, c * C, C, N, lane, R, hp_acc, lane_min, P.sm);
 #endif
             };
             for (int k = 0; k < nchunks; k += 2) {
@@ -1119,8 +1389,13 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane, wprof);
         else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane, wprof);
 #else
-        if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane);      // one barrier behind every chunk
-        else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane);
+        if constexpr (WIDE) {
+            if (P.mt) pipe_wide_walker<LC, true>(g0, words0, wide0, wslot0, C, nchunks, N, lane);
+            else pipe_wide_walker<LC, false>(g0, words0, wide0, wslot0, C, nchunks, N, lane);
+        } else {
+            if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane);      // one barrier behind every chunk
+            else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane);
+        }
 #endif
         PIPE_BARRIER();                                             // tail
         if ((aborted = ctl->abort != 0)) break;

@@ -269,3 +269,105 @@ def test_far_lags_made_by_the_loaders_or_read(L, band, kw, synth, monkeypatch):
     assert b.pipe_info()["windows"] == 3, b.pipe_info()
     for (h, o), r in zip(wins, res):
         _same(r, o.spin(9), h, o)
+
+
+# ---- windows with a few five-candidate positions (round 6: k_wpipe<.., WIDE>, wpipe.hpp) -------------------------------------------
+def _wide_pair(seed, n, reads, k, frac=0.02, L=None, band=None, n_haps=8, k_max=21, **kw):
+    """A window with '-' at `frac` of its POSITIONS (gretel/util.py:178-190: a deletion is an ordinary symbol): those positions offer
+    five candidates, the rest at most four."""
+    from gretel_amd.synth import sprinkle_deletions
+    t = make_support_table(n, reads, k=k, seed=seed, n_haps=n_haps, err=0.01, k_max=k_max)
+    sprinkle_deletions(t, frac, seed=seed + 1)
+    W = band if band is not None else t.band
+    h = Hansel(t.n_snps, band=W, **kw)
+    o = COracle(t.n_snps, W, **kw)
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    if L is not None:
+        h.L = L
+        o.L = L
+    return h, o
+
+
+def _n_wide(h):
+    return int((h.candidate_masks()[1:] == 0x2F).sum())
+
+
+@pytest.mark.parametrize("L", [2, 3, 4, 5, 6])
+def test_wide_pipeline_equals_the_oracle(L):
+    wins = [_wide_pair(900 + s, 700, 20000, 6, L=L) for s in range(4)]
+    assert all(_n_wide(h) > 0 for h, _ in wins)
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(12)
+    info = b.pipe_info()
+    assert info["windows"] == 4 and info["handed_back"] == 0, info
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(12), h, o)
+
+
+@pytest.mark.parametrize("L", [7, 8, 10])
+def test_wide_pipeline_with_longer_memories(L):
+    wins = [_wide_pair(920 + s, 600, 12000, None, L=L, band=21, n_haps=6) for s in range(3)]
+    assert all(_n_wide(h) > 0 for h, _ in wins)
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(8)
+    info = b.pipe_info()
+    assert info["windows"] == 3, info
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(8), h, o)
+
+
+@pytest.mark.parametrize("kw", [dict(storage="f64"), dict(cond_mode="B"), dict(cond_mode="D"), dict(cond_mode="C"), dict(cond_mode="E"),
+                                dict(marginal_term=True), dict(cond_mode="E", marginal_term=True), dict(cond_mode="C", marginal_term=True, storage="f64"),
+                                dict(cand_order="TGCA-"), dict(cand_order="-TGCA", marginal_term=True), dict(cond_mode="E", cand_order="G-TCA"),
+                                dict(cond_mode="B", marginal_term=True, storage="f64")],
+                         ids=lambda kw: "-".join("%s=%s" % x for x in sorted(kw.items())))
+def test_wide_pipeline_under_every_spec(kw):
+    wins = [_wide_pair(940 + s, 500, 15000, 5, **kw) for s in range(3)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(10)
+    assert b.pipe_info()["windows"] == 3, b.pipe_info()
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(10), h, o)
+
+
+def test_wide_and_narrow_windows_in_one_batch():
+    wins = [_pair(960, 700, 20000, 5), _wide_pair(961, 700, 20000, 5), _pair(962, 700, 20000, 5), _wide_pair(963, 700, 20000, 5, frac=0.05)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(15)
+    assert b.pipe_info()["windows"] == 4, b.pipe_info()
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(15), h, o)
+
+
+def test_wide_pipeline_in_a_deep_spin_and_afterwards():
+    """Counts reach zero, masks move (a five-candidate position may lose a candidate): the window is handed back with its tensor exact,
+    gh_spin finishes it; the handles stay usable."""
+    wins = [_wide_pair(970 + s, 400, 5000, 5, n_haps=3) for s in range(3)]
+    b = HanselBatch([h for h, _ in wins])
+    res = b.spin(60)
+    for (h, o), r in zip(wins, res):
+        _same(r, o.spin(60), h, o)
+    for h, o in wins:
+        r2, ref2 = h.spin(3), o.spin(3)
+        assert r2["n"] == ref2["n"] and np.array_equal(r2["paths"], ref2["paths"])
+
+
+def test_too_many_wide_positions_are_left_to_the_launches():
+    from spec_util import with_dels
+    t = with_dels(make_support_table(600, 18000, k=5, seed=980), 0.05, 7)      # (nearly every position offers five candidates)
+    h = Hansel(t.n_snps, band=t.band)
+    o = COracle(t.n_snps, t.band)
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    b = HanselBatch([h])
+    r = b.spin(9)[0]
+    assert b.pipe_info()["windows"] == 0
+    _same(r, o.spin(9), h, o)
+
+
+def test_the_switch_that_leaves_wide_windows_to_the_launches(monkeypatch):
+    monkeypatch.setenv("GH_PIPE_WIDE", "0")
+    h, o = _wide_pair(985, 500, 15000, 5)
+    b = HanselBatch([h])
+    r = b.spin(9)[0]
+    assert b.pipe_info()["windows"] == 0
+    _same(r, o.spin(9), h, o)
