@@ -2846,6 +2846,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
             else if (hs[w].pipe_status != PIPE_DONE) return fail(GH_ERR_STATE, "gh_batch_spin: window %d left the pipeline in state %d", w, hs[w].pipe_status);
         }
         b->pipe_windows = n - (int)rest.size();
+        auto print_stamps = [&]() {
         if (getenv("GH_PIPE_STAMPS")) {         // 100 MHz ticks per path as the bookkeepers of a few windows saw them
             for (int w = 0; w < n; w += (n > 4 ? n / 4 : 1)) {
 #ifdef PIPE_PROF
@@ -2853,6 +2854,8 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                         hs[w].dbg8[0] / 1e6, hs[w].dbg8[1] / 1e6, hs[w].dbg8[2] / 1e6, hs[w].dbg8[3] / 1e6, hs[w].dbg8[4] / 1e6, hs[w].dbg8[5] / 1e6,
                         hs[w].dbg8[6] / 1e6, hs[w].dbg8[7] / 1e6, hs[w].dbg8[8] / 1e6);
                 fprintf(stderr, "walker: %.2f Mcycles walking, %.2f at its barriers; bookkeeper: %.2f per-position part, %.2f sequential sums\n", hs[w].dbg8[10] / 1e6, hs[w].dbg8[11] / 1e6, hs[w].dbg[0] / 1e6, hs[w].dbg[1] / 1e6);
+                fprintf(stderr, "wide walker: %.2f Mcycles in %llu groups by the exact stepper, %.2f Mcycles inside the speculative blocks, %llu primes\n", (double)(hs[w].dbg[2] & ((1ull << 40) - 1)) / 1e6,
+                        (unsigned long long)(hs[w].dbg[2] >> 40), (double)(hs[w].dbg[3] & ((1ull << 40) - 1)) / 1e6, (unsigned long long)(hs[w].dbg[3] >> 40));
                 fprintf(stderr, "SIMD of waves 0..15:");
                 for (int q = 0; q < 16; q++) fprintf(stderr, " %d", (int)((hs[w].dbg8[9] >> (2 * q)) & 3));
                 fprintf(stderr, "\n");
@@ -2864,6 +2867,8 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
 #endif
             }
         }
+        };
+        print_stamps();
         // What the narrow pipeline left untouched: windows in which a position offers five candidates.  The WIDE pipeline takes those
         // whose five-candidate positions are few (GH_PIPE_WIDE=0: not)
         {
@@ -2889,6 +2894,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
                     if ((rc = batch_run_pipe_wide(b, wrest, max_paths, min_remove, pipe_nt))) return rc;
                     phase("wide pipeline kernel");
                     if ((rc = fetch_states())) return rc;
+                    print_stamps();
                     rest.clear();
                     for (int w = 0; w < n; w++) {
                         if (hs[w].pipe_status == PIPE_NOT_STARTED) rest.push_back(wd[w]);

@@ -293,8 +293,8 @@ __device__ __forceinline__ void pipe_book_consume(uint8_t *path_out, uint8_t *s_
     const int j = j0 + lane + 1;
     if (lane < ns && j <= Nw) {
         const unsigned long long word = words[lane / LC];
-        // (WIDE: the exact stepper leaves three bits per pick -- a rank may be 4)
-        const int rank = WIDE ? (int)((word >> (3 * (LC - 1 - lane % LC))) & 7ull) : (int)((word >> (2 * (LC - 1 - lane % LC))) & 3ull);
+        // (WIDE: a group walked by the exact stepper has three bits per pick -- a rank may be 4 -- and bit 63 set)
+        const int rank = (WIDE && (word >> 63)) ? (int)((word >> (3 * (LC - 1 - lane % LC))) & 7ull) : (int)((word >> (2 * (LC - 1 - lane % LC))) & 3ull);
         const int sym = (WIDE && rank == 4) ? PK_SYM4(R.pk) : PK_SYM(R.pk, rank);      // the symbol of that rank at j (pipe_pack)
         const int b5 = a6_of_sym(sm, sym);
         const double cs[8] = {R.c[0].x, R.c[0].y, R.c[1].x, R.c[1].y, R.c[2].x, R.c[2].y, R.c[3].x, R.c[3].y};
@@ -450,74 +450,296 @@ __device__ __forceinline__ void spec2x_walker(double *g0, unsigned long long *wo
 // lane 4 -- same lag-ascending IEEE additions as everywhere ((lm + x1) + x2 + ...; lags in front of the window are not added:
 // gretel/gretel.py:155, the reference's own loop bound), first-wins arg-max over the lanes (gretel.py:166-174).  Buffer position
 // bi holds source k C - L + bi: target k C + q sits at bi = q + L, its sources at q + L - l.
+// f(integral_constant<0>), f(integral_constant<1>), ... : the steps of a group with their index as a compile-time constant
+template <typename F, int... U>
+__device__ __forceinline__ void pipe_unrolled(F &&f, std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }
+
 template <int LC, bool MT>
 __device__ __forceinline__ void pipe_wide_walker(const double *g0, unsigned long long *words0, const double *wide0, const uint8_t *wslot0,
-                                                 int C, int nchunks, int N, int lane)
+                                                 int C, int nchunks, int N, int lane,
+                                                 unsigned long long *prof = nullptr /* diagnostic builds: [0] += cycles walking, [1] += cycles at the barriers */)
 {
+    // Two walkers in one: groups of LC targets that have no five-candidate position in sight (none among the group's targets and the
+    // L positions in front of them: every rank involved is below 4) are walked by spec2x_walker's body -- depth-2 speculation, 16
+    // hypothesis groups x 4 lanes -- and the others by the exact stepper (slow_step: lane b = 0..4 of every eight holds candidate b; the
+    // term of lag l is the entry (row = the pick made l positions ago, column b) of source t - l, from the chunk's tables where both
+    // ranks are below 4, from the S record of the source where its pick was its fifth candidate, from the T record of the target for
+    // lane 4).  Between the two the speculative state is made afresh from the picks (prime).  Same lag-ascending IEEE additions in both
+    // ((lm + x1) + x2 + ...), first-wins arg-max (gretel.py:166-174).  Buffer position bi holds source k C - L + bi.
     typedef deep_layout<LC> DL;
-    constexpr int XD = MT ? 36 : 32, YPOS = DL::YPOS, NYP = DL::NYP, RS = XD + YPOS;
-    constexpr int RECD = pipe_wrec_doubles(LC);
-    static_assert(3 * LC < 64, "a group's picks, three bits each, in one word");
-    const int npos = C + LC + WALK_OV;
-    const int b = lane & 7, b3 = lane & 3;
-    const int bc = b < 5 ? b : 4;
-    unsigned long long h3 = 0;                              // the picks so far, three bits each, the latest lowest (uniform)
+    constexpr int NY = DL::NY;
+    constexpr unsigned XD = MT ? 36 : 32, YPOS = DL::YPOS, NYP = DL::NYP, RS = XD + YPOS;
+    constexpr unsigned XB = XD * 8u, YB = YPOS * 8u, YWB = 4u * NYP * 8u;
+    constexpr unsigned RECD = (unsigned)pipe_wrec_doubles(LC);
+    static_assert(3 * LC < 63, "a group's picks, three bits each, in one word beside the format bit");
+    typedef __attribute__((address_space(3))) const unsigned long long lds_cu64;
+    const unsigned npos = (unsigned)(C + LC + WALK_OV);
+    // (LDS addresses as 32-bit numbers, reads through address space 3: through generic pointers hipcc emits flat loads)
+    const unsigned g0a = (unsigned)(uintptr_t)g0, wa0 = (unsigned)(uintptr_t)wide0, ws0 = (unsigned)(uintptr_t)wslot0;
+    const unsigned bufB = npos * RS * 8u;
+    // the exact stepper's lanes
+    const unsigned b = (unsigned)lane & 7u, b3 = (unsigned)lane & 3u;
+    const bool lane4 = b >= 4u;
+    // the speculative walker's lanes: hypothesis (a1, a2) = (lane >> 2 & 3, lane >> 4), candidate b3
+    const unsigned x10l = (unsigned)(lane & 15) * 8u, x20l = 128u + (unsigned)((lane >> 4) * 4 + (lane & 3)) * 8u, yl = b3 * (NYP * 8u), lml = 256u + b3 * 8u;
+    double Y[LC][LC];
+#pragma unroll
+    for (int u = 0; u < LC; u++)
+#pragma unroll
+        for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
+    unsigned long long B = 0;
+    double accP = 0.0, H12 = 0.0;
+    unsigned hist = 0, sh = 0;                              // the speculative walker's picks, two bits each
+    unsigned long long h3 = 0;                              // the exact stepper's, three bits each, the latest lowest (uniform)
+    // any of the last LC picks a fifth candidate?  (bit 2 of a pick is set only for rank 4)
+    constexpr unsigned long long M4 = []() { unsigned long long m = 0; for (int l = 0; l < LC; l++) m |= 4ull << (3 * l); return m; }();
+    bool primed = false, in_slow = false;                   // (uniform)
+    unsigned yw_v;
+    asm("v_mov_b32 %0, %1" : "=v"(yw_v) : "i"(YWB));
     for (int k = 0; k < nchunks; k++) {
-        const double *X = g0 + (size_t)(k & 1) * npos * RS;
-        const double *Yr = X + (size_t)npos * XD;
-        const double *WA = wide0 + (size_t)(k & 1) * PIPE_WREC * RECD;
-        const uint8_t *WS = wslot0 + (k & 1) * PIPE_WSLOT_BYTES;
+        const unsigned Xb = g0a + (unsigned)(k & 1) * bufB, Yb = Xb + npos * XB;
+        const unsigned Wb = wa0 + (unsigned)(k & 1) * (PIPE_WREC * RECD * 8u);
+        // which positions of the buffer have their record here (bit bi; the loaders' ballot): a record's slot is its rank among them
+        unsigned long long wmask;
+        {
+            const unsigned long long wm = *(lds_cu64 *)(ws0 + (unsigned)(k & 1) * PIPE_WSLOT_BYTES);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wm), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wm >> 32));
+            wmask = ((unsigned long long)hi << 32) | lo;
+        }
+        auto slot_of = [&](int bi) __attribute__((always_inline)) -> unsigned { return (unsigned)__builtin_popcountll(wmask & ((1ull << bi) - 1ull)); };
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
-        for (int g = 0; g < ngroups; g++) {
-#pragma unroll
-            for (int u = 0; u < LC; u++) {
-                const int q = g * LC + u + 1;               // chunk-local target 1 .. C
-                const int t = k * C + q;
-                unsigned pick = 0;
-                if (t <= N) {
-                    const unsigned slot_t = (unsigned)__builtin_amdgcn_readfirstlane((int)WS[q + LC]);
-                    const bool wide_t = slot_t != 0xffu;
-                    const unsigned st_c = wide_t ? slot_t : 0u;
-                    double x[LC];
-#pragma unroll
-                    for (int l = 1; l <= LC; l++) {
-                        x[l - 1] = 0.0;
-                        if (l <= t) {
-                            const unsigned r = (unsigned)__builtin_amdgcn_readfirstlane((int)((h3 >> (3 * (l - 1))) & 7ull));
-                            const int bi = q + LC - l;
-                            const double *addr;
-                            if (b >= 4) addr = WA + st_c * RECD + 8 * LC + (l - 1) * 8 + r;                  // (column 4: the target's record)
-                            else if (r == 4u) {
-                                const unsigned ss = (unsigned)WS[bi];                                          // (row 4: the source's record)
-                                addr = WA + (ss != 0xffu ? ss : 0u) * RECD + (l - 1) * 8 + bc;
-                            } else if (l <= 2) addr = X + (size_t)bi * XD + (l - 1) * 16 + r * 4 + b3;
-                            else addr = Yr + (size_t)bi * YPOS + (r * 4 + b3) * NYP + (l - 3);
-                            x[l - 1] = *addr;
-                        }
-                    }
-                    double acc = x[0];
-                    if constexpr (MT) {
-                        // the marginal term in front of the first addition: (0.0 + lm) + x1 -- it rides with the lag-1 source's record,
-                        // the fifth candidate's in the target's record
-                        const double lm = b >= 4 ? WA[st_c * RECD + 16 * LC] : X[(size_t)(q + LC - 1) * XD + 32 + b3];
-                        acc = lm + acc;
-                    }
-#pragma unroll
-                    for (int l = 2; l <= LC; l++) acc = (l <= t) ? acc + x[l - 1] : acc;
-                    if (b > 4 || (b == 4 && !wide_t)) acc = -INFINITY;
-                    double m = acc;
-                    m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
-                    m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
-                    m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
-                    const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
-                    pick = (unsigned)__builtin_ctz((unsigned)win & 0xffu) & 7u;      // first wins (gretel.py:166-174)
-                }
-                h3 = (h3 << 3) | (unsigned long long)pick;
+        int nw = -1;                                        // the next group (>= g) with a five-candidate target; ngroups: none
+        for (int g = 0; g < ngroups;) {
+            if (nw < g) {
+                const unsigned long long rem = wmask >> (g * LC + LC + 1);       // (target q of the chunk: buffer position q + LC)
+                nw = rem != 0ull ? g + (int)((unsigned)__builtin_ctzll(rem) / (unsigned)LC) : ngroups;
             }
-            wk[g] = h3 & ((1ull << (3 * LC)) - 1ull);
+            // a five-candidate position among the group's targets, or a fifth candidate among the last LC picks (only the exact stepper
+            // makes such picks: h3 is then current)?  Else the groups up to nw go to the speculative walker, two at a time, with nothing
+            // between them but the loop (a lone wavefront issues an instruction every five cycles: what stands between two groups counts)
+            const bool slowg = g == nw || (in_slow && (h3 & M4) != 0ull);
+            if (slowg) {
+#ifdef PIPE_PROF
+                const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+                if (!in_slow) {
+                    // the picks the speculative walker made, as the stepper keeps them
+                    h3 = 0;
+#pragma unroll
+                    for (int l = 0; l < LC; l++) h3 |= (unsigned long long)((hist >> (2 * l)) & 3u) << (3 * l);
+                    in_slow = true;
+                }
+#pragma unroll
+                for (int u = 0; u < LC; u++) {
+                    const int q = g * LC + u + 1;           // chunk-local target 1 .. C (buffer position q + LC)
+                    const int t = k * C + q;
+                    unsigned pick = 0;
+                    const bool wide_t = ((wmask >> (q + LC)) & 1ull) != 0;
+                    if (t <= N && t > LC && !wide_t && (h3 & M4) == 0ull) {
+                        // four candidates here and no fifth among the last LC picks (most steps of such a group): the tables only --
+                        // lanes 4..7 of every eight repeat lanes 0..3, the first maximum among the four is the pick
+                        double acc;
+                        {
+                            const unsigned r1 = (unsigned)h3 & 7u;
+                            const double x1 = *(lds_cdouble *)(Xb + (unsigned)(q + LC - 1) * XB + r1 * 32u + b3 * 8u);
+                            if constexpr (MT) acc = *(lds_cdouble *)(Xb + (unsigned)(q + LC - 1) * XB + (32u + b3) * 8u) + x1;
+                            else acc = x1;
+                        }
+                        if constexpr (LC >= 2) acc = acc + *(lds_cdouble *)(Xb + (unsigned)(q + LC - 2) * XB + 128u + ((unsigned)(h3 >> 3) & 7u) * 32u + b3 * 8u);
+#pragma unroll
+                        for (int l = 3; l <= LC; l++)
+                            acc = acc + *(lds_cdouble *)(Yb + (unsigned)(q + LC - l) * YB + ((unsigned)(h3 >> (3 * (l - 1))) & 7u) * YWB + yl + (unsigned)(l - 3) * 8u);
+                        double m = acc;
+                        m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
+                        m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
+                        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+                        pick = (unsigned)__builtin_ctz(((unsigned)win & 0xfu) | 0x10u) & 3u;
+                    } else if (t <= N) {
+                        const unsigned recT = Wb + (wide_t ? slot_of(q + LC) : 0u) * (RECD * 8u);
+                        double x[LC];
+#pragma unroll
+                        for (int l = 1; l <= LC; l++) {
+                            x[l - 1] = 0.0;
+                            if (l <= t) {
+                                const unsigned r = (unsigned)(h3 >> (3 * (l - 1))) & 7u;
+                                const int bi = q + LC - l;
+                                const unsigned aT = recT + (8u * LC + (unsigned)(l - 1) * 8u + r) * 8u;            // (column 4: the target's record)
+                                unsigned aR, stride = 8u;
+                                if (r == 4u) aR = Wb + slot_of(bi) * (RECD * 8u) + (unsigned)(l - 1) * 64u;         // (row 4: the source's record)
+                                else if (l <= 2) aR = Xb + (unsigned)bi * XB + ((unsigned)(l - 1) * 16u + r * 4u) * 8u;
+                                else { aR = Yb + (unsigned)bi * YB + (r * 4u * NYP + (unsigned)(l - 3)) * 8u; stride = NYP * 8u; }
+                                const unsigned addr = lane4 ? aT : aR + b3 * stride;
+                                x[l - 1] = *(lds_cdouble *)addr;
+                            }
+                        }
+                        double acc = x[0];
+                        if constexpr (MT) {
+                            // the marginal term in front of the first addition: (0.0 + lm) + x1 -- it rides with the lag-1 source's record,
+                            // the fifth candidate's in the target's record
+                            const unsigned al = lane4 ? recT + 16u * LC * 8u : Xb + (unsigned)(q + LC - 1) * XB + (32u + b3) * 8u;
+                            acc = *(lds_cdouble *)al + acc;
+                        }
+#pragma unroll
+                        for (int l = 2; l <= LC; l++) acc = (l <= t) ? acc + x[l - 1] : acc;
+                        if (b > 4u || (b == 4u && !wide_t)) acc = -INFINITY;
+                        double m = acc;
+                        m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
+                        m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
+                        m = vmax_f64(m, dpp_f64<0x141>(m));     // row_half_mirror
+                        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+                        pick = (unsigned)__builtin_ctz(((unsigned)win & 0xffu) | 0x100u) & 7u;      // first wins (gretel.py:166-174)
+                    }
+                    h3 = (h3 << 3) | (unsigned long long)pick;
+                }
+                wk[g] = (1ull << 63) | (h3 & ((1ull << (3 * LC)) - 1ull));       // (bit 63: three bits per pick)
+                primed = false;
+#ifdef PIPE_PROF
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                prof[3] += __builtin_amdgcn_s_memtime() - ts0; prof[5] += 1;
+#endif
+                g++;
+                continue;
+            }
+            // ---- a group without a fifth candidate in sight: spec2x_walker's bodies
+            const unsigned pb = (unsigned)(LC + g * LC);        // buffer position of source j0 = k C + g LC (the group's first body)
+            if (in_slow) {
+                hist = 0;
+#pragma unroll
+                for (int l = 0; l < LC && l < 16; l++) hist |= ((unsigned)(h3 >> (3 * l)) & 3u) << (2 * l);
+                sh = hist << 2;
+                in_slow = false;
+            }
+#ifdef PIPE_PROF
+            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+            const bool was_primed = primed;
+#endif
+            if (!primed) {
+                if (k == 0 && g == 0) {
+                    // the start of a path (spec2x_walker's prologue): target 1 has the single term x1 of source 0, targets 2 and 3 both
+                    const unsigned p0 = Xb + pb * XB;
+                    auto h_at = [&](unsigned a1, unsigned a2, unsigned al) __attribute__((always_inline)) {
+                        if constexpr (MT) return (*(lds_cdouble *)al + *(lds_cdouble *)a1) + *(lds_cdouble *)a2;
+                        else return *(lds_cdouble *)a1 + *(lds_cdouble *)a2;
+                    };
+                    if constexpr (MT) B = group_argmax<true>(*(lds_cdouble *)(p0 + lml) + *(lds_cdouble *)(p0 + x10l));
+                    else B = group_argmax<true>(*(lds_cdouble *)(p0 + x10l));
+                    accP = h_at(p0 + XB + x10l, p0 + x20l, p0 + XB + lml);
+                    H12 = h_at(p0 + 2 * XB + x10l, p0 + XB + x20l, p0 + 2 * XB + lml);
+#pragma unroll
+                    for (int u = 0; u < LC; u++)
+#pragma unroll
+                        for (int l = 0; l < LC; l++) Y[u][l] = 0.0;
+#pragma unroll
+                    for (int l = 2; l < LC; l++) Y[0][l] = *(lds_cdouble *)(Yb + pb * YB + yl + (unsigned)(l - 2) * 8u);
+                    hist = 0; sh = 0;
+                } else {
+                    // the speculative state in front of body j0 from the picks: every source below is at least L positions behind a
+                    // five-candidate position's reach, its pick a rank below 4
+                    auto pick_of = [&](int back) __attribute__((always_inline)) -> unsigned { return (hist >> (2 * back)) & 3u; };     // pick of source j0 - back
+                    auto yrow = [&](int back, int lag) __attribute__((always_inline)) -> double {      // row of source j0 - back under its pick, lag `lag` >= 3
+                        return *(lds_cdouble *)(Yb + (pb - (unsigned)back) * YB + pick_of(back) * YWB + yl + (unsigned)(lag - 3) * 8u);
+                    };
+                    auto x1_at = [&](int fwd) __attribute__((always_inline)) -> double { return *(lds_cdouble *)(Xb + (pb + fwd) * XB + x10l); };   // source j0 + fwd (fwd may be -1)
+                    auto x2_at = [&](int fwd) __attribute__((always_inline)) -> double { return *(lds_cdouble *)(Xb + (pb + fwd) * XB + x20l); };
+                    auto lm_at = [&](int fwd) __attribute__((always_inline)) -> double { return *(lds_cdouble *)(Xb + (pb + fwd) * XB + lml); };
+                    // target j0 + 1: x1 of source j0 (hypothesis a1), x2 of source j0 - 1 (a2), lag l of source j0 + 1 - l
+                    double a0;
+                    if constexpr (MT) a0 = (lm_at(0) + x1_at(0)) + x2_at(-1);
+                    else a0 = x1_at(0) + x2_at(-1);
+#pragma unroll
+                    for (int l = 3; l <= LC; l++) a0 = a0 + yrow(l - 1, l);
+                    B = group_argmax<true>(a0);
+                    // target j0 + 2
+                    double a1_;
+                    if constexpr (MT) a1_ = (lm_at(1) + x1_at(1)) + x2_at(0);
+                    else a1_ = x1_at(1) + x2_at(0);
+#pragma unroll
+                    for (int l = 3; l <= LC; l++) a1_ = a1_ + yrow(l - 2, l);
+                    accP = a1_;
+                    if constexpr (MT) H12 = (lm_at(2) + x1_at(2)) + x2_at(1);
+                    else H12 = x1_at(2) + x2_at(1);
+                    // the rows of sources j0 + 3 - LC .. j0 (slot = source mod LC; j0 is a multiple of LC)
+#pragma unroll
+                    for (int back = 0; back <= LC - 3; back++)
+#pragma unroll
+                        for (int l = 2; l < LC; l++) Y[(LC - back) % LC][l] = yrow(back, l + 1);
+                    sh = hist << 2;
+                }
+                primed = true;
+            }
+#ifdef PIPE_PROF
+            if (!was_primed) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); prof[4] += __builtin_amdgcn_s_memtime() - tp0; prof[6] += 1; }
+#endif
+            // (two groups in one straight-line block where the next one is of this kind too -- nearly always: hipcc then issues the
+            // x1 / x2 reads of all ten bodies up front, as in spec2x_walker; one group at a time the fast bodies took 230 cycles
+            // per step instead of 150)
+            auto fast = [&](auto ng_, int g) __attribute__((always_inline)) {
+                constexpr int NG = decltype(ng_)::value;
+                const unsigned pb = (unsigned)(LC + g * LC);
+                const unsigned v1 = Xb + pb * XB + x10l, v2 = Xb + pb * XB + x20l, vl = Xb + pb * XB + lml, vy = Yb + pb * YB + yl;
+#pragma unroll
+                for (int gg = 0; gg < NG; gg++) {
+                    // the x1 / x2 (/ log-marginal) terms of the group's bodies, all on their way before the first body: left to itself
+                    // hipcc issues them two bodies ahead of their use here (in spec2x_walker, with registers to spare, ten) and every
+                    // other body waits out an LDS round trip
+                    double hx1[LC], hx2[LC], hlm[LC];
+#pragma unroll
+                    for (int u = 0; u < LC; u++) {
+                        hx1[u] = *(lds_cdouble *)(v1 + (unsigned)(gg * LC + u + 3) * XB);
+                        hx2[u] = *(lds_cdouble *)(v2 + (unsigned)(gg * LC + u + 2) * XB);
+                        if constexpr (MT) hlm[u] = *(lds_cdouble *)(vl + (unsigned)(gg * LC + u + 3) * XB);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < LC; u++) {
+                        // A: resolve w_{j+1}   (body j = k C + (g + gg) LC + u)
+                        const unsigned w = (unsigned)__builtin_ctzll(B >> (sh & 63u)) & 3u;
+                        hist = (hist << 2) + w;
+                        sh = hist << 2;
+                        // M: ballot of target j+2
+                        B = group_argmax<true>(accP);
+                        // S: target j+3, lag l+1 from source j-(l-2), l ascending
+                        double acc = H12;
+#pragma unroll
+                        for (int l = 2; l < LC; l++) acc += Y[(u - (l - 2) + 2 * LC) % LC][l];
+                        accP = acc;
+                        // R: row of source j+1 under its real symbol (lags 3..L); x1 + x2 of target j+4 (sources j+3 and j+2)
+                        if constexpr (NY > 0) {
+                            unsigned vrow;
+                            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(vrow) : "s"(w), "v"(yw_v), "v"(vy));
+                            const unsigned rb = vrow + (unsigned)(gg * LC + u + 1) * YB;
+#pragma unroll
+                            for (int l = 2; l + 1 < LC; l += 2) {
+                                const lds_v2d pr = *(const __attribute__((address_space(3))) lds_v2d *)(rb + (unsigned)(l - 2) * 8u);
+                                Y[(u + 1) % LC][l] = pr.x;
+                                Y[(u + 1) % LC][l + 1] = pr.y;
+                            }
+                            if constexpr (NY & 1) Y[(u + 1) % LC][LC - 1] = *(lds_cdouble *)(rb + (unsigned)(NY - 1) * 8u);
+                        }
+                        if constexpr (MT) H12 = (hlm[u] + hx1[u]) + hx2[u];
+                        else H12 = hx1[u] + hx2[u];
+                    }
+                    wk[g + gg] = (unsigned long long)hist;     // (two bits per pick)
+                }
+            };
+#ifdef PIPE_PROF
+            const unsigned long long tf0 = __builtin_amdgcn_s_memtime();
+#endif
+            for (; g + 2 <= nw; g += 2) fast(std::integral_constant<int, 2>{}, g);
+            if (g < nw) { fast(std::integral_constant<int, 1>{}, g); g++; }
+#ifdef PIPE_PROF
+            prof[7] += __builtin_amdgcn_s_memtime() - tf0;
+#endif
         }
+#ifdef PIPE_PROF
+        const unsigned long long tw = __builtin_amdgcn_s_memtime();
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef PIPE_PROF
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        prof[0] += tw - prof[2]; prof[1] += tb - tw; prof[2] = tb;
+#endif
     }
 }
 
@@ -772,8 +994,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
     // the entries, eight per round: a quotient and its log10 each (the marginals of the position are the bookkeeper's:
     // pipe_book_consume).  Row conditionals: entry (lag, column rb of the path's row); column conditionals: entry (lag, row ra,
     // the column of the path's to-symbol).
-    constexpr int EPL = WIDE ? 5 : 4;                          // entries per lag: WIDE also the fifth column (row conditionals) / the fifth row (column conditionals)
-    const int NT4 = EPL * Lw;
+    const int NT4 = 4 * Lw;
     const int nrows = p == 0 ? 1 : PK_NCAND(pkp);              // (column conditionals: position 0 has its '_' row only)
     // WIDE: where an entry goes.  Row conditionals: entry (row of the path's symbol at p, lag li + 1, column rb of the target whose word
     // stands in the slot) -- the table where both ranks are below 4; the S record of p where the path's symbol is p's fifth candidate;
@@ -798,9 +1019,7 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             if (rb == 4u) dst2 = g_W + (unsigned)PK_WIDX(pkp) * RECD + li * 8u + 4u;
         }
     };
-#pragma unroll 1
-    for (int t = s; t < NT4; t += 8) {
-        const int li = WIDE ? t / 5 : t >> 2, rb = WIDE ? t - 5 * (t / 5) : t & 3;
+    auto entry = [&](int li, int rb) __attribute__((always_inline)) {
         const double *sl = s_deal + li * SD;
         const unsigned long long word = reinterpret_cast<const unsigned long long *>(sl)[SD - 1];
         bool live;
@@ -822,6 +1041,17 @@ __device__ __forceinline__ void pipe_sweep_compute(const pipe_params &P, const w
             const double v = gh_log10_is_normal(xq) ? gh_log10_normal_tab(xq, 0, s_logtab, GH_LOG_SERIAL) : gh_log10_tab(xq, s_logtab, GH_LOG_SERIAL);
             *dst = v;
             if constexpr (WIDE) { if (dst2) *dst2 = v; }
+        }
+    };
+#pragma unroll 1
+    for (int t = s; t < NT4; t += 8) entry(t >> 2, t & 3);
+    if constexpr (WIDE) {
+        // the fifth column of a lag whose target offers five candidates (row conditionals) / the fifth row of a position that does
+        // (column conditionals): one lag per lane, and nothing but the look at the slot's word where there is none -- nearly everywhere
+#pragma unroll 1
+        for (int li = s; li < Lw; li += 8) {
+            const unsigned long long word = reinterpret_cast<const unsigned long long *>(s_deal + li * SD)[SD - 1];
+            if (!COL ? PK_NCAND(word) == 5 : ((word & 8ull) != 0 && nrows == 5)) entry(li, 4);
         }
     }
     if (P.mt) {
@@ -1127,6 +1357,8 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         const PIPE_GLOBAL(double) *gLM = pipe_gptr((const double *)d.lmr);
         typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(16)));     // (32 bytes per (row, lag) of the pipeline's table)
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
+        unsigned w_dir = 0;                     // WIDE: the directory word of the chunk being fetched (first record | records << 16)
+        unsigned long long w_pk = 0;            // ... and the packed word of buffer position `lane`
         const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.gp);
         const PIPE_GLOBAL(double) *gPK = pipe_gptr((const double *)(const void *)d.pk);      // (a made entry's two packed words ride in lo.x / hi.x)
         // Lags beyond the band are not read but MADE (conditionals other than B): their rows of the tensor are zeros, so an entry
@@ -1184,25 +1416,39 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 R.lo[it] = ld_v2d{a_.x, a_.y};
                 R.hi[it] = ld_v2d{b_.x, b_.y};
             }
+            if constexpr (WIDE) {
+                // the chunk's directory word and the packed word of this lane's buffer position: on their way with the table (in place, in
+                // store(), the two were a dependent round trip in front of every chunk: +28 % on the loaders' time)
+                w_dir = (unsigned)pipe_gptr((const int *)d.wdir)[k < nchunks ? k : 0];
+                const int pq = i0 + lane;
+                w_pk = pipe_gptr((const unsigned long long *)d.pk)[(pq >= 1 && pq <= N) ? pq : N + 1];
+            }
         };
         auto store = [&](int k) {
             const int i0 = k * C - (WIDE ? LC : 0);
             double *dst = g0 + (size_t)(k & 1) * npos * RS;
             double *yr = dst + (size_t)npos * XD;
+            // WIDE: the records of the wide positions this chunk can see (one contiguous run of the side table: they are numbered in
+            // position order) are requested first and written to LDS last: their round trip passes under the table's stores
+            constexpr int MAXW = WIDE ? (PIPE_WREC * RECD + NL - 1) / NL : 1;
+            double wrec[MAXW];
+            int w_cnt = 0;
             if constexpr (WIDE) {
-                // the records of the wide positions this chunk can see (one contiguous run of the side table: they are numbered in
-                // position order), and for every position of the buffer the slot its record stands in (0xff: none here)
-                const unsigned wd_ = (unsigned)pipe_gptr((const int *)d.wdir)[k];
-                const int first = (int)(wd_ & 0xffffu), cnt = (int)(wd_ >> 16);
-                double *WA = wide0 + (size_t)(k & 1) * PIPE_WREC * RECD;
+                const int first = (int)(w_dir & 0xffffu);
+                w_cnt = (int)(w_dir >> 16);
                 const PIPE_GLOBAL(double) *gW = pipe_gptr((const double *)d.gw) + (size_t)first * RECD;
-                for (int e = t; e < cnt * RECD; e += NL) WA[e] = gW[e];
-                uint8_t *WS = wslot0 + (k & 1) * PIPE_WSLOT_BYTES;
-                for (int pp = t; pp < npos; pp += NL) {
-                    const int pq = i0 + pp;
-                    const unsigned long long w = pipe_gptr((const unsigned long long *)d.pk)[(pq >= 1 && pq <= N) ? pq : N + 1];
-                    const int wi = PK_WIDX(w) - first;
-                    WS[pp] = (PK_WIDX(w) >= 0 && wi >= 0 && wi < cnt) ? (uint8_t)wi : (uint8_t)0xff;
+#pragma unroll
+                for (int it = 0; it < MAXW; it++) {
+                    const int e = t + it * NL;
+                    wrec[it] = gW[e < w_cnt * RECD ? e : 0];
+                }
+                if (ridx == 0) {
+                    // which positions of the buffer have their record here: one bit per position (C + L < 64), by ballot -- the records are in
+                    // position order, so a record's slot is its rank among the bits below its own
+                    const int pp = lane;
+                    const int wi = PK_WIDX(w_pk) - first;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(PK_WIDX(w_pk) >= 0 && wi >= 0 && wi < w_cnt && pp >= 1 && pp <= C + LC);
+                    if (lane == 0) *reinterpret_cast<unsigned long long *>(wslot0 + (k & 1) * PIPE_WSLOT_BYTES) = mask;
                 }
             }
 #pragma unroll
@@ -1250,6 +1496,14 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 }
                 // (pacing these stores with s_sleep, as k_walk_spec's loaders do, changed nothing here: 66.7 ms per 100 paths either
                 // way at 64 windows, 70.1 with 24 units of sleep per round -- scratch/README.md)
+            }
+            if constexpr (WIDE) {
+                double *WA = wide0 + (size_t)(k & 1) * PIPE_WREC * RECD;
+#pragma unroll
+                for (int it = 0; it < MAXW; it++) {
+                    const int e = t + it * NL;
+                    if (e < w_cnt * RECD) WA[e] = wrec[it];
+                }
             }
         };
         bool aborted = false;
@@ -1380,14 +1634,19 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     __builtin_amdgcn_s_setprio(3);
     bool aborted = false;
 #ifdef PIPE_PROF
-    unsigned long long wprof[3] = {0, 0, 0};
+    unsigned long long wprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (int sp = 0; sp < P.max_paths; sp++) {
         PIPE_BARRIER(); PIPE_BARRIER(); PIPE_BARRIER();             // epochs 0..2
 #ifdef PIPE_PROF
         wprof[2] = __builtin_amdgcn_s_memtime();
-        if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane, wprof);
-        else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane, wprof);
+        if constexpr (WIDE) {
+            if (P.mt) pipe_wide_walker<LC, true>(g0, words0, wide0, wslot0, C, nchunks, N, lane, wprof);
+            else pipe_wide_walker<LC, false>(g0, words0, wide0, wslot0, C, nchunks, N, lane, wprof);
+        } else {
+            if (P.mt) spec2x_walker<LC, true>(g0, words0, C, nchunks, lane, wprof);
+            else spec2x_walker<LC, false>(g0, words0, C, nchunks, lane, wprof);
+        }
 #else
         if constexpr (WIDE) {
             if (P.mt) pipe_wide_walker<LC, true>(g0, words0, wide0, wslot0, C, nchunks, N, lane);
@@ -1403,7 +1662,10 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
     }
     if (!aborted) PIPE_BARRIER();
 #ifdef PIPE_PROF
-    if (blockIdx.x == 0 && lane == 0) { st->dbg8[10] = wprof[0]; st->dbg8[11] = wprof[1]; }
+    if (blockIdx.x == 0 && lane == 0) {
+        st->dbg8[10] = wprof[0]; st->dbg8[11] = wprof[1];
+        if (WIDE) { st->dbg[2] = wprof[3] | (wprof[5] << 40); st->dbg[3] = wprof[7] | (wprof[6] << 40); }     // (cycles | count << 40: groups by the exact stepper, primes; cycles inside the speculative blocks)
+    }
 #endif
 #undef PIPE_BARRIER
 #undef PIPE_PROF_BEGIN

@@ -1,6 +1,7 @@
 """Throughput of the window pipeline (csrc/wpipe.hpp) on replicas of a config's contig.  argv: windows [paths] [reps] [config]
 env: GH_PIPE=0 -> the batched launches of rounds 1-4; GH_PIPE_NT; GH_PIPE_STAMPS=1 -> per-path times of a few windows;
-PB_COND (A..E), PB_MT (0/1), PB_STORAGE (f32/f64): the spec."""
+PB_COND (A..E), PB_MT (0/1), PB_STORAGE (f32/f64): the spec; PB_DEL=frac -> '-' at that fraction of the POSITIONS (bench.py's
+wide_window_sparse window: 0.01), the windows then go through the WIDE launch of the pipeline."""
 import os, sys, time
 import numpy as np
 import torch
@@ -15,6 +16,10 @@ spec = dict(cond_mode=os.environ.get("PB_COND", "A"), marginal_term=bool(int(os.
             storage=os.environ.get("PB_STORAGE", "f32"))
 tag = "%s%s %s" % (spec["cond_mode"], "+mt" if spec["marginal_term"] else "", spec["storage"])
 t = make_config(cfg, seed=0)
+if float(os.environ.get("PB_DEL", "0")) > 0:
+    from gretel_amd.synth import sprinkle_deletions
+    sprinkle_deletions(t, float(os.environ["PB_DEL"]), seed=4321)
+    tag += " del %s" % os.environ["PB_DEL"]
 h0 = Hansel(t.n_snps, band=t.band, **spec)
 reads = DeviceReads(h0, t.rank, t.off, t.bases)
 hs = [Hansel(t.n_snps, band=t.band, **spec) for _ in range(nw)]
