@@ -16,6 +16,7 @@ t_end = time.time() + budget
 n_cases = 0
 n_batch = 0
 n_pipe = 0
+n_wide = 0
 variants = {}
 while time.time() < t_end:
     n = int(rng.choice([4000, 7777, 12000, 20011])) if big else int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
@@ -54,6 +55,10 @@ while time.time() < t_end:
         # batched launch over 3 windows of one shape (same N, band, switches, L)
         ts = [t] + [make_support_table(n, reads, k=k, n_haps=int(rng.integers(1, 9)), err=err, seed=int(rng.integers(0, 1 << 30)))
                     for _ in range(2)]
+        # (round 6: the other windows get deletion columns of their own now and then -- the pipeline's WIDE launch, wpipe.hpp)
+        for x in ts[1:]:
+            if rng.random() < 0.4 and n >= 17:
+                sprinkle_deletions(x, float(rng.choice([0.004, 0.02, 0.06])), frac_reads=float(rng.choice([0.1, 0.3, 0.6])), seed=int(rng.integers(0, 1 << 30)))
         if len({x.band for x in ts}) == 1:
             hs, os_ = [], []
             for x in ts:
@@ -87,6 +92,7 @@ while time.time() < t_end:
                     print("MISMATCH batch", desc, dict(way=way, deep=deep, pipe=hb.pipe_info(), nt=os.environ.get("GH_PIPE_NT")), flush=True)
                     sys.exit(1)
             n_pipe += 1 if hb.pipe_info()["windows"] else 0
+            n_wide += 1 if hb.pipe_info()["windows"] and any((hh.candidate_masks()[1:] == 0x2F).any() for hh in hs) else 0
             n_batch += 1
             continue
     # the serial walkers instead of the segment-parallel / pool extension now and then (GH_WALK is read when a handle is created)
@@ -166,4 +172,4 @@ while time.time() < t_end:
         print("ERROR", repr(e), desc, flush=True)
         sys.exit(1)
     n_cases += 1
-print("fuzz ok: %d cases + %d batched triples (%d through the window pipeline), walker variants %s" % (n_cases, n_batch, n_pipe, variants))
+print("fuzz ok: %d cases + %d batched triples (%d through the window pipeline, %d of them with five-candidate positions), walker variants %s" % (n_cases, n_batch, n_pipe, n_wide, variants))
