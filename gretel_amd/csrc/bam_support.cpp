@@ -136,7 +136,10 @@ static int n_threads()
         if (t < 1) t = 1;
         // (measured on a 256-core host, C3 file: 8 threads 50 ms, 16 38 ms, 32 39 ms, 64 50 ms -- the serial parts bind; an explicit
         // GIO_THREADS may go to 64)
-        if (t > (asked ? 64 : 16)) t = asked ? 64 : 16;
+        // round 6, the pool and the kept buffers in place (C3 file, one MI355X host, ms inside the library: inflate / framing + records /
+        // key table): 16 threads 4 / 5 / 7, 24 threads 3 / 4 / 5, 32 threads 3 / 3 / 8, 48 threads 2 / 3 / 11 -- the first two stages
+        // scale, the key table's placing pass wants no more than 16 partitions
+        if (t > (asked ? 64 : 24)) t = asked ? 64 : 24;
         return t;
     }();
     return n;
@@ -799,7 +802,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         }
     };
     int n_part = 1;
-    while (n_part * 2 <= n_threads()) n_part *= 2;
+    while (n_part * 2 <= n_threads() && n_part * 2 <= 16) n_part *= 2;
     std::vector<ptable> tabs((size_t)n_part);
     // room for `rows` keys at half load in one partition; rehashing walks the old table front to back
     auto ptable_reserve = [&](ptable &T, size_t rows) -> bool {
