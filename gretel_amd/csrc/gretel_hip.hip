@@ -2463,13 +2463,12 @@ static bool pipe_instantiated(int L, int nt)
 
 // the window pipeline over the windows `wd` describes: marginals, snapshot and the full table for every window (what the batched
 // launches do in front of their first path), then ONE launch that carries every window through all its paths (wpipe.hpp)
-static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, int nt)
+// launch_only: the preamble has run (batch_pipe_preamble) and b->d_wd + d_off holds the n descriptors this launch takes
+static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, int nt, bool launch_only = false, int d_off = 0, bool no_sync = false)
 {
     const int n = (int)wd.size();
     if (n == 0) return GH_OK;
-    HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
-    hipLaunchKernelGGL(k_batch_reset, dim3(n), dim3(64), 0, b->stream, (const win_desc *)b->d_wd);
-    HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
+    if (!launch_only) HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
     gh_handle *h0 = b->hs[0];
     const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
     const int N = b->N, W = b->W, L = b->L;
@@ -2478,7 +2477,10 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
     size_t lt_nb = ((size_t)(N + LT_PAD) * L * LT_BLK + 255) / 256;
     if (lt_nb > 4096) lt_nb = 4096;
     hipStream_t st = b->stream;
-    const win_desc *gwd = b->d_wd;
+    const win_desc *gwd = b->d_wd + d_off;
+    if (!launch_only) {
+    hipLaunchKernelGGL(k_batch_reset, dim3(n), dim3(64), 0, b->stream, (const win_desc *)b->d_wd);
+    HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
     hipLaunchKernelGGL(k_rearm, dim3(n), dim3(64), 0, st, (dev_state *)nullptr, gwd, 0);
     if (f64) {
         hipLaunchKernelGGL((k_marg<double, false>), dim3(marg_gx, n), dim3(256), 0, st, (double *)nullptr, N, W,
@@ -2503,6 +2505,8 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
                            (const uint8_t *)nullptr, gwd, 0, walk_depth2_ok(bwm, L), (double *)nullptr, (double *)nullptr, h0->sm, (const float *)nullptr);
     }
     HIPCHK(hipGetLastError());
+    if (nt == 0) return GH_OK;                      // (the preamble only: batch_pipe_preamble)
+    }
     const int nr = pipe_sweep_threads(nt);
     pipe_params P;
     P.N = N; P.W = W; P.L = L; P.mt = h0->cfg.marginal_term ? 1 : 0; P.col = (h0->cfg.cond_mode == GH_COND_C || h0->cfg.cond_mode == GH_COND_E) ? 1 : 0;
@@ -2524,7 +2528,7 @@ static int batch_run_pipe(gh_batch *b, const std::vector<win_desc> &wd, int max_
     const hipError_t le = f64 ? launch_wpipe<double>(L, nt, P, gwd, n, lds, st) : launch_wpipe<float>(L, nt, P, gwd, n, lds, st);
     if (le != hipSuccess) return fail(GH_ERR_HIP, "gh_batch_spin: the pipeline launch failed (L=%d, %d threads, %zu bytes of LDS): %s", L, nt, lds, hipGetErrorString(le));
     if (sample) pmark(st);
-    HIPCHK(hipStreamSynchronize(st));
+    if (!no_sync) HIPCHK(hipStreamSynchronize(st));
     {
         // algorithmic bytes per window over the whole launch, the pipeline's own accounting: per position
         // and path the walk reads its compact table (4 rows x L lags x 32 bytes) and the bookkeeper the counts, the original
@@ -2662,14 +2666,15 @@ static int batch_run_launches(gh_batch *b, const std::vector<win_desc> &wd, int 
 // the windows the narrow pipeline left untouched because a position offers five candidates: the WIDE pipeline (wpipe.hpp) over them --
 // marginals, snapshot and table stand (batch_run_pipe's preamble ran over every window); a window it cannot take either (too many such
 // positions) keeps PIPE_NOT_STARTED
-static int batch_run_pipe_wide(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, int nt)
+static int batch_run_pipe_wide(gh_batch *b, const std::vector<win_desc> &wd, int max_paths, double min_remove, int nt, hipStream_t stream = nullptr, int d_off = -1)
 {
     const int n = (int)wd.size();
     if (n == 0) return GH_OK;
     gh_handle *h0 = b->hs[0];
     const bool f64 = h0->cfg.storage == GH_STORAGE_F64;
     const int N = b->N, W = b->W, L = b->L;
-    HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream));
+    const bool own = d_off < 0;                     // (else: the descriptors stand at b->d_wd + d_off, the caller waits for `stream`)
+    if (own) { stream = b->stream; d_off = 0; HIPCHK(hipMemcpyAsync(b->d_wd, wd.data(), sizeof(win_desc) * n, hipMemcpyHostToDevice, b->stream)); }
     const int nr = pipe_sweep_threads(nt);
     pipe_params P;
     P.N = N; P.W = W; P.L = L; P.mt = h0->cfg.marginal_term ? 1 : 0; P.col = (h0->cfg.cond_mode == GH_COND_C || h0->cfg.cond_mode == GH_COND_E) ? 1 : 0;
@@ -2677,9 +2682,9 @@ static int batch_run_pipe_wide(gh_batch *b, const std::vector<win_desc> &wd, int
     P.synth = getenv("GH_PIPE_SYNTH") ? (atoi(getenv("GH_PIPE_SYNTH")) != 0) : 1;
     P.offer_zero = h0->cfg.offer_zero; P.prof = 0; P.min_remove = min_remove; P.sm = h0->sm;
     const size_t lds = pipe_lds_bytes_w(N, L, P.C, nr, f64 ? 8 : 4, P.mt);
-    const hipError_t le = f64 ? launch_wpipe_w<double>(L, nt, P, b->d_wd, n, lds, b->stream) : launch_wpipe_w<float>(L, nt, P, b->d_wd, n, lds, b->stream);
+    const hipError_t le = f64 ? launch_wpipe_w<double>(L, nt, P, b->d_wd + d_off, n, lds, stream) : launch_wpipe_w<float>(L, nt, P, b->d_wd + d_off, n, lds, stream);
     if (le != hipSuccess) return fail(GH_ERR_HIP, "gh_batch_spin: the wide pipeline launch failed (L=%d, %d threads, %zu bytes of LDS): %s", L, nt, lds, hipGetErrorString(le));
-    HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
+    if (own) HIPCHK(hipStreamSynchronize(b->stream));        // wd is a host temporary
     return GH_OK;
 }
 
@@ -2835,9 +2840,52 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
     b->pipe_windows = 0;
     phase("descriptors");
     if (pipe_nt) {
-        if ((rc = batch_run_pipe(b, wd, max_paths, min_remove, pipe_nt))) return rc;
+        // Windows in which a position offers five candidates (deletion columns) go to the pipeline's WIDE launch (wpipe.hpp), the
+        // others to the narrow one -- side by side on two streams: which is which is only known once the marginals stand, so the
+        // preamble runs first and the host looks at the states (one wait, 30 us).  GH_PIPE_WIDE=0: the narrow launch alone, what it
+        // leaves goes to the batched launches as until round 5.
+        gh_handle *hp0 = b->hs[0];
+        const bool wide_on = !(getenv("GH_PIPE_WIDE") && atoi(getenv("GH_PIPE_WIDE")) == 0) && pipe_wide_instantiated(b->L, pipe_nt) &&
+                             !hp0->cfg.offer_zero && b->N < 65536 &&
+                             pipe_chunk_w(b->N, b->L, pipe_sweep_threads(pipe_nt), hp0->cfg.storage == GH_STORAGE_F64 ? 8 : 4, hp0->cfg.marginal_term) > 0;
+        std::vector<win_desc> both;             // (the descriptors of the two launches: alive until both have ended)
+        std::vector<char> listed((size_t)n, 1);
+        if (!wide_on) {
+            if ((rc = batch_run_pipe(b, wd, max_paths, min_remove, pipe_nt))) return rc;
+        } else {
+            if ((rc = batch_run_pipe(b, wd, max_paths, min_remove, 0))) return rc;          // reset + marginals, snapshot, table
+            if ((rc = fetch_states())) return rc;
+            std::vector<win_desc> nar, wid;
+            const size_t need = pipe_gw_bytes(b->N, b->L);
+            for (int w = 0; w < n; w++) {
+                const bool live = !hs[w].stop && hs[w].first_hole > b->N;
+                if (live && hs[w].ranked != 0 && hs[w].narrow != 0) nar.push_back(wd[w]);
+                else if (live && hs[w].ranked == 0) {
+                    gh_handle *h = b->hs[w];
+                    if (h->pipe_gw_bytes < need) {
+                        hipFree(h->pipe_gw); h->pipe_gw = nullptr; h->pipe_gw_bytes = 0;
+                        HIPCHK(hipMalloc((void **)&h->pipe_gw, need));
+                        h->pipe_gw_bytes = need;
+                    }
+                    wd[w].gw = h->pipe_gw;
+                    wd[w].wdir = reinterpret_cast<int *>(h->pipe_gw + (size_t)PIPE_WMAX * pipe_wrec_doubles(b->L));
+                    wid.push_back(wd[w]);
+                } else listed[(size_t)w] = 0;       // (a hole: neither launch takes it)
+            }
+            both = nar;
+            both.insert(both.end(), wid.begin(), wid.end());
+            if (!both.empty()) HIPCHK(hipMemcpyAsync(b->d_wd, both.data(), sizeof(win_desc) * both.size(), hipMemcpyHostToDevice, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            if (!wid.empty() && !b->gstream[0]) HIPCHK(hipStreamCreateWithFlags(&b->gstream[0], hipStreamNonBlocking));
+            if (!nar.empty() && (rc = batch_run_pipe(b, nar, max_paths, min_remove, pipe_nt, true, 0, true))) return rc;
+            if (!wid.empty() && (rc = batch_run_pipe_wide(b, wid, max_paths, min_remove, pipe_nt, b->gstream[0], (int)nar.size()))) return rc;
+            HIPCHK(hipStreamSynchronize(b->stream));
+            if (!wid.empty()) HIPCHK(hipStreamSynchronize(b->gstream[0]));
+        }
         phase("preamble + pipeline kernel");
         if ((rc = fetch_states())) return rc;
+        for (int w = 0; w < n; w++)
+            if (!listed[(size_t)w]) hs[w].pipe_status = PIPE_NOT_STARTED;
         phase("states to host");
         std::vector<win_desc> rest;     // not eligible when the kernel looked (a position offers five candidates, a hole): the batched launches
         for (int w = 0; w < n; w++) {
@@ -2869,42 +2917,7 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         }
         };
         print_stamps();
-        // What the narrow pipeline left untouched: windows in which a position offers five candidates.  The WIDE pipeline takes those
-        // whose five-candidate positions are few (GH_PIPE_WIDE=0: not)
-        {
-            gh_handle *h0 = b->hs[0];
-            const bool wide_on = !(getenv("GH_PIPE_WIDE") && atoi(getenv("GH_PIPE_WIDE")) == 0);
-            if (!rest.empty() && wide_on && pipe_wide_instantiated(b->L, pipe_nt) && !h0->cfg.offer_zero && b->N < 65536 &&
-                pipe_chunk_w(b->N, b->L, pipe_sweep_threads(pipe_nt), h0->cfg.storage == GH_STORAGE_F64 ? 8 : 4, h0->cfg.marginal_term) > 0) {
-                std::vector<win_desc> wrest;
-                const size_t need = pipe_gw_bytes(b->N, b->L);
-                for (int w = 0; w < n; w++) {
-                    if (hs[w].pipe_status != PIPE_NOT_STARTED || hs[w].stop || hs[w].ranked != 0 || hs[w].first_hole <= b->N) continue;
-                    gh_handle *h = b->hs[w];
-                    if (h->pipe_gw_bytes < need) {
-                        hipFree(h->pipe_gw); h->pipe_gw = nullptr; h->pipe_gw_bytes = 0;
-                        HIPCHK(hipMalloc((void **)&h->pipe_gw, need));
-                        h->pipe_gw_bytes = need;
-                    }
-                    wd[w].gw = h->pipe_gw;
-                    wd[w].wdir = reinterpret_cast<int *>(h->pipe_gw + (size_t)PIPE_WMAX * pipe_wrec_doubles(b->L));
-                    wrest.push_back(wd[w]);
-                }
-                if (!wrest.empty()) {
-                    if ((rc = batch_run_pipe_wide(b, wrest, max_paths, min_remove, pipe_nt))) return rc;
-                    phase("wide pipeline kernel");
-                    if ((rc = fetch_states())) return rc;
-                    print_stamps();
-                    rest.clear();
-                    for (int w = 0; w < n; w++) {
-                        if (hs[w].pipe_status == PIPE_NOT_STARTED) rest.push_back(wd[w]);
-                        else if (hs[w].pipe_status == PIPE_ABORTED) { if (std::find(aborted.begin(), aborted.end(), w) == aborted.end()) aborted.push_back(w); }
-                        else if (hs[w].pipe_status != PIPE_DONE) return fail(GH_ERR_STATE, "gh_batch_spin: window %d left the wide pipeline in state %d", w, hs[w].pipe_status);
-                    }
-                    b->pipe_windows = n - (int)rest.size();
-                }
-            }
-        }
+        // What the two launches left untouched (a hole; too many five-candidate positions for the WIDE launch's records).
         // A FEW such windows (a deletion column in one window of a batch of narrow ones) go the
         // single window's way, each on its own stream from a few host threads -- the segment-parallel / candidate-pool spins (mixed
         // radix at five lags): 25-37k haplotypes/s where the batched serial walkers, one wavefront per window, give 16k for eight
