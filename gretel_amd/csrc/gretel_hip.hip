@@ -2917,8 +2917,8 @@ extern "C" int gh_batch_spin(gh_batch_t *b, int max_paths, double min_remove, ui
         }
         };
         print_stamps();
-        // What the two launches left untouched (a hole; too many five-candidate positions for the WIDE launch's records).
-        // A FEW such windows (a deletion column in one window of a batch of narrow ones) go the
+        // What the two launches left untouched (a hole; too many five-candidate positions for the WIDE launch's records; every
+        // five-candidate window under GH_PIPE_WIDE=0).  A FEW such windows go the
         // single window's way, each on its own stream from a few host threads -- the segment-parallel / candidate-pool spins (mixed
         // radix at five lags): 25-37k haplotypes/s where the batched serial walkers, one wavefront per window, give 16k for eight
         // windows; from four dozen on the batched launches over all of them.

@@ -148,10 +148,10 @@ __host__ __device__ constexpr int pipe_chunk_w(int N, int L, int nr_threads, int
     const size_t fixed = pipe_fixed_bytes(N, nr_threads, esize) + pipe_wide_extra_bytes(L);
     if (L < 2 || fixed + 2 * (size_t)(2 * L + WALK_OV) * pipe_pos_doubles(L, mt) * 8 > WALK_LDS_MAX) return 0;
     long c = (long)((WALK_LDS_MAX - fixed) / (2 * (size_t)pipe_pos_doubles(L, mt) * 8)) - WALK_OV - L;
-    const long cap = nr_threads / 8 - WALK_OV - L;
+    const long cap = nr_threads / 8 - WALK_OV;      // (the sweep's positions per pass, as in the narrow launch; the buffer holds L more)
     if (c > cap) c = cap;
     if (c > 60) c = 60;
-    if (c > PIPE_WSLOT_BYTES - WALK_OV - L) c = PIPE_WSLOT_BYTES - WALK_OV - L;
+    if (c > 127 - L) c = 127 - L;                   // (the walker's mask of the buffer's wide positions: two 64-bit words)
     c = (c / L) * L;
     return c >= L ? (int)c : 0;
 }
@@ -500,20 +500,29 @@ __device__ __forceinline__ void pipe_wide_walker(const double *g0, unsigned long
         const unsigned Xb = g0a + (unsigned)(k & 1) * bufB, Yb = Xb + npos * XB;
         const unsigned Wb = wa0 + (unsigned)(k & 1) * (PIPE_WREC * RECD * 8u);
         // which positions of the buffer have their record here (bit bi; the loaders' ballot): a record's slot is its rank among them
-        unsigned long long wmask;
+        unsigned long long wmask, wmask2;                   // (bit bi of the pair: positions 0..63, 64..127)
         {
-            const unsigned long long wm = *(lds_cu64 *)(ws0 + (unsigned)(k & 1) * PIPE_WSLOT_BYTES);
+            const unsigned long long wm = *(lds_cu64 *)(ws0 + (unsigned)(k & 1) * PIPE_WSLOT_BYTES), wm2 = *(lds_cu64 *)(ws0 + (unsigned)(k & 1) * PIPE_WSLOT_BYTES + 8u);
             const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wm), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wm >> 32));
+            const unsigned lo2 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wm2), hi2 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wm2 >> 32));
             wmask = ((unsigned long long)hi << 32) | lo;
+            wmask2 = ((unsigned long long)hi2 << 32) | lo2;
         }
-        auto slot_of = [&](int bi) __attribute__((always_inline)) -> unsigned { return (unsigned)__builtin_popcountll(wmask & ((1ull << bi) - 1ull)); };
+        auto slot_of = [&](int bi) __attribute__((always_inline)) -> unsigned {
+            return bi < 64 ? (unsigned)__builtin_popcountll(wmask & ((1ull << bi) - 1ull))
+                           : (unsigned)(__builtin_popcountll(wmask) + __builtin_popcountll(wmask2 & ((1ull << (bi - 64)) - 1ull)));
+        };
+        auto wide_at = [&](int bi) __attribute__((always_inline)) -> bool { return ((bi < 64 ? wmask >> bi : wmask2 >> (bi - 64)) & 1ull) != 0; };
         unsigned long long *wk = words0 + (k & 1) * 64;
         const int ngroups = C / LC;
         int nw = -1;                                        // the next group (>= g) with a five-candidate target; ngroups: none
         for (int g = 0; g < ngroups;) {
             if (nw < g) {
-                const unsigned long long rem = wmask >> (g * LC + LC + 1);       // (target q of the chunk: buffer position q + LC)
-                nw = rem != 0ull ? g + (int)((unsigned)__builtin_ctzll(rem) / (unsigned)LC) : ngroups;
+                const int sft = g * LC + LC + 1;                                  // (target q of the chunk: buffer position q + LC; 1 <= sft < 64)
+                const unsigned long long rem = (wmask >> sft) | (wmask2 << (64 - sft)), rem2 = wmask2 >> sft;
+                nw = rem != 0ull ? g + (int)((unsigned)__builtin_ctzll(rem) / (unsigned)LC)
+                                 : (rem2 != 0ull ? g + (int)((64u + (unsigned)__builtin_ctzll(rem2)) / (unsigned)LC) : ngroups);
+                if (nw > ngroups) nw = ngroups;
             }
             // a five-candidate position among the group's targets, or a fifth candidate among the last LC picks (only the exact stepper
             // makes such picks: h3 is then current)?  Else the groups up to nw go to the speculative walker, two at a time, with nothing
@@ -535,7 +544,7 @@ __device__ __forceinline__ void pipe_wide_walker(const double *g0, unsigned long
                     const int q = g * LC + u + 1;           // chunk-local target 1 .. C (buffer position q + LC)
                     const int t = k * C + q;
                     unsigned pick = 0;
-                    const bool wide_t = ((wmask >> (q + LC)) & 1ull) != 0;
+                    const bool wide_t = wide_at(q + LC);
                     if (t <= N && t > LC && !wide_t && (h3 & M4) == 0ull) {
                         // four candidates here and no fifth among the last LC picks (most steps of such a group): the tables only --
                         // lanes 4..7 of every eight repeat lanes 0..3, the first maximum among the four is the pick
@@ -1351,14 +1360,14 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
         // tasks per position: (row, lag), and with the marginal term one more: the log10 marginals of the candidates of the
         // position's lag-1 TARGET by rank (lmr, kept by the sweep), which the walker adds in front of x1
         const int TPP = 4 * LC + (P.mt ? 1 : 0);
-        constexpr int MAXT = (MAXPOS * (4 * LC + 1) + NL - 1) / NL;
+        constexpr int MAXT = ((MAXPOS + (WIDE ? LC : 0)) * (4 * LC + 1) + NL - 1) / NL;     // (WIDE: L more sources in front of the chunk)
         const int nsrc_all = N + LT_PAD;
         const int ntask = npos * TPP;
         const PIPE_GLOBAL(double) *gLM = pipe_gptr((const double *)d.lmr);
         typedef double ld_v2d __attribute__((ext_vector_type(2), aligned(16)));     // (32 bytes per (row, lag) of the pipeline's table)
         struct regs { ld_v2d lo[MAXT], hi[MAXT]; } R;
         unsigned w_dir = 0;                     // WIDE: the directory word of the chunk being fetched (first record | records << 16)
-        unsigned long long w_pk = 0;            // ... and the packed word of buffer position `lane`
+        unsigned long long w_pk = 0, w_pk2 = 0; // ... and the packed words of buffer positions `lane` and 64 + `lane`
         const PIPE_GLOBAL(double) *gG = pipe_gptr((const double *)d.gp);
         const PIPE_GLOBAL(double) *gPK = pipe_gptr((const double *)(const void *)d.pk);      // (a made entry's two packed words ride in lo.x / hi.x)
         // Lags beyond the band are not read but MADE (conditionals other than B): their rows of the tensor are zeros, so an entry
@@ -1422,6 +1431,8 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                 w_dir = (unsigned)pipe_gptr((const int *)d.wdir)[k < nchunks ? k : 0];
                 const int pq = i0 + lane;
                 w_pk = pipe_gptr((const unsigned long long *)d.pk)[(pq >= 1 && pq <= N) ? pq : N + 1];
+                const int pq2 = pq + 64;
+                w_pk2 = pipe_gptr((const unsigned long long *)d.pk)[(pq2 >= 1 && pq2 <= N) ? pq2 : N + 1];
             }
         };
         auto store = [&](int k) {
@@ -1443,12 +1454,16 @@ __global__ void __launch_bounds__(NT, (NT == 512 && LC <= 6) ? 4 : (NT == 1024 ?
                     wrec[it] = gW[e < w_cnt * RECD ? e : 0];
                 }
                 if (ridx == 0) {
-                    // which positions of the buffer have their record here: one bit per position (C + L < 64), by ballot -- the records are in
+                    // which positions of the buffer have their record here: one bit per position (two words: C + L may reach 65), by ballot -- the records are in
                     // position order, so a record's slot is its rank among the bits below its own
                     const int pp = lane;
-                    const int wi = PK_WIDX(w_pk) - first;
+                    const int wi = PK_WIDX(w_pk) - first, wi2 = PK_WIDX(w_pk2) - first;
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(PK_WIDX(w_pk) >= 0 && wi >= 0 && wi < w_cnt && pp >= 1 && pp <= C + LC);
-                    if (lane == 0) *reinterpret_cast<unsigned long long *>(wslot0 + (k & 1) * PIPE_WSLOT_BYTES) = mask;
+                    const unsigned long long mask2 = __builtin_amdgcn_ballot_w64(PK_WIDX(w_pk2) >= 0 && wi2 >= 0 && wi2 < w_cnt && pp + 64 <= C + LC);
+                    if (lane == 0) {
+                        unsigned long long *wm = reinterpret_cast<unsigned long long *>(wslot0 + (k & 1) * PIPE_WSLOT_BYTES);
+                        wm[0] = mask; wm[1] = mask2;
+                    }
                 }
             }
 #pragma unroll

@@ -44,6 +44,7 @@ export PYTHONPATH=$GRAFT_REPO_ROOT
 (for w in 64 128 256; do PB_DEL=0.01 python3 scratch/pipe_bench.py $w 100 3 2>&1 | grep -v amdgpu.ids | tail -1; python3 scratch/pipe_bench.py $w 100 3 2>&1 | grep -v amdgpu.ids | tail -1; done
  echo "--- GH_PIPE_WIDE=0 (the batched launches of rounds 1-4 for such windows)"; PB_DEL=0.01 GH_PIPE_WIDE=0 python3 scratch/pipe_bench.py 256 100 2 2>&1 | grep -v amdgpu.ids | tail -1
  echo "--- conditional E + marginal term"; PB_DEL=0.01 PB_COND=E PB_MT=1 python3 scratch/pipe_bench.py 256 100 3 2>&1 | grep -v amdgpu.ids | tail -1; PB_COND=E PB_MT=1 python3 scratch/pipe_bench.py 256 100 3 2>&1 | grep -v amdgpu.ids | tail -1
+ echo "--- a batch of narrow and wide windows (every 4th / every 2nd window has the deletion columns): the two launches side by side"; for m in 4 2; do PB_DEL=0.01 PB_MIX=$m python3 scratch/pipe_bench.py 256 100 2 2>&1 | grep -v amdgpu.ids | tail -1; done
  echo "--- '-' at 0.02 % / 0.2 % / 3 % of the positions, 256 windows"; for f in 0.0002 0.002 0.03; do PB_DEL=$f python3 scratch/pipe_bench.py 256 100 2 2>&1 | grep -v amdgpu.ids | tail -1; done) > $out/pipe_wide.txt 2>&1
 if [ -f scratch/lib_pipe_prof.so ]; then
   (GH_LIB=$GRAFT_REPO_ROOT/scratch/lib_pipe_prof.so GH_PIPE_STAMPS=1 python3 scratch/pipe_bench.py 256 21 1 2>&1 | grep -v "amdgpu.ids\|gh_batch_spin" | tail -4
