@@ -146,3 +146,10 @@ def test_the_bench_line_keeps_its_contract():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "haplotypes/s"
     assert d["value"] > 50 * c["value"]                      # north_star: >= 50x the reference's CPU path
+    # the secondary figures stand right behind the contract's keys (a stored tail of the line had lost them)
+    keys = list(d)
+    assert keys.index("summary") == keys.index("config") + 1 and keys.index("summary") < keys.index("roofline")
+    for k in ("value_published_spec", "throughput_mode_256", "throughput_mode_256_published_spec", "throughput_mode_256_sparse_deletions",
+              "wide_window_sparse", "end_to_end_wall_s", "roofline_frac"):
+        assert k in d["summary"], k
+    assert d["summary"]["roofline_frac"] == r["frac"]
