@@ -27,7 +27,7 @@
  * <stem>.bai): the scan starts at the first block that can hold an alignment overlapping the window and ends at the
  * first record behind it.  Without an index every record of the file is visited.  Record fields are validated
  * against the record size (-4 on a malformed or truncated file); long-read CIGARs kept in the CG:B,I tag are resolved.
- * Environment: GIO_THREADS (inflating threads, default = cores, <= 16), GIO_NO_INDEX=1, GIO_ZLIB=1.
+ * Environment: GIO_THREADS (decoder threads, default = cores, <= 24; an explicit value up to 64), GIO_NO_INDEX=1, GIO_ZLIB=1.
  */
 #ifndef GRETEL_IO_H
 #define GRETEL_IO_H
