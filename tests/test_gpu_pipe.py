@@ -371,3 +371,71 @@ def test_the_switch_that_leaves_wide_windows_to_the_launches(monkeypatch):
     r = b.spin(9)[0]
     assert b.pipe_info()["windows"] == 0
     _same(r, o.spin(9), h, o)
+
+
+def _wide_table(seed, n, reads, k, positions, frac_reads=0.4, n_haps=6, k_max=21, err=0.01):
+    """'-' on `frac_reads` of the reads at exactly the given positions (1-based SNP numbers)."""
+    t = make_support_table(n, reads, k=k, seed=seed, n_haps=n_haps, err=err, k_max=k_max)
+    rng = np.random.default_rng(seed + 7)
+    ks = np.diff(t.off)
+    read_of = np.repeat(np.arange(t.n_reads, dtype=np.int64), ks)
+    snp = t.rank[read_of].astype(np.int64) + (np.arange(len(t.bases), dtype=np.int64) - t.off[read_of]) + 1
+    hit = np.isin(snp, np.asarray(positions)) & (rng.random(len(t.bases)) < frac_reads)
+    bases = t.bases.copy()
+    bases[hit] = ord('-')
+    t.bases = bases
+    return t
+
+
+def _run_wide(t, paths, L=None, band=None, expect_pipe=True, **kw):
+    W = band if band is not None else t.band
+    h = Hansel(t.n_snps, band=W, **kw)
+    o = COracle(t.n_snps, W, **kw)
+    assert h.fill_from_support(t.rank, t.off, t.bases) == o.fill(t)
+    if L is not None:
+        h.L = L
+        o.L = L
+    b = HanselBatch([h])
+    r = b.spin(paths)[0]
+    if expect_pipe is not None:
+        assert (b.pipe_info()["windows"] == 1) == expect_pipe, b.pipe_info()
+    _same(r, o.spin(paths), h, o)
+    return h
+
+
+@pytest.mark.parametrize("n", [7, 12, 30, 59, 60, 61, 64, 65, 119, 121, 241, 1203])
+def test_wide_window_lengths_around_the_chunk(n):
+    pos = sorted({1, 2, max(1, n // 2), n - 1, n} & set(range(1, n + 1)))
+    t = _wide_table(1100 + n, n, 40 * n, min(5, n), pos)
+    h = _run_wide(t, 9)
+    assert _n_wide(h) > 0
+
+
+def test_wide_positions_next_to_one_another_and_at_the_ends():
+    # runs of adjacent five-candidate positions (the stepper's records feed one another: entry (row 4, column 4) stands in both),
+    # the first and the last position of the window
+    t = _wide_table(1200, 400, 16000, 5, [1, 2, 3, 50, 51, 52, 53, 54, 200, 399, 400], frac_reads=0.5)
+    for kw in (dict(), dict(cond_mode="E", marginal_term=True), dict(cond_mode="B"), dict(cond_mode="C", storage="f64")):
+        h = _run_wide(t, 12, **kw)
+        assert _n_wide(h) >= 3
+
+
+def test_more_wide_positions_than_a_chunk_holds_records_for_is_refused():
+    # twenty in a row, every base seen at each of them (5 % substitutions): more five-candidate positions than PIPE_WREC in one reach
+    t = _wide_table(1210, 400, 40000, 5, list(range(100, 120)), frac_reads=0.5, n_haps=8, err=0.05)
+    h = _run_wide(t, 6, expect_pipe=False)
+    assert _n_wide(h) >= 12
+
+
+@pytest.mark.parametrize("paths", [1, 2, 3])
+def test_wide_very_short_spins(paths):
+    t = _wide_table(1220, 300, 9000, 5, [40, 41, 150, 299])
+    _run_wide(t, paths)
+
+
+@pytest.mark.parametrize("L,band", [(2, 9), (3, 12), (5, 12), (6, 20), (8, 20), (9, 12), (10, 20), (10, 9)])
+def test_wide_lag_counts_and_bands(L, band):
+    # bands wider than the eight lanes of a sweep's lane group, lag counts beyond eight (the sweep's further rounds), lags beyond the band
+    t = _wide_table(1230 + L, 500, 12000, None, [30, 31, 100, 260, 261, 262, 470], n_haps=5, k_max=band + 1)
+    for kw in (dict(), dict(cond_mode="E", marginal_term=True)):
+        _run_wide(t, 7, L=L, band=band, **kw)
