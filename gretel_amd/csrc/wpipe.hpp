@@ -564,6 +564,31 @@ __device__ __forceinline__ void pipe_wide_walker(const double *g0, unsigned long
                         m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
                         const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
                         pick = (unsigned)__builtin_ctz(((unsigned)win & 0xfu) | 0x10u) & 3u;
+                    } else if (t <= N && t > LC && !wide_t) {
+                        // four candidates here, a fifth among the last LC picks: as above, but the term of a source whose pick was its
+                        // fifth candidate comes from that source's S record (one lag in L, as a rule: the steps behind a wide position
+                        // where '-' was picked)
+                        auto term = [&](int l) __attribute__((always_inline)) -> double {
+                            const unsigned r = (unsigned)(h3 >> (3 * (l - 1))) & 7u;
+                            const int bi = q + LC - l;
+                            unsigned a;
+                            if (r == 4u) a = Wb + slot_of(bi) * (RECD * 8u) + (unsigned)(l - 1) * 64u + b3 * 8u;
+                            else if (l <= 2) a = Xb + (unsigned)bi * XB + (unsigned)(l - 1) * 128u + r * 32u + b3 * 8u;
+                            else a = Yb + (unsigned)bi * YB + r * YWB + yl + (unsigned)(l - 3) * 8u;
+                            return *(lds_cdouble *)a;
+                        };
+                        double x[LC];
+#pragma unroll
+                        for (int l = 1; l <= LC; l++) x[l - 1] = term(l);
+                        double acc = x[0];
+                        if constexpr (MT) acc = *(lds_cdouble *)(Xb + (unsigned)(q + LC - 1) * XB + (32u + b3) * 8u) + acc;
+#pragma unroll
+                        for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
+                        double m = acc;
+                        m = vmax_f64(m, dpp_f64<0xB1>(m));      // quad_perm [1,0,3,2]
+                        m = vmax_f64(m, dpp_f64<0x4E>(m));      // quad_perm [2,3,0,1]
+                        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+                        pick = (unsigned)__builtin_ctz(((unsigned)win & 0xfu) | 0x10u) & 3u;
                     } else if (t <= N) {
                         const unsigned recT = Wb + (wide_t ? slot_of(q + LC) : 0u) * (RECD * 8u);
                         double x[LC];
