@@ -287,14 +287,17 @@ class _gio_table(C.Structure):
 class gio_stats(C.Structure):
     _fields_ = [("compressed_bytes", C.c_int64), ("blocks", C.c_int64), ("records", C.c_int64), ("reads_kept", C.c_int64),
                 ("used_index", C.c_int32), ("libdeflate", C.c_int32), ("threads", C.c_int32), ("reframed", C.c_int32),
-                ("seconds", C.c_double), ("depth_dropped", C.c_int64)]
+                ("seconds", C.c_double), ("depth_dropped", C.c_int64), ("max_row_len", C.c_int32), ("prefetched", C.c_int32)]
+
+
+GIO_ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_size_t)          # include/gretel_io.h: gio_alloc_fn
 
 
 def native_last_stats():
     """dict of what the last native_support_table call did (bytes, blocks, records, index use, seconds)."""
     st = gio_stats()
     io_lib().gio_last_stats(C.byref(st))
-    return {k: getattr(st, k) for k, _ in gio_stats._fields_ if k != "_pad"}
+    return {k: getattr(st, k) for k, _ in gio_stats._fields_ if k != "reserved_"}
 
 
 def io_lib():
@@ -309,6 +312,11 @@ def io_lib():
                                                  C.POINTER(_gio_table)]
         L.gio_support_table_from_bam_depth.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_int32,
                                                        C.POINTER(_gio_table)]
+        L.gio_support_table_from_bam_alloc.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int, C.c_int32,
+                                                       GIO_ALLOC_FN, C.c_void_p, C.POINTER(_gio_table)]
+        L.gio_prefetch.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32]
+        L.gio_prefetch_cancel.argtypes = []
+        L.gio_prefetch_cancel.restype = None
         L.gio_table_free.argtypes = [C.POINTER(_gio_table)]
         L.gio_last_stats.argtypes = [C.POINTER(gio_stats)]
         L.gio_last_stats.restype = None
@@ -325,6 +333,18 @@ def native_release_buffers():
     io_lib().gio_release_buffers()
 
 
+def native_prefetch(bam_path, contig, start_pos, end_pos):
+    """Start reading and inflating the window's part of the BAM on a thread of the library (include/gretel_io.h: gio_prefetch) and
+    return at once: the native_support_table call for the same window takes it over.  For callers that still have a VCF to parse."""
+    L = io_lib()
+    if L.gio_prefetch(bam_path.encode(), contig.encode(), int(start_pos), int(end_pos)):
+        raise IOError(L.gio_last_error().decode())
+
+
+def native_prefetch_cancel():
+    io_lib().gio_prefetch_cancel()
+
+
 def native_ref_len(bam_path, contig):
     L = io_lib()
     out = C.c_int64()
@@ -336,22 +356,43 @@ def native_ref_len(bam_path, contig):
 PYSAM_MAX_DEPTH = 8000          # bam.pileup's default, which the reference inherits (gretel/util.py:137 passes no max_depth)
 
 
-def native_support_table(bam_path, contig, start_pos, end_pos, region, stepper="samtools", max_depth=PYSAM_MAX_DEPTH):
-    """max_depth: the pileup's read-buffer cap (pysam's default 8000; 0 or None: keep every read)."""
+def native_support_table(bam_path, contig, start_pos, end_pos, region, stepper="samtools", max_depth=PYSAM_MAX_DEPTH, arena=None):
+    """max_depth: the pileup's read-buffer cap (pysam's default 8000; 0 or None: keep every read).
+    arena: where the table's three arrays go instead of the library's own malloc (gio_support_table_from_bam_alloc) -- an object with
+    alloc(which, nbytes) -> address (0: none) and view(which, dtype, count) -> numpy array over what alloc(which, ...) returned last;
+    gretel_amd.hansel.PinnedTableArena keeps page-locked blocks from call to call.  The arrays returned are then the ARENA's:
+    their contents stand until the arena is used for the next table."""
     L = io_lib()
     reg = np.ascontiguousarray(np.asarray(region) != 0, dtype=np.uint8)
     if len(reg) < end_pos + 1:
         reg = np.concatenate([reg, np.zeros(end_pos + 1 - len(reg), dtype=np.uint8)])
     t = _gio_table()
-    rc = L.gio_support_table_from_bam_depth(bam_path.encode(), contig.encode(), int(start_pos), int(end_pos),
-                                            reg.ctypes.data, int(stepper == "all"), int(max_depth or 0), C.byref(t))
+    if arena is not None:
+        failed = []
+
+        def _alloc(_ctx, which, nbytes):
+            try:
+                return int(arena.alloc(int(which), int(nbytes))) or None
+            except Exception as exc:                    # (an exception cannot cross the C frames: NULL, and said afterwards)
+                failed.append(exc)
+                return None
+
+        rc = L.gio_support_table_from_bam_alloc(bam_path.encode(), contig.encode(), int(start_pos), int(end_pos), reg.ctypes.data,
+                                                int(stepper == "all"), int(max_depth or 0), GIO_ALLOC_FN(_alloc), None, C.byref(t))
+        if failed:
+            raise failed[0]
+    else:
+        rc = L.gio_support_table_from_bam_depth(bam_path.encode(), contig.encode(), int(start_pos), int(end_pos),
+                                                reg.ctypes.data, int(stepper == "all"), int(max_depth or 0), C.byref(t))
     if rc:
         msg = L.gio_last_error().decode()
         raise (KeyError if rc == -5 else IOError)(msg)
+    n, nb = t.n_reads, t.n_bases
+    if arena is not None:
+        return arena.view(0, np.int32, n), arena.view(1, np.int64, n + 1), arena.view(2, np.uint8, nb)
     # the three arrays are views of the library's buffers (no copy of 30 MB per million reads); the buffers are released
     # when the last of them is garbage-collected
     owner = _TableOwner(L, t)
-    n, nb = t.n_reads, t.n_bases
 
     def view(ptr, ctype, count, dtype):
         if count == 0:

@@ -203,6 +203,9 @@ def main(argv=None):
     if args.end == -1:
         args.end = util.get_ref_len_from_bam(args.bam, args.contig)               # cmd.py:53-55
         sys.stderr.write("[NOTE] Setting end_pos to %d" % args.end)
+    if not (args.debugreads or args.debugpos):
+        # (the BAM's blocks are read and inflated on the decoder's threads while the VCF is parsed here: include/gretel_io.h, gio_prefetch)
+        util.prefetch_bam(args.bam, args.contig, args.start, args.end)
     vcf_h = util.process_vcf(args.vcf, args.contig, args.start, args.end)         # cmd.py:69
     if args.dumpsnps:                                                             # cmd.py:70-74
         with open(args.dumpsnps, "w") as fh:

@@ -370,6 +370,18 @@ public:
     const uint8_t *data() const { return p_; }
     void clear() { n_ = 0; }
     void drop_front(size_t k) { if (k) { memmove(p_, p_ + k, n_ - k); n_ -= k; } }
+    // room for `c` bytes without another move (the bytes held stay)
+    bool reserve(size_t c)
+    {
+        if (c <= cap_) return true;
+        uint8_t *q = (uint8_t *)big_alloc(c);
+        if (!q) return false;
+        if (n_) memcpy(q, p_, n_);
+        big_free(p_, cap_);
+        p_ = q;
+        cap_ = c;
+        return true;
+    }
     bool resize_uninit(size_t n)
     {
         if (n > cap_) {
@@ -434,6 +446,10 @@ public:
     // share of the file behind the last seek that has been read (for sizing what grows with the records)
     double progress() const { return fsize_ > start_ ? (double)taken_ / (double)(fsize_ - start_) : 1.0; }
     void consume(size_t n) { rd_ += n; }
+    size_t window_cap() const { return WINDOW; }
+    // a window that is filled by several refills in a row (gio_prefetch) grows in place: moving 80 MB to make room for the next
+    // 35 was most of a prefetch's time.  Address space only -- pages are touched as they are written.
+    void reserve_window(size_t bytes) { out_.reserve(bytes); }
 
 private:
     struct blk { size_t coff, clen, isize, uoff; };
@@ -710,28 +726,115 @@ static int parse_record(const uint8_t *r, int32_t block_size, bam_rec &out)
 
 static const char SEQ[] = "=ACMGRSVTWYHKDBN";
 
+// gio_prefetch: everything of a decode that does not need the SNP positions -- the header, the index seek, the window's BGZF
+// blocks read and inflated (up to the inflated window's cap) -- on a thread of the library, so that the caller can parse its VCF
+// meanwhile (gretel/cmd.py:69-78: process_vcf, then load_from_bam).  One at a time; the decode of the same (path, contig, start,
+// end) takes it over, anything else discards it.  A prefetch that failed is dropped and the decode starts afresh (and reports).
+struct prefetched {
+    std::string path, contig;
+    int32_t start = 0, end = 0;
+    std::thread th;
+    std::unique_ptr<bgzf_stream> z;
+    bam_header hd;
+    int tid = -1, rc = 0;
+    bool used_index = false;
+    int64_t compressed = 0, blocks = 0;
+};
+static std::mutex &prefetch_mu() { static std::mutex *m = new std::mutex(); return *m; }
+static prefetched *&prefetch_slot()
+{
+    static prefetched *p = nullptr;
+    static std::once_flag once;
+    // (a forked child has no such thread: what the slot held is the parent's, and is left alone there)
+    std::call_once(once, [] { pthread_atfork(nullptr, nullptr, [] { prefetch_slot() = nullptr; }); });
+    return p;
+}
+static void prefetch_body(prefetched *p)
+{
+    memset(&g_stats, 0, sizeof g_stats);
+    g_err[0] = 0;
+    try {
+        p->z.reset(new bgzf_stream());
+        int rc = p->z->open(p->path.c_str());
+        if (!rc) rc = read_header(*p->z, p->hd, p->path.c_str());
+        if (!rc) {
+            for (size_t i = 0; i < p->hd.refs.size(); i++)
+                if (p->hd.refs[i].first == p->contig) p->tid = (int)i;
+            if (p->tid < 0) rc = -5;
+        }
+        uint64_t voff = 0;
+        if (!rc && bai_start(p->path.c_str(), p->tid, (int64_t)p->start - 1, &voff)) {
+            rc = p->z->seek(voff >> 16, (unsigned)(voff & 0xffff));
+            p->used_index = true;
+        }
+        if (!rc) {
+            p->z->reserve_window(2 * p->z->window_cap());
+            const int64_t av = p->z->ensure(p->z->window_cap());
+            if (av < 0) rc = (int)av;
+        }
+        p->rc = rc;
+    } catch (...) { p->rc = -6; }
+    p->compressed = g_stats.compressed_bytes;
+    p->blocks = g_stats.blocks;
+}
+static void prefetch_discard(prefetched *p)
+{
+    if (!p) return;
+    if (p->th.joinable()) p->th.join();
+    delete p;
+}
+// the prefetch of exactly this window, finished and good -- or nullptr (whatever else was there is discarded)
+static prefetched *prefetch_take(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos)
+{
+    prefetched *p = nullptr;
+    {
+        std::lock_guard<std::mutex> g(prefetch_mu());
+        p = prefetch_slot();
+        prefetch_slot() = nullptr;
+    }
+    if (!p) return nullptr;
+    if (p->th.joinable()) p->th.join();
+    if (p->rc == 0 && p->path == bam_path && p->contig == contig && p->start == start_pos && p->end == end_pos) return p;
+    delete p;
+    return nullptr;
+}
+
 static int gio_support_table_from_bam_impl(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
-                                           const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out)
+                                           const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out,
+                                           gio_alloc_fn alloc = nullptr, void *alloc_ctx = nullptr)
 {
     if (!bam_path || !contig || !region || !out || end_pos < 0) return fail(-1, "bad argument");
     memset(out, 0, sizeof *out);
     memset(&g_stats, 0, sizeof g_stats);
     g_err[0] = 0;
     const auto t_begin = std::chrono::steady_clock::now();
-    bgzf_stream z;
-    int rc = z.open(bam_path);
-    if (rc) return rc;
+    std::unique_ptr<bgzf_stream> z_own;
     bam_header hd;
-    if ((rc = read_header(z, hd, bam_path))) return rc;
     int tid = -1;
-    for (size_t i = 0; i < hd.refs.size(); i++)
-        if (hd.refs[i].first == contig) tid = (int)i;
-    if (tid < 0) return fail(-5, "contig %s not in %s", contig, bam_path);
-    uint64_t voff = 0;
-    if (bai_start(bam_path, tid, (int64_t)start_pos - 1, &voff)) {
-        if ((rc = z.seek(voff >> 16, (unsigned)(voff & 0xffff)))) return rc;
-        g_stats.used_index = 1;
+    int rc = 0;
+    if (std::unique_ptr<prefetched> pf{prefetch_take(bam_path, contig, start_pos, end_pos)}) {
+        // (gio_prefetch has read the header, sought and inflated the window's blocks meanwhile)
+        z_own = std::move(pf->z);
+        hd = std::move(pf->hd);
+        tid = pf->tid;
+        g_stats.used_index = pf->used_index ? 1 : 0;
+        g_stats.compressed_bytes += pf->compressed;
+        g_stats.blocks += pf->blocks;
+        g_stats.prefetched = 1;
+    } else {
+        z_own.reset(new bgzf_stream());
+        if ((rc = z_own->open(bam_path))) return rc;
+        if ((rc = read_header(*z_own, hd, bam_path))) return rc;
+        for (size_t i = 0; i < hd.refs.size(); i++)
+            if (hd.refs[i].first == contig) tid = (int)i;
+        if (tid < 0) return fail(-5, "contig %s not in %s", contig, bam_path);
+        uint64_t voff = 0;
+        if (bai_start(bam_path, tid, (int64_t)start_pos - 1, &voff)) {
+            if ((rc = z_own->seek(voff >> 16, (unsigned)(voff & 0xffff)))) return rc;
+            g_stats.used_index = 1;
+        }
     }
+    bgzf_stream &z = *z_own;
 
     // csum[x] = number of SNPs in [0, x)
     std::vector<int32_t> csum((size_t)end_pos + 2, 0);
@@ -784,44 +887,69 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     // (linear probing, at most half full); the hash's lower half says where the probe starts, a slot holds the upper half
     // and the gid -- 8 bytes, lazily-zeroed memory; a matching tag is confirmed on the lower half and the key bytes.
     struct slot { uint32_t tag, gid1; };                    // gid1 = gid + 1, 0 = empty
+    // (a partition's slots come from the kept blocks like the other working buffers and go back there: mapping 16 MB of fresh pages
+    // per decode and unmapping them on the way out was 2.5-3 ms of a 17 ms call.  A kept block is not zero: the partition's own
+    // thread clears it before its first record -- `stale` -- so the clearing is spread over the threads as the page faults were)
     struct ptable {
         slot *p = nullptr;
         size_t n = 0, count = 0;
+        bool stale = false;                                 // allocated, not cleared yet (and nothing placed)
         std::vector<uint32_t> dups;                         // this batch's records whose key was there already
         bool oom = false;
         ptable() = default;
         ptable(const ptable &) = delete;
         ptable &operator=(const ptable &) = delete;
-        ~ptable() { if (p) munmap(p, n * sizeof(slot)); }
+        ~ptable() { release(p, n); }
+        static size_t bytes_of(size_t slots) { return big_round(slots * sizeof(slot)); }
         static slot *alloc(size_t slots)
         {
-            void *q = mmap(nullptr, slots * sizeof(slot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-            if (q == MAP_FAILED) return nullptr;
-            madvise(q, slots * sizeof(slot), MADV_HUGEPAGE);
+            const size_t sz = bytes_of(slots);
+            if (void *q = big_cache::get().take(sz)) return (slot *)q;
+            void *q = aligned_alloc((size_t)2 << 20, sz);
+            if (q) madvise(q, sz, MADV_HUGEPAGE);
             return (slot *)q;
+        }
+        static void release(slot *q, size_t slots)
+        {
+            if (q && !big_cache::get().give(q, bytes_of(slots))) free(q);
+        }
+        void clear_if_stale()
+        {
+            if (stale) { memset(p, 0, n * sizeof(slot)); stale = false; }
         }
     };
     int n_part = 1;
     while (n_part * 2 <= n_threads() && n_part * 2 <= 16) n_part *= 2;
     std::vector<ptable> tabs((size_t)n_part);
-    // room for `rows` keys at half load in one partition; rehashing walks the old table front to back
-    auto ptable_reserve = [&](ptable &T, size_t rows) -> bool {
+    // room for `rows` keys at half load in one partition; rehashing walks the old table front to back.  clear_now: the caller is
+    // the partition's thread (or nothing runs beside it); else an empty partition's new slots are cleared by its thread later
+    auto ptable_reserve = [&](ptable &T, size_t rows, bool clear_now) -> bool {
         if (T.p && rows * 2 <= T.n) return true;
         size_t want = T.n ? T.n : ((size_t)1 << 12);
         while (rows * 2 > want) want *= 2;
         slot *np = ptable::alloc(want);
         if (!np) return false;
-        const size_t nm = want - 1;
-        for (size_t i = 0; i < T.n; i++) {
-            const slot e = T.p[i];
-            if (!e.gid1) continue;
-            size_t j = (size_t)info[e.gid1 - 1].h_lo & nm;
-            while (np[j].gid1) j = (j + 1) & nm;
-            np[j] = e;
+        if (T.count == 0 && !clear_now) {
+            ptable::release(T.p, T.n);
+            T.p = np;
+            T.n = want;
+            T.stale = true;
+            return true;
         }
-        if (T.p) munmap(T.p, T.n * sizeof(slot));
+        memset(np, 0, want * sizeof(slot));
+        const size_t nm = want - 1;
+        if (!T.stale)
+            for (size_t i = 0; i < T.n; i++) {
+                const slot e = T.p[i];
+                if (!e.gid1) continue;
+                size_t j = (size_t)info[e.gid1 - 1].h_lo & nm;
+                while (np[j].gid1) j = (j + 1) & nm;
+                np[j] = e;
+            }
+        ptable::release(T.p, T.n);
         T.p = np;
         T.n = want;
+        T.stale = false;
         return true;
     };
 
@@ -975,6 +1103,9 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     // the depth cap's state across batches: the position the iterator stands on, the reads that entered, their ends
     int64_t dc_pos = -1, dc_base = -1, dc_exp_upto = 0, dc_accepted = 0, dc_expired = 0;
     std::vector<uint32_t> dc_ends;                                          // [end - dc_base] reads that entered and end there
+    // ... and of the showing that the cap cannot bind (below): reads per bucket of B positions from pos0 on, the longest reference
+    // span, the last start, the parts whose candidates were set aside
+    struct { std::vector<uint32_t> H; int64_t pos0 = -1, B = 16, maxspan = 0, last_pos = -1; bool off = false; std::vector<size_t> deferred; } dq;
     bool done = false;
     bool front_to_back = false;                                             // this batch again on one thread (a guessed start was wrong)
     while (!done) {
@@ -1076,8 +1207,67 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         // sentinel node, and is dropped when that is more than max_depth.  One pass over the batch's records, the ends in a
         // histogram (the starts ascend: what has expired is a running sum).
         if (max_depth > 0) {
-            for (int t = 0; t < n_valid; t++) {
-                part &P = *kept_parts[p0 + (size_t)t];
+            // The pass below is one thread over every record (2 ms per million).  Most windows never come near the cap, and that
+            // can be SHOWN batch by batch on all threads: a read in the buffer when read c is pushed starts at or before c and ends
+            // at or behind it, so it starts within the longest reference span seen so far in front of c -- if no stretch of that
+            // length (in buckets of dq.B positions, over every batch so far) holds max_depth reads, nothing is dropped, by
+            // induction over the file order.  Such a batch's candidates are set aside; the first batch that cannot be shown
+            // (or is out of order: the pass says where) takes the pass over everything set aside first -- its state then is what
+            // it would have been -- and the pass runs from there on.
+            bool shown = false;
+            if (!dq.off) {
+                struct pstat { int64_t first = -1, last = -1, span = 0; bool sorted = true; };
+                std::vector<pstat> ps((size_t)n_valid);
+                worker_pool::get().run(n_valid, [&](int t) {
+                    const part &P = *kept_parts[p0 + (size_t)t];
+                    pstat &o = ps[(size_t)t];
+                    for (size_t ci = 0; ci < P.cands.size(); ci++) {
+                        const depth_cand &c = P.cands[ci];
+                        if (o.first < 0) o.first = c.pos;
+                        if ((int64_t)c.pos < o.last) o.sorted = false;
+                        o.last = c.pos;
+                        if ((int64_t)c.end - (int64_t)c.pos > o.span) o.span = (int64_t)c.end - (int64_t)c.pos;
+                    }
+                });
+                bool sorted = true;
+                int64_t last = dq.last_pos, first = -1, span = dq.maxspan;
+                for (int t = 0; t < n_valid; t++) {
+                    const pstat &o = ps[(size_t)t];
+                    if (o.first < 0) continue;                              // (pos >= 0 on a candidate: the record is mapped)
+                    if (!o.sorted || o.first < last) sorted = false;
+                    if (first < 0) first = o.first;
+                    last = o.last;
+                    if (o.span > span) span = o.span;
+                }
+                if (sorted && first >= 0) {
+                    if (dq.pos0 < 0) {
+                        dq.pos0 = first;
+                        const int64_t range = (int64_t)end_pos - first + 1;
+                        dq.B = 16;
+                        while (range / dq.B + 2 > ((int64_t)1 << 20)) dq.B *= 2;
+                        dq.H.assign((size_t)(range / dq.B + 2), 0u);
+                    }
+                    worker_pool::get().run(n_valid, [&](int t) {
+                        const part &P = *kept_parts[p0 + (size_t)t];
+                        for (size_t ci = 0; ci < P.cands.size(); ci++)
+                            __atomic_fetch_add(&dq.H[(size_t)(((int64_t)P.cands[ci].pos - dq.pos0) / dq.B)], 1u, __ATOMIC_RELAXED);
+                    });
+                    const int64_t k = span / dq.B + 1;                      // buckets a span reaches back
+                    const int64_t jlo = (first - dq.pos0) / dq.B, jhi = (last - dq.pos0) / dq.B;
+                    uint64_t S = 0;
+                    for (int64_t j = jlo - k < 0 ? 0 : jlo - k; j < jlo; j++) S += dq.H[(size_t)j];
+                    shown = true;
+                    for (int64_t j = jlo; j <= jhi && shown; j++) {
+                        S += dq.H[(size_t)j];
+                        if (j - k - 1 >= 0) S -= dq.H[(size_t)(j - k - 1)];
+                        if (S + 1 > (uint64_t)max_depth) shown = false;
+                    }
+                    if (shown) { dq.last_pos = last; dq.maxspan = span; }
+                } else if (sorted) {
+                    shown = true;                                           // (no candidate in this batch)
+                }
+            }
+            auto depth_pass = [&](part &P, bool deferred) -> int {
                 bool any = false;
                 for (size_t ci = 0; ci < P.cands.size(); ci++) {
                     const depth_cand &c = P.cands[ci];
@@ -1106,6 +1296,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                         drop = dc_accepted - dc_expired + 1 > (int64_t)max_depth;
                     }
                     if (drop) {
+                        if (deferred) return fail(-7, "internal: the pileup's depth cap dropped a read of a batch that was shown to need none");
                         g_stats.depth_dropped++;
                         if (c.kept_idx >= 0) { P.recs[(size_t)c.kept_idx].ch_len = 0xffffffffu; any = true; }
                         continue;
@@ -1124,6 +1315,17 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                     P.recs.resize(w);
                 }
                 bigvec<depth_cand>().swap(P.cands);
+                return 0;
+            };
+            if (shown) {
+                for (int t = 0; t < n_valid; t++) dq.deferred.push_back(p0 + (size_t)t);
+            } else {
+                dq.off = true;
+                for (size_t pi : dq.deferred)
+                    if (int rc2 = depth_pass(*kept_parts[pi], true)) return rc2;
+                dq.deferred.clear();
+                for (int t = 0; t < n_valid; t++)
+                    if (int rc2 = depth_pass(*kept_parts[p0 + (size_t)t], false)) return rc2;
             }
         }
         // gids of this batch: the parts' records behind one another
@@ -1139,7 +1341,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
             if (est < g_end || est > (size_t)1 << 32) est = g_end;
             if (!info.reserve(est) || !info.resize_uninit(g_end)) return fail(-6, "out of memory");
             for (auto &T : tabs)
-                if (!ptable_reserve(T, est / (size_t)n_part + est / (size_t)(4 * n_part) + 1024)) return fail(-6, "out of memory");
+                if (!ptable_reserve(T, est / (size_t)n_part + est / (size_t)(4 * n_part) + 1024, false)) return fail(-6, "out of memory");
         }
         // (a) the parts' records into info, each part by the thread that made it
         if (lists.size() < (size_t)n_valid * (size_t)n_part) lists.resize((size_t)n_valid * (size_t)n_part);
@@ -1165,6 +1367,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
         auto place = [&](int q) {
             ptable &T = tabs[(size_t)q];
             T.dups.clear();
+            T.clear_if_stale();
             const rinfo *in = info.data();
             for (int t = 0; t < n_valid; t++) {
             const std::vector<uint32_t> &lst = lists[(size_t)t * (size_t)n_part + (size_t)q];
@@ -1175,7 +1378,7 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
                 if (li + 8 < nl && T.n) __builtin_prefetch(&T.p[(size_t)in[lst[li + 8]].h_lo & (T.n - 1)]);
                 const uint32_t g = lst[li];
                 const rinfo &r = in[g];
-                if ((T.count + 1) * 2 > T.n && !ptable_reserve(T, T.count * 2 + 1024)) { T.oom = true; return; }
+                if ((T.count + 1) * 2 > T.n && !ptable_reserve(T, T.count * 2 + 1024, true)) { T.oom = true; return; }
                 const size_t mask = T.n - 1;
                 size_t si = (size_t)r.h_lo & mask;
                 uint32_t found1 = 0;
@@ -1241,22 +1444,32 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     const int64_t n_rec = (int64_t)info.size();
     const int nt_out = (int)std::min<int64_t>((int64_t)n_threads(), n_rec / 65536 + 1);
     std::vector<int64_t> rows_in((size_t)nt_out + 1, 0), chars_in((size_t)nt_out + 1, 0);
+    std::vector<int32_t> longest((size_t)nt_out, 0);
     auto run_out = [&](auto &&fn) {
         worker_pool::get().run(nt_out, fn);
     };
     run_out([&](int t) {
         int64_t r = 0, c = 0;
+        int32_t mx = 0;
         for (int64_t g = n_rec * t / nt_out, hi = n_rec * (t + 1) / nt_out; g < hi; g++)
-            if (!info[(size_t)g].dup_of1) { r++; c += (int64_t)info[(size_t)g].len; }
+            if (!info[(size_t)g].dup_of1) { r++; c += (int64_t)info[(size_t)g].len; if (info[(size_t)g].len > mx) mx = info[(size_t)g].len; }
         rows_in[(size_t)t + 1] = r;
         chars_in[(size_t)t + 1] = c;
+        longest[(size_t)t] = mx;
     });
+    for (int t = 0; t < nt_out; t++) if (longest[(size_t)t] > g_stats.max_row_len) g_stats.max_row_len = longest[(size_t)t];
     for (int t = 0; t < nt_out; t++) { rows_in[(size_t)t + 1] += rows_in[(size_t)t]; chars_in[(size_t)t + 1] += chars_in[(size_t)t]; }
     const int64_t n = rows_in[(size_t)nt_out], total = chars_in[(size_t)nt_out];
-    out->rank = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n ? n : 1));
-    out->off = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
-    out->bases = (uint8_t *)malloc((size_t)(total ? total : 1));
-    if (!out->rank || !out->off || !out->bases) { gio_table_free(out); return fail(-6, "out of memory"); }
+    // (the caller's allocator: e.g. page-locked memory kept from call to call, which the upload then reads by DMA and which needs
+    // no fresh pages -- 17 MB per million reads otherwise)
+    auto grab = [&](int which, size_t bytes) -> void * { return alloc ? alloc(alloc_ctx, which, bytes) : malloc(bytes); };
+    out->rank = (int32_t *)grab(0, sizeof(int32_t) * (size_t)(n ? n : 1));
+    out->off = (int64_t *)grab(1, sizeof(int64_t) * (size_t)(n + 1));
+    out->bases = (uint8_t *)grab(2, (size_t)(total ? total : 1));
+    if (!out->rank || !out->off || !out->bases) {
+        if (alloc) memset(out, 0, sizeof *out); else gio_table_free(out);
+        return fail(-6, alloc ? "the caller's allocator returned no memory" : "out of memory");
+    }
     run_out([&](int t) {
         int64_t r = rows_in[(size_t)t], c = chars_in[(size_t)t];
         for (int64_t g = n_rec * t / nt_out, hi = n_rec * (t + 1) / nt_out; g < hi; g++) {
@@ -1276,6 +1489,16 @@ static int gio_support_table_from_bam_impl(const char *bam_path, const char *con
     g_stats.libdeflate = libdeflate().ok ? 1 : 0;
     g_stats.threads = n_threads();
     g_stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    if (getenv("GIO_TIMING")) {
+        auto R0 = now();
+        kept_parts.clear();
+        auto R1 = now();
+        tabs.clear();
+        auto R2 = now();
+        moved.clear(); lists.clear();
+        auto R3 = now();
+        fprintf(stderr, "gio: table written at %.4f s; releasing: the threads' parts %.4f s, key table %.4f, copies + lists %.4f\n", g_stats.seconds, secs(R0, R1), secs(R1, R2), secs(R2, R3));
+    }
     return 0;
 }
 
@@ -1439,9 +1662,64 @@ extern "C" int gio_ref_len(const char *bam_path, const char *contig, int64_t *le
 extern "C" int gio_support_table_from_bam_depth(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
                                                 const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out)
 {
-    try { return gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, max_depth, out); }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    try { rc = gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, max_depth, out); }
     catch (const std::bad_alloc &) { return fail(-6, "out of memory"); }
     catch (const std::exception &e) { return fail(-6, "%s", e.what()); }
+    // (the call's own clock: the working buffers the function releases on its way out belong to it)
+    const double all = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("GIO_TIMING")) fprintf(stderr, "gio: the call %.4f s, of which %.4f s behind the table (buffers released)\n", all, all - g_stats.seconds);
+    if (rc == 0) g_stats.seconds = all;
+    return rc;
+}
+
+extern "C" int gio_prefetch(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos)
+{
+    if (!bam_path || !contig) return fail(-1, "bad argument");
+    prefetched *p = nullptr;
+    try {
+        p = new prefetched();
+        p->path = bam_path; p->contig = contig; p->start = start_pos; p->end = end_pos;
+    } catch (...) { delete p; return fail(-6, "out of memory"); }
+    prefetched *old = nullptr;
+    {
+        std::lock_guard<std::mutex> g(prefetch_mu());
+        old = prefetch_slot();
+        prefetch_slot() = nullptr;
+    }
+    prefetch_discard(old);
+    try { p->th = std::thread(prefetch_body, p); }
+    catch (...) { delete p; return fail(-6, "cannot start the prefetch thread"); }
+    std::lock_guard<std::mutex> g(prefetch_mu());
+    prefetch_discard(prefetch_slot());                      // (another thread's, started meanwhile)
+    prefetch_slot() = p;
+    return 0;
+}
+
+extern "C" void gio_prefetch_cancel(void)
+{
+    prefetched *old = nullptr;
+    {
+        std::lock_guard<std::mutex> g(prefetch_mu());
+        old = prefetch_slot();
+        prefetch_slot() = nullptr;
+    }
+    prefetch_discard(old);
+}
+
+extern "C" int gio_support_table_from_bam_alloc(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                                                const uint8_t *region, int stepper_all, int32_t max_depth,
+                                                gio_alloc_fn alloc, void *ctx, gio_table *out)
+{
+    if (!alloc) return fail(-1, "bad argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc;
+    try { rc = gio_support_table_from_bam_impl(bam_path, contig, start_pos, end_pos, region, stepper_all, max_depth, out, alloc, ctx); }
+    catch (const std::bad_alloc &) { if (out) memset(out, 0, sizeof *out); return fail(-6, "out of memory"); }
+    catch (const std::exception &e) { if (out) memset(out, 0, sizeof *out); return fail(-6, "%s", e.what()); }
+    if (rc == 0) g_stats.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 extern "C" int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,

@@ -556,60 +556,77 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
     r->rank = nullptr; r->off = nullptr; r->bases = nullptr;
     r->max_k = 0;
     r->sorted = true;
-    for (int64_t q = 0; q < n_reads; q++) {
-        int64_t k = off[q + 1] - off[q];
-        if (k < 0) { delete r; return fail(GH_ERR_ARG, "off[] not monotone at read %lld", (long long)q); }
-        if (k > r->max_k) r->max_k = (int)k;
-        if (q > 0 && rank[q] < rank[q - 1]) r->sorted = false;
-    }
     r->span_pos = 0;
-    if (r->sorted)
-        for (int64_t q0 = 0; q0 < n_reads; q0 += FILL_RPB) {
-            const int64_t q1 = q0 + FILL_RPB < n_reads ? q0 + FILL_RPB : n_reads;
-            const int span = rank[q1 - 1] - rank[q0] + r->max_k + 1;      // the slice k_fill_sorted counts in LDS
-            if (span > r->span_pos) r->span_pos = span;
-        }
     r->dens128 = 0;
     r->first_at = nullptr; r->n_first = 0;
-    std::vector<int64_t> first_at;
-    if (r->sorted && n_reads > 0 && rank[0] >= 0) {
-        // where the reads of every rank start (k_fill_own's workgroups find their reads with two lookups instead of a bisection
-        // of 20 dependent loads each)
-        const int64_t top = (int64_t)rank[n_reads - 1] + 2;
-        if (top <= ((int64_t)1 << 28)) {
-            first_at.assign((size_t)top, n_reads);
-            int64_t q = 0;
-            for (int64_t p = 0; p < top; p++) {
-                while (q < n_reads && rank[q] < p) q++;
-                first_at[(size_t)p] = q;
-            }
-        }
+    // The table's properties (longest read, off[] ascending, ranks ascending and then span / density / first_at) are found on the
+    // device behind the copies (k_reads_meta): the host looks at the two ends of rank[] only, to size first_at for a table that
+    // turns out to be sorted.  Page-locked sources (gh_host_alloc: what gretel_amd.util.load_from_bam decodes into) are read by DMA.
+    int64_t top = 0;
+    if (n_reads > 0 && rank[0] >= 0 && rank[n_reads - 1] >= rank[0]) {
+        top = (int64_t)rank[n_reads - 1] + 2;
+        if (top > ((int64_t)1 << 28)) top = 0;
     }
-    if (r->sorted) {
-        int64_t lo = 0;
-        for (int64_t q = 0; q < n_reads; q++) {
-            while (rank[q] - rank[lo] >= 128) lo++;
-            if (q - lo + 1 > r->dens128) r->dens128 = q - lo + 1;
-        }
-    }
+    reads_meta *dm = nullptr;
+    reads_meta hm;
+    hm.max_k = 0; hm.unsorted = 0; hm.bad_off = 0x7fffffffffffffffll; hm.span = 0; hm.dens128 = 0;
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void **)&r->rank, (size_t)(n_reads ? n_reads : 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&r->off, (size_t)(n_reads + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&r->bases, (size_t)(r->n_bases ? r->n_bases : 1));
-    if (e == hipSuccess && !first_at.empty()) {
-        e = hipMalloc((void **)&r->first_at, first_at.size() * 8);
-        if (e == hipSuccess) e = hipMemcpy(r->first_at, first_at.data(), first_at.size() * 8, hipMemcpyHostToDevice);
-        r->n_first = (int)first_at.size();
+    if (e == hipSuccess && top > 0) e = hipMalloc((void **)&r->first_at, (size_t)top * 8);
+    if (e == hipSuccess && n_reads) e = hipMalloc((void **)&dm, sizeof(reads_meta));
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(dm, &hm, sizeof hm, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->rank, rank, (size_t)n_reads * 4, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && n_reads) {
+        const int grid = (int)std::min<int64_t>((n_reads + 256) / 256, 2048);
+        k_reads_meta<<<grid, 256, 0, h->stream>>>(r->rank, r->off, n_reads, dm);
+        if (top > 0) {
+            k_reads_first_at<<<grid, 256, 0, h->stream>>>(r->rank, n_reads, r->first_at, top, dm);
+            k_reads_meta2<<<grid, 256, 0, h->stream>>>(r->rank, n_reads, r->first_at, FILL_RPB, dm);
+        }
+        e = hipGetLastError();
     }
-    if (e == hipSuccess && n_reads) e = hipMemcpy(r->rank, rank, (size_t)n_reads * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_reads) e = hipMemcpy(r->off, off, (size_t)(n_reads + 1) * 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess && r->n_bases) e = hipMemcpy(r->bases, bases, (size_t)r->n_bases, hipMemcpyHostToDevice);
+    if (e == hipSuccess && r->n_bases) e = hipMemcpyAsync(r->bases, bases, (size_t)r->n_bases, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(&hm, dm, sizeof hm, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(dm);
     if (e != hipSuccess) {
         hipFree(r->rank); hipFree(r->off); hipFree(r->bases); hipFree(r->first_at);
         delete r;
         return fail(GH_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
     }
+    if (hm.bad_off != 0x7fffffffffffffffll) {
+        hipFree(r->rank); hipFree(r->off); hipFree(r->bases); hipFree(r->first_at);
+        delete r;
+        return fail(GH_ERR_ARG, "off[] not monotone at read %lld", hm.bad_off);
+    }
+    r->max_k = hm.max_k;
+    r->sorted = !hm.unsorted;
+    if (r->sorted && n_reads > 0) {
+        r->span_pos = hm.span + r->max_k + 1;             // the slice k_fill_sorted counts in LDS
+        if (r->first_at) { r->n_first = (int)top; r->dens128 = hm.dens128; }
+        else {
+            // (ranks ascend from a negative one, or reach beyond 2^28: no first_at; the density the slow way)
+            int64_t lo = 0;
+            for (int64_t q = 0; q < n_reads; q++) {
+                while (rank[q] - rank[lo] >= 128) lo++;
+                if (q - lo + 1 > r->dens128) r->dens128 = q - lo + 1;
+            }
+        }
+    } else if (r->first_at) {
+        hipFree(r->first_at);
+        r->first_at = nullptr;
+    }
     *out = r;
+    return GH_OK;
+}
+
+extern "C" int gh_reads_max_k(const gh_reads_t *r, int32_t *max_k)
+{
+    if (!r || !max_k) return fail(GH_ERR_ARG, "bad argument");
+    *max_k = r->max_k;
     return GH_OK;
 }
 

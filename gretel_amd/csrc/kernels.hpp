@@ -542,6 +542,65 @@ k_fill_own(T *__restrict__ band, int N, int W, const int32_t *__restrict__ rank,
 }
 
 // ---------------------------------------------------------------------------------------------
+// What gh_reads_upload has to know about a support table before a fill can be chosen, found on the device behind the upload (three
+// passes of one host thread over a million reads were 1.5 ms of every upload): the longest read, whether off[] ascends (the first
+// read where it does not), whether the ranks ascend; and for a table whose ranks ascend -- launched on that assumption, thrown
+// away when it does not hold -- first_at[p] = the first read whose rank is >= p, p in [0, top) with top = rank[n - 1] + 2.
+struct reads_meta {
+    int max_k;                      // longest read
+    int unsorted;                   // a rank below the one in front of it
+    long long bad_off;              // the first read whose off[] runs backwards (LLONG_MAX: none)
+    int span;                       // most positions between the first and the last rank of a block of `rpb` reads
+    long long dens128;              // most reads whose ranks fall into 128 consecutive positions
+};
+__global__ void __launch_bounds__(256)
+k_reads_meta(const int32_t *__restrict__ rank, const int64_t *__restrict__ off, int64_t n, reads_meta *m)
+{
+    int mk = 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = off[q + 1] - off[q];
+        if (k < 0) atomicMin((unsigned long long *)&m->bad_off, (unsigned long long)q);
+        else if (k > mk) mk = (int)(k > 0x7fffffff ? 0x7fffffff : k);
+        if (q > 0 && rank[q] < rank[q - 1]) m->unsorted = 1;
+    }
+    for (int o = 32; o; o >>= 1) { const int v = __shfl_xor(mk, o); mk = v > mk ? v : mk; }
+    if ((threadIdx.x & 63) == 0 && mk > 0) atomicMax(&m->max_k, mk);
+}
+// (behind k_reads_meta; nothing for a table whose ranks do not ascend -- the jumps of an unsorted table would be written out at
+// length.  Read q writes the entries (rank[q - 1], rank[q]]; q = n the last one, top - 1)
+__global__ void __launch_bounds__(256)
+k_reads_first_at(const int32_t *__restrict__ rank, int64_t n, int64_t *__restrict__ first_at, int64_t top, const reads_meta *m)
+{
+    if (m->unsorted) return;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q <= n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t prev = q > 0 ? (int64_t)rank[q - 1] : -1, cur = q < n ? (int64_t)rank[q] : top - 1;
+        for (int64_t pp = prev + 1 < 0 ? 0 : prev + 1; pp <= cur && pp < top; pp++) first_at[pp] = q;
+    }
+}
+// (behind k_reads_first_at: span and density)
+__global__ void __launch_bounds__(256)
+k_reads_meta2(const int32_t *__restrict__ rank, int64_t n, const int64_t *__restrict__ first_at, int rpb, reads_meta *m)
+{
+    if (m->unsorted) return;
+    int sp = 0;
+    long long dn = 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        if (q % rpb == 0) {
+            const int64_t q1 = q + rpb < n ? q + rpb : n;
+            const int d = rank[q1 - 1] - rank[q];
+            sp = d > sp ? d : sp;
+        }
+        const int lo_p = rank[q] - 127 < 0 ? 0 : rank[q] - 127;
+        const long long d = (long long)q - (long long)first_at[lo_p] + 1;
+        dn = d > dn ? d : dn;
+    }
+    for (int o = 32; o; o >>= 1) {
+        const int v = __shfl_xor(sp, o); sp = v > sp ? v : sp;
+        const long long w = __shfl_xor(dn, o); dn = w > dn ? w : dn;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&m->span, sp); atomicMax((unsigned long long *)&m->dens128, (unsigned long long)dn); }
+}
+
 // k_fill_sorted: the same pair loop for a support table sorted by rank (what a coordinate-sorted
 // BAM gives).  A workgroup owns a contiguous run of reads, so all its observations fall into a
 // narrow slice of positions: it counts them in LDS (integer adds) and flushes the slice once

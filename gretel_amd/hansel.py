@@ -276,16 +276,13 @@ class Hansel:
         return g.value
 
     # -- fused fast paths --------------------------------------------------------------------
-    def fill_from_support(self, rank, off, bases, use_end_sentinels=False, reads_handle=None):
+    def fill_from_support(self, rank, off, bases, use_end_sentinels=False, reads_handle=None, max_k=None):
         """The pair loop of gretel/util.py:226-286 for a whole support table at once.
-        Returns (n_slices, n_crumbs, covered_snps) and sets L like util.py:333."""
+        Returns (n_slices, n_crumbs, covered_snps) and sets L like util.py:333.
+        max_k: the longest row of the table, where the caller knows it (the native decoder reports it: gio_stats.max_row_len) --
+        a pass over off[] less; gh_reads_upload finds it again on the device and the band is checked against that."""
         if reads_handle is None:
-            rank = np.ascontiguousarray(rank, dtype=np.int32)
-            off = np.ascontiguousarray(off, dtype=np.int64)
-            bases = np.ascontiguousarray(bases, dtype=np.uint8)
-            max_k = int(np.diff(off).max()) if len(rank) else 0
-            self._ensure(max(1, max_k - 1))
-            reads_handle = DeviceReads(self, rank, off, bases)
+            reads_handle = DeviceReads(self, rank, off, bases, max_k=max_k)
         else:
             self._ensure(max(1, reads_handle.max_k - 1))
         st = _lib.gh_fill_stats()
@@ -445,6 +442,46 @@ class _PinnedBlock:
             pass
 
 
+class PinnedTableArena:
+    """Page-locked homes for a support table's three arrays (rank, off, bases), kept and grown from window to window: the native
+    decoder writes the table straight into them (gretel_amd.bamio.native_support_table(arena=...), include/gretel_io.h:
+    gio_support_table_from_bam_alloc) and gh_reads_upload reads them by DMA -- no 17 MB of fresh pages per million reads for the
+    decoder to fault in, no staging copy for the upload.  The arrays handed out are views: their contents stand until the arena
+    takes the next table, the memory for as long as a view refers to it (_PinnedBlock)."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self._blocks = [None, None, None]
+
+    def alloc(self, which, nbytes):
+        b = self._blocks[which]
+        if b is None or b.nbytes < nbytes:
+            # (half as much again: the next window of a contig is about as deep, not exactly)
+            b = self._blocks[which] = _PinnedBlock(self._lib, max(4096, nbytes + nbytes // 2))
+        return b._p.value
+
+    def view(self, which, dtype, count):
+        if count == 0:
+            return np.zeros(0, dtype=dtype)
+        return self._blocks[which].array(dtype, count)
+
+
+_table_arena = None
+
+
+def table_arena():
+    """The process's PinnedTableArena (made at first use; None where page-locked memory cannot be had: no GPU runtime)."""
+    global _table_arena
+    if _table_arena is None:
+        try:
+            a = PinnedTableArena()
+            a.alloc(2, 4096)
+            _table_arena = a
+        except Exception:
+            _table_arena = False
+    return _table_arena or None
+
+
 class HanselBatch:
     """Many windows of one shape recovered together (gh_batch_*): every kernel of the spin loop
     (gretel/cmd.py:148-179) is launched over all windows at once, one path-extension workgroup per
@@ -535,17 +572,22 @@ class HanselBatch:
 class DeviceReads:
     """A support table resident in HBM (gh_reads_upload)."""
 
-    def __init__(self, hansel, rank, off, bases):
+    def __init__(self, hansel, rank, off, bases, max_k=None):
         rank = np.ascontiguousarray(rank, dtype=np.int32)
         off = np.ascontiguousarray(off, dtype=np.int64)
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         self.n_reads = len(rank)
-        self.max_k = int(np.diff(off).max()) if self.n_reads else 0
-        hansel._ensure(max(1, self.max_k - 1))
+        if max_k is None:
+            max_k = int(np.diff(off).max()) if self.n_reads else 0
+        hansel._ensure(max(1, int(max_k) - 1))
         self._lib = hansel._lib
         r = C.c_void_p()
         check(self._lib.gh_reads_upload(hansel._h, _p(rank), _p(off), _p(bases), self.n_reads, C.byref(r)))
         self._r = r
+        # (what the device found: a caller's max_k that is too small shows as GH_ERR_BAND in the fill, as any read too long for the band)
+        mk = C.c_int()
+        check(self._lib.gh_reads_max_k(r, C.byref(mk)))
+        self.max_k = int(mk.value)
 
     def __del__(self):
         try:

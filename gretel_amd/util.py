@@ -239,17 +239,18 @@ PYSAM_MAX_DEPTH = 8000
 
 
 def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper="samtools",
-                           decoder="native", max_depth=PYSAM_MAX_DEPTH, debug_reads=None, debug_pos=None, debug_out=None):
+                           decoder="native", max_depth=PYSAM_MAX_DEPTH, debug_reads=None, debug_pos=None, debug_out=None, arena=None):
     """The pileup half of load_from_bam (gretel/util.py:137-209) -> support table arrays.
     decoder="native": libgretel_io.so (C++/zlib, include/gretel_io.h); "python": the pure-Python restatement
     below (same rules; kept as the readable specification and as a cross-check in the tests).
     max_depth: the read-buffer cap of the pileup the reference inherits (pysam's default 8000, gretel/util.py:137 passes none;
     0: keep every read), by htslib's rule in both decoders: the first read of a position always enters; a later one is dropped
     when the reads that entered and end behind position - 1, plus the list's sentinel node, number more than max_depth.
-    debug_reads / debug_pos: the prints of gretel/util.py:211-224 (python decoder), to debug_out (default stdout)."""
+    debug_reads / debug_pos: the prints of gretel/util.py:211-224 (python decoder), to debug_out (default stdout).
+    arena (native decoder): where the three arrays go (gretel_amd.hansel.PinnedTableArena; see bamio.native_support_table)."""
     if decoder == "native" and not (debug_reads or debug_pos):
         from . import bamio
-        return bamio.native_support_table(bam_path, target_contig, start_pos, end_pos, vcf_handler["region"], stepper, max_depth)
+        return bamio.native_support_table(bam_path, target_contig, start_pos, end_pos, vcf_handler["region"], stepper, max_depth, arena=arena)
     refs, records = read_bam(bam_path)
     names = [n for n, _ in refs]
     if target_contig not in names:
@@ -326,6 +327,18 @@ def support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_hand
     return rank, off, bases
 
 
+def prefetch_bam(bam_path, target_contig, start_pos, end_pos):
+    """Tell the native decoder which window load_from_bam is going to ask for: it reads and inflates the window's part of the BAM
+    on its own threads from now on (everything that does not need the SNP positions) while the caller parses the VCF -- the
+    reference's order is process_vcf, then load_from_bam (gretel/cmd.py:69-78).  Never an error: a BAM that cannot be read is
+    reported by load_from_bam."""
+    try:
+        from . import bamio
+        bamio.native_prefetch(bam_path, target_contig, start_pos, end_pos)
+    except Exception:
+        pass
+
+
 def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_end_sentinels=False,
                   n_threads=1, debug_reads=False, debug_pos=False, stepper="samtools", decoder="native", max_depth=PYSAM_MAX_DEPTH,
                   **hansel_kw):
@@ -334,11 +347,21 @@ def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_
     threads and the fill is one kernel, so the value changes nothing here -- said once on stderr when it is not 1."""
     if n_threads not in (None, 1):
         sys.stderr.write("[NOTE] -@/--threads %s ignored: the BAM is decoded by libgretel_io.so's own threads and the matrix is filled on the GPU\n" % n_threads)
+    native = decoder == "native" and not (debug_reads or debug_pos)
+    arena = None
+    if native:
+        # (the table goes straight into page-locked memory kept from window to window, which the upload reads by DMA)
+        from .hansel import table_arena
+        arena = table_arena()
     rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper, decoder,
-                                              max_depth=max_depth, debug_reads=debug_reads or None, debug_pos=debug_pos or None)
-    max_k = int(np.diff(off).max()) if len(rank) else 0
+                                              max_depth=max_depth, debug_reads=debug_reads or None, debug_pos=debug_pos or None, arena=arena)
+    if native:
+        from . import bamio
+        max_k = int(bamio.native_last_stats()["max_row_len"])           # (the decoder knows its longest row: no pass over off[])
+    else:
+        max_k = int(np.diff(off).max()) if len(rank) else 0
     hansel = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, vcf_handler["N"], band=max(1, max_k - 1), **hansel_kw)
-    n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels)
+    n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels, max_k=max_k)
     sys.stderr.write("[NOTE] Loaded %d breadcrumbs from %d bread slices.\n" % (n_crumbs, n_slices))   # util.py:331
     if n_slices == 0:
         raise ZeroDivisionError("no read carries more than one SNP (gretel/util.py:333 divides by n_reads)")

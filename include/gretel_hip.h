@@ -115,10 +115,14 @@ int gh_get_fill_stats(const gh_t *h, gh_fill_stats *out);
 int gh_set_fill_stats(gh_t *h, const gh_fill_stats *in);
 
 /* Support table (per read: rank of gretel/util.py:198, support_seq of util.py:238 as ASCII)
- * copied to HBM once; off has n_reads+1 entries. */
+ * copied to HBM once; off has n_reads+1 entries.  The arrays may lie in page-locked memory (gh_host_alloc): they are then read
+ * by DMA instead of through a staging copy.  GH_ERR_ARG when off[] runs backwards somewhere. */
 int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t *off, const uint8_t *bases,
                     int64_t n_reads, gh_reads_t **out);
 int gh_reads_free(gh_reads_t *r);
+/* the longest read of an uploaded table (max of off[q + 1] - off[q]; found on the device behind the upload): a matrix needs a band
+ * of at least max_k - 1 to take it */
+int gh_reads_max_k(const gh_reads_t *r, int32_t *max_k);
 
 /* The per-read pair loop of load_from_bam -- gretel/util.py:226-286 -- and the
  * counters/L of util.py:329-333, over a device-resident support table.

@@ -32,6 +32,7 @@
 #ifndef GRETEL_IO_H
 #define GRETEL_IO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -57,6 +58,8 @@ typedef struct {
     int32_t reframed;           /* batches done again front to back because a thread's guessed first record was none */
     double seconds;             /* wall time of the call */
     int64_t depth_dropped;      /* records the max_depth cap dropped */
+    int32_t max_row_len;        /* characters of the longest row (max of off[q + 1] - off[q]): what sizes the matrix's band */
+    int32_t prefetched;         /* 1: the call took over what gio_prefetch had read and inflated */
 } gio_stats;
 
 const char *gio_last_error(void);
@@ -76,6 +79,22 @@ int gio_support_table_from_bam(const char *bam_path, const char *contig, int32_t
 int gio_support_table_from_bam_depth(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
                                      const uint8_t *region, int stepper_all, int32_t max_depth, gio_table *out);
 void gio_table_free(gio_table *t);
+/* Everything of a decode that does not need the SNP positions -- header, index seek, the window's BGZF blocks read and inflated (up
+ * to the inflated window's cap) -- started on a thread of the library; returns at once.  The reference's CLI parses the VCF and
+ * then loads the BAM (gretel/cmd.py:69-78): a caller that knows the window before it has the SNPs calls this first and parses the
+ * VCF meanwhile.  The next gio_support_table_from_bam* call for the same (path, contig, start_pos, end_pos) takes the work over
+ * (gio_stats.prefetched); any other decode, another gio_prefetch or gio_prefetch_cancel discards it.  A prefetch that fails is
+ * dropped silently: the decode then starts afresh and reports.  Returns 0, or -6 when no thread could be started. */
+int gio_prefetch(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos);
+void gio_prefetch_cancel(void);
+/* The same, the table's three arrays allocated by the CALLER: alloc(ctx, which, bytes) is called once each for which = 0 (rank),
+ * 1 (off), 2 (bases) on the calling thread and returns the memory or NULL (-> -6) -- e.g. page-locked blocks (gh_host_alloc,
+ * include/gretel_hip.h) kept from window to window, which gh_reads_upload then reads by DMA: no fresh pages for the decoder to
+ * fault in, no staging copy for the upload.  Such a table is the caller's: gio_table_free must not be called on it. */
+typedef void *(*gio_alloc_fn)(void *ctx, int which, size_t bytes);
+int gio_support_table_from_bam_alloc(const char *bam_path, const char *contig, int32_t start_pos, int32_t end_pos,
+                                     const uint8_t *region, int stepper_all, int32_t max_depth,
+                                     gio_alloc_fn alloc, void *ctx, gio_table *out);
 /* The decoder keeps its large working buffers (the inflated window, the reads' entries, keys and characters: about 130 bytes per
  * read) from one call to the next instead of unmapping them before it returns and faulting them in again -- a third of a decode's
  * time.  GIO_KEEP_MB in the environment bounds what is kept (default 512, 0: nothing); this frees it. */

@@ -250,6 +250,39 @@ def test_the_depth_histogram_stays_short_over_a_long_window(tmp_path):
     assert 0 < len(a[0]) < 40
 
 
+def test_the_depth_cap_shown_idle_batch_by_batch_then_binding(tmp_path, monkeypatch):
+    # The native decoder first SHOWS, on all threads, that a batch cannot reach the cap (reads per stretch of the longest span)
+    # and sets its candidates aside; the first batch it cannot show this for takes the sequential pass over everything set aside
+    # and goes on from that state.  Sparse reads over 3 Mb (several inflated windows of ~1 block each), a crowd, sparse reads
+    # again, a second crowd: the same rows as the Python decoder's one sequential pass, with caps that bind nowhere / in the
+    # crowds only / nearly everywhere.
+    monkeypatch.setenv("GIO_WINDOW", "70000")
+    rng = np.random.default_rng(11)
+    seq = lambda n: "".join(rng.choice(list("ACGT"), size=n))
+    reads = [("s%d" % i, 0, 0, 100 + 997 * i + int(rng.integers(0, 300)), 60, "50M", seq(50)) for i in range(1500)]
+    reads += [("t%d" % i, 0, 0, 1_500_000 + (i // 5), 60, "%dM" % (30 + i % 40), seq(30 + i % 40)) for i in range(300)]
+    reads += [("u%d" % i, 0, 0, 1_600_000 + 911 * i, 60, "50M", seq(50)) for i in range(1500)]
+    reads += [("w%d" % i, 0, 0, 2_990_000 + (i // 3), 60, "60M", seq(60)) for i in range(200)]
+    reads.sort(key=lambda r: r[3])
+    bam = str(tmp_path / "crowds.bam")
+    vcf = str(tmp_path / "crowds.vcf.gz")
+    bamio.write_bam(bam, [("c", 3_000_100)], reads)
+    snps = sorted(set([int(x) for x in rng.integers(1, 3_000_000, size=60000)] + list(range(1_500_001, 1_500_100, 7)) + list(range(2_990_001, 2_990_120, 5))))
+    bamio.write_vcf_gz(vcf, "c", snps)
+    v = util.process_vcf(vcf, "c", 1, 3_000_100)
+    n_rows = []
+    for cap in (0, 8000, 40, 6, 1):
+        a = util.support_table_from_bam(bam, "c", 1, 3_000_100, v, decoder="native", max_depth=cap)
+        st = bamio.native_last_stats()
+        b = util.support_table_from_bam(bam, "c", 1, 3_000_100, v, decoder="python", max_depth=cap)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), cap
+        assert st["blocks"] >= 5                           # (several windows: the state is carried from batch to batch)
+        n_rows.append(len(a[0]))
+        assert (st["depth_dropped"] > 0) == (cap in (40, 6, 1)), (cap, st)
+    assert n_rows[0] == n_rows[1] > n_rows[2] > n_rows[3] > n_rows[4]
+
+
 def test_the_decoders_kept_buffers_change_nothing(tmp_path, monkeypatch):
     """libgretel_io.so keeps its large working buffers between calls (include/gretel_io.h: gio_release_buffers, GIO_KEEP_MB): the same
     table with fresh buffers, with reused ones (handed out as the decode before left them) and after they were released."""
@@ -318,3 +351,91 @@ def test_a_forked_child_decodes_with_a_pool_of_its_own(tmp_path):
     finally:
         stop.set()
         th.join(30.0)
+
+
+def test_prefetch_is_taken_over_by_the_matching_decode_only(tmp_path):
+    """gio_prefetch (include/gretel_io.h): the window's blocks read and inflated on the library's thread while the caller parses its
+    VCF.  The decode of the same window takes the work over and gives the same table; a decode of another window, a prefetch of a
+    file that is not there, a cancelled prefetch change nothing."""
+    t = make_support_table(300, 6000, k=None, seed=3, k_max=6)
+    bam, vcf = str(tmp_path / "p.bam"), str(tmp_path / "p.vcf.gz")
+    contig, start, end = bamio.synth_to_files(t, bam, vcf)
+    v = util.process_vcf(vcf, contig, start, end)
+    plain = util.support_table_from_bam(bam, contig, start, end, v)
+    assert bamio.native_last_stats()["prefetched"] == 0
+    util.prefetch_bam(bam, contig, start, end)
+    got = util.support_table_from_bam(bam, contig, start, end, v)
+    st = bamio.native_last_stats()
+    assert st["prefetched"] == 1 and st["records"] > 0 and st["blocks"] > 0
+    for x, y in zip(plain, got):
+        assert np.array_equal(x, y)
+    # (taken: the next decode starts afresh)
+    util.support_table_from_bam(bam, contig, start, end, v)
+    assert bamio.native_last_stats()["prefetched"] == 0
+    # another window than the one announced: discarded
+    util.prefetch_bam(bam, contig, start, end - 7)
+    got = util.support_table_from_bam(bam, contig, start, end, v)
+    assert bamio.native_last_stats()["prefetched"] == 0
+    for x, y in zip(plain, got):
+        assert np.array_equal(x, y)
+    # a file that is not there / a contig the file does not have: no error here, the decode reports
+    util.prefetch_bam(str(tmp_path / "nothing.bam"), contig, start, end)
+    util.prefetch_bam(bam, "no_such_contig", start, end)
+    with pytest.raises(KeyError):
+        util.support_table_from_bam(bam, "no_such_contig", start, end, v)
+    bamio.native_prefetch(bam, contig, start, end)
+    bamio.native_prefetch_cancel()
+    got = util.support_table_from_bam(bam, contig, start, end, v)
+    assert bamio.native_last_stats()["prefetched"] == 0
+    # several windows of inflated data: the prefetch stops at the window's cap and the decode reads on
+    os.environ["GIO_WINDOW"] = "70000"
+    try:
+        util.prefetch_bam(bam, contig, start, end)
+        got = util.support_table_from_bam(bam, contig, start, end, v)
+        assert bamio.native_last_stats()["prefetched"] == 1
+    finally:
+        del os.environ["GIO_WINDOW"]
+    for x, y in zip(plain, got):
+        assert np.array_equal(x, y)
+
+
+def test_the_table_in_the_callers_memory(tmp_path):
+    """gio_support_table_from_bam_alloc: the three arrays where the caller's allocator puts them (here: numpy buffers), the same
+    table; an allocator that has nothing gives an error, not a crash; the longest row is reported (gio_stats.max_row_len)."""
+    t = make_support_table(300, 6000, k=None, seed=4, k_max=6)
+    bam, vcf = str(tmp_path / "a.bam"), str(tmp_path / "a.vcf.gz")
+    contig, start, end = bamio.synth_to_files(t, bam, vcf)
+    v = util.process_vcf(vcf, contig, start, end)
+    plain = util.support_table_from_bam(bam, contig, start, end, v)
+    assert bamio.native_last_stats()["max_row_len"] == int(np.diff(plain[1]).max())
+
+    class Arena:
+        def __init__(self, broke=None):
+            self.bufs, self.broke, self.asked = {}, broke, []
+
+        def alloc(self, which, nbytes):
+            self.asked.append((which, nbytes))
+            if which == self.broke:
+                return 0
+            self.bufs[which] = np.empty(nbytes + 64, dtype=np.uint8)
+            return self.bufs[which].ctypes.data
+
+        def view(self, which, dtype, count):
+            return np.frombuffer(self.bufs[which], dtype=dtype, count=count)
+
+    a = Arena()
+    got = util.support_table_from_bam(bam, contig, start, end, v, arena=a)
+    assert [w for w, _ in a.asked] == [0, 1, 2]
+    assert a.asked[0][1] == 4 * len(plain[0]) and a.asked[1][1] == 8 * (len(plain[0]) + 1) and a.asked[2][1] == len(plain[2])
+    for x, y in zip(plain, got):
+        assert np.array_equal(x, y)
+    with pytest.raises(IOError) as ei:
+        util.support_table_from_bam(bam, contig, start, end, v, arena=Arena(broke=1))
+    assert "allocator" in str(ei.value)
+
+    class Raises(Arena):
+        def alloc(self, which, nbytes):
+            raise MemoryError("nothing left")
+
+    with pytest.raises(MemoryError):
+        util.support_table_from_bam(bam, contig, start, end, v, arena=Raises())
