@@ -85,6 +85,7 @@ def load():
         "gh_reads_upload": [vp, vp, vp, vp, i64, P(vp)],
         "gh_reads_free": [vp],
         "gh_reads_max_k": [vp, P(i32)],
+        "gh_reads_info": [vp, vp, vp],
         "gh_fill": [vp, vp, i32, P(gh_fill_stats)],
         "gh_add": [vp, i32, i32, i32, i32],
         "gh_add_batch": [vp, vp, vp, vp, vp, i64],

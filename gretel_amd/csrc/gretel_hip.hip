@@ -582,10 +582,8 @@ extern "C" int gh_reads_upload(const gh_t *h, const int32_t *rank, const int64_t
     if (e == hipSuccess && n_reads) {
         const int grid = (int)std::min<int64_t>((n_reads + 256) / 256, 2048);
         k_reads_meta<<<grid, 256, 0, h->stream>>>(r->rank, r->off, n_reads, dm);
-        if (top > 0) {
-            k_reads_first_at<<<grid, 256, 0, h->stream>>>(r->rank, n_reads, r->first_at, top, dm);
-            k_reads_meta2<<<grid, 256, 0, h->stream>>>(r->rank, n_reads, r->first_at, FILL_RPB, dm);
-        }
+        if (top > 0) k_reads_first_at<<<grid, 256, 0, h->stream>>>(r->rank, n_reads, r->first_at, top, dm);
+        k_reads_meta2<<<grid, 256, 0, h->stream>>>(r->rank, n_reads, r->first_at, FILL_RPB, dm);
         e = hipGetLastError();
     }
     if (e == hipSuccess && r->n_bases) e = hipMemcpyAsync(r->bases, bases, (size_t)r->n_bases, hipMemcpyHostToDevice, h->stream);
@@ -627,6 +625,17 @@ extern "C" int gh_reads_max_k(const gh_reads_t *r, int32_t *max_k)
 {
     if (!r || !max_k) return fail(GH_ERR_ARG, "bad argument");
     *max_k = r->max_k;
+    return GH_OK;
+}
+
+extern "C" int gh_reads_info(const gh_reads_t *r, int64_t info[5], int64_t *first_at)
+{
+    if (!r || !info) return fail(GH_ERR_ARG, "bad argument");
+    info[0] = r->max_k; info[1] = r->sorted ? 1 : 0; info[2] = r->span_pos; info[3] = r->dens128; info[4] = r->first_at ? r->n_first : 0;
+    if (first_at && r->first_at) {
+        HIPCHK(hipSetDevice(r->dev));
+        HIPCHK(hipMemcpy(first_at, r->first_at, (size_t)r->n_first * 8, hipMemcpyDeviceToHost));
+    }
     return GH_OK;
 }
 

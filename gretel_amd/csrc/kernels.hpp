@@ -577,7 +577,7 @@ k_reads_first_at(const int32_t *__restrict__ rank, int64_t n, int64_t *__restric
         for (int64_t pp = prev + 1 < 0 ? 0 : prev + 1; pp <= cur && pp < top; pp++) first_at[pp] = q;
     }
 }
-// (behind k_reads_first_at: span and density)
+// (behind k_reads_first_at: the span; the density where there is a first_at)
 __global__ void __launch_bounds__(256)
 k_reads_meta2(const int32_t *__restrict__ rank, int64_t n, const int64_t *__restrict__ first_at, int rpb, reads_meta *m)
 {
@@ -590,9 +590,11 @@ k_reads_meta2(const int32_t *__restrict__ rank, int64_t n, const int64_t *__rest
             const int d = rank[q1 - 1] - rank[q];
             sp = d > sp ? d : sp;
         }
-        const int lo_p = rank[q] - 127 < 0 ? 0 : rank[q] - 127;
-        const long long d = (long long)q - (long long)first_at[lo_p] + 1;
-        dn = d > dn ? d : dn;
+        if (first_at) {
+            const int lo_p = rank[q] - 127 < 0 ? 0 : rank[q] - 127;
+            const long long d = (long long)q - (long long)first_at[lo_p] + 1;
+            dn = d > dn ? d : dn;
+        }
     }
     for (int o = 32; o; o >>= 1) {
         const int v = __shfl_xor(sp, o); sp = v > sp ? v : sp;

@@ -589,6 +589,15 @@ class DeviceReads:
         check(self._lib.gh_reads_max_k(r, C.byref(mk)))
         self.max_k = int(mk.value)
 
+    def info(self):
+        """What the upload found out about the table (gh_reads_info): dict(max_k, sorted, span_pos, dens128, first_at)."""
+        inf = np.zeros(5, dtype=np.int64)
+        check(self._lib.gh_reads_info(self._r, _p(inf), None))
+        fa = np.zeros(int(inf[4]), dtype=np.int64)
+        if len(fa):
+            check(self._lib.gh_reads_info(self._r, _p(inf), _p(fa)))
+        return dict(max_k=int(inf[0]), sorted=bool(inf[1]), span_pos=int(inf[2]), dens128=int(inf[3]), first_at=fa)
+
     def __del__(self):
         try:
             if getattr(self, "_r", None):

@@ -123,6 +123,12 @@ int gh_reads_free(gh_reads_t *r);
 /* the longest read of an uploaded table (max of off[q + 1] - off[q]; found on the device behind the upload): a matrix needs a band
  * of at least max_k - 1 to take it */
 int gh_reads_max_k(const gh_reads_t *r, int32_t *max_k);
+/* What the upload found out about the table (for the tests; the fills choose their kernel and their counter width by it):
+ * info[0] longest read, [1] 1 when the ranks ascend, [2] the widest run of positions a block of 2048 reads covers + longest read + 1,
+ * [3] the most reads whose ranks fall into 128 consecutive positions, [4] entries of first_at (0: none); the last three are 0 for
+ * a table whose ranks do not ascend.  first_at (may be NULL): room for info[4] entries, first_at[p] = the first read whose
+ * rank is >= p -- call once with NULL for the count. */
+int gh_reads_info(const gh_reads_t *r, int64_t info[5], int64_t *first_at);
 
 /* The per-read pair loop of load_from_bam -- gretel/util.py:226-286 -- and the
  * counters/L of util.py:329-333, over a device-resident support table.

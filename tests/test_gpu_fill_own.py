@@ -93,3 +93,70 @@ def test_owner_fill_at_c5_and_c3_sizes():
                 if i + d <= t.n_snps + 1:
                     assert h.get_observation(a, b, i, i + d) == o.get(a, b, i, i + d)
             assert h.spin(3)["paths"].tolist() == o.spin(3)["paths"].tolist()
+
+
+def _table_properties(rank, off, rpb=2048):
+    """What gh_reads_upload used to work out on the host (round 1-5), in numpy."""
+    n = len(rank)
+    ks = np.diff(off)
+    max_k = int(ks.max()) if n else 0
+    srt = bool(n == 0 or (np.diff(rank) >= 0).all())
+    if not srt or n == 0:
+        return dict(max_k=max_k, sorted=srt, span_pos=0, dens128=0, first_at=np.zeros(0, dtype=np.int64))
+    q0 = np.arange(0, n, rpb)
+    q1 = np.minimum(q0 + rpb, n)
+    span = int((rank[q1 - 1].astype(np.int64) - rank[q0]).max()) + max_k + 1
+    lo = np.searchsorted(rank, rank.astype(np.int64) - 127, side="left")
+    dens = int((np.arange(n) - lo + 1).max())
+    fa = np.zeros(0, dtype=np.int64)
+    if rank[0] >= 0 and int(rank[-1]) + 2 <= (1 << 28):
+        fa = np.searchsorted(rank, np.arange(int(rank[-1]) + 2), side="left").astype(np.int64)
+    return dict(max_k=max_k, sorted=srt, span_pos=span, dens128=dens, first_at=fa)
+
+
+@pytest.mark.parametrize("case", ["c3", "ragged", "gaps", "one_read", "one_rank", "unsorted", "negative_first", "empty", "exact_block"])
+def test_the_tables_properties_found_on_the_device(case):
+    """gh_reads_upload finds the longest read, whether the ranks ascend, and for tables whose ranks do the span of a block, the
+    density and first_at ON THE DEVICE behind the copies (k_reads_meta, k_reads_first_at, k_reads_meta2): the same values as the
+    host passes of rounds 1-5 (the fills pick their kernel and the width of their LDS counters by them)."""
+    from gretel_amd.hansel import DeviceReads
+    rng = np.random.default_rng(17)
+    if case == "c3":
+        t = make_config("C3", seed=1)
+        rank, off, bases, n_snps = t.rank, t.off, t.bases, t.n_snps
+    else:
+        n_snps = 5000
+        n = dict(ragged=30000, gaps=5000, one_read=1, one_rank=700, unsorted=20000, negative_first=300, empty=0, exact_block=4096)[case]
+        ks = rng.integers(1, 9, size=n)
+        if case == "gaps":
+            rank = np.sort(np.concatenate([rng.integers(0, 40, size=n // 2), rng.integers(3000, 4900, size=n - n // 2)]))
+        elif case == "one_rank":
+            rank = np.full(n, 77)
+        elif case == "unsorted":
+            rank = rng.integers(0, 4900, size=n)
+        elif case == "negative_first":
+            rank = np.sort(rng.integers(0, 4000, size=n)); rank[0] = -1
+        else:
+            rank = np.sort(rng.integers(0, 4900, size=n))
+        rank = rank.astype(np.int32)
+        off = np.concatenate([[0], np.cumsum(ks)]).astype(np.int64)
+        bases = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(off[-1]))
+    h = Hansel(n_snps, band=16)
+    r = DeviceReads(h, rank, off, bases)
+    got, want = r.info(), _table_properties(rank, off)
+    if case == "negative_first":
+        want["first_at"] = np.zeros(0, dtype=np.int64)             # (no first_at for ranks that start below zero; the density all the same)
+    assert got["max_k"] == want["max_k"] == r.max_k and got["sorted"] == want["sorted"], (got, want)
+    assert got["span_pos"] == want["span_pos"] and got["dens128"] == want["dens128"], (case, got["span_pos"], want["span_pos"], got["dens128"], want["dens128"])
+    assert np.array_equal(got["first_at"], want["first_at"])
+
+
+def test_upload_refuses_offsets_that_run_backwards():
+    from gretel_amd.hansel import DeviceReads
+    h = Hansel(100, band=4)
+    rank = np.arange(50, dtype=np.int32)
+    off = np.arange(0, 153, 3, dtype=np.int64)
+    off[31] = off[30] - 1
+    with pytest.raises(Exception) as ei:
+        DeviceReads(h, rank, off, np.full(int(off[-1]), ord("A"), dtype=np.uint8), max_k=3)
+    assert "not monotone at read 30" in str(ei.value)
