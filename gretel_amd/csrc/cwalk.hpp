@@ -151,11 +151,18 @@ __device__ __forceinline__ cw_key cw_hash_digits(const uint8_t *d, int L)
     h ^= h >> 32; h *= 0x9e3779b97f4a7c15ull; h ^= h >> 29;
     return h;
 }
+// (states lie LD = L rounded up to 4 bytes apart in 4-byte-aligned arrays: compared as words, every load on its way before the
+// first comparison -- byte by byte with an early exit it was a chain of up to L dependent loads, 15-30 us of k_clink at 33-48 lags;
+// the bytes of the last word beyond L are not looked at)
 __device__ __forceinline__ bool cw_same_digits(const uint8_t *a, const uint8_t *b, int L)
 {
-    for (int l = 0; l < L; l++)
-        if (a[l] != b[l]) return false;
-    return true;
+    const uint32_t *x = reinterpret_cast<const uint32_t *>(a), *y = reinterpret_cast<const uint32_t *>(b);
+    const int nw = (L + 3) >> 2;
+    const uint32_t tail = (L & 3) ? ((1u << (8 * (L & 3))) - 1u) : 0xffffffffu;
+    uint32_t diff = 0;
+    for (int w = 0; w + 1 < nw; w++) diff |= x[w] ^ y[w];
+    diff |= (x[nw - 1] ^ y[nw - 1]) & tail;
+    return diff == 0;
 }
 
 // -------------------------------------------------------------------------------------------------------------
@@ -693,6 +700,329 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
                         P.pend_ready[(size_t)(seg + 1) * CW_K + slot] = 0;
                         if (hop < P.runon) go_on = 1 + slot;
                     }
+                }
+            }
+        }
+    }
+    go_on = __shfl(go_on, (int)(tid & 63 & ~(LPE - 1)));      // lane b == 0 of the group decides
+    active = go_on != 0;
+    if (!__syncthreads_or(active ? 1 : 0)) break;           // nobody walks on: done
+    seg++;
+    pslot = active ? go_on - 1 : 0;
+    hdst = P.phist + (size_t)seg * nw_e * CW_K + pslot;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------
+// k_cwalk2<LC>: 33..48 lags over ranks (round 6).  k_cwalkg's pools -- a state is its L picks as bytes next to their hash -- with
+// k_cwalk's step: the row offsets of the last LC picks rotate through registers (slot u = the pick of the step that is u (mod LC)
+// into a block of LC steps, every index a compile-time constant), the terms of a step are LC LDS reads at compile-time offsets
+// and LC - 1 additions in lag order, and the next chunk's slice waits in registers under the walk.  A block of LC steps is two
+// chunks of the slice (LC x 16 x 8 bytes per target: 24 targets are 148 KB at 48 lags), so a chunk boundary always falls on the
+// same two steps of the unrolled block.  One instantiation serves every lag count L <= LC: the slice's blocks of lags beyond L
+// are zeros, and x + 0.0 is x for the arg-max (as for the positions in front of the window everywhere here) -- LC = 36, 40, 44, 48
+// are compiled.  Picks also go to a ring in LDS (one byte store per step, off the chain): the exit state is read from there, as
+// in k_cwalkg.  k_cwalkg took 6.5 rounds of 36 us per path at L = 33; this takes k_cwalk<32>'s 2.7 with run-on.
+// -------------------------------------------------------------------------------------------------------------
+#define CW2_MAX_L 48
+#define CW2_RING 64
+template <typename F, int... U>
+__device__ __forceinline__ void cw_unrolled(F &&f, std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }
+__host__ __device__ constexpr int cw2_chunk(int LC) { return (LC + 1) / 2; }
+__host__ __device__ constexpr size_t cw2_lds_bytes(int LC) { return (size_t)cw2_chunk(LC) * (LC * 16 + 5) * 8; }
+__host__ __device__ constexpr int cw2_lc(int L) { return L <= 36 ? 36 : (L <= 40 ? 40 : (L <= 44 ? 44 : 48)); }
+
+template <int LC>
+__global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
+{
+    constexpr int R = 4, LPE = 4, PPW = 16, WB = 2;
+    constexpr int ROWS = 4, COLS = 4, ENT = ROWS * COLS, NTHR = CW_K * LPE;
+    constexpr int CHA = cw2_chunk(LC), CHB = LC - CHA;      // the two halves of a block of LC steps
+    static_assert(LC > CW_MAX_L && LC <= CW2_MAX_L && LC < CW2_RING, "lag counts of k_cwalk2");
+    __shared__ __align__(16) uint8_t ring[CW_K][CW2_RING];  // ring[q][t & 63] = pick at position t
+    extern __shared__ __align__(16) unsigned char cw2_smem[];
+    dev_state *st = P.st;
+    const dev_ctl c = load_ctl(st);
+    if (c.stop || c.lt_stale || c.cw_unres) return;
+    if (P.round > 0 && c.cw_open_at < 0) return;
+    if (P.check_masks == 2 || (P.check_masks && c.cm_same == 0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
+        return;
+    }
+    if (c.ranked == 0) {                                    // a five-candidate position somewhere: the host looks again (k_cwalkg<5>)
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->cur_hole = c.first_hole;
+        if (P.round == 0) st->cw_open_at = 0;
+    }
+    const cw_geom g = cw_geometry(P.N, P.L);
+    const int s = blockIdx.x, tid = threadIdx.x, L = P.L, LD = P.LD;
+    if (s >= g.S) return;
+    // (1) pending states join the pool: k_cwalkg's merge, word for word (equal hashes are confirmed on the bytes; a request that
+    // arrives with its walk joins as a walked entry)
+    __shared__ int s_n;
+    if (tid < 64) {
+        int n0 = P.npool[s];
+        const int np = P.npend_c[s] < CW_K ? P.npend_c[s] : CW_K;
+        cw_key *keys = P.keys + (size_t)s * CW_K;
+        int32_t *lh = P.last_hit + (size_t)s * CW_K;
+        const int nw_m = g.NW;
+        for (int k = 0; k < np; k++) {
+            const cw_key x = P.pend_c[(size_t)s * CW_K + k];
+            const uint8_t *xd = P.pend_d_c + ((size_t)s * CW_K + k) * LD;
+            const bool mine_dup = tid < n0 && keys[tid] == x && cw_same_digits(P.keys_d + ((size_t)s * CW_K + tid) * LD, xd, L);
+            if (__builtin_amdgcn_ballot_w64(mine_dup) != 0) continue;
+            int slot = n0;
+            if (n0 >= CW_K) {
+                int mine = (tid == 0 && s == 0) ? 0x7fffffff : lh[tid], who = tid;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int om = __shfl_xor(mine, o), ow = __shfl_xor(who, o);
+                    if (om < mine || (om == mine && ow < who)) { mine = om; who = ow; }
+                }
+                if (mine >= P.stamp) continue;
+                slot = who;
+            } else n0++;
+            const bool ready = P.pend_ready_c && P.pend_ready_c[(size_t)s * CW_K + k] == P.stamp && P.stamp != 0;
+            if (tid == 0) {
+                keys[slot] = x; lh[slot] = P.stamp - 1; P.walked[(size_t)s * CW_K + slot] = ready ? 1 : 0;
+                if (ready) P.exits[(size_t)s * CW_K + slot] = P.pend_exit_c[(size_t)s * CW_K + k];
+            }
+            for (int l = tid; l < L; l += 64) P.keys_d[((size_t)s * CW_K + slot) * LD + l] = xd[l];
+            if (ready) {
+                const uint8_t *ed = P.pend_exit_d_c + ((size_t)s * CW_K + k) * LD;
+                for (int l = tid; l < L; l += 64) P.exits_d[((size_t)s * CW_K + slot) * LD + l] = ed[l];
+                for (int w = tid; w < nw_m; w += 64) P.hist[((size_t)s * nw_m + w) * CW_K + slot] = P.phist_c[((size_t)s * nw_m + w) * CW_K + k];
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        if (tid == 0) { P.npool[s] = n0; P.npend_c[s] = 0; s_n = n0; }
+    }
+    __syncthreads();
+    const int n = s_n;
+    const int q = tid / LPE, b = tid & (LPE - 1);
+    const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
+    if (!__syncthreads_or(live ? 1 : 0)) return;
+    const unsigned shift = (unsigned)(tid & 63 & ~(LPE - 1));
+    const int nw_e = g.NW;
+    // the entry's last L picks into its ring (an idle lane group reads row 0 everywhere)
+    for (int w = b; w < CW2_RING / 4; w += LPE) reinterpret_cast<uint32_t *>(ring[q])[w] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (live)
+        for (int l = 1 + b; l <= L; l += LPE)
+            ring[q][(s * g.seglen + 1 - l) & (CW2_RING - 1)] = P.keys_d[((size_t)s * CW_K + q) * LD + (l - 1)];
+    __syncthreads();
+    double *Gs = reinterpret_cast<double *>(cw2_smem);      // [<= CHA][LC][ROWS][COLS]
+    double *Lms = Gs + (size_t)CHA * LC * ENT;
+    bool active = live;
+    int seg = s, pslot = 0;
+    uint32_t *hdst = P.hist + (size_t)s * nw_e * CW_K + q;
+    // the slice of a chunk (k_cwalk's, with the lag count known at run time: blocks of lags beyond L are zeros), fetched into
+    // registers while the chunk before is walked
+    constexpr int UNITS = CHA * LC * ROWS;
+    constexpr int NV = (UNITS + NTHR - 1) / NTHR;
+    constexpr int NLM = (CHA * LT_ROW + NTHR - 1) / NTHR;
+    double pre[NV][COLS];
+    double prelm[NLM];
+    auto fetch = [&](int c0, int nc) {
+        if (P.mt) {
+#pragma unroll
+            for (int k = 0; k < NLM; k++) {
+                const int e = tid + k * NTHR;
+                const int tl = e / LT_ROW, bb = e - tl * LT_ROW;
+                prelm[k] = 0.0;
+                if (tl < nc && bb < R) prelm[k] = P.rinfo[(size_t)(c0 + 1 + tl) * RINFO + bb];
+            }
+        }
+        const int total = nc * LC * ROWS;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int u = tid + k * NTHR;
+#pragma unroll
+            for (int cc = 0; cc < COLS; cc++) pre[k][cc] = 0.0;
+            if (u < total) {
+                const int row = u % ROWS, l1 = (u / ROWS) % LC, tl = u / (ROWS * LC);
+                const int i = c0 + tl - l1;                           // source of lag l1 + 1 at target c0 + 1 + tl
+                if (i >= 0 && l1 < L) {
+                    const double *src = P.G + (((size_t)i * 6 + (i == 0 ? 5 : row)) * L + l1) * LT_ROW;
+#pragma unroll
+                    for (int cc = 0; cc < COLS; cc++) pre[k][cc] = src[cc];
+                }
+            }
+        }
+    };
+    auto store = [&](int nc) {
+        const int total = nc * LC * ROWS;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            const int u = tid + k * NTHR;
+            if (u < total) {
+#pragma unroll
+                for (int cc = 0; cc < COLS; cc++) Gs[(size_t)u * COLS + cc] = pre[k][cc];
+            }
+        }
+        if (P.mt) {
+#pragma unroll
+            for (int k = 0; k < NLM; k++) {
+                const int e = tid + k * NTHR;
+                if (e < nc * LT_ROW) Lms[e] = prelm[k];
+            }
+            __syncthreads();
+            for (int e = tid; e < nc * ENT; e += NTHR) {              // lag 1: (0.0 + lm) + x1, the reference's first addition
+                const int tl = e / ENT, rc = e - tl * ENT, bb = rc % COLS;
+                double *gp = Gs + (size_t)tl * LC * ENT + rc;
+                *gp = Lms[tl * LT_ROW + bb] + *gp;
+            }
+        }
+    };
+    // the hashes of the pool behind the segment being walked, for the closure search at its end (as k_cwalk: one lane per key while
+    // the walk has not begun, instead of a chain of dependent global loads behind it)
+    __shared__ cw_key s_next[CW_K];
+    __shared__ int s_nn;
+    constexpr int NW4 = (LC + 3) / 4;                       // words of a state
+    const int nwr = LD >> 2;                                // ... at this lag count
+    const uint32_t tailm = (L & 3) ? ((1u << (8 * (L & 3))) - 1u) : 0xffffffffu;
+    for (int hop = 0; ; hop++) {
+    const int t0 = seg * g.seglen;
+    const int t1 = t0 + g.seglen < P.N ? t0 + g.seglen : P.N;
+    if (tid < CW_K) s_next[tid] = seg + 1 < g.S ? P.keys[(size_t)(seg + 1) * CW_K + tid] : 0ull;
+    if (tid == 0) s_nn = seg + 1 < g.S ? P.npool[seg + 1] : 0;      // (entries behind the count are leftovers of earlier tensors)
+    int word_i = 0;
+    unsigned word = 0;
+    constexpr unsigned ROWD = COLS;
+    // slot (LC - l) % LC = the pick l positions in front of the segment's first target (lags beyond L: whatever the ring holds, a
+    // valid row of a block of zeros)
+    unsigned dig[LC];
+#pragma unroll
+    for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = (unsigned)ring[q][(t0 + 1 - l) & (CW2_RING - 1)] * ROWD;
+    auto step = [&](int c0, int tl, auto rowoff) __attribute__((always_inline)) {
+        const double *base = Gs + (size_t)tl * LC * ENT + b;
+        double x[LC];
+#pragma unroll
+        for (int l = 1; l <= LC; l++) x[l - 1] = base[(l - 1) * ENT + rowoff(l)];
+        double acc = x[0];
+#pragma unroll
+        for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
+        double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
+        m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
+        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
+        const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & 15u);       // first wins (gretel.py:166-174)
+        const int t = c0 + 1 + tl;
+        if (active && b == 0) ring[q][t & (CW2_RING - 1)] = (uint8_t)d;      // (read again behind the segment only)
+        const int gt = t - t0 - 1;
+        word |= d << (WB * (gt % PPW));
+        if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
+            if (active && b == 0) hdst[(size_t)word_i * CW_K] = word;
+            word = 0;
+            word_i++;
+        }
+        return d;
+    };
+    int c0 = t0;
+    fetch(c0, t1 - c0 < CHA ? t1 - c0 : CHA);
+    while (c0 < t1) {
+        // first half of the block: steps 0 .. CHA - 1
+        {
+            const int nc = t1 - c0 < CHA ? t1 - c0 : CHA;
+            __syncthreads();                                          // the chunk before has been walked
+            store(nc);
+            __syncthreads();
+            if (c0 + nc < t1) fetch(c0 + nc, t1 - c0 - nc < CHB ? t1 - c0 - nc : CHB);
+            cw_unrolled([&](auto u_) __attribute__((always_inline)) {
+                constexpr int u = decltype(u_)::value;
+                if (u < nc) {
+                    const unsigned d = step(c0, u, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
+                    dig[u] = d * ROWD;
+                }
+            }, std::make_integer_sequence<int, CHA>{});
+            c0 += nc;
+        }
+        if (c0 >= t1) break;
+        // second half: steps CHA .. LC - 1
+        {
+            const int nc = t1 - c0 < CHB ? t1 - c0 : CHB;
+            __syncthreads();
+            store(nc);
+            __syncthreads();
+            if (c0 + nc < t1) fetch(c0 + nc, t1 - c0 - nc < CHA ? t1 - c0 - nc : CHA);
+            cw_unrolled([&](auto u_) __attribute__((always_inline)) {
+                constexpr int u = CHA + decltype(u_)::value;
+                if (u - CHA < nc) {
+                    const unsigned d = step(c0, u - CHA, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
+                    dig[u] = d * ROWD;
+                }
+            }, std::make_integer_sequence<int, CHB>{});
+            c0 += nc;
+        }
+    }
+    // the segment is walked.  Its exit state -- the last L picks, lag 1 first -- out of the ring, as the words it is kept in
+    // (bytes beyond L zero), and its hash; hop 0: the entry's own walk, later hops: a walk on behalf of the pending request
+    // `pslot` of pool `seg`.  Every lane of the group holds the whole state: each then compares its share of the next pool.
+    __syncthreads();
+    uint32_t xw[NW4];
+    unsigned long long hh = 0xcbf29ce484222325ull;          // (cw_hash_digits)
+#pragma unroll
+    for (int j = 0; j < NW4; j++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int l = 4 * j + e + 1, i = t1 + 1 - l;
+            const uint32_t d = (l <= L && i >= 1) ? (uint32_t)ring[q][i & (CW2_RING - 1)] : 0u;
+            w |= d << (8 * e);
+            if (l <= L) { hh ^= (unsigned long long)d; hh *= 0x100000001b3ull; }
+        }
+        xw[j] = w;
+    }
+    hh ^= hh >> 32; hh *= 0x9e3779b97f4a7c15ull; hh ^= hh >> 29;
+    const cw_key sigma = hh;
+    if (active) {
+        uint32_t *xd = reinterpret_cast<uint32_t *>(hop == 0 ? P.exits_d + ((size_t)s * CW_K + q) * LD : P.pend_exit_d + ((size_t)seg * CW_K + pslot) * LD);
+#pragma unroll
+        for (int j = 0; j < NW4; j++)
+            if ((j & (LPE - 1)) == b && j < nwr) xd[j] = xw[j];
+    }
+    bool there = false;
+    {
+        const int nn = s_nn < CW_K ? s_nn : CW_K;
+        bool mine = false;
+        for (int k = b; k < nn; k += LPE) {
+            if (s_next[k] != sigma) continue;
+            const uint32_t *kd = reinterpret_cast<const uint32_t *>(P.keys_d + ((size_t)(seg + 1) * CW_K + k) * LD);
+            uint32_t diff = 0;
+#pragma unroll
+            for (int j = 0; j < NW4; j++)
+                if (j < nwr) diff |= (kd[j] ^ xw[j]) & (j == nwr - 1 ? tailm : 0xffffffffu);
+            mine |= diff == 0;
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
+        there = ((bal >> shift) & 15ull) != 0ull;
+    }
+    int go_on = 0;
+    if (active && b == 0) {
+        if (hop == 0) {
+            P.exits[(size_t)s * CW_K + q] = sigma;
+            P.walked[(size_t)s * CW_K + q] = 1;
+        } else {
+            const size_t pe = (size_t)seg * CW_K + (size_t)pslot;
+            P.pend_exit[pe] = sigma;
+            P.pend_ready[pe] = P.stamp;                     // (read by the owner in a later launch: the bytes above are there by then)
+        }
+        // closure, as in k_cwalk: an exit state the next pool does not hold asks to join it -- and, run-on, is walked on from here
+        if (seg + 1 < g.S && !there) {
+            const int slot = atomicAdd(&P.npend[seg + 1], 1);
+            if (slot < CW_K) {
+                P.pend[(size_t)(seg + 1) * CW_K + slot] = sigma;
+                uint32_t *pd = reinterpret_cast<uint32_t *>(P.pend_d + ((size_t)(seg + 1) * CW_K + slot) * LD);
+#pragma unroll
+                for (int j = 0; j < NW4; j++)
+                    if (j < nwr) pd[j] = xw[j];
+                if (P.pend_ready) {
+                    P.pend_ready[(size_t)(seg + 1) * CW_K + slot] = 0;
+                    if (hop < P.runon) go_on = 1 + slot;
                 }
             }
         }

@@ -202,3 +202,46 @@ def test_run_on_changes_nothing(L, dels, monkeypatch):
     monkeypatch.setenv("GH_CW_ROUND_CAP", "1")
     h1, _ = _pair(t, L=L)
     _same(h1.spin(30), ref)
+
+
+@pytest.mark.parametrize("L", [33, 34, 36, 37, 40, 41, 44, 45, 47, 48])
+@pytest.mark.parametrize("spec", ["A", "E+mt"])
+def test_33_to_48_lags_through_registers(L, spec, monkeypatch):
+    """k_cwalk2<36 | 40 | 44 | 48> (round 6): 33..48 lags over ranks with k_cwalk's step -- the last LC picks' row offsets in
+    registers, a block of LC steps unrolled over two chunks of the slice, lags beyond L as blocks of zeros -- on k_cwalkg's pools
+    (states as bytes next to their hash).  The oracle's paths; the same with k_cwalkg (GH_CWALK2=0), without run-on and with the
+    chain followed behind every round; every lag count that shares an instantiation with another."""
+    kw = dict(cond_mode="E", marginal_term=True) if spec == "E+mt" else {}
+    t = make_support_table(2500, 30000, k=None, seed=700 + L, k_max=L + 4, k_lambda=float(L))
+    h, o = _pair(t, L=L, **kw)
+    res, ref = h.spin(16), o.spin(16)
+    assert h.walk_clock()[3] == 4
+    _same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    if L in (33, 41, 48):
+        monkeypatch.setenv("GH_CWALK2", "0")
+        hg, _ = _pair(t, L=L, **kw)
+        _same(hg.spin(16), ref)
+        monkeypatch.delenv("GH_CWALK2")
+        monkeypatch.setenv("GH_CW_RUNON", "0")
+        monkeypatch.setenv("GH_CW_SKIP0", "0")
+        h0, _ = _pair(t, L=L, **kw)
+        _same(h0.spin(16), ref)
+
+
+def test_33_to_48_lags_short_window_and_lone_paths():
+    # a window shorter than two segments (the block of LC steps never completes), then gh_generate_path out of the same pools
+    t = make_support_table(70, 2500, k=None, seed=77, k_max=45, k_lambda=30.0)
+    h, o = _pair(t, L=39)
+    _same(h.spin(10), o.spin(10))
+    t = make_support_table(1200, 20000, k=None, seed=78, k_max=46, k_lambda=38.0)
+    h, o = _pair(t, L=42)
+    for it in range(4):
+        pg, po = h.generate_path(), o.generate_path()
+        if po[0] is None:
+            assert pg[0] is None and pg[1] == po[1]
+            break
+        assert np.array_equal(pg[0], po[0]) and pg[1:] == po[1]
+        ratio = max(pg[3], 0.01)
+        h.reweight_from_path(pg[0], ratio); o.reweight_path(po[0], ratio)
+    assert np.array_equal(h.export_band(), o.export_band())
