@@ -42,6 +42,10 @@ typedef unsigned long long cw_key;
 #define CW_BOOT_ROUNDS 8        /* rounds queued for the first path of a tensor (pools started from k_cguess) */
 #define CW_RUNON 8              /* segments a walker may run on into, behind its own, with an exit state the next pool does not hold */
 
+// f(integral_constant<0>), f(integral_constant<1>), ...: a run of steps with their index as a compile-time constant
+template <typename F, int... U>
+__device__ __forceinline__ void cw_unrolled(F &&f, std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }
+
 // Segments: a wavefront alone on its SIMD issues an instruction every ~5 cycles, so where the table slice of a chunk
 // leaves room for two workgroups per CU (L <= 13: 76 KB each) the window is cut into twice as many, half as long
 // segments, and every SIMD has two walkers to interleave.
@@ -84,7 +88,12 @@ __host__ __device__ constexpr int cw_chunk(int L, int R)
     // (the next chunk's slice waits in registers under the walk: from 18 lags on no more targets than a segment of the
     // usual length has, or the walk's own registers go through the accumulator file)
     if (L >= 18 && c > CW_CH_CAP) c = CW_CH_CAP > L ? CW_CH_CAP : L;
-    return c > 64 ? 64 : (c < 2 ? 2 : c);
+    c = c > 64 ? 64 : (c < 2 ? 2 : c);
+    // (round 6) whole blocks of L steps, at most 48 targets: a chunk is walked as ONE unrolled run of steps whose slot in the
+    // register rotation and whose LDS offsets are compile-time constants -- a chunk boundary in the middle of a block would
+    // need a second unrolling per phase.  (Every lag count here leaves room for at least one block.)
+    if (c >= L) { c = c / L * L; while (c > 48 && c > L) c -= L; }
+    return c;
 }
 __host__ __device__ constexpr size_t cw_lds_bytes(int L, int R) { return (size_t)cw_chunk(L, R) * (L * cw_rows(R) * cw_cols(R) + 5) * 8; }
 
@@ -328,58 +337,57 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk(cw_params P)
     if (tid < CW_K) s_next[tid] = seg + 1 < g.S ? P.keys[(size_t)(seg + 1) * CW_K + tid] : 0ull;
     if (tid == 0) s_nn = seg + 1 < g.S ? P.npool[seg + 1] : 0;      // (entries behind the count are leftovers of earlier tensors)
     fetch(t0);
+    // the row addresses of the last LC picks in front of the segment: slot (LC - l) % LC = the pick l positions back
+    constexpr unsigned ROWD = COLS;                              // doubles per row of a (target, lag) block
+    const unsigned lane_base = (unsigned)(uintptr_t)Gs + (unsigned)bcol * 8u;
+    unsigned dig[LC];
+#pragma unroll
+    for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = lane_base + ((unsigned)(sigma >> (BITS * (l - 1))) & DMASK) * (ROWD * 8u);
     for (int c0 = t0; c0 < t1; c0 += CH) {
         const int nc = t1 - c0 < CH ? t1 - c0 : CH;
         __syncthreads();                                          // the previous chunk has been walked
         store(c0);
         __syncthreads();
         if (c0 + CH < t1) fetch(c0 + CH);
-        // One step: lag l of chunk-local target tl, row = the pick made l positions ago:
-        // Gs[((tl * LC + (l - 1)) * ROWS + row) * COLS + b].  rowoff(l) = that pick's row offset in doubles.
-        auto step = [&](int tl, auto rowoff) {
-            const double *base = Gs + (size_t)tl * LC * ENT + bcol;
-            double x[LC];
+        // One step (round 6: no arithmetic per term).  Slot u of `dig` holds the LDS byte address of (row = the pick of the step
+        // that is u (mod LC) into the segment, column = this lane's candidate) inside the FIRST (target, lag) block of the slice;
+        // the term of lag l at the chunk's v-th target is one LDS read from the slot of the pick made l steps ago at the
+        // compile-time offset of block (v, l) -- hipcc folds it into the instruction where it is below 64 KB and adds it where
+        // not (the last targets of the larger slices).  Chunks are whole blocks of LC steps and a segment starts at slot 0, so
+        // every index is a constant; the steps behind the segment's end are skipped by a uniform branch.  (Rounds 2-5: blocks of
+        // LC steps in a run-time loop, an address addition per term, and the steps a chunk had beyond its last whole block --
+        // 9 of 53 at C5 -- with the rows shifted out of the state word term by term.)
+        static_assert(CH % LC == 0 || CH < LC, "chunks are whole blocks");
+        typedef const __attribute__((address_space(3))) double lds_cd;
+        cw_unrolled([&](auto v_) __attribute__((always_inline)) {
+            constexpr int v = decltype(v_)::value, u = v % LC;
+            if (v < nc) {
+                double x[LC];
 #pragma unroll
-            for (int l = 1; l <= LC; l++) x[l - 1] = base[(l - 1) * ENT + rowoff(l)];
-            double acc = x[0];
+                for (int l = 1; l <= LC; l++) x[l - 1] = *(lds_cd *)(dig[((u - l) % LC + LC) % LC] + (unsigned)((v * LC + (l - 1)) * ENT * 8));
+                double acc = x[0];
 #pragma unroll
-            for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
-            if (R == 5 && b >= R) acc = -INFINITY;                   // (the idle lanes of the group)
-            double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
-            m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
-            if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));          // row_half_mirror: the other quad of the eight lanes
-            // (R = 5: a NaN weight in first place is the reference's incumbent and stays it -- kernels.hpp, argmax8)
-            const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
-            const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));       // first wins (gretel.py:166-174)
-            sigma = ((sigma << BITS) | (cw_key)d) & SMASK;
-            const int gt = c0 - t0 + tl;                             // position inside the segment
-            word |= d << (WB * (gt % PPW));
-            if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
-                if (active && b == 0) hdst[(size_t)word_i * CW_K] = word;
-                word = 0;
-                word_i++;
-            }
-            return d;
-        };
-        // blocks of LC steps: the row offsets of the last LC picks sit in registers, slot k = the pick of the step that is
-        // k (mod LC) into the block, so every index below is a compile-time constant (no shuffling of registers, no
-        // bit-field extraction per lag); what is left of the chunk takes the offsets out of the state word
-        constexpr unsigned ROWD = COLS;                              // doubles per row of a (target, lag) block
-        int tl = 0;
-        if (nc >= LC) {
-            unsigned dig[LC];
-#pragma unroll
-            for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = ((unsigned)(sigma >> (BITS * (l - 1))) & DMASK) * ROWD;
-            for (; tl + LC <= nc; tl += LC) {
-#pragma unroll
-                for (int u = 0; u < LC; u++) {
-                    const unsigned d = step(tl + u, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
-                    dig[u] = d * ROWD;
+                for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
+                if (R == 5 && b >= R) acc = -INFINITY;                   // (the idle lanes of the group)
+                double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
+                m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
+                if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));          // row_half_mirror: the other quad of the eight lanes
+                // (R = 5: a NaN weight in first place is the reference's incumbent and stays it -- kernels.hpp, argmax8)
+                const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
+                const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));       // first wins (gretel.py:166-174)
+                sigma = (sigma << BITS) | (cw_key)d;                     // (what is shifted beyond LC picks is masked off behind the segment)
+                dig[u] = lane_base + d * (ROWD * 8u);
+                const int gt = c0 - t0 + v;                              // position inside the segment
+                word |= d << (WB * (gt % PPW));
+                if ((gt % PPW) == PPW - 1 || gt == t1 - t0 - 1) {
+                    if (active && b == 0) hdst[(size_t)word_i * CW_K] = word;
+                    word = 0;
+                    word_i++;
                 }
             }
-        }
-        for (; tl < nc; tl++) step(tl, [&](int l) { return ((unsigned)(sigma >> (BITS * (l - 1))) & DMASK) * ROWD; });
+        }, std::make_integer_sequence<int, CH>{});
     }
+    sigma &= SMASK;
     // the segment is walked.  hop 0: the entry's own walk; later hops: a walk on behalf of a pending request of pool `seg`
     int go_on = 0;
     bool there = false;
@@ -726,8 +734,6 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
 // -------------------------------------------------------------------------------------------------------------
 #define CW2_MAX_L 48
 #define CW2_RING 64
-template <typename F, int... U>
-__device__ __forceinline__ void cw_unrolled(F &&f, std::integer_sequence<int, U...>) { (f(std::integral_constant<int, U>{}), ...); }
 __host__ __device__ constexpr int cw2_chunk(int LC) { return (LC + 1) / 2; }
 __host__ __device__ constexpr size_t cw2_lds_bytes(int LC) { return (size_t)cw2_chunk(LC) * (LC * 16 + 5) * 8; }
 __host__ __device__ constexpr int cw2_lc(int L) { return L <= 36 ? 36 : (L <= 40 ? 40 : (L <= 44 ? 44 : 48)); }
