@@ -20,6 +20,7 @@ every operation raises (gretel_amd._lib).
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -467,6 +468,9 @@ class PinnedTableArena:
 
 
 _table_arena = None
+# (one table at a time in the process-wide arena: load_from_bam holds this from the decode until the upload has read the table --
+# ctypes releases the GIL inside both, and a second thread's decode would write into the blocks the first one is uploading from)
+table_arena_lock = threading.RLock()
 
 
 def table_arena():

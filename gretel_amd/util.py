@@ -28,6 +28,7 @@ Known divergences from pysam's pileup, all irrelevant to the synthetic configs:
 """
 from __future__ import annotations
 
+import contextlib
 import gzip
 import struct
 import sys
@@ -348,20 +349,24 @@ def load_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, use_
     if n_threads not in (None, 1):
         sys.stderr.write("[NOTE] -@/--threads %s ignored: the BAM is decoded by libgretel_io.so's own threads and the matrix is filled on the GPU\n" % n_threads)
     native = decoder == "native" and not (debug_reads or debug_pos)
-    arena = None
+    arena, guard = None, contextlib.nullcontext()
     if native:
-        # (the table goes straight into page-locked memory kept from window to window, which the upload reads by DMA)
-        from .hansel import table_arena
-        arena = table_arena()
-    rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper, decoder,
-                                              max_depth=max_depth, debug_reads=debug_reads or None, debug_pos=debug_pos or None, arena=arena)
-    if native:
-        from . import bamio
-        max_k = int(bamio.native_last_stats()["max_row_len"])           # (the decoder knows its longest row: no pass over off[])
-    else:
-        max_k = int(np.diff(off).max()) if len(rank) else 0
-    hansel = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, vcf_handler["N"], band=max(1, max_k - 1), **hansel_kw)
-    n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels, max_k=max_k)
+        # (the table goes straight into page-locked memory kept from window to window, which the upload reads by DMA; the arena is
+        # the process's: held from the decode until the fill has taken the table to the device)
+        from . import hansel as _hansel_mod
+        arena = _hansel_mod.table_arena()
+        if arena is not None:
+            guard = _hansel_mod.table_arena_lock
+    with guard:
+        rank, off, bases = support_table_from_bam(bam_path, target_contig, start_pos, end_pos, vcf_handler, stepper, decoder,
+                                                  max_depth=max_depth, debug_reads=debug_reads or None, debug_pos=debug_pos or None, arena=arena)
+        if native:
+            from . import bamio
+            max_k = int(bamio.native_last_stats()["max_row_len"])           # (the decoder knows its longest row: no pass over off[])
+        else:
+            max_k = int(np.diff(off).max()) if len(rank) else 0
+        hansel = Hansel.init_matrix(SYMBOLS, UNSYMBOLS, vcf_handler["N"], band=max(1, max_k - 1), **hansel_kw)
+        n_slices, n_crumbs, covered = hansel.fill_from_support(rank, off, bases, use_end_sentinels, max_k=max_k)
     sys.stderr.write("[NOTE] Loaded %d breadcrumbs from %d bread slices.\n" % (n_crumbs, n_slices))   # util.py:331
     if n_slices == 0:
         raise ZeroDivisionError("no read carries more than one SNP (gretel/util.py:333 divides by n_reads)")

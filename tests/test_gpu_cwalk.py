@@ -245,3 +245,14 @@ def test_33_to_48_lags_short_window_and_lone_paths():
         ratio = max(pg[3], 0.01)
         h.reweight_from_path(pg[0], ratio); o.reweight_path(po[0], ratio)
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [49, 64])
+def test_beyond_48_lags_bytes_and_ring(L):
+    # k_cwalkg (states walked out of a byte ring) still serves what k_cwalk2 does not: here 49 and 64 lags over ranks; its epilogue
+    # shares k_cwalk2's word compares and LDS-staged hashes since round 6
+    t = make_support_table(1500, 16000, k=None, seed=900 + L, k_max=L + 4, k_lambda=float(L))
+    h, o = _pair(t, L=L)
+    _same(h.spin(10), o.spin(10))
+    assert h.walk_clock()[3] == 4
+    assert np.array_equal(h.export_band(), o.export_band())
