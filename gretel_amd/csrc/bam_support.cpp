@@ -15,7 +15,10 @@
 // behind it (coordinate-sorted input, as the reference's pysam fetch/pileup requires as well); without one the whole
 // contig is scanned.  Every record field that is used as a length or an offset is checked against the record's size:
 // malformed input is an error (-4), never an out-of-bounds read.
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <dlfcn.h>
 #include <zlib.h>
 
@@ -404,16 +407,18 @@ private:
 
 class bgzf_stream {
 public:
-    ~bgzf_stream() { if (fp_) fclose(fp_); }
+    ~bgzf_stream() { if (fd_ >= 0) close(fd_); }
 
     int open(const char *path)
     {
-        fp_ = fopen(path, "rb");
-        if (!fp_) return fail(-1, "cannot open %s", path);
+        fd_ = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd_ < 0) return fail(-1, "cannot open %s", path);
         path_ = path;
-        if (fseeko(fp_, 0, SEEK_END) == 0) { fsize_ = (uint64_t)ftello(fp_); fseeko(fp_, 0, SEEK_SET); }
+        struct stat sb;
+        if (fstat(fd_, &sb) == 0 && S_ISREG(sb.st_mode)) { fsize_ = (uint64_t)sb.st_size; regular_ = true; }
+        // (a pipe or the like is read front to back, one read after the other; what is no BGZF shows at its first block header)
         uint8_t magic[4];
-        if (fread(magic, 1, 4, fp_) != 4 || magic[0] != 0x1f || magic[1] != 0x8b)
+        if (regular_ && (pread(fd_, magic, 4, 0) != 4 || magic[0] != 0x1f || magic[1] != 0x8b))
             return fail(-2, "%s is not gzip/BGZF", path);
         return seek(0, 0);
     }
@@ -421,7 +426,8 @@ public:
     // continue at virtual offset (coffset, uoffset)
     int seek(uint64_t coffset, unsigned uoffset)
     {
-        if (fseeko(fp_, (off_t)coffset, SEEK_SET) != 0) return fail(-1, "seek failed in %s", path_.c_str());
+        if (!regular_ && coffset != fpos_) return fail(-1, "seek failed in %s", path_.c_str());
+        fpos_ = coffset;
         cbuf_.clear();
         out_.clear();
         rd_ = 0;
@@ -432,6 +438,11 @@ public:
         more_ = false;
         return 0;
     }
+    // the next read takes everything up to `bytes` in one go, its slices on all threads (gio_prefetch: the file's remainder is
+    // wanted anyway, and copying 7 MB out of the page cache on one thread, 4 MB at a time between the inflates, was 1.3-1.5 ms of
+    // a 4.5-5.7 ms prefetch)
+    void read_ahead(size_t bytes) { batch_ = bytes > batch_ ? bytes : batch_; }
+    uint64_t unread_file_bytes() const { return fsize_ > fpos_ ? fsize_ - fpos_ : 0; }
 
     // at least `need` unread bytes in the window unless the file ends first; returns <0 on error, else bytes available
     int64_t ensure(size_t need)
@@ -447,6 +458,7 @@ public:
     double progress() const { return fsize_ > start_ ? (double)taken_ / (double)(fsize_ - start_) : 1.0; }
     void consume(size_t n) { rd_ += n; }
     size_t window_cap() const { return WINDOW; }
+    double read_seconds() const { return read_s_; }
     // a window that is filled by several refills in a row (gio_prefetch) grows in place: moving 80 MB to make room for the next
     // 35 was most of a prefetch's time.  Address space only -- pages are touched as they are written.
     void reserve_window(size_t bytes) { out_.reserve(bytes); }
@@ -457,7 +469,9 @@ private:
     int refill()
     {
         // keep the unread tail, read another batch of compressed bytes, inflate its complete blocks
-        if (rd_ > 0) {
+        // (only when at least half of it has been read: behind an index seek the first block is entered a few KB in, and moving a
+        // 115 MB window by those few KB to make room for nothing -- the refill that finds the file's end -- was 6-10 ms of a prefetch)
+        if (rd_ > 0 && rd_ >= out_.size() / 2) {
             out_.drop_front(rd_);
             rd_ = 0;
         }
@@ -468,14 +482,45 @@ private:
         const size_t have = cbuf_.size();
         size_t got = 0;
         if (have < ((size_t)1 << 17) || !more_) {
-            cbuf_.resize(have + BATCH);
-            got = fread(cbuf_.data() + have, 1, BATCH, fp_);
-            cbuf_.resize(have + got);
+            const auto r0 = std::chrono::steady_clock::now();
+            // (no more than the file holds: what a slice reads short of that is a file that shrank under us)
+            size_t want = BATCH;
+            if (regular_ && (uint64_t)want > unread_file_bytes()) want = (size_t)unread_file_bytes();
+            if (!cbuf_.resize_uninit(have + want)) return fail(-6, "out of memory");
+            const int nr = regular_ ? (int)std::min<size_t>((size_t)n_threads(), want / ((size_t)1 << 20)) : 1;
+            if (nr >= 2) {
+                std::vector<size_t> part((size_t)nr, 0);
+                worker_pool::get().run(nr, [&](int t) {
+                    const size_t lo = want * (size_t)t / (size_t)nr, hi = want * (size_t)(t + 1) / (size_t)nr;
+                    size_t done = 0;
+                    while (lo + done < hi) {
+                        const ssize_t k = pread(fd_, cbuf_.data() + have + lo + done, hi - lo - done, (off_t)(fpos_ + lo + done));
+                        if (k <= 0) break;
+                        done += (size_t)k;
+                    }
+                    part[(size_t)t] = done;
+                });
+                for (int t = 0; t < nr; t++) {
+                    const size_t lo = want * (size_t)t / (size_t)nr, hi = want * (size_t)(t + 1) / (size_t)nr;
+                    got += part[(size_t)t];
+                    if (part[(size_t)t] != hi - lo) break;           // (a short slice ends the contiguous part)
+                }
+            } else {
+                while (got < want) {
+                    const ssize_t k = regular_ ? pread(fd_, cbuf_.data() + have + got, want - got, (off_t)(fpos_ + got))
+                                               : read(fd_, cbuf_.data() + have + got, want - got);
+                    if (k <= 0) break;
+                    got += (size_t)k;
+                }
+            }
+            fpos_ += got;
+            cbuf_.resize_uninit(have + got);
+            read_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - r0).count();
             g_stats.compressed_bytes += (int64_t)got;
             taken_ += got;
             if (got == 0 && !more_) {
                 eof_ = true;
-                if (!cbuf_.empty()) return fail(-4, "truncated BGZF block at the end of %s", path_.c_str());
+                if (cbuf_.size() != 0) return fail(-4, "truncated BGZF block at the end of %s", path_.c_str());
                 return 0;
             }
         }
@@ -522,7 +567,7 @@ private:
         else worker_pool::get().run(nt, [&](int) { work(); });
         if (bad.load()) return fail(-3, "inflate failed in %s", path_.c_str());
         g_stats.blocks += (int64_t)blocks.size();
-        cbuf_.erase(cbuf_.begin(), cbuf_.begin() + (ptrdiff_t)o);
+        cbuf_.drop_front(o);
         if (skip_) {                                              // first refill behind a seek: start inside the first block
             if (skip_ > total) return fail(-4, "index offset beyond its block in %s", path_.c_str());
             rd_ = skip_;
@@ -531,14 +576,17 @@ private:
         return 0;
     }
 
-    FILE *fp_ = nullptr;
+    int fd_ = -1;
+    bool regular_ = false;                                            // a regular file: its size is known, slices can be read side by side
+    uint64_t fpos_ = 0;                                               // where the next read starts
     std::string path_;
-    std::vector<uint8_t> cbuf_;
+    rawbuf cbuf_;                                                     // (grown without zero-filling what the read is about to write)
     rawbuf out_;
     // (GIO_WINDOW: the tests make it one block.  128 MB since the buffers are kept between decodes -- it was 32 MB to bound what a
     // decode touches once and unmaps: a C3-sized file is then one window instead of three, 13-18 ms inside the library against 18-25,
     // and 32 against 39 ms for a first decode with nothing kept)
     const size_t WINDOW = getenv("GIO_WINDOW") ? (size_t)atol(getenv("GIO_WINDOW")) : ((size_t)128 << 20);
+    double read_s_ = 0.0;                                             // (GIO_TIMING: resize + fread of the compressed bytes)
     bool more_ = false;                                               // whole blocks are waiting in cbuf_
     size_t rd_ = 0, skip_ = 0, batch_ = (size_t)1 << 18;
     uint64_t fsize_ = 0, start_ = 0, taken_ = 0;
@@ -753,6 +801,7 @@ static void prefetch_body(prefetched *p)
 {
     memset(&g_stats, 0, sizeof g_stats);
     g_err[0] = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     try {
         p->z.reset(new bgzf_stream());
         int rc = p->z->open(p->path.c_str());
@@ -767,11 +816,16 @@ static void prefetch_body(prefetched *p)
             rc = p->z->seek(voff >> 16, (unsigned)(voff & 0xffff));
             p->used_index = true;
         }
+        const auto t1 = std::chrono::steady_clock::now();
         if (!rc) {
             p->z->reserve_window(2 * p->z->window_cap());
+            if (!getenv("GIO_NO_READ_AHEAD")) p->z->read_ahead((size_t)std::min<uint64_t>(p->z->unread_file_bytes(), (uint64_t)p->z->window_cap() / 2));
             const int64_t av = p->z->ensure(p->z->window_cap());
             if (av < 0) rc = (int)av;
         }
+        if (getenv("GIO_TIMING"))
+            fprintf(stderr, "gio: prefetch: open + header + index %.4f s, read + inflate %.4f s (of which reading the file %.4f)\n",
+                    std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(), p->z->read_seconds());
         p->rc = rc;
     } catch (...) { p->rc = -6; }
     p->compressed = g_stats.compressed_bytes;

@@ -27,7 +27,9 @@
  * <stem>.bai): the scan starts at the first block that can hold an alignment overlapping the window and ends at the
  * first record behind it.  Without an index every record of the file is visited.  Record fields are validated
  * against the record size (-4 on a malformed or truncated file); long-read CIGARs kept in the CG:B,I tag are resolved.
- * Environment: GIO_THREADS (decoder threads, default = cores, <= 24; an explicit value up to 64), GIO_NO_INDEX=1, GIO_ZLIB=1.
+ * Environment: GIO_THREADS (decoder threads, default = cores, <= 24; an explicit value up to 64), GIO_NO_INDEX=1, GIO_ZLIB=1,
+ * GIO_NO_READ_AHEAD=1 (gio_prefetch reads the file batch by batch, as a decode without it does, instead of in one piece on all threads).
+ * The path may name a FIFO or another non-regular file: it is then read front to back with plain reads (no index).
  */
 #ifndef GRETEL_IO_H
 #define GRETEL_IO_H

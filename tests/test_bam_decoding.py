@@ -439,3 +439,30 @@ def test_the_table_in_the_callers_memory(tmp_path):
 
     with pytest.raises(MemoryError):
         util.support_table_from_bam(bam, contig, start, end, v, arena=Raises())
+
+
+def test_a_bam_through_a_pipe(tmp_path):
+    """A path that is no regular file (a FIFO: `samtools view -b ... > fifo`) is read front to back with plain reads -- no index,
+    no size, no parallel slices -- and gives the table the file gives."""
+    import threading
+    t = make_support_table(200, 5000, k=None, seed=9, k_max=6)
+    bam, vcf = str(tmp_path / "f.bam"), str(tmp_path / "f.vcf.gz")
+    contig, start, end = bamio.synth_to_files(t, bam, vcf)
+    v = util.process_vcf(vcf, contig, start, end)
+    want = util.support_table_from_bam(bam, contig, start, end, v)
+    fifo = str(tmp_path / "pipe.bam")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(bam, "rb") as src, open(fifo, "wb") as dst:
+            dst.write(src.read())
+
+    th = threading.Thread(target=feed)
+    th.start()
+    try:
+        got = util.support_table_from_bam(fifo, contig, start, end, v)
+    finally:
+        th.join(timeout=30)
+    assert bamio.native_last_stats()["used_index"] == 0
+    for x, y in zip(want, got):
+        assert np.array_equal(x, y)
