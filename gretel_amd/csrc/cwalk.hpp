@@ -722,29 +722,31 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
 }
 
 // -------------------------------------------------------------------------------------------------------------
-// k_cwalk2<LC>: 33..48 lags over ranks (round 6).  k_cwalkg's pools -- a state is its L picks as bytes next to their hash -- with
+// k_cwalk2<LC>: 33..64 lags over ranks (round 6).  k_cwalkg's pools -- a state is its L picks as bytes next to their hash -- with
 // k_cwalk's step: the row offsets of the last LC picks rotate through registers (slot u = the pick of the step that is u (mod LC)
 // into a block of LC steps, every index a compile-time constant), the terms of a step are LC LDS reads at compile-time offsets
 // and LC - 1 additions in lag order, and the next chunk's slice waits in registers under the walk.  A block of LC steps is two
 // chunks of the slice (LC x 16 x 8 bytes per target: 24 targets are 148 KB at 48 lags), so a chunk boundary always falls on the
 // same two steps of the unrolled block.  One instantiation serves every lag count L <= LC: the slice's blocks of lags beyond L
-// are zeros, and x + 0.0 is x for the arg-max (as for the positions in front of the window everywhere here) -- LC = 36, 40, 44, 48
-// are compiled.  Picks also go to a ring in LDS (one byte store per step, off the chain): the exit state is read from there, as
+// are zeros, and x + 0.0 is x for the arg-max (as for the positions in front of the window everywhere here) -- LC = 36, 40, ..., 64
+// are compiled; beyond 48 lags a block is FOUR chunks (16 targets of 8 KB at 64 lags).  Picks also go to a ring in LDS (one byte store per step, off the chain): the exit state is read from there, as
 // in k_cwalkg.  k_cwalkg took 6.5 rounds of 36 us per path at L = 33; this takes k_cwalk<32>'s 2.7 with run-on.
 // -------------------------------------------------------------------------------------------------------------
-#define CW2_MAX_L 48
+#define CW2_MAX_L 64
 #define CW2_RING 64
-__host__ __device__ constexpr int cw2_chunk(int LC) { return (LC + 1) / 2; }
+// a block of LC steps is K chunks of the slice: two up to 48 lags (24 targets of 6 KB), four beyond (16 of 8 KB at 64)
+__host__ __device__ constexpr int cw2_parts(int LC) { return LC <= 48 ? 2 : 4; }
+__host__ __device__ constexpr int cw2_chunk(int LC) { return (LC + cw2_parts(LC) - 1) / cw2_parts(LC); }
 __host__ __device__ constexpr size_t cw2_lds_bytes(int LC) { return (size_t)cw2_chunk(LC) * (LC * 16 + 5) * 8; }
-__host__ __device__ constexpr int cw2_lc(int L) { return L <= 36 ? 36 : (L <= 40 ? 40 : (L <= 44 ? 44 : 48)); }
+__host__ __device__ constexpr int cw2_lc(int L) { return L <= 36 ? 36 : (L + 3) / 4 * 4; }
 
 template <int LC>
 __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
 {
     constexpr int R = 4, LPE = 4, PPW = 16, WB = 2;
     constexpr int ROWS = 4, COLS = 4, ENT = ROWS * COLS, NTHR = CW_K * LPE;
-    constexpr int CHA = cw2_chunk(LC), CHB = LC - CHA;      // the two halves of a block of LC steps
-    static_assert(LC > CW_MAX_L && LC <= CW2_MAX_L && LC < CW2_RING, "lag counts of k_cwalk2");
+    constexpr int KP = cw2_parts(LC), CHA = cw2_chunk(LC);  // a block of LC steps: KP chunks of at most CHA targets
+    static_assert(LC > CW_MAX_L && LC <= CW2_MAX_L && LC <= CW2_RING && (KP - 1) * CHA < LC, "lag counts of k_cwalk2");
     __shared__ __align__(16) uint8_t ring[CW_K][CW2_RING];  // ring[q][t & 63] = pick at position t
     extern __shared__ __align__(16) unsigned char cw2_smem[];
     dev_state *st = P.st;
@@ -931,39 +933,27 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
     int c0 = t0;
     fetch(c0, t1 - c0 < CHA ? t1 - c0 : CHA);
     while (c0 < t1) {
-        // first half of the block: steps 0 .. CHA - 1
-        {
-            const int nc = t1 - c0 < CHA ? t1 - c0 : CHA;
-            __syncthreads();                                          // the chunk before has been walked
-            store(nc);
-            __syncthreads();
-            if (c0 + nc < t1) fetch(c0 + nc, t1 - c0 - nc < CHB ? t1 - c0 - nc : CHB);
-            cw_unrolled([&](auto u_) __attribute__((always_inline)) {
-                constexpr int u = decltype(u_)::value;
-                if (u < nc) {
-                    const unsigned d = step(c0, u, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
-                    dig[u] = d * ROWD;
-                }
-            }, std::make_integer_sequence<int, CHA>{});
-            c0 += nc;
-        }
-        if (c0 >= t1) break;
-        // second half: steps CHA .. LC - 1
-        {
-            const int nc = t1 - c0 < CHB ? t1 - c0 : CHB;
-            __syncthreads();
-            store(nc);
-            __syncthreads();
-            if (c0 + nc < t1) fetch(c0 + nc, t1 - c0 - nc < CHA ? t1 - c0 - nc : CHA);
-            cw_unrolled([&](auto u_) __attribute__((always_inline)) {
-                constexpr int u = CHA + decltype(u_)::value;
-                if (u - CHA < nc) {
-                    const unsigned d = step(c0, u - CHA, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
-                    dig[u] = d * ROWD;
-                }
-            }, std::make_integer_sequence<int, CHB>{});
-            c0 += nc;
-        }
+        // the block's parts in turn: part p holds steps p CHA .. min((p + 1) CHA, LC) - 1, its chunk of the slice staged in front of
+        // them and the next part's on its way under them
+        cw_unrolled([&](auto p_) __attribute__((always_inline)) {
+            constexpr int p = decltype(p_)::value, U0 = p * CHA, CNT = U0 + CHA <= LC ? CHA : LC - U0;
+            constexpr int pn = (p + 1) % KP, CNTN = pn * CHA + CHA <= LC ? CHA : LC - pn * CHA;      // (the part behind it)
+            if (c0 < t1) {
+                const int nc = t1 - c0 < CNT ? t1 - c0 : CNT;
+                __syncthreads();                                      // the chunk before has been walked
+                store(nc);
+                __syncthreads();
+                if (c0 + nc < t1) fetch(c0 + nc, t1 - c0 - nc < CNTN ? t1 - c0 - nc : CNTN);
+                cw_unrolled([&](auto u_) __attribute__((always_inline)) {
+                    constexpr int u = U0 + decltype(u_)::value;
+                    if (u - U0 < nc) {
+                        const unsigned d = step(c0, u - U0, [&](int l) { return dig[((u - l) % LC + LC) % LC]; });
+                        dig[u] = d * ROWD;
+                    }
+                }, std::make_integer_sequence<int, CNT>{});
+                c0 += nc;
+            }
+        }, std::make_integer_sequence<int, KP>{});
     }
     // the segment is walked.  Its exit state -- the last L picks, lag 1 first -- out of the ring, as the words it is kept in
     // (bytes beyond L zero), and its hash; hop 0: the entry's own walk, later hops: a walk on behalf of the pending request

@@ -1121,7 +1121,7 @@ static bool walk_depth2_ok(int wm, int L)
 static bool cw_ok(int wm, int L) { return wm == WM_SEG && L >= CW_MIN_L && L <= CW_MAX_LG; }
 // beyond what a 64-bit state holds (2 bits per pick over ranks, 3 over symbols): states as bytes next to their hash, k_cwalkg
 static bool cw_digit_mode(const gh_handle *h) { return h->cw_wide ? h->L > CW_MAX_L5 : h->L > CW_MAX_L; }
-// ... of which 33..48 lags over ranks are walked by k_cwalk2 (registers and an unrolled block, as k_cwalk) instead of k_cwalkg
+// ... of which 33..64 lags over ranks are walked by k_cwalk2 (registers and an unrolled block, as k_cwalk) instead of k_cwalkg
 // (GH_CWALK2=0: k_cwalkg, for the tests and A/B; read per launch)
 static bool cw2_ok(const gh_handle *h)
 {
@@ -1620,7 +1620,7 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     if (runon > CW_RUNON) runon = CW_RUNON;
     // (states as bytes, beyond 32 lags: a step of k_cwalkg costs several times k_cwalk's, and a launch lasts as long as its longest
     // walker -- 736 us per path without run-on at L = 33, 855..897 with one to three segments of it)
-    // (33..48 lags over ranks go through k_cwalk2 since round 6: k_cwalk's step, and its run-on)
+    // (33..64 lags over ranks go through k_cwalk2 since round 6: k_cwalk's step, and its run-on)
     if (cw_digit_mode(h) && !cw2_ok(h)) runon = 0;
     if (getenv("GH_CW_RUNON")) runon = atoi(getenv("GH_CW_RUNON"));
     if (runon > CW_RUNON) runon = CW_RUNON;
@@ -1704,7 +1704,11 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
                 case 36: launch_cwalk2_lc<36>(P, h->stream, g.S, h->dev); break;
                 case 40: launch_cwalk2_lc<40>(P, h->stream, g.S, h->dev); break;
                 case 44: launch_cwalk2_lc<44>(P, h->stream, g.S, h->dev); break;
-                default: launch_cwalk2_lc<48>(P, h->stream, g.S, h->dev); break;
+                case 48: launch_cwalk2_lc<48>(P, h->stream, g.S, h->dev); break;
+                case 52: launch_cwalk2_lc<52>(P, h->stream, g.S, h->dev); break;
+                case 56: launch_cwalk2_lc<56>(P, h->stream, g.S, h->dev); break;
+                case 60: launch_cwalk2_lc<60>(P, h->stream, g.S, h->dev); break;
+                default: launch_cwalk2_lc<64>(P, h->stream, g.S, h->dev); break;
             }
         } else if (cw_digit_mode(h)) {
             static std::atomic<size_t> set_g[2][64];

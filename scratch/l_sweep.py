@@ -1,5 +1,5 @@
 """Per-path time of a spin over the lag count: the same 10k-SNP window (long-read-style reads, k ~ Poisson(10) up to 25)
-at L = 1 .. 50 (or the lag counts given as arguments), 200 paths each (fill not included); the walker variant the last path took (3 = every state of every
+at L = 1 .. 66 (or the lag counts given as arguments), 200 paths each (fill not included); the walker variant the last path took (3 = every state of every
 segment, 4 = candidate pools, 0/2 = serial walker)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +9,7 @@ t = make_support_table(10000, 150000, k=None, seed=5, n_haps=8, err=0.0, k_max=2
 h = Hansel(t.n_snps, band=t.band)
 reads = DeviceReads(h, t.rank, t.off, t.bases)
 print("N %d band %d reads %d" % (t.n_snps, t.band, t.n_reads))
-for L in ([int(x) for x in sys.argv[1:]] or list(range(1, 51))):
+for L in ([int(x) for x in sys.argv[1:]] or list(range(1, 67))):
     best = None
     for it in range(2):
         h.clear(); h.fill_from_support(None, None, None, reads_handle=reads); h.L = L

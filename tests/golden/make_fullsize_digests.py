@@ -22,7 +22,7 @@ Round 6 (VERDICT r5 "offline-closable gaps": no digest covered deletions or L >=
       also under E + marginal term
     the same window with 5 % of the BASES read as deletions (nearly every position offers five candidates) at L = 4, 6, 8, 12 x 50
     C3 with 5 % of the bases read as deletions (bench.py's wide_window: 5^5 states per target) x 100, also under E + marginal term
-    the lag-sweep window without deletions at L = 33, 40, 48 x 50 (k_cwalkg: states as bytes)
+    the lag-sweep window without deletions at L = 33, 40, 48, 56, 64 x 50 (states as bytes: k_cwalk2, k_cwalkg when first written)
 
 Run from the repo root:   python tests/golden/make_fullsize_digests.py [--jobs 6] [--only NAME_SUBSTRING]
 Writes tests/golden/fullsize_digests.json (one entry per case, keyed by name).  Inputs come from the seeded generator
@@ -79,7 +79,7 @@ def cases():
         out.append(("sweep/seed5/dense_deletions/L=%d/50" % L, dict(config="sweep", seed=5, paths=50, spec={}, table="dense_deletions", L=L)))
     out.append(("C3/seed0/dense_deletions/default/100", dict(config="C3", seed=0, paths=100, spec={}, table="dense_deletions")))
     out.append(("C3/seed0/dense_deletions/%s/100" % spec_name(pub), dict(config="C3", seed=0, paths=100, spec=pub, table="dense_deletions")))
-    for L in (33, 40, 48):
+    for L in (33, 40, 48, 56, 64):                       # (56, 64: round 6, k_cwalk2's four-chunk blocks)
         out.append(("sweep/seed5/none/L=%d/50" % L, dict(config="sweep", seed=5, paths=50, spec={}, table=None, L=L)))
     return out
 

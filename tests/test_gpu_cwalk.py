@@ -204,11 +204,11 @@ def test_run_on_changes_nothing(L, dels, monkeypatch):
     _same(h1.spin(30), ref)
 
 
-@pytest.mark.parametrize("L", [33, 34, 36, 37, 40, 41, 44, 45, 47, 48])
+@pytest.mark.parametrize("L", [33, 34, 36, 37, 40, 41, 44, 45, 47, 48, 49, 52, 53, 57, 60, 61, 64])
 @pytest.mark.parametrize("spec", ["A", "E+mt"])
 def test_33_to_48_lags_through_registers(L, spec, monkeypatch):
-    """k_cwalk2<36 | 40 | 44 | 48> (round 6): 33..48 lags over ranks with k_cwalk's step -- the last LC picks' row offsets in
-    registers, a block of LC steps unrolled over two chunks of the slice, lags beyond L as blocks of zeros -- on k_cwalkg's pools
+    """k_cwalk2<36 | 40 | ... | 64> (round 6): 33..64 lags over ranks with k_cwalk's step -- the last LC picks' row offsets in
+    registers, a block of LC steps unrolled over two chunks of the slice (four beyond 48 lags), lags beyond L as blocks of zeros -- on k_cwalkg's pools
     (states as bytes next to their hash).  The oracle's paths; the same with k_cwalkg (GH_CWALK2=0), without run-on and with the
     chain followed behind every round; every lag count that shares an instantiation with another."""
     kw = dict(cond_mode="E", marginal_term=True) if spec == "E+mt" else {}
@@ -218,7 +218,7 @@ def test_33_to_48_lags_through_registers(L, spec, monkeypatch):
     assert h.walk_clock()[3] == 4
     _same(res, ref)
     assert np.array_equal(h.export_band(), o.export_band())
-    if L in (33, 41, 48):
+    if L in (33, 41, 48, 53, 64):
         monkeypatch.setenv("GH_CWALK2", "0")
         hg, _ = _pair(t, L=L, **kw)
         _same(hg.spin(16), ref)
@@ -247,10 +247,9 @@ def test_33_to_48_lags_short_window_and_lone_paths():
     assert np.array_equal(h.export_band(), o.export_band())
 
 
-@pytest.mark.parametrize("L", [49, 64])
-def test_beyond_48_lags_bytes_and_ring(L):
-    # k_cwalkg (states walked out of a byte ring) still serves what k_cwalk2 does not: here 49 and 64 lags over ranks; its epilogue
-    # shares k_cwalk2's word compares and LDS-staged hashes since round 6
+@pytest.mark.parametrize("L", [65, 80])
+def test_beyond_64_lags_bytes_and_ring(L):
+    # k_cwalkg (states walked out of a byte ring) still serves what k_cwalk2 does not: here 65 and 80 lags over ranks
     t = make_support_table(1500, 16000, k=None, seed=900 + L, k_max=L + 4, k_lambda=float(L))
     h, o = _pair(t, L=L)
     _same(h.spin(10), o.spin(10))
