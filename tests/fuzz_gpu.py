@@ -22,7 +22,7 @@ while time.time() < t_end:
     n = int(rng.choice([4000, 7777, 12000, 20011])) if big else int(rng.choice([2, 3, 5, 17, 64, 130, 333, 700, 1500, 3000]))
     k = int(rng.integers(2, min(n, 12) + 1)) if rng.random() < 0.7 else None
     # reads of up to 21 SNPs mostly (C5's shape), up to 33 / 64 now and then: bands beyond the 32 lanes of the wide reweight kernels
-    kmx = int(rng.choice([21, 21, 21, 33, 48, 64]))
+    kmx = int(rng.choice([21, 21, 21, 33, 48, 64, 72]))
     lam = 10.0 if kmx == 21 else float(rng.choice([10.0, kmx * 0.6]))
     n_haps = int(rng.integers(1, 9))
     err = float(rng.choice([0.0, 0.0, 0.01, 0.05]))
@@ -46,7 +46,8 @@ while time.time() < t_end:
     order = "".join(rng.permutation(list("ACGT-"))) if rng.random() < 0.25 else "ACGT-"
     zero = bool(rng.random() < 0.15)
     sw = dict(cand_order=order, offer_zero=zero)
-    L = None if rng.random() < 0.4 else (int(rng.integers(1, 27)) if rng.random() < 0.85 else int(rng.integers(25, 48)))
+    # (25..69: the packed pools' last lag counts, k_cwalk2's 33..64 with its two- and four-chunk blocks, k_cwalkg behind them)
+    L = None if rng.random() < 0.4 else (int(rng.integers(1, 27)) if rng.random() < 0.85 else int(rng.integers(25, 70)))
     if sparse and rng.random() < 0.8:
         L = 5
     paths = int(rng.integers(1, 9))
