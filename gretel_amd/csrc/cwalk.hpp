@@ -732,21 +732,25 @@ __global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalkg(cw_params P)
 // are compiled; beyond 48 lags a block is FOUR chunks (16 targets of 8 KB at 64 lags).  Picks also go to a ring in LDS (one byte store per step, off the chain): the exit state is read from there, as
 // in k_cwalkg.  k_cwalkg took 6.5 rounds of 36 us per path at L = 33; this takes k_cwalk<32>'s 2.7 with run-on.
 // -------------------------------------------------------------------------------------------------------------
-#define CW2_MAX_L 64
+#define CW2_MAX_L 64            /* over ranks */
+#define CW2_MAX_L5 40           /* over the symbols (512 threads: 256 registers per lane) */
 #define CW2_RING 64
-// a block of LC steps is K chunks of the slice: two up to 48 lags (24 targets of 6 KB), four beyond (16 of 8 KB at 64)
-__host__ __device__ constexpr int cw2_parts(int LC) { return LC <= 48 ? 2 : 4; }
-__host__ __device__ constexpr int cw2_chunk(int LC) { return (LC + cw2_parts(LC) - 1) / cw2_parts(LC); }
-__host__ __device__ constexpr size_t cw2_lds_bytes(int LC) { return (size_t)cw2_chunk(LC) * (LC * 16 + 5) * 8; }
-__host__ __device__ constexpr int cw2_lc(int L) { return L <= 36 ? 36 : (L + 3) / 4 * 4; }
+// a block of LC steps is K chunks of the slice.  Over ranks (16 doubles per target and lag): two up to 48 lags (24 targets of 6 KB),
+// four beyond (16 of 8 KB at 64); over the symbols (25 doubles): one at 24 lags (117 KB), two up to 32, four beyond (10 of 8 KB at 40:
+// with three the next chunk's slice in registers pushed the walk's own into scratch memory)
+__host__ __device__ constexpr int cw2_parts(int LC, int R = 4) { return R == 4 ? (LC <= 48 ? 2 : 4) : (LC <= 24 ? 1 : (LC <= 32 ? 2 : 4)); }
+__host__ __device__ constexpr int cw2_chunk(int LC, int R = 4) { return (LC + cw2_parts(LC, R) - 1) / cw2_parts(LC, R); }
+__host__ __device__ constexpr size_t cw2_lds_bytes(int LC, int R = 4) { return (size_t)cw2_chunk(LC, R) * (LC * cw_rows(R) * cw_cols(R) + 5) * 8; }
+__host__ __device__ constexpr int cw2_lc(int L, int R = 4) { return R == 4 ? (L <= 36 ? 36 : (L + 3) / 4 * 4) : (L <= 24 ? 24 : (L + 3) / 4 * 4); }
 
-template <int LC>
-__global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
+template <int LC, int R>
+__global__ void __launch_bounds__(CW_K * cw_lanes(R)) k_cwalk2(cw_params P)
 {
-    constexpr int R = 4, LPE = 4, PPW = 16, WB = 2;
-    constexpr int ROWS = 4, COLS = 4, ENT = ROWS * COLS, NTHR = CW_K * LPE;
-    constexpr int KP = cw2_parts(LC), CHA = cw2_chunk(LC);  // a block of LC steps: KP chunks of at most CHA targets
-    static_assert(LC > CW_MAX_L && LC <= CW2_MAX_L && LC <= CW2_RING && (KP - 1) * CHA < LC, "lag counts of k_cwalk2");
+    constexpr int LPE = cw_lanes(R), PPW = R == 4 ? 16 : 8, WB = R == 4 ? 2 : 4;
+    constexpr int ROWS = cw_rows(R), COLS = cw_cols(R), ENT = ROWS * COLS, NTHR = CW_K * LPE;
+    constexpr int KP = cw2_parts(LC, R), CHA = cw2_chunk(LC, R);  // a block of LC steps: KP chunks of at most CHA targets
+    static_assert(R == 4 ? (LC > CW_MAX_L && LC <= CW2_MAX_L) : (LC > CW_MAX_L5 && LC <= CW2_MAX_L5), "lag counts of k_cwalk2");
+    static_assert(LC <= CW2_RING && (KP - 1) * CHA < LC, "a block's parts");
     __shared__ __align__(16) uint8_t ring[CW_K][CW2_RING];  // ring[q][t & 63] = pick at position t
     extern __shared__ __align__(16) unsigned char cw2_smem[];
     dev_state *st = P.st;
@@ -757,7 +761,7 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
         if (blockIdx.x == 0 && threadIdx.x == 0) st->lt_stale = 1;
         return;
     }
-    if (c.ranked == 0) {                                    // a five-candidate position somewhere: the host looks again (k_cwalkg<5>)
+    if ((c.ranked != 0) != (R == 4)) {                      // the table is not in this instantiation's layout (it was rebuilt): the host looks again
         if (blockIdx.x == 0 && threadIdx.x == 0) st->cw_unres = 2;
         return;
     }
@@ -776,7 +780,7 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
         const int np = P.npend_c[s] < CW_K ? P.npend_c[s] : CW_K;
         cw_key *keys = P.keys + (size_t)s * CW_K;
         int32_t *lh = P.last_hit + (size_t)s * CW_K;
-        const int nw_m = g.NW;
+        const int nw_m = R == 4 ? g.NW : g.NW5;
         for (int k = 0; k < np; k++) {
             const cw_key x = P.pend_c[(size_t)s * CW_K + k];
             const uint8_t *xd = P.pend_d_c + ((size_t)s * CW_K + k) * LD;
@@ -811,10 +815,11 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
     __syncthreads();
     const int n = s_n;
     const int q = tid / LPE, b = tid & (LPE - 1);
+    const int bcol = b < R ? b : R - 1;                     // (R = 5: lanes 5..7 of the group read a valid column and carry -inf)
     const bool live = q < n && P.walked[(size_t)s * CW_K + q] == 0;
     if (!__syncthreads_or(live ? 1 : 0)) return;
     const unsigned shift = (unsigned)(tid & 63 & ~(LPE - 1));
-    const int nw_e = g.NW;
+    const int nw_e = R == 4 ? g.NW : g.NW5;
     // the entry's last L picks into its ring (an idle lane group reads row 0 everywhere)
     for (int w = b; w < CW2_RING / 4; w += LPE) reinterpret_cast<uint32_t *>(ring[q])[w] = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -843,7 +848,7 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
                 const int e = tid + k * NTHR;
                 const int tl = e / LT_ROW, bb = e - tl * LT_ROW;
                 prelm[k] = 0.0;
-                if (tl < nc && bb < R) prelm[k] = P.rinfo[(size_t)(c0 + 1 + tl) * RINFO + bb];
+                if (tl < nc && bb < R) prelm[k] = R == 4 ? P.rinfo[(size_t)(c0 + 1 + tl) * RINFO + bb] : P.minfo[(size_t)(c0 + 1 + tl) * MINFO + bb];
             }
         }
         const int total = nc * LC * ROWS;
@@ -908,17 +913,20 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
 #pragma unroll
     for (int l = 1; l <= LC; l++) dig[(LC - l) % LC] = (unsigned)ring[q][(t0 + 1 - l) & (CW2_RING - 1)] * ROWD;
     auto step = [&](int c0, int tl, auto rowoff) __attribute__((always_inline)) {
-        const double *base = Gs + (size_t)tl * LC * ENT + b;
+        const double *base = Gs + (size_t)tl * LC * ENT + bcol;
         double x[LC];
 #pragma unroll
         for (int l = 1; l <= LC; l++) x[l - 1] = base[(l - 1) * ENT + rowoff(l)];
         double acc = x[0];
 #pragma unroll
         for (int l = 2; l <= LC; l++) acc = acc + x[l - 1];
+        if (R == 5 && b >= R) acc = -INFINITY;                   // (the idle lanes of the group)
         double m = vmax_f64(acc, dpp_f64<0xB1>(acc));            // quad_perm [1,0,3,2]
         m = vmax_f64(m, dpp_f64<0x4E>(m));                       // quad_perm [2,3,0,1]
-        const unsigned long long win = __builtin_amdgcn_ballot_w64(acc == m);
-        const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & 15u);       // first wins (gretel.py:166-174)
+        if (R == 5) m = vmax_f64(m, dpp_f64<0x141>(m));          // row_half_mirror: the other quad of the eight lanes
+        // (R = 5: a NaN weight in first place is the reference's incumbent and stays it -- kernels.hpp, argmax8)
+        const unsigned long long win = __builtin_amdgcn_ballot_w64(R == 5 ? (acc == m || (b == 0 && acc != acc)) : acc == m);
+        const unsigned d = (unsigned)__builtin_ctz((unsigned)(win >> shift) & ((1u << LPE) - 1u));       // first wins (gretel.py:166-174)
         const int t = c0 + 1 + tl;
         if (active && b == 0) ring[q][t & (CW2_RING - 1)] = (uint8_t)d;      // (read again behind the segment only)
         const int gt = t - t0 - 1;
@@ -995,7 +1003,7 @@ __global__ void __launch_bounds__(CW_K * 4) k_cwalk2(cw_params P)
             mine |= diff == 0;
         }
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine);
-        there = ((bal >> shift) & 15ull) != 0ull;
+        there = ((bal >> shift) & ((1ull << LPE) - 1ull)) != 0ull;
     }
     int go_on = 0;
     if (active && b == 0) {

@@ -1121,11 +1121,12 @@ static bool walk_depth2_ok(int wm, int L)
 static bool cw_ok(int wm, int L) { return wm == WM_SEG && L >= CW_MIN_L && L <= CW_MAX_LG; }
 // beyond what a 64-bit state holds (2 bits per pick over ranks, 3 over symbols): states as bytes next to their hash, k_cwalkg
 static bool cw_digit_mode(const gh_handle *h) { return h->cw_wide ? h->L > CW_MAX_L5 : h->L > CW_MAX_L; }
-// ... of which 33..64 lags over ranks are walked by k_cwalk2 (registers and an unrolled block, as k_cwalk) instead of k_cwalkg
-// (GH_CWALK2=0: k_cwalkg, for the tests and A/B; read per launch)
+// ... of which 33..64 lags over ranks and 22..40 over the symbols are walked by k_cwalk2 (registers and an unrolled block, as
+// k_cwalk) instead of k_cwalkg (GH_CWALK2=0: k_cwalkg, for the tests and A/B; read per launch)
 static bool cw2_ok(const gh_handle *h)
 {
-    return !h->cw_wide && h->L > CW_MAX_L && h->L <= CW2_MAX_L && !(getenv("GH_CWALK2") && atoi(getenv("GH_CWALK2")) == 0);
+    if (getenv("GH_CWALK2") && atoi(getenv("GH_CWALK2")) == 0) return false;
+    return h->cw_wide ? (h->L > CW_MAX_L5 && h->L <= CW2_MAX_L5) : (h->L > CW_MAX_L && h->L <= CW2_MAX_L);
 }
 
 // single windows: may k_lt build the ranked layout?  (the segment-parallel walk reads either layout)
@@ -1620,7 +1621,7 @@ static cw_params cw_make_params(gh_handle *h, uint8_t *d_path, double *d_lmsel)
     if (runon > CW_RUNON) runon = CW_RUNON;
     // (states as bytes, beyond 32 lags: a step of k_cwalkg costs several times k_cwalk's, and a launch lasts as long as its longest
     // walker -- 736 us per path without run-on at L = 33, 855..897 with one to three segments of it)
-    // (33..64 lags over ranks go through k_cwalk2 since round 6: k_cwalk's step, and its run-on)
+    // (33..64 lags over ranks and 22..40 over the symbols go through k_cwalk2 since round 6: k_cwalk's step, and its run-on)
     if (cw_digit_mode(h) && !cw2_ok(h)) runon = 0;
     if (getenv("GH_CW_RUNON")) runon = atoi(getenv("GH_CW_RUNON"));
     if (runon > CW_RUNON) runon = CW_RUNON;
@@ -1666,15 +1667,15 @@ static void launch_cwalk_lc(const cw_params &P, hipStream_t stream, int S, int d
     hipLaunchKernelGGL((k_cwalk<LC, R>), dim3(S), dim3(CW_K * cw_lanes(R)), cw_lds_bytes(LC, R), stream, P);
 }
 
-template <int LC>
+template <int LC, int R = 4>
 static void launch_cwalk2_lc(const cw_params &P, hipStream_t stream, int S, int dev)
 {
     static std::atomic<bool> set[64];
     if (!set[dev & 63]) {
-        hipFuncSetAttribute((const void *)k_cwalk2<LC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cw2_lds_bytes(LC));
+        hipFuncSetAttribute((const void *)k_cwalk2<LC, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cw2_lds_bytes(LC, R));
         set[dev & 63] = true;
     }
-    hipLaunchKernelGGL((k_cwalk2<LC>), dim3(S), dim3(CW_K * 4), cw2_lds_bytes(LC), stream, P);
+    hipLaunchKernelGGL((k_cwalk2<LC, R>), dim3(S), dim3(CW_K * cw_lanes(R)), cw2_lds_bytes(LC, R), stream, P);
 }
 
 // the kernels of one path: `rounds` x (walk what is new, link + chain), emit
@@ -1699,7 +1700,15 @@ static int launch_cw_path(gh_handle *h, uint8_t *d_path, double *d_lmsel, int ro
             P.pend_d = Q.pend_d; P.pend_d_c = Q.pend_d_c; P.pend_exit_d = Q.pend_exit_d; P.pend_exit_d_c = Q.pend_exit_d_c;
         }
         if (r == 0) prof_begin(h, GH_K_SEG);                // (bench.py: the pool walker alone, first round of a path)
-        if (cw_digit_mode(h) && cw2_ok(h)) {
+        if (cw_digit_mode(h) && cw2_ok(h) && h->cw_wide) {
+            switch (cw2_lc(h->L, 5)) {
+                case 24: launch_cwalk2_lc<24, 5>(P, h->stream, g.S, h->dev); break;
+                case 28: launch_cwalk2_lc<28, 5>(P, h->stream, g.S, h->dev); break;
+                case 32: launch_cwalk2_lc<32, 5>(P, h->stream, g.S, h->dev); break;
+                case 36: launch_cwalk2_lc<36, 5>(P, h->stream, g.S, h->dev); break;
+                default: launch_cwalk2_lc<40, 5>(P, h->stream, g.S, h->dev); break;
+            }
+        } else if (cw_digit_mode(h) && cw2_ok(h)) {
             switch (cw2_lc(h->L)) {
                 case 36: launch_cwalk2_lc<36>(P, h->stream, g.S, h->dev); break;
                 case 40: launch_cwalk2_lc<40>(P, h->stream, g.S, h->dev); break;

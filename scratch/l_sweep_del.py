@@ -2,7 +2,7 @@
 reads, k ~ Poisson(10) up to 25) as it is (every position offers at most four candidates) and with '-' at 1 % of the POSITIONS
 on 30 % of the reads that cover them (gretel_amd.synth.sprinkle_deletions: a deletion column here and there, what a real pileup
 shows, gretel/util.py:178-190).  VERDICT r5 item 1: no L in 2..16 may cost more than 1.5x its narrow figure.
-Usage: l_sweep_del.py [L ...]     (default 2..16; 200 paths per spin, best of two spins, fill not included)"""
+Usage: l_sweep_del.py [L ...]     (default 2..16 and a dozen lag counts up to 41; 200 paths per spin, best of two spins, fill not included)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gretel_amd.hansel import Hansel, DeviceReads
@@ -27,7 +27,7 @@ def per_path(h, reads, L, paths=200):
     return best, res["n"], wc
 
 if __name__ == "__main__":
-    Ls = [int(x) for x in sys.argv[1:]] or list(range(2, 17))
+    Ls = [int(x) for x in sys.argv[1:]] or (list(range(2, 17)) + [18, 20, 21, 22, 24, 28, 32, 33, 36, 40, 41])
     tn, hn, rn = window(0.0)
     td, hd, rd = window(0.01)
     print("N %d band %d reads %d" % (tn.n_snps, tn.band, tn.n_reads))

@@ -70,7 +70,7 @@ def cases():
     # round 6: deletions beyond L = 5, dense deletions, byte states.  `L` overrides what the fill gives (util.py:333), as
     # scratch/l_sweep.py does: the same window at every lag count
     pub = dict(cond_mode="E", marginal_term=True)       # the published method's form (README.md:79-94)
-    for L in (3, 4, 6, 7, 8, 11, 16, 22):
+    for L in (3, 4, 6, 7, 8, 11, 16, 22, 30, 38):       # (30, 38: round 6, k_cwalk2<LC, 5>)
         out.append(("sweep/seed5/sparse_deletions/L=%d/100" % L, dict(config="sweep", seed=5, paths=100, spec={}, table="sparse_deletions", L=L)))
     for L in (6, 8):
         out.append(("sweep/seed5/sparse_deletions/L=%d/%s/100" % (L, spec_name(pub)),

@@ -72,10 +72,11 @@ def test_pools_persist_across_spins_and_reset_on_fill():
     assert np.array_equal(h.export_band(), o2.export_band())
 
 
-@pytest.mark.parametrize("L", [6, 7, 11, 16, 19, 21, 22, 30])
+@pytest.mark.parametrize("L", [6, 7, 11, 16, 19, 21, 22, 24, 25, 30, 32, 33, 37, 40, 41, 45])
 def test_window_with_five_candidates(L):
     # a position that shows A, C, G, T and '-': the conditional table is over the symbols, not over candidate ranks; the
-    # pools then hold 3-bit picks (k_cwalk<L, 5>: 21 lags fit a state; beyond that k_cwalkg<5>)
+    # pools then hold 3-bit picks (k_cwalk<L, 5>: 21 lags fit a state; 22..40: k_cwalk2<24 | 28 | .. | 40, 5>, states as bytes,
+    # round 6; beyond that k_cwalkg<5>)
     t = make_support_table(1500, 36000, k=None, seed=5 + L, k_max=max(24, L + 4), k_lambda=10.0 if L <= 21 else float(L))
     bases = t.bases.copy()
     bases[np.random.default_rng(1).random(len(bases)) < 0.1] = ord('-')
@@ -255,3 +256,29 @@ def test_beyond_64_lags_bytes_and_ring(L):
     _same(h.spin(10), o.spin(10))
     assert h.walk_clock()[3] == 4
     assert np.array_equal(h.export_band(), o.export_band())
+
+
+@pytest.mark.parametrize("L", [22, 29, 36, 40])
+@pytest.mark.parametrize("spec", ["A", "E+mt"])
+def test_22_to_40_lags_over_the_symbols(L, spec, monkeypatch):
+    """k_cwalk2<LC, 5> (round 6): a window with deletion COLUMNS (a five-candidate position here and there, what a pileup shows)
+    at 22..40 lags -- eight lanes per pool entry, the table over the symbols, a block of LC steps over one, two or four chunks of
+    the slice.  The oracle's paths; the same with k_cwalkg<5> and without run-on."""
+    from gretel_amd.synth import sprinkle_deletions
+    kw = dict(cond_mode="E", marginal_term=True) if spec == "E+mt" else {}
+    t = make_support_table(2500, 30000, k=None, seed=800 + L, k_max=L + 4, k_lambda=float(L))
+    sprinkle_deletions(t, 0.02, seed=L)
+    h, o = _pair(t, L=L, **kw)
+    assert (h.candidate_masks()[1:] == 0x2F).any()
+    res, ref = h.spin(16), o.spin(16)
+    assert h.walk_clock()[3] == 4
+    _same(res, ref)
+    assert np.array_equal(h.export_band(), o.export_band())
+    monkeypatch.setenv("GH_CWALK2", "0")
+    hg, _ = _pair(t, L=L, **kw)
+    _same(hg.spin(16), ref)
+    monkeypatch.delenv("GH_CWALK2")
+    monkeypatch.setenv("GH_CW_RUNON", "0")
+    monkeypatch.setenv("GH_CW_SKIP0", "0")
+    h0, _ = _pair(t, L=L, **kw)
+    _same(h0.spin(16), ref)
